@@ -1,0 +1,401 @@
+"""numpy fp64 restatement of espm's SmoothNMF multiplicative-update path (the ORACLE).
+
+TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Parity pinned by ``tests/golden``.
+
+Every function names the reference lines it restates (paths relative to the reference
+repository root, adriente/espm @ v1.1.3).  The code is written from the algorithm, in a
+functional style, and keeps the reference's observable quirks:
+
+* the bisection stops on a GLOBAL criterion (max over columns), dicotomy.py:152;
+* ``H @ L`` uses the un-clamped input H, updates.py:93-96 precede :104;
+* ``G=None`` becomes a dense identity, updates.py:163-166;
+* the W-step associates ``(G.T @ R) @ H.T``, updates.py:58-59;
+* the KL loss is ``sum(Y) - sum(max(X,eps) * log(Y)) + const``, measures.py:493-504,
+  base.py:200-203.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+# espm/conf.py:55-59
+LOG_SHIFT = 1e-14
+DICOTOMY_TOL = 1e-5
+SIGMA_L = 8
+MAXIT_DICHOTOMY = 100
+
+
+# --------------------------------------------------------------------------------------
+# simplex root finder  (espm/estimators/dicotomy.py:4-55 and :111-173)
+# --------------------------------------------------------------------------------------
+def simplex_bracket(num, den, log_shift=LOG_SHIFT):
+    """Bracket [a, b] of the Lagrange multiplier, dicotomy.py:17-49.
+
+    a_j = max over {i : num_ij > 0} of num_ij / 2 - den_ij     (f(a) > 0)
+    b_j = 2 * k * max_i num_ij - min_i den_ij                  (f(b) < 0)
+    """
+    num = np.asarray(num)
+    den = np.asarray(den)
+    if not (num >= 0).all() or not (den >= 0).all() or not (num.sum(axis=0) > 0).all():
+        raise AssertionError("dichotomy_simplex preconditions violated")  # dicotomy.py:17-19
+    k = den.shape[0]
+    if log_shift > 0 and k * log_shift >= 1:
+        raise ValueError("No solution exists!")  # dicotomy.py:22-23
+    den_b = np.broadcast_to(den, num.shape)
+    cand = np.where(num > 0, num / 2 - den_b, -np.inf)
+    a = cand.max(axis=0)
+    b = k * num.max(axis=0) / 0.5 - den.min(axis=0)
+    b = np.broadcast_to(b, a.shape).copy()
+    return a.astype(np.result_type(num, den), copy=True), b
+
+
+def simplex_residual(nu, num, den, log_shift=LOG_SHIFT):
+    """f(nu) = sum_i max(num_i / (nu + den_i), eps) - 1, dicotomy.py:51-53."""
+    return np.maximum(num / (nu + den), log_shift).sum(axis=0) - 1
+
+
+def bisect(a, b, func, maxit, tol):
+    """Vectorised bisection with the reference's GLOBAL stop rule, dicotomy.py:111-173.
+
+    ``a`` / ``b`` are updated in place exactly like the reference does.
+    Returns (root estimate, number of sweeps).
+    """
+    fa0, fb0 = func(a), func(b)
+    if (fb0 >= 0).any() or (fa0 <= 0).any() or np.isnan(fa0).any() or np.isnan(fb0).any():
+        raise AssertionError("bisection bracket is not a sign change")  # dicotomy.py:141-144
+    sweeps = 0
+    mid = (a + b) / 2
+    fmid = func(mid)
+    while np.max(np.abs(fmid)) > tol:
+        sweeps += 1
+        to_b = func(a) * fmid <= 0  # dicotomy.py:155-159
+        b[to_b] = mid[to_b]
+        a[~to_b] = mid[~to_b]
+        mid = (a + b) / 2
+        fmid = func(mid)
+        if sweeps >= maxit:
+            break
+    return mid, sweeps
+
+
+def dichotomy_simplex(num, denum, log_shift=LOG_SHIFT, tol=DICOTOMY_TOL, maxit=MAXIT_DICHOTOMY,
+                      return_sweeps=False):
+    """nu (p,) such that sum_i max(num_ij/(nu_j+den_ij), eps) = 1, dicotomy.py:4-55."""
+    num = np.asarray(num)
+    denum = np.asarray(denum)
+    a, b = simplex_bracket(num, denum, log_shift)
+    nu, sweeps = bisect(a, b, lambda x: simplex_residual(x, num, denum, log_shift), maxit, tol)
+    return (nu, sweeps) if return_sweeps else nu
+
+
+# --------------------------------------------------------------------------------------
+# Laplacian  (espm/utils.py:39-76)
+# --------------------------------------------------------------------------------------
+def laplacian_matrix(nx, ny=None):
+    """Sparse (p, p) 5-point graph Laplacian, zero-flux boundary, row-major pixel index.
+
+    Entry (q, q) is the number of in-image 4-neighbours of pixel q, entry (q, r) is -1 for
+    each neighbour r (utils.py:56-75).  float32 like the reference.
+    """
+    if ny is None:
+        ny = nx
+    assert nx > 1 and ny > 1  # utils.py:58-59
+    idx = np.arange(nx * ny).reshape(nx, ny)
+    rows, cols = [], []
+    for src, dst in ((idx[:, :-1], idx[:, 1:]), (idx[:-1, :], idx[1:, :])):
+        rows += [src.ravel(), dst.ravel()]
+        cols += [dst.ravel(), src.ravel()]
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    adj = sp.coo_matrix((np.ones(rows.size, np.float32), (rows, cols)), shape=(nx * ny,) * 2).tocsr()
+    deg = sp.diags(np.asarray(adj.sum(axis=1)).ravel().astype(np.float32))
+    return (deg - adj).tocsr()
+
+
+def laplacian_apply(H, nx, ny):
+    """(H @ L) for the matrix above, written as a stencil on the (nx, ny) grid."""
+    k = H.shape[0]
+    img = H.reshape(k, nx, ny)
+    out = np.zeros_like(img)
+    out[:, 1:, :] += img[:, 1:, :] - img[:, :-1, :]
+    out[:, :-1, :] += img[:, :-1, :] - img[:, 1:, :]
+    out[:, :, 1:] += img[:, :, 1:] - img[:, :, :-1]
+    out[:, :, :-1] += img[:, :, :-1] - img[:, :, 1:]
+    return out.reshape(k, nx * ny)
+
+
+def identity_L(p):
+    """L_ when shape_2d is None, base.py:289-291."""
+    return sp.identity(p, dtype=np.float32, format="csr")
+
+
+# --------------------------------------------------------------------------------------
+# update rules  (espm/estimators/updates.py:6-78, :83-156)
+# --------------------------------------------------------------------------------------
+def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT, epsilon_reg=1,
+                          safe=True, dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, l2=False,
+                          sigmaL=SIGMA_L, fixed_H=None):
+    """One multiplicative H update, updates.py:83-156 (KL branch :127-132, l2 branch :109-118)."""
+    if lambda_L != 0:
+        if L is None:
+            raise ValueError("Please provide the laplacian")  # updates.py:94-95
+        HL = H @ L  # from the un-clamped H
+    if safe:  # updates.py:98-105
+        assert (H >= -log_shift / 2).all() and (W >= -log_shift / 2).all() and (G >= -log_shift / 2).all()
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    GW = G @ W
+    if l2:
+        assert lambda_L == 0 and np.all(np.asarray(mu) == 0)
+        num = GW.T @ X
+        den = (GW.T @ GW) @ H
+    else:
+        Y = GW @ H
+        num = GW.T @ (X / Y)
+        if np.isnan(num).any():  # updates.py:129-131
+            num = GW.T @ (X / np.maximum(Y, log_shift))
+        den = GW.sum(axis=0)[:, None]
+        if not (np.isscalar(mu) and mu == 0):
+            mu_col = np.asarray(mu, dtype=float)
+            if mu_col.ndim == 1:
+                mu_col = mu_col[:, None]
+            den = den + mu_col / (H + epsilon_reg)  # updates.py:134-137
+        if lambda_L != 0:
+            maxH = H.max(axis=1, keepdims=True)  # GLOBAL over pixels, updates.py:139
+            num = num + lambda_L * sigmaL * maxH
+            den = den + lambda_L * sigmaL * maxH + lambda_L * HL
+    num = H * num
+    nu = dichotomy_simplex(num, den, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
+    if safe:
+        assert (den >= 0).all() and (num >= 0).all()
+    new_H = np.maximum(num / (den + nu), log_shift)
+    if fixed_H is not None:
+        keep = fixed_H >= 0
+        new_H[keep] = fixed_H[keep]
+    return new_H
+
+
+def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=LOG_SHIFT, safe=True, l2=False,
+                          fixed_W=None, simplex_rows=None):
+    """One multiplicative W update, updates.py:6-78.
+
+    ``simplex_rows`` stands for ``physics_model.NMF_simplex()`` (updates.py:62-65).
+    """
+    if safe:
+        assert (H >= -log_shift / 2).all() and (W >= -log_shift / 2).all() and (G >= -log_shift / 2).all()
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    if l2:
+        new_W = W / ((G.T @ G) @ W @ (H @ H.T)) * (G.T @ (X @ H.T))  # updates.py:30-36
+    else:
+        Y = (G @ W) @ H
+        R = X / Y
+        if np.isnan(R).any():  # updates.py:54-56
+            R = X / np.maximum(Y, log_shift)
+        num = W * ((G.T @ R) @ H.T)  # the reference's association
+        den = G.sum(axis=0)[:, None] @ H.sum(axis=1)[None, :]
+        if simplex_W:
+            if simplex_rows is not None:
+                nu = dichotomy_simplex(num[simplex_rows, :], den[simplex_rows, :], log_shift=log_shift,
+                                       tol=DICOTOMY_TOL)
+                den[simplex_rows, :] = den[simplex_rows, :] + nu
+            else:
+                den = den + dichotomy_simplex(num, den, log_shift=log_shift, tol=DICOTOMY_TOL)
+        new_W = num / den
+    new_W = np.maximum(new_W, log_shift)
+    if fixed_W is not None:
+        keep = fixed_W >= 0
+        new_W[keep] = fixed_W[keep]
+    return new_W
+
+
+# --------------------------------------------------------------------------------------
+# losses  (espm/measures.py:456-504, :524-548, :560-577; base.py:167-207; smooth_nmf.py:457-475)
+# --------------------------------------------------------------------------------------
+def KLdiv_loss(X, D, H, log_shift=LOG_SHIFT, average=False):
+    """sum(Y) - sum(max(X,eps) log Y) with clamped D, H, measures.py:456-504."""
+    Y = np.maximum(D, log_shift) @ np.maximum(H, log_shift)
+    Xc = np.maximum(X, log_shift)
+    red = np.mean if average else np.sum
+    return red(Y) - red(Xc * np.log(Y))
+
+
+def const_KL(X, log_shift=LOG_SHIFT):
+    """base.py:200-201."""
+    return np.sum(X * np.log(np.maximum(X, log_shift))) - np.sum(X)
+
+
+def log_reg(H, mu, epsilon=1, average=False):
+    """sum_ij mu_i log(H_ij + eps), measures.py:524-548."""
+    mu = mu if np.isscalar(mu) else np.asarray(mu)[:, None]
+    red = np.mean if average else np.sum
+    return red(mu * np.log(H + epsilon))
+
+
+def trace_xtLx(L, x, average=False):
+    """sum(x * (L @ x)), measures.py:560-577."""
+    red = np.mean if average else np.sum
+    return red(x * (L @ x))
+
+
+def Frobenius_loss(X, D, H, average=False):
+    """measures.py:350-385."""
+    red = np.mean if average else np.sum
+    return red((D @ H - X) ** 2)
+
+
+def smooth_nmf_loss(X, G, W, H, L, mu=0, epsilon_reg=1, lambda_L=0.0, log_shift=LOG_SHIFT,
+                    average=True, c_kl=None, gamma=SIGMA_L):
+    """SmoothNMF.loss: returns (total, [lkl, reg, lap, gamma]), smooth_nmf.py:457-475."""
+    numel = G.shape[0] * H.shape[1]
+    if c_kl is None:
+        c_kl = const_KL(X, log_shift)
+    lkl = KLdiv_loss(X, G @ W, H, log_shift) + c_kl
+    reg = log_reg(H, mu, epsilon_reg)
+    lap = 0.5 * lambda_L * trace_xtLx(L, H.T)
+    if average:
+        lkl, reg, lap = lkl / numel, reg / numel, lap / numel
+    return lkl + reg + lap, [lkl, reg, lap, gamma]
+
+
+# --------------------------------------------------------------------------------------
+# initialisation and fit loop  (updates.py:160-223, base.py:16-18, :209-420, :519-528)
+# --------------------------------------------------------------------------------------
+def normalization_factor(X, nc):
+    """base.py:16-18."""
+    return nc / (np.mean(X) * X.shape[0])
+
+
+def remove_zeros_lines(X, epsilon):
+    """All-zero rows / columns of X become epsilon, base.py:519-528."""
+    if not np.all(X >= 0):
+        raise ValueError("Negative values in data")
+    out = X.copy()
+    out[:, X.sum(axis=0) == 0] = epsilon
+    out[X.sum(axis=1) == 0, :] = epsilon
+    return out
+
+
+def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_H, simplex_W,
+                          logshift=LOG_SHIFT):
+    """updates.py:160-223 without the physics-model branch (G is None or an ndarray)."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+
+    identity = G is None
+    if identity:
+        G = np.diag(np.ones(X.shape[0]).astype(X.dtype))
+    if W is None:
+        if H is None:
+            D, H = _initialize_nmf(X, n_components=n_components, init=init, random_state=random_state)
+            if simplex_H:
+                H = np.nan_to_num(H, nan=1.0 / H.shape[0])
+                scale = H.sum(axis=0, keepdims=True)
+                H = H / scale
+                D = D * np.mean(scale)
+        else:
+            D = np.abs(np.linalg.lstsq(H.T, X.T, rcond=None)[0].T)
+        if identity:
+            W = D
+        else:
+            W = np.abs(np.linalg.lstsq(G, D, rcond=None)[0])
+            if simplex_W:
+                W = np.nan_to_num(W, nan=1.0 / W.shape[0])
+                W = W / W.sum(axis=0, keepdims=True)
+    elif H is None:
+        H = np.abs(np.linalg.lstsq(G @ W, X, rcond=None)[0])
+        if simplex_H:
+            H = H / H.sum(axis=0, keepdims=True)
+    return G, np.maximum(W, logshift), np.maximum(H, logshift)
+
+
+def rescaled_DH(D, H):
+    """espm/utils.py:79-96."""
+    from scipy.optimize import nnls
+
+    o = np.ones(H.shape[1])
+    s = np.linalg.lstsq(H.T, o, rcond=None)[0]
+    if (s <= 0).any():
+        s = np.maximum(nnls(H.T, o)[0], 1e-10)
+    return D @ np.diag(1 / s), np.diag(s) @ H
+
+
+def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_reg=1,
+        simplex_H=False, simplex_W=True, shape_2d=None, tol=1e-4, max_iter=200, init=None,
+        random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
+        gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
+        record_at=(), time_iterations=False):
+    """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
+    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", no linesearch).
+
+    Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
+    """
+    if simplex_H and simplex_W:  # smooth_nmf.py:218-222
+        simplex_W, simplex_H = True, False
+    X_ = remove_zeros_lines(np.asarray(X), log_shift)
+    norm = None
+    if normalize:
+        norm = normalization_factor(X_, n_components)
+        X_ = norm * X_
+    G_, W_, H_ = initialize_algorithms(X_, G, W, H, n_components, init, random_state, simplex_H, simplex_W)
+    p = X_.shape[1]
+    L_ = laplacian_matrix(*shape_2d) if shape_2d is not None else identity_L(p)
+    gamma_ = SIGMA_L if gamma is None else gamma  # smooth_nmf.py:290-306
+    c_kl = const_KL(X_, log_shift)
+
+    def loss(Wc, Hc):
+        return smooth_nmf_loss(X_, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl, gamma_)
+
+    eval_before = np.inf
+    # the reference evaluates the initial loss before gamma_ is set (it is None then); only the
+    # value matters here
+    eval_init, _ = loss(W_, H_)
+    losses, detailed, rel, snaps = [], [], [], {}
+    n_iter, reason = 0, None
+    t0 = time.perf_counter()
+    while True:
+        old_W, old_H = W_.copy(), H_.copy()
+        H_ = multiplicative_step_h(X_, G_, W_, H_, simplex_H=simplex_H, mu=mu, log_shift=log_shift,
+                                   epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
+                                   lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_)
+        W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
+                                   simplex_W=simplex_W, fixed_W=fixed_W)
+        eval_after, det = loss(W_, H_)
+        n_iter += 1
+        rel_W = np.max(np.abs(W_ - old_W) / (W_ + tol * np.mean(W_)))  # base.py:323-324
+        rel_H = np.max(np.abs(H_ - old_H) / (H_ + tol * np.mean(H_)))
+        losses.append(eval_after)
+        detailed.append(det)
+        rel.append([rel_W, rel_H])
+        if n_iter in record_at:
+            snaps[n_iter] = (W_.copy(), H_.copy())
+        if n_iter >= max_iter:  # base.py:354-378
+            reason = "max_iter"
+            break
+        if not no_stop_criterion:
+            if max(rel_H, rel_W) < tol:
+                reason = "rel"
+                break
+            elif abs((eval_before - eval_after) / eval_init) < tol:
+                reason = "loss"
+                break
+            elif np.isnan(eval_after):
+                reason = "nan"
+                break
+            elif (eval_before - eval_after) < 0:
+                reason = "increase"
+                break
+        eval_before = eval_after
+    elapsed = time.perf_counter() - t0
+    if not simplex_H and not simplex_W:
+        W_, H_ = rescaled_DH(W_, H_)  # base.py:399-400
+    recon, _ = loss(W_, H_)
+    if normalize:
+        W_ = W_ / norm
+    out = dict(W=W_, H=H_, G=G_, GW=G_ @ W_, losses=np.array(losses), detailed_losses=np.array(detailed, dtype=float),
+               rel=np.array(rel), n_iter=n_iter, exit=reason, reconstruction_err=recon, snapshots=snaps,
+               eval_init=eval_init, const_KL=c_kl, norm_factor=norm)
+    if time_iterations:
+        out["seconds"] = elapsed
+    return out

@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the UNMODIFIED reference.
+
+Runs only in the build container, where the reference checkout is mounted read-only at
+/root/reference.  The reference imports ``exspy`` (absent here) at module import time
+(espm/conf.py:2-4, espm/utils.py:8) without ever touching it on the multiplicative-update
+path, so an empty stand-in package is put on sys.path from a temp dir (outside the repo).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Only DATA is stored: inputs and the reference's outputs.  Each archive also records the
+library versions used.  Fixture families follow SURVEY.md section 8(c): F1..F8.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("ESPM_REFERENCE", "/root/reference")
+
+
+def _install_exspy_stub():
+    root = tempfile.mkdtemp(prefix="exspy_stub_")
+    for sub in ("exspy", "exspy/_misc", "exspy/_misc/eds"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+        open(os.path.join(root, sub, "__init__.py"), "w").close()
+    with open(os.path.join(root, "exspy/_misc/eds/ffast_mac.py"), "w") as f:
+        f.write("ffast_mac = {}\n")
+    with open(os.path.join(root, "exspy/material.py"), "w") as f:
+        f.write("def atomic_to_weight(*a, **k):\n    raise NotImplementedError\n"
+                "def density_of_mixture(*a, **k):\n    raise NotImplementedError\n")
+    sys.path.insert(0, root)
+
+
+_install_exspy_stub()
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import sklearn  # noqa: E402
+from espm.conf import dicotomy_tol, log_shift  # noqa: E402
+from espm.estimators import SmoothNMF  # noqa: E402
+from espm.estimators.base import normalization_factor  # noqa: E402
+from espm.estimators.dicotomy import dichotomy_simplex  # noqa: E402
+from espm.estimators.updates import (initialize_algorithms, multiplicative_step_h,  # noqa: E402
+                                     multiplicative_step_w)
+from espm.measures import Frobenius_loss, KLdiv_loss, log_reg, trace_xtLx  # noqa: E402
+from espm.utils import create_laplacian_matrix, rescaled_DH  # noqa: E402
+
+VERSIONS = json.dumps({"numpy": np.__version__, "scipy": scipy.__version__, "sklearn": sklearn.__version__,
+                       "reference": "adriente/espm v1.1.3 (2025-02-05)"})
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, versions=np.array(VERSIONS), **arrays)
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def synth(rng, n, nx, ny, k, m=None, counts=40.0, poisson=True):
+    """Small Poisson spectrum image: X ~ Poisson(G W H) with H on the simplex."""
+    p = nx * ny
+    H = rng.random((k, p)) ** 2 + 0.05
+    H /= H.sum(axis=0, keepdims=True)
+    if m is None:
+        G = None
+        W = rng.random((n, k)) ** 3 * counts / n * 4 + 1e-3
+        D = W
+    else:
+        G = rng.random((n, m)) * (rng.random((n, m)) < 0.4) + 0.01
+        W = rng.random((m, k)) * counts / n
+        D = G @ W
+    Y = D @ H
+    X = rng.poisson(Y).astype(np.float64) if poisson else Y
+    return X, G, W, H
+
+
+# ------------------------------------------------------------------ F1: dichotomy_simplex
+def f1():
+    out = {}
+    # known-answer vectors of espm/tests/test_updates.py:131-141 and :146-151
+    kat = [
+        (np.array([[1, 1, 0, 0, 0, 2]], float).T, np.array([[1, 1, 3, 5, 4, 2]], float).T, 0.0, 1e-6),
+        (np.array([[1, 1, 0, 0, 0, 2]], float).T, np.array([[1, 1, 0, 5, 0, 2]], float).T, 0.0, 1e-6),
+        (np.array([[3, 0.5]], float).T, np.array([[1, 1]], float).T, 0.25, 1e-8),
+    ]
+    for i, (num, den, eps, tol) in enumerate(kat):
+        out[f"kat{i}_num"], out[f"kat{i}_den"] = num, den
+        out[f"kat{i}_eps"], out[f"kat{i}_tol"] = np.array(eps), np.array(tol)
+        out[f"kat{i}_nu"] = dichotomy_simplex(num.copy(), den.copy(), eps, tol=tol)
+    rng = np.random.default_rng(101)
+    span = np.logspace(-6, 6, 17)
+    k, p = 5, 64
+    case = 0
+    for eps in (0.0, 0.02):
+        for den_cols in (p, 1):
+            for zeros in (False, True):
+                num = rng.choice(span, (k, p)) * rng.random((k, p))
+                if zeros:
+                    num[np.tile(np.arange(k), p // k + 1)[:p], np.arange(p)] = 0
+                den = rng.choice(span, (k, den_cols)) * rng.random((k, den_cols))
+                for tol, tag in ((dicotomy_tol, "t5"), (0.0, "t0")):
+                    nu = dichotomy_simplex(num.copy(), den.copy(), eps, tol=tol, maxit=100)
+                    out[f"rnd{case}_{tag}_nu"] = nu
+                out[f"rnd{case}_num"], out[f"rnd{case}_den"] = num, den
+                out[f"rnd{case}_eps"] = np.array(eps)
+                case += 1
+    out["n_rnd"] = np.array(case)
+    out["n_kat"] = np.array(len(kat))
+    save("f1_dichotomy", **out)
+
+
+# ------------------------------------------------------------------ F2: multiplicative_step_h
+def f2():
+    rng = np.random.default_rng(202)
+    n, nx, ny, k, m = 40, 6, 9, 4, 7
+    out, case = {}, 0
+    L = create_laplacian_matrix(nx, ny)
+    mu_vec = np.array([0.0, 0.7, 1.3, 0.2])
+    for with_G in (False, True):
+        X, G, W, H = synth(rng, n, nx, ny, k, m if with_G else None)
+        Gd = np.diag(np.ones(n)) if G is None else G
+        H0 = rng.random((k, nx * ny)) + 0.01
+        H0 /= H0.sum(axis=0, keepdims=True)
+        W0 = W * (0.5 + rng.random(W.shape))
+        fixed = -np.ones_like(H0)
+        fixed[0, :5] = 0.3
+        fixed[1, :5] = 0.0
+        out[f"in{int(with_G)}_X"], out[f"in{int(with_G)}_G"] = X, Gd
+        out[f"in{int(with_G)}_W"], out[f"in{int(with_G)}_H"] = W0, H0
+        out[f"in{int(with_G)}_fixed"] = fixed
+        for simplex in (False, True):
+            for lam in (0.0, 2.0):
+                for mu_on in (False, True):
+                    for fix_on in (False, True):
+                        mu = mu_vec if mu_on else 0
+                        Hn = multiplicative_step_h(X, Gd, W0, H0.copy(), simplex_H=simplex, mu=mu,
+                                                   log_shift=log_shift, epsilon_reg=0.8, safe=True,
+                                                   dicotomy_tol=dicotomy_tol, lambda_L=lam, L=L,
+                                                   fixed_H=fixed if fix_on else None)
+                        out[f"c{case}_H"] = Hn
+                        out[f"c{case}_cfg"] = np.array([int(with_G), int(simplex), lam, int(mu_on), int(fix_on)])
+                        case += 1
+        # l2 branch, reachable only by direct call (updates.py:109-118)
+        out[f"l2_{int(with_G)}_H"] = multiplicative_step_h(X, Gd, W0, H0.copy(), simplex_H=True, l2=True)
+        # scalar mu and a non-default sigmaL
+        out[f"smu_{int(with_G)}_H"] = multiplicative_step_h(X, Gd, W0, H0.copy(), simplex_H=True, mu=0.4,
+                                                            lambda_L=0.5, L=L, sigmaL=11.0)
+        # identity "Laplacian" used when shape_2d is None (base.py:289-291)
+        from scipy.sparse import lil_matrix
+        Lid = lil_matrix((nx * ny, nx * ny), dtype=np.float32)
+        Lid.setdiag([1] * (nx * ny))
+        out[f"lid_{int(with_G)}_H"] = multiplicative_step_h(X, Gd, W0, H0.copy(), simplex_H=True,
+                                                            lambda_L=1.5, L=Lid)
+    out["n_cases"] = np.array(case)
+    out["mu_vec"], out["shape_2d"], out["epsilon_reg"] = mu_vec, np.array([nx, ny]), np.array(0.8)
+    save("f2_step_h", **out)
+
+
+# ------------------------------------------------------------------ F3: multiplicative_step_w
+def f3():
+    rng = np.random.default_rng(303)
+    n, nx, ny, k, m = 40, 6, 9, 4, 7
+    out, case = {}, 0
+    for with_G in (False, True):
+        X, G, W, H = synth(rng, n, nx, ny, k, m if with_G else None)
+        Gd = np.diag(np.ones(n)) if G is None else G
+        W0 = W * (0.5 + rng.random(W.shape))
+        fixed = -np.ones_like(W0)
+        fixed[0, 0] = 0.0
+        fixed[2, 1] = 0.25
+        t = int(with_G)
+        out[f"in{t}_X"], out[f"in{t}_G"], out[f"in{t}_W"], out[f"in{t}_H"] = X, Gd, W0, H
+        out[f"in{t}_fixed"] = fixed
+        for simplex in (False, True):
+            for fix_on in (False, True):
+                Wn = multiplicative_step_w(X, Gd, W0.copy(), H, simplex_W=simplex, log_shift=log_shift,
+                                           safe=True, fixed_W=fixed if fix_on else None)
+                out[f"c{case}_W"] = Wn
+                out[f"c{case}_cfg"] = np.array([t, int(simplex), int(fix_on)])
+                case += 1
+        out[f"l2_{t}_W"] = multiplicative_step_w(X, Gd, W0.copy(), H, simplex_W=False, l2=True)
+    out["n_cases"] = np.array(case)
+    save("f3_step_w", **out)
+
+
+# ------------------------------------------------------------------ F4: Laplacian
+def f4():
+    rng = np.random.default_rng(404)
+    out = {}
+    shapes = [(2, 2), (3, 7), (8, 4), (16, 16)]
+    for i, (nx, ny) in enumerate(shapes):
+        L = create_laplacian_matrix(nx, ny)
+        H = rng.random((3, nx * ny))
+        out[f"s{i}_H"] = H
+        out[f"s{i}_HL"] = H @ L
+        out[f"s{i}_trace"] = np.array(trace_xtLx(L, H.T))
+        if nx * ny <= 64:
+            out[f"s{i}_dense"] = np.asarray(L.todense())
+    out["shapes"] = np.array(shapes)
+    save("f4_laplacian", **out)
+
+
+# ------------------------------------------------------------------ F5: losses
+def f5():
+    rng = np.random.default_rng(505)
+    n, nx, ny, k = 30, 5, 8, 3
+    X, G, W, H = synth(rng, n, nx, ny, k)
+    X[3, :] = 0  # an all-zero channel: exercised by remove_zeros_lines
+    mu = np.array([0.0, 0.5, 2.0])
+    out = dict(X=X, W=W, H=H, mu=mu)
+    out["KLdiv_loss"] = np.array(KLdiv_loss(X, W, H, log_shift))
+    out["KLdiv_loss_avg"] = np.array(KLdiv_loss(X, W, H, log_shift, average=True))
+    out["Frobenius_loss"] = np.array(Frobenius_loss(X, W, H))
+    out["log_reg"] = np.array(log_reg(H, mu, 0.8))
+    out["log_reg_scalar"] = np.array(log_reg(H, 0.3, 1))
+    for avg in (True, False):
+        est = SmoothNMF(n_components=k, lambda_L=1.5, mu=mu, epsilon_reg=0.8, shape_2d=(nx, ny),
+                        simplex_H=True, simplex_W=False, max_iter=1, verbose=0)
+        quiet(est.fit_transform, X, W=W.copy(), H=H.copy())
+        # loss of an arbitrary state through the fitted estimator (uses est.X_, est.G_, est.L_)
+        val = est.loss(W, H, average=avg)
+        out[f"loss_avg{int(avg)}"] = np.array(val)
+        out[f"detailed_avg{int(avg)}"] = np.array(est.detailed_loss_, dtype=float)
+        out["X_"] = est.X_
+        out["const_KL"] = np.array(est.const_KL_)
+    out["shape_2d"] = np.array([nx, ny])
+    save("f5_losses", **out)
+
+
+# ------------------------------------------------------------------ F6: trajectories
+TRAJ = {
+    # scaled-down analogues of BASELINE.json configs 1, 2, 3, 5
+    "c1": dict(n=24, nx=6, ny=5, k=3, m=None, kw=dict(simplex_H=False, simplex_W=False, lambda_L=0.0, mu=0)),
+    "c2": dict(n=48, nx=8, ny=8, k=3, m=None, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.0, mu=0)),
+    "c3": dict(n=64, nx=12, ny=10, k=5, m=None, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0)),
+    "c5": dict(n=60, nx=10, ny=12, k=4, m=9, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0.05)),
+    "cw": dict(n=32, nx=6, ny=6, k=3, m=None, kw=dict(simplex_H=False, simplex_W=True, lambda_L=0.5, mu=0)),
+}
+
+
+def f6():
+    rng = np.random.default_rng(606)
+    out = {}
+    for name, c in TRAJ.items():
+        X, G, W, H = synth(rng, c["n"], c["nx"], c["ny"], c["k"], c["m"])
+        p = c["nx"] * c["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c["nx"], c["ny"]])
+        for mode, extra in (("free", dict(tol=0, no_stop_criterion=True, max_iter=50)),
+                            ("stop", dict(tol=1e-3, max_iter=200))):
+            snaps = {}
+
+            class Rec(SmoothNMF):
+                def _iteration(self, W, H):
+                    W, H = super()._iteration(W, H)
+                    if self.n_iter_ + 1 in (1, 2, 5, 50):
+                        snaps[self.n_iter_ + 1] = (W.copy(), H.copy())
+                    return W, H
+
+            est = Rec(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, **c["kw"], **extra)
+            GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+            pre = f"{name}_{mode}"
+            out[f"{pre}_GW"], out[f"{pre}_W"], out[f"{pre}_H"] = GW, est.W_, est.H_
+            out[f"{pre}_losses"] = np.array(est.losses_)
+            out[f"{pre}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+            out[f"{pre}_rel"] = np.array(est.rel_)
+            out[f"{pre}_n_iter"] = np.array(est.n_iter_)
+            out[f"{pre}_recon"] = np.array(est.reconstruction_err_)
+            if mode == "free":
+                for t, (Wt, Ht) in snaps.items():
+                    out[f"{pre}_W{t}"], out[f"{pre}_H{t}"] = Wt, Ht
+    out["names"] = np.array(list(TRAJ))
+    out["configs"] = np.array(json.dumps({k: {**v, "kw": v["kw"]} for k, v in TRAJ.items()}))
+    save("f6_trajectories", **out)
+
+
+# ------------------------------------------------------------------ F7: initialize_algorithms
+def f7():
+    rng = np.random.default_rng(707)
+    X, G, W, H = synth(rng, 36, 6, 7, 3, 8)
+    out = dict(X=X, G=G)
+    for init in (None, "random", "nndsvd"):
+        for use_G in (False, True):
+            for simplex_H in (False, True):
+                G_, W_, H_ = initialize_algorithms(X, G if use_G else None, None, None, n_components=3,
+                                                   init=init, random_state=0, simplex_H=simplex_H,
+                                                   simplex_W=not simplex_H)
+                tag = f"{init}_{int(use_G)}_{int(simplex_H)}"
+                out[f"{tag}_W"], out[f"{tag}_H"] = W_, H_
+    # warm starts: only W or only H given (updates.py:188-189, :213-218)
+    G_, W_, H_ = initialize_algorithms(X, G, W, None, 3, None, 0, True, False)
+    out["Wgiven_W0"], out["Wgiven_H"] = W, H_
+    G_, W_, H_ = initialize_algorithms(X, G, None, H, 3, None, 0, True, False)
+    out["Hgiven_H0"], out["Hgiven_W"] = H, W_
+    D, Hr = rescaled_DH(G @ W * 3.0, H / 3.0)
+    out["rescaled_D"], out["rescaled_H"] = D, Hr
+    save("f7_init", **out)
+
+
+# ------------------------------------------------------------------ F8: API behaviour
+def f8():
+    out = {}
+    est = quiet(SmoothNMF)
+    params = est.get_params()
+    out["default_params"] = np.array(json.dumps({k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(v))
+                                                 for k, v in params.items()}, sort_keys=True))
+    e2 = quiet(SmoothNMF, simplex_H=True, simplex_W=True, l2=True, lambda_L=-1, algo="nope", epsilon_reg=0)
+    out["coerced"] = np.array(json.dumps(dict(simplex_H=e2.simplex_H, simplex_W=e2.simplex_W, l2=e2.l2,
+                                              lambda_L=e2.lambda_L, algo=e2.algo, epsilon_reg=e2.epsilon_reg)))
+    e3 = quiet(SmoothNMF, linesearch=True, lambda_L=0.0)
+    out["coerced_linesearch"] = np.array(json.dumps(dict(lambda_L=e3.lambda_L, linesearch=e3.linesearch)))
+    rng = np.random.default_rng(808)
+    X, G, W, H = synth(rng, 20, 4, 5, 2)
+    est = SmoothNMF(n_components=2, max_iter=3, simplex_H=True, simplex_W=False, verbose=0, hspy_comp=True)
+    ret = quiet(est.fit_transform, X.T.copy(), W=W.copy(), H=H.copy())
+    out["hspy_X"], out["hspy_W0"], out["hspy_H0"] = X, W, H
+    out["hspy_ret"], out["hspy_components"] = ret, est.components_
+    out["loss_names"] = np.array(json.dumps(list(est.get_losses().dtype.names)))
+    out["get_losses"] = np.array(est.get_losses().tolist())
+    out["inverse_transform"] = est.inverse_transform(est.W_)
+    # normalize=True scale invariance inputs/outputs (espm/tests/test_estimators.py:207-247)
+    rs = np.random.RandomState(0)
+    Xn = rs.rand(10, 32) * 100
+    fac = rs.rand() * 50 + 0.1
+    est = SmoothNMF(n_components=5, lambda_L=1.0, max_iter=10, init="nndsvd", normalize=True, shape_2d=[8, 4],
+                    random_state=0, simplex_W=False, simplex_H=True, verbose=0)
+    GP = quiet(est.fit_transform, Xn)
+    out["norm_X"], out["norm_fac"], out["norm_GP"], out["norm_H"] = Xn, np.array(fac), GP, est.H_
+    out["norm_W"], out["norm_factor"] = est.W_, np.array(normalization_factor(est.remove_zeros_lines(Xn, log_shift), 5))
+    # no simplex at all -> rescaled_DH post-processing (base.py:399-400)
+    est = SmoothNMF(n_components=2, max_iter=4, simplex_H=False, simplex_W=False, verbose=0)
+    GW = quiet(est.fit_transform, X, W=W.copy(), H=H.copy())
+    out["nosimplex_GW"], out["nosimplex_W"], out["nosimplex_H"] = GW, est.W_, est.H_
+    out["nosimplex_recon"] = np.array(est.reconstruction_err_)
+    save("f8_api", **out)
+
+
+if __name__ == "__main__":
+    for fn in (f1, f2, f3, f4, f5, f6, f7, f8):
+        fn()

@@ -1,0 +1,179 @@
+"""Pins the numpy oracle (oracle/mu_oracle.py) to golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import mu_oracle as oc
+
+RT = dict(rtol=1e-12, atol=1e-14)
+
+
+def test_f1_dichotomy_known_answers(golden):
+    g = golden("f1_dichotomy")
+    for i in range(int(g["n_kat"])):
+        nu = oc.dichotomy_simplex(g[f"kat{i}_num"], g[f"kat{i}_den"], float(g[f"kat{i}_eps"]), tol=float(g[f"kat{i}_tol"]))
+        np.testing.assert_allclose(nu, g[f"kat{i}_nu"], **RT)
+    # espm/tests/test_updates.py:146-151: the answer is nu = 3
+    assert abs(g["kat2_nu"][0] - 3) < 2e-8
+
+
+def test_f1_dichotomy_random_scales(golden):
+    g = golden("f1_dichotomy")
+    for c in range(int(g["n_rnd"])):
+        num, den, eps = g[f"rnd{c}_num"], g[f"rnd{c}_den"], float(g[f"rnd{c}_eps"])
+        for tol, tag in ((oc.DICOTOMY_TOL, "t5"), (0.0, "t0")):
+            nu = oc.dichotomy_simplex(num, den, eps, tol=tol, maxit=100)
+            np.testing.assert_allclose(nu, g[f"rnd{c}_{tag}_nu"], rtol=1e-12, atol=0)
+
+
+def test_dichotomy_errors():
+    rng = np.random.default_rng(0)
+    with pytest.raises(ValueError):  # k * log_shift >= 1, espm/tests/test_updates.py:160-167
+        oc.dichotomy_simplex(rng.random((3, 10)), rng.random((3, 10)), 0.5)
+    with pytest.raises(AssertionError):
+        oc.dichotomy_simplex(np.zeros((3, 4)), np.ones((3, 4)), 0.0)
+
+
+def _step_h_inputs(g, t):
+    return g[f"in{t}_X"], g[f"in{t}_G"], g[f"in{t}_W"], g[f"in{t}_H"], g[f"in{t}_fixed"]
+
+
+def test_f2_step_h_grid(golden):
+    g = golden("f2_step_h")
+    nx, ny = g["shape_2d"]
+    L = oc.laplacian_matrix(nx, ny)
+    for c in range(int(g["n_cases"])):
+        t, simplex, lam, mu_on, fix_on = g[f"c{c}_cfg"]
+        X, G, W, H, fixed = _step_h_inputs(g, int(t))
+        Hn = oc.multiplicative_step_h(X, G, W, H.copy(), simplex_H=bool(simplex), mu=g["mu_vec"] if mu_on else 0,
+                                      epsilon_reg=float(g["epsilon_reg"]), lambda_L=float(lam), L=L,
+                                      fixed_H=fixed if fix_on else None)
+        np.testing.assert_allclose(Hn, g[f"c{c}_H"], rtol=1e-11, atol=1e-15, err_msg=f"case {c}")
+
+
+def test_f2_step_h_special(golden):
+    g = golden("f2_step_h")
+    nx, ny = g["shape_2d"]
+    L = oc.laplacian_matrix(nx, ny)
+    for t in (0, 1):
+        X, G, W, H, _ = _step_h_inputs(g, t)
+        np.testing.assert_allclose(oc.multiplicative_step_h(X, G, W, H.copy(), simplex_H=True, l2=True),
+                                   g[f"l2_{t}_H"], rtol=1e-11)
+        np.testing.assert_allclose(oc.multiplicative_step_h(X, G, W, H.copy(), simplex_H=True, mu=0.4, lambda_L=0.5,
+                                                            L=L, sigmaL=11.0), g[f"smu_{t}_H"], rtol=1e-11)
+        np.testing.assert_allclose(oc.multiplicative_step_h(X, G, W, H.copy(), simplex_H=True, lambda_L=1.5,
+                                                            L=oc.identity_L(nx * ny)), g[f"lid_{t}_H"], rtol=1e-11)
+    with pytest.raises(ValueError):
+        oc.multiplicative_step_h(X, G, W, H, lambda_L=1.0, L=None)
+
+
+def test_f3_step_w(golden):
+    g = golden("f3_step_w")
+    for c in range(int(g["n_cases"])):
+        t, simplex, fix_on = g[f"c{c}_cfg"]
+        X, G, W, H, fixed = (g[f"in{t}_{s}"] for s in ("X", "G", "W", "H", "fixed"))
+        Wn = oc.multiplicative_step_w(X, G, W.copy(), H, simplex_W=bool(simplex), fixed_W=fixed if fix_on else None)
+        np.testing.assert_allclose(Wn, g[f"c{c}_W"], rtol=1e-11, atol=1e-15, err_msg=f"case {c}")
+    for t in (0, 1):
+        X, G, W, H = (g[f"in{t}_{s}"] for s in ("X", "G", "W", "H"))
+        np.testing.assert_allclose(oc.multiplicative_step_w(X, G, W.copy(), H, l2=True), g[f"l2_{t}_W"], rtol=1e-11)
+
+
+def test_f4_laplacian(golden):
+    g = golden("f4_laplacian")
+    for i, (nx, ny) in enumerate(g["shapes"]):
+        L = oc.laplacian_matrix(nx, ny)
+        H = g[f"s{i}_H"]
+        np.testing.assert_allclose(H @ L, g[f"s{i}_HL"], **RT)
+        np.testing.assert_allclose(oc.laplacian_apply(H, nx, ny), g[f"s{i}_HL"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(oc.trace_xtLx(L, H.T), g[f"s{i}_trace"], rtol=1e-12)
+        if f"s{i}_dense" in g:
+            np.testing.assert_array_equal(np.asarray(L.todense()), g[f"s{i}_dense"])
+    # espm/tests/test_measures.py:212-221: 0 for a constant map, 4 for a unit bump
+    L = oc.laplacian_matrix(4, 6)
+    x = np.ones((4, 6))
+    assert oc.trace_xtLx(L, x.ravel()) == 0
+    x[2, 3] = 2
+    np.testing.assert_allclose(oc.trace_xtLx(L, x.ravel()), 4)
+
+
+def test_f5_losses(golden):
+    g = golden("f5_losses")
+    X, W, H, mu = g["X"], g["W"], g["H"], g["mu"]
+    np.testing.assert_allclose(oc.KLdiv_loss(X, W, H), g["KLdiv_loss"], rtol=1e-13)
+    np.testing.assert_allclose(oc.KLdiv_loss(X, W, H, average=True), g["KLdiv_loss_avg"], rtol=1e-13)
+    np.testing.assert_allclose(oc.Frobenius_loss(X, W, H), g["Frobenius_loss"], rtol=1e-13)
+    np.testing.assert_allclose(oc.log_reg(H, mu, 0.8), g["log_reg"], rtol=1e-13)
+    np.testing.assert_allclose(oc.log_reg(H, 0.3, 1), g["log_reg_scalar"], rtol=1e-13)
+    X_ = oc.remove_zeros_lines(X, oc.LOG_SHIFT)
+    np.testing.assert_array_equal(X_, g["X_"])
+    np.testing.assert_allclose(oc.const_KL(X_), g["const_KL"], rtol=1e-13)
+    nx, ny = g["shape_2d"]
+    L = oc.laplacian_matrix(nx, ny)
+    G = np.eye(X.shape[0])
+    for avg in (True, False):
+        tot, det = oc.smooth_nmf_loss(X_, G, W, H, L, mu, 0.8, 1.5, average=avg)
+        np.testing.assert_allclose(tot, g[f"loss_avg{int(avg)}"], rtol=1e-12)
+        np.testing.assert_allclose(det, g[f"detailed_avg{int(avg)}"], rtol=1e-11)
+
+
+def test_f6_trajectories(golden):
+    g = golden("f6_trajectories")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        G = g.get(f"{name}_G")
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        for mode, extra in (("free", dict(tol=0, no_stop_criterion=True, max_iter=50)),
+                            ("stop", dict(tol=1e-3, max_iter=200))):
+            r = oc.fit(g[f"{name}_X"], c["k"], G=G, W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy(),
+                       shape_2d=shape, record_at=(1, 2, 5, 50), **c["kw"], **extra)
+            pre = f"{name}_{mode}"
+            assert r["n_iter"] == int(g[f"{pre}_n_iter"]), pre
+            np.testing.assert_allclose(r["losses"], g[f"{pre}_losses"], rtol=1e-9, err_msg=pre)
+            np.testing.assert_allclose(r["detailed_losses"], g[f"{pre}_detailed"], rtol=1e-9, atol=1e-18, err_msg=pre)
+            np.testing.assert_allclose(r["rel"], g[f"{pre}_rel"], rtol=1e-7, atol=1e-12, err_msg=pre)
+            np.testing.assert_allclose(r["W"], g[f"{pre}_W"], rtol=1e-8, atol=1e-14, err_msg=pre)
+            np.testing.assert_allclose(r["H"], g[f"{pre}_H"], rtol=1e-8, atol=1e-14, err_msg=pre)
+            np.testing.assert_allclose(r["GW"], g[f"{pre}_GW"], rtol=1e-8, atol=1e-14, err_msg=pre)
+            np.testing.assert_allclose(r["reconstruction_err"], g[f"{pre}_recon"], rtol=1e-9)
+            if mode == "free":
+                for t, (Wt, Ht) in r["snapshots"].items():
+                    np.testing.assert_allclose(Wt, g[f"{pre}_W{t}"], rtol=1e-8, atol=1e-14)
+                    np.testing.assert_allclose(Ht, g[f"{pre}_H{t}"], rtol=1e-8, atol=1e-14)
+
+
+def test_f7_init(golden):
+    g = golden("f7_init")
+    X, G = g["X"], g["G"]
+    for init in (None, "random", "nndsvd"):
+        for use_G in (False, True):
+            for simplex_H in (False, True):
+                _, W, H = oc.initialize_algorithms(X, G if use_G else None, None, None, 3, init, 0, simplex_H,
+                                                   not simplex_H)
+                tag = f"{init}_{int(use_G)}_{int(simplex_H)}"
+                np.testing.assert_allclose(W, g[f"{tag}_W"], rtol=1e-9, atol=1e-14, err_msg=tag)
+                np.testing.assert_allclose(H, g[f"{tag}_H"], rtol=1e-9, atol=1e-14, err_msg=tag)
+    _, _, H = oc.initialize_algorithms(X, G, g["Wgiven_W0"], None, 3, None, 0, True, False)
+    np.testing.assert_allclose(H, g["Wgiven_H"], rtol=1e-9, atol=1e-14)
+    _, W, _ = oc.initialize_algorithms(X, G, None, g["Hgiven_H0"], 3, None, 0, True, False)
+    np.testing.assert_allclose(W, g["Hgiven_W"], rtol=1e-9, atol=1e-14)
+
+
+def test_f8_fit_outputs(golden):
+    g = golden("f8_api")
+    X, W0, H0 = g["hspy_X"], g["hspy_W0"], g["hspy_H0"]
+    r = oc.fit(X, 2, W=W0.copy(), H=H0.copy(), simplex_H=True, simplex_W=False, max_iter=3)
+    np.testing.assert_allclose(r["H"].T, g["hspy_ret"], rtol=1e-9)
+    np.testing.assert_allclose(r["GW"].T, g["hspy_components"], rtol=1e-9)
+    r = oc.fit(g["norm_X"], 5, lambda_L=1.0, max_iter=10, init="nndsvd", normalize=True, shape_2d=(8, 4),
+               random_state=0, simplex_W=False, simplex_H=True)
+    np.testing.assert_allclose(r["norm_factor"], g["norm_factor"], rtol=1e-12)
+    np.testing.assert_allclose(r["GW"], g["norm_GP"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(r["H"], g["norm_H"], rtol=1e-7, atol=1e-12)
+    r = oc.fit(X, 2, W=W0.copy(), H=H0.copy(), simplex_H=False, simplex_W=False, max_iter=4)
+    np.testing.assert_allclose(r["GW"], g["nosimplex_GW"], rtol=1e-8)
+    np.testing.assert_allclose(r["H"], g["nosimplex_H"], rtol=1e-8)
+    np.testing.assert_allclose(r["reconstruction_err"], g["nosimplex_recon"], rtol=1e-9)
