@@ -1,0 +1,307 @@
+// extern "C" surface of libespm_mu.so (declared in include/espm_mu.h): argument checking, kernel
+// selection and launch sequencing.  No allocation, no host synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mu_common.hpp"
+
+namespace espm {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return ESPM_OK;
+  return set_error(ESPM_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+static int check_state(const espm_mu_state* st) {
+  ESPM_REQUIRE(st != nullptr, "state is NULL");
+  ESPM_REQUIRE(st->n >= 1 && st->p >= 1, "n=%d, p=%d must be >= 1", st->n, st->p);
+  if (st->k < 1 || st->k > ESPM_MAX_K)
+    return set_error(ESPM_EUNSUPPORTED, "k=%d: this build supports 1..%d components", st->k, ESPM_MAX_K);
+  ESPM_REQUIRE(st->n_pad == roundup(st->n, ESPM_NPAD) && st->p_pad == roundup(st->p, ESPM_PPAD),
+               "n_pad/p_pad (%d, %d) do not match n, p (%d, %d); call espm_mu_query", st->n_pad, st->p_pad, st->n,
+               st->p);
+  ESPM_REQUIRE(st->x_dtype == ESPM_X_F32 || st->x_dtype == ESPM_X_BF16, "bad x_dtype %d", st->x_dtype);
+  ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
+               "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
+  ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
+  ESPM_REQUIRE(st->m >= 0, "m must be >= 0");
+  ESPM_REQUIRE(st->m == 0 || (st->g && st->colsum_g), "m=%d needs g and colsum_g", st->m);
+  if (st->log_shift > 0.f && st->simplex_h && (double)st->k * (double)st->log_shift >= 1.0)
+    return set_error(ESPM_ENOSOLUTION, "No solution exists! (k * log_shift >= 1)");
+  return ESPM_OK;
+}
+
+static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / st->tile_px; }
+
+}  // namespace espm
+
+using namespace espm;
+
+extern "C" {
+
+const char* espm_mu_version(void) { return "espm_mu 0.1 (gfx950)"; }
+const char* espm_mu_last_error(void) { return g_err; }
+
+int espm_mu_query(espm_mu_state* st) {
+  ESPM_REQUIRE(st != nullptr, "state is NULL");
+  ESPM_REQUIRE(st->n >= 1 && st->p >= 1, "n=%d, p=%d must be >= 1", st->n, st->p);
+  st->n_pad = roundup(st->n, ESPM_NPAD);
+  st->p_pad = roundup(st->p, ESPM_PPAD);
+  int cus = 256;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  // H-step: the large tile (4 waves, 16-byte loads) needs >= 2 workgroups per CU to fill the
+  // chip; otherwise the 128-pixel tile with 16 waves splitting the channel range.
+  const int big = st->x_dtype == ESPM_X_BF16 ? 512 : 256;
+  st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
+  // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
+  const int ychunks = st->x_dtype == ESPM_X_BF16 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
+  int target = (2 * cus + ychunks - 1) / ychunks;
+  int by_px = (st->p + 15) / 16;
+  int nb = target < by_px ? target : by_px;
+  if (nb < 1) nb = 1;
+  const int ppb = (st->p + nb - 1) / nb;
+  st->nblk_w = (st->p + ppb - 1) / ppb;
+  return ESPM_OK;
+}
+
+int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
+                   int x_dtype, int n_pad, int p_pad, espm_stream_t stream) {
+  ESPM_REQUIRE(src && x_cm && x_pm, "pack_x: NULL pointer");
+  ESPM_REQUIRE(n >= 1 && p >= 1 && n_pad == roundup(n, ESPM_NPAD) && p_pad == roundup(p, ESPM_PPAD),
+               "pack_x: bad shape n=%d p=%d n_pad=%d p_pad=%d", n, p, n_pad, p_pad);
+  ESPM_REQUIRE(src_dtype == ESPM_SRC_F32 || src_dtype == ESPM_SRC_F64, "pack_x: bad src_dtype %d", src_dtype);
+  ESPM_REQUIRE(src_layout == ESPM_LAYOUT_CM || src_layout == ESPM_LAYOUT_PM, "pack_x: bad layout %d", src_layout);
+  ESPM_REQUIRE(ld >= (src_layout == ESPM_LAYOUT_CM ? p : n), "pack_x: leading dimension too small");
+  return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad,
+                       static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(which == 0 || which == 1, "which must be 0/1");
+  return launch_hstat(st->h[which], st->k, st->p, st->p_pad, st->hstat[which], static_cast<hipStream_t>(stream));
+}
+
+static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
+  WFinishArgs a;
+  a.g = st->m > 0 ? st->g : nullptr;
+  a.colsum_g = st->colsum_g;
+  a.w_old = st->w[src];
+  a.w_new = update_w ? st->w[1 - src] : st->w[src];
+  a.a = st->a;
+  a.hstat = st->hstat[hsrc];
+  a.fixed_w = st->fixed_w;
+  a.simplex_rows = st->simplex_rows;
+  a.scratch = st->w_scratch;
+  a.gw_s = st->gw_s;
+  a.colsum_gw = st->colsum_gw;
+  a.hist_slot = (slot >= 0 && st->hist) ? st->hist + (size_t)slot * ESPM_HI_STRIDE : nullptr;
+  a.n = st->n;
+  a.m = st->m;
+  a.k = st->k;
+  a.n_pad = st->n_pad;
+  a.simplex_w = st->simplex_w;
+  a.update_w = update_w;
+  a.log_shift = st->log_shift;
+  a.tol = st->dicotomy_tol;
+  a.rel_tol = st->rel_tol;
+  a.xscale = st->xscale;
+  a.gw_floor = st->gw_floor;
+  return a;
+}
+
+int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(which == 0 || which == 1, "which must be 0/1");
+  return launch_w_finish(finish_args(st, which, 0, -1, 0), static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  HStepArgs a;
+  a.x_cm = st->x_cm;
+  a.gw_s = st->gw_s;
+  a.colsum_gw = st->colsum_gw;
+  a.h_in = st->h[src];
+  a.h_out = st->h[1 - src];
+  a.h_t = st->h_t;
+  a.mu = st->mu;
+  a.fixed_h = st->fixed_h;
+  a.halo_top = st->grid_mode ? st->halo_top : nullptr;
+  a.halo_bot = st->grid_mode ? st->halo_bot : nullptr;
+  a.hstat_in = st->hstat[src];
+  a.hpart = st->hpart;
+  a.n = st->n;
+  a.k = st->k;
+  a.p = st->p;
+  a.nx = st->nx;
+  a.ny = st->ny;
+  a.p_pad = st->p_pad;
+  a.simplex_h = st->simplex_h;
+  a.grid_mode = st->grid_mode;
+  a.compute_loss = st->compute_loss;
+  a.write_h = write_h;
+  a.lambda_l = st->lambda_l;
+  a.sigma_l = st->sigma_l;
+  a.eps_reg = st->eps_reg;
+  a.log_shift = st->log_shift;
+  a.tol = st->dicotomy_tol;
+  a.xscale = st->xscale;
+  return dispatch_h_step(a, st->x_dtype, st->tile_px, nblk_h(st), static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  HFinalizeArgs a;
+  a.hpart = st->hpart;
+  a.colsum_gw = st->colsum_gw;
+  a.hstat_in = st->hstat[src];
+  a.hstat_out = st->hstat[1 - src];
+  a.hist_slot = st->hist + (size_t)slot * ESPM_HI_STRIDE;
+  a.nblk = nblk_h(st);
+  a.k = st->k;
+  a.compute_loss = st->compute_loss;
+  a.xscale = st->xscale;
+  return launch_h_finalize(a, static_cast<hipStream_t>(stream));
+}
+
+/* loss-only variant: does not touch hstat[1-src] */
+static int h_finalize_loss_only(const espm_mu_state* st, int src, int slot, hipStream_t stream) {
+  HFinalizeArgs a;
+  a.hpart = st->hpart;
+  a.colsum_gw = st->colsum_gw;
+  a.hstat_in = st->hstat[src];
+  a.hstat_out = nullptr;
+  a.hist_slot = st->hist + (size_t)slot * ESPM_HI_STRIDE;
+  a.nblk = nblk_h(st);
+  a.k = st->k;
+  a.compute_loss = st->compute_loss;
+  a.xscale = st->xscale;
+  return launch_h_finalize(a, stream);
+}
+
+int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  if (int rc = espm_mu_step_h(st, src, 0, stream)) return rc;
+  return h_finalize_loss_only(st, src, slot, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(st->nblk_w >= 1, "nblk_w must be >= 1");
+  WAccumArgs a;
+  a.x_pm = st->x_pm;
+  a.gw_s = st->gw_s;
+  a.h_t = st->h_t;
+  a.a_slab = st->a_slab;
+  a.n_pad = st->n_pad;
+  a.p = st->p;
+  a.ppb = (st->p + st->nblk_w - 1) / st->nblk_w;
+  return dispatch_w_accum(a, st->k, st->x_dtype, st->nblk_w, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE((src == 0 || src == 1) && (hsrc == 0 || hsrc == 1), "src/hsrc must be 0/1");
+  ESPM_REQUIRE(slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  if (st->simplex_w && st->log_shift > 0.f) {
+    const double rows = st->m > 0 ? st->m : st->n;
+    if (!st->simplex_rows && rows * (double)st->log_shift >= 1.0)
+      return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
+  }
+  return launch_w_finish(finish_args(st, src, hsrc, slot, 1), static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_rel_h(const espm_mu_state* st, int old, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(old == 0 || old == 1, "old must be 0/1");
+  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  const int64_t pt = st->p_total > 0 ? st->p_total : st->p;
+  return launch_rel_h(st->h[old], st->h[1 - old], st->hstat[1 - old], st->hist + (size_t)slot * ESPM_HI_STRIDE, st->k,
+                      st->p, st->p_pad, 1.0 / ((double)st->k * (double)pt), st->rel_tol,
+                      static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
+  ESPM_REQUIRE(st->it + n_iter < st->hist_len, "history too short: it=%d + %d >= %d", st->it, n_iter, st->hist_len);
+  for (int i = 0; i < n_iter; ++i) {
+    const int cur = st->cur, slot = st->it;
+    int rc;
+    if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
+    if ((rc = espm_mu_h_finalize(st, cur, slot, stream))) return rc;
+    if ((rc = espm_mu_w_accum(st, stream))) return rc;
+    if ((rc = espm_mu_w_reduce(st, stream))) return rc;
+    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, stream))) return rc;
+    if ((rc = espm_mu_rel_h(st, cur, slot + 1, stream))) return rc;
+    st->cur = 1 - cur;
+    st->it = slot + 1;
+  }
+  if (final_loss) return espm_mu_loss_only(st, st->cur, st->it, stream);
+  return ESPM_OK;
+}
+
+int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, int den_cols, double log_shift,
+                           double tol, int maxit, double* nu_out, int32_t* status_out, espm_stream_t stream) {
+  ESPM_REQUIRE(num && den && nu_out && status_out, "dichotomy: NULL pointer");
+  ESPM_REQUIRE(k >= 1 && p >= 1 && (den_cols == 1 || den_cols == p), "dichotomy: bad shape k=%d p=%d den_cols=%d", k,
+               p, den_cols);
+  if (log_shift > 0 && (double)k * log_shift >= 1.0) return set_error(ESPM_ENOSOLUTION, "No solution exists!");
+  return launch_dichotomy(num, den, k, p, den_cols, log_shift, tol, maxit, nu_out, status_out,
+                          static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, espm_stream_t stream) {
+  ESPM_REQUIRE(h && out && k >= 1 && nx >= 1 && ny >= 1 && ld >= (int64_t)nx * ny, "laplacian: bad arguments");
+  return launch_laplacian(h, k, nx, ny, ld, out, static_cast<hipStream_t>(stream));
+}
+
+
+size_t espm_mu_shard_record_bytes(const espm_mu_state* st) {
+  if (!st) return 0;
+  size_t b = (size_t)st->k * st->n_pad * 4 + ESPM_HS_STRIDE * 8 + 2 * (size_t)st->k * (st->ny > 0 ? st->ny : 0) * 4;
+  return (b + 15) / 16 * 16;
+}
+
+int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(record && (hnew == 0 || hnew == 1), "shard_pack: bad arguments");
+  const int with_halo = st->grid_mode && st->lambda_l != 0.f;
+  return launch_shard_pack(st->a, st->hstat[hnew], st->h[hnew], st->k, st->n_pad, st->nx, st->ny, st->p_pad,
+                           with_halo, record, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int world, int hnew, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(records && world >= 1 && (hnew == 0 || hnew == 1), "shard_combine: bad arguments");
+  return launch_shard_combine(records, world, espm_mu_shard_record_bytes(st), st->k * st->n_pad, st->a,
+                              st->hstat[hnew], static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

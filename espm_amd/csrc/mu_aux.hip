@@ -1,0 +1,230 @@
+// Small kernels around the two streaming passes: layout packing of X, statistics of an H buffer,
+// the stand-alone simplex root finder (module-level dichotomy_simplex) and the stand-alone
+// Laplacian product H @ L.
+#include "mu_common.hpp"
+
+namespace espm {
+
+// ---- X packing: src (n, p) or (p, n), f32/f64 -> channel-major (n, p_pad) and pixel-major (p, n_pad)
+template <typename DT>
+__device__ __forceinline__ DT to_store(float v);
+template <>
+__device__ __forceinline__ float to_store<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t to_store<bf16_t>(float v) {
+  // round to nearest even; X is finite and non-negative on this path (base.py:519-528)
+  uint32_t u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src, int src_layout, int64_t ld, int n,
+                                                     int p, DT* __restrict__ x_cm, DT* __restrict__ x_pm, int n_pad,
+                                                     int p_pad) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  // tile[cc][jj] = X[c0 + cc, j0 + jj]
+  for (int r = ty; r < 32; r += 8) {
+    float v = 0.f;
+    if (src_layout == ESPM_LAYOUT_CM) {
+      const int c = c0 + r, j = j0 + tx;
+      if (c < n && j < p) v = (float)src[(int64_t)c * ld + j];
+      tile[r][tx] = v;
+    } else {
+      const int j = j0 + r, c = c0 + tx;
+      if (c < n && j < p) v = (float)src[(int64_t)j * ld + c];
+      tile[tx][r] = v;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, j = j0 + tx;
+    if (c < n && j < p_pad) x_cm[(size_t)c * p_pad + j] = to_store<DT>(tile[r][tx]);
+    const int j2 = j0 + r, c2 = c0 + tx;
+    if (j2 < p && c2 < n_pad) x_pm[(size_t)j2 * n_pad + c2] = to_store<DT>(tile[tx][r]);
+  }
+}
+
+template <typename ST>
+static int pack_dispatch(const void* src, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
+                         int x_dtype, int n_pad, int p_pad, hipStream_t stream) {
+  dim3 grid((p_pad + 31) / 32, (n_pad + 31) / 32);
+  if (x_dtype == ESPM_X_BF16)
+    hipLaunchKernelGGL((pack_x_kernel<ST, bf16_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
+                       src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad);
+  else
+    hipLaunchKernelGGL((pack_x_kernel<ST, float>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
+                       src_layout, ld, n, p, static_cast<float*>(x_cm), static_cast<float*>(x_pm), n_pad, p_pad);
+  return check_hip(hipGetLastError(), "pack_x launch");
+}
+
+int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
+                  int x_dtype, int n_pad, int p_pad, hipStream_t stream) {
+  if (src_dtype == ESPM_SRC_F64)
+    return pack_dispatch<double>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, stream);
+  return pack_dispatch<float>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, stream);
+}
+
+// ---- statistics of an H buffer (one workgroup; used at initialisation only) ---------------------
+__global__ __launch_bounds__(1024) void hstat_kernel(const float* __restrict__ h, int k, int p, int p_pad,
+                                                     double* __restrict__ out) {
+  __shared__ double scratch[16 * 2];
+  for (int kk = 0; kk < KP; ++kk) {
+    double v[2] = {0.0, 0.0};
+    if (kk < k) {
+      for (int q = threadIdx.x; q < p; q += blockDim.x) {
+        const double x = h[(size_t)kk * p_pad + q];
+        v[0] += x;
+        v[1] = fmax(v[1], x);
+      }
+    }
+    block_reduce<2, 1>(v, scratch);
+    if (threadIdx.x == 0) {
+      out[ESPM_HS_ROWSUM + kk] = v[0];
+      out[ESPM_HS_MAX + kk] = v[1];
+    }
+  }
+}
+
+int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(hstat_kernel, dim3(1), dim3(1024), 0, stream, h, k, p, p_pad, out);
+  return check_hip(hipGetLastError(), "hstat launch");
+}
+
+// ---- stand-alone simplex multiplier (fp64) ------------------------------------------------------
+constexpr int DS_MAXK = 64;
+
+__global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict__ num, const double* __restrict__ den,
+                                                        int k, int p, int den_cols, double eps, double tol, int maxit,
+                                                        double* __restrict__ nu_out, int32_t* __restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p) return;
+  // generic-k variant of simplex_root (k is a run-time value here)
+  double a = -INFINITY, nmax = 0, dmin = INFINITY, nsum = 0;
+  bool ok = true;
+  for (int i = 0; i < k; ++i) {
+    const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
+    ok = ok && nn >= 0 && dd >= 0;
+    if (nn > 0) a = fmax(a, nn / 2 - dd);
+    nmax = fmax(nmax, nn);
+    dmin = fmin(dmin, dd);
+    nsum += nn;
+  }
+  if (!ok || !(nsum > 0)) {
+    atomicAdd(status, 1);
+    nu_out[j] = NAN;
+    return;
+  }
+  double lo = a, hi = 2.0 * k * nmax - dmin, x = a;
+  for (int it = 0; it < maxit; ++it) {
+    double f = -1, fp = 0;
+    for (int i = 0; i < k; ++i) {
+      const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
+      const double inv = 1.0 / (x + dd);
+      const double t = nn > 0 ? nn * inv : 0.0;
+      if (t > eps) {
+        f += t;
+        fp -= t * inv;
+      } else {
+        f += eps;
+      }
+    }
+    if (fabs(f) <= tol) break;
+    if (f > 0) lo = x; else hi = x;
+    double xn = fp < 0 ? x - f / fp : (lo + hi) / 2;
+    if (!(xn > lo && xn < hi)) xn = (lo + hi) / 2;
+    if (xn == x) break;
+    x = xn;
+  }
+  nu_out[j] = x;
+}
+
+int launch_dichotomy(const double* num, const double* den, int k, int p, int den_cols, double eps, double tol,
+                     int maxit, double* nu_out, int32_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(dichotomy_kernel, dim3((p + 255) / 256), dim3(256), 0, stream, num, den, k, p, den_cols, eps,
+                     tol, maxit, nu_out, status);
+  return check_hip(hipGetLastError(), "dichotomy launch");
+}
+
+// ---- stand-alone H @ L ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void laplacian_kernel(const float* __restrict__ h, int k, int nx, int ny, int64_t ld,
+                                                        float* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nx * ny) return;
+  for (int kk = 0; kk < k; ++kk) {
+    const float* row = h + (size_t)kk * ld;
+    out[(size_t)kk * ld + q] = stencil_hl(row, nullptr, nullptr, q, nx, ny, row[q]);
+  }
+}
+
+int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(laplacian_kernel, dim3((nx * ny + 255) / 256), dim3(256), 0, stream, h, k, nx, ny, ld, out);
+  return check_hip(hipGetLastError(), "laplacian launch");
+}
+
+
+// ---- sharded image: per-rank exchange record ------------------------------------------------------
+// One record per rank and iteration:  [ A (k*n_pad f32) | hstat of the new H
+// (ESPM_HS_STRIDE f64) | first owned image row of the new H (k*ny f32) | last owned row (k*ny f32) ].
+// The A block starts the record, the f64 block is 8-byte aligned because k*n_pad is a multiple of 8.
+__global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict__ a, const double* __restrict__ hstat,
+                                                         const float* __restrict__ h_new, int k, int n_pad, int nx,
+                                                         int ny, int p_pad, int with_halo, unsigned char* rec) {
+  const int na = k * n_pad;
+  float* ra = reinterpret_cast<float*>(rec);
+  double* rs = reinterpret_cast<double*>(rec + (size_t)na * 4);
+  float* rt = reinterpret_cast<float*>(rec + (size_t)na * 4 + ESPM_HS_STRIDE * 8);
+  float* rb = rt + (size_t)k * ny;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int e = tid; e < na; e += nt) ra[e] = a[e];
+  for (int e = tid; e < ESPM_HS_STRIDE; e += nt) rs[e] = hstat[e];
+  if (with_halo) {
+    for (int e = tid; e < k * ny; e += nt) {
+      const int kk = e / ny, j = e - kk * ny;
+      rt[e] = h_new[(size_t)kk * p_pad + j];
+      rb[e] = h_new[(size_t)kk * p_pad + (size_t)(nx - 1) * ny + j];
+    }
+  }
+}
+
+// Fixed-order sum over ranks (bit-identical on every rank), global row sums / maxima.
+__global__ __launch_bounds__(256) void shard_combine_kernel(const unsigned char* __restrict__ recs, int world,
+                                                            size_t stride, int na, float* __restrict__ a_out,
+                                                            double* __restrict__ hstat_out) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int e = tid; e < na; e += nt) {
+    float s = 0.f;
+    for (int r = 0; r < world; ++r) s += reinterpret_cast<const float*>(recs + r * stride)[e];
+    a_out[e] = s;
+  }
+  for (int e = tid; e < ESPM_HS_STRIDE; e += nt) {
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) {
+      const double v = reinterpret_cast<const double*>(recs + r * stride + (size_t)na * 4)[e];
+      s = e < ESPM_HS_MAX ? s + v : fmax(s, v);
+    }
+    hstat_out[e] = s;
+  }
+}
+
+int launch_shard_pack(const float* a, const double* hstat, const float* h_new, int k, int n_pad, int nx, int ny,
+                      int p_pad, int with_halo, void* rec, hipStream_t stream) {
+  int blocks = (k * n_pad + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(shard_pack_kernel, dim3(blocks), dim3(256), 0, stream, a, hstat, h_new, k, n_pad, nx, ny, p_pad,
+                     with_halo, static_cast<unsigned char*>(rec));
+  return check_hip(hipGetLastError(), "shard_pack launch");
+}
+
+int launch_shard_combine(const void* recs, int world, size_t stride, int na, float* a_out, double* hstat_out,
+                         hipStream_t stream) {
+  int blocks = (na + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(shard_combine_kernel, dim3(blocks), dim3(256), 0, stream,
+                     static_cast<const unsigned char*>(recs), world, stride, na, a_out, hstat_out);
+  return check_hip(hipGetLastError(), "shard_combine launch");
+}
+
+}  // namespace espm

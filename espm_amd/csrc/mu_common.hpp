@@ -1,0 +1,278 @@
+// Shared device helpers for libespm_mu (gfx950 / CDNA4 only: wave64, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "espm_mu.h"
+
+namespace espm {
+
+constexpr int KP = ESPM_KP;
+constexpr int WAVE = 64;
+
+typedef uint16_t bf16_t;  // raw storage; converted with shifts (exact)
+
+int set_error(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define ESPM_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return espm::set_error(ESPM_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ---- vector loads of PX consecutive X values as fp32 -------------------------------------
+template <typename XT, int PX>
+struct XVec;
+
+template <>
+struct XVec<bf16_t, 8> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void get(float (&x)[8]) const {
+    x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+    x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+    x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
+    x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <>
+struct XVec<bf16_t, 4> {
+  uint2 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
+  __device__ __forceinline__ void get(float (&x)[4]) const {
+    x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+    x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+};
+template <>
+struct XVec<bf16_t, 2> {
+  uint32_t v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ void zero() { v = 0; }
+  __device__ __forceinline__ void get(float (&x)[2]) const {
+    x[0] = __uint_as_float(v << 16); x[1] = __uint_as_float(v & 0xffff0000u);
+  }
+};
+template <>
+struct XVec<float, 4> {
+  float4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void get(float (&x)[4]) const { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+};
+template <>
+struct XVec<float, 2> {
+  float2 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float2*>(p); }
+  __device__ __forceinline__ void zero() { v = make_float2(0.f, 0.f); }
+  __device__ __forceinline__ void get(float (&x)[2]) const { x[0] = v.x; x[1] = v.y; }
+};
+
+template <int PX>
+__device__ __forceinline__ void load_f32(const float* p, float (&x)[PX]) {
+  if constexpr (PX % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < PX; i += 4) {
+      float4 t = *reinterpret_cast<const float4*>(p + i);
+      x[i] = t.x; x[i + 1] = t.y; x[i + 2] = t.z; x[i + 3] = t.w;
+    }
+  } else if constexpr (PX == 2) {
+    float2 t = *reinterpret_cast<const float2*>(p);
+    x[0] = t.x; x[1] = t.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < PX; ++i) x[i] = p[i];
+  }
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    T o = __shfl_xor(v, off, WAVE);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// Block-wide reduction of NV doubles (sum for the first NSUM, max for the rest).  `scratch`
+// holds at least (blockDim.x / 64) * NV doubles.  Result valid in thread 0.
+template <int NV, int NSUM>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double o = scratch[w * NV + i];
+        v[i] = (i < NSUM) ? v[i] + o : (o > v[i] ? o : v[i]);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- per-column simplex multiplier ----------------------------------------------------------
+// Root of f(nu) = sum_i max(num_i / (nu + den_i), eps) - 1 inside the reference's bracket
+// (espm/estimators/dicotomy.py:29-49).  f is convex and decreasing to the right of its last
+// pole, so Newton from the left end converges monotonically; every iterate is kept inside the
+// running bisection bracket, and a plain bisection step is taken whenever Newton leaves it.
+// Returns false when the reference's preconditions (dicotomy.py:17-19) do not hold.
+template <typename T>
+__device__ __forceinline__ T fast_rcp(T x);
+template <>
+__device__ __forceinline__ float fast_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <>
+__device__ __forceinline__ double fast_rcp<double>(double x) { return 1.0 / x; }
+
+template <typename T, int K>
+__device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K], int k, T eps, T tol,
+                                             int maxit, T& nu) {
+  T a = -INFINITY, nmax = 0, dmin = INFINITY, nsum = 0;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    if (i < k) {
+      ok = ok && (num[i] >= 0) && (den[i] >= 0);
+      if (num[i] > 0) a = fmax(a, num[i] / 2 - den[i]);
+      nmax = fmax(nmax, num[i]);
+      dmin = fmin(dmin, den[i]);
+      nsum += num[i];
+    }
+  }
+  ok = ok && (nsum > 0) && (nsum < (T)INFINITY);
+  if (!ok) {
+    nu = 0;
+    return false;
+  }
+  T lo = a, hi = (T)(2 * k) * nmax - dmin, x = a;
+  for (int it = 0; it < maxit; ++it) {
+    T f = -1, fp = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      if (i < k) {
+        T inv = fast_rcp<T>(x + den[i]);
+        T t = num[i] > 0 ? num[i] * inv : (T)0;
+        if (t > eps) {
+          f += t;
+          fp -= t * inv;
+        } else {
+          f += eps;
+        }
+      }
+    }
+    if (fabs(f) <= tol) break;
+    if (f > 0) lo = x; else hi = x;
+    T xn = fp < 0 ? x - f / fp : (lo + hi) / 2;
+    if (!(xn > lo && xn < hi)) xn = (lo + hi) / 2;
+    if (xn == x) break;
+    x = xn;
+  }
+  nu = x;
+  return true;
+}
+
+// ---- 5-point graph Laplacian (espm/utils.py:39-76) as a stencil on the local row block ------
+// (H L)[q] = deg(q) H[q] - sum of the existing 4-neighbours; rows above/below the local block
+// come from halo_top / halo_bot when present (sharded image), otherwise the block edge is the
+// image edge (zero-flux boundary).
+__device__ __forceinline__ float stencil_hl(const float* hrow, const float* halo_top, const float* halo_bot,
+                                            int q, int nx, int ny, float hc) {
+  const int i = q / ny, j = q - i * ny;
+  float acc = 0.f;
+  int deg = 0;
+  if (j > 0) { acc += hrow[q - 1]; ++deg; }
+  if (j < ny - 1) { acc += hrow[q + 1]; ++deg; }
+  if (i > 0) { acc += hrow[q - ny]; ++deg; }
+  else if (halo_top) { acc += halo_top[j]; ++deg; }
+  if (i < nx - 1) { acc += hrow[q + ny]; ++deg; }
+  else if (halo_bot) { acc += halo_bot[j]; ++deg; }
+  return (float)deg * hc - acc;
+}
+
+// kernel-side argument blocks and launchers (mu_h_step.hip, mu_w_step.hip, mu_aux.hip)
+struct HStepArgs {
+  const void* x_cm;
+  const float* gw_s;
+  const double* colsum_gw;
+  const float* h_in;
+  float* h_out;
+  float* h_t;
+  const float* mu;
+  const float* fixed_h;
+  const float* halo_top;
+  const float* halo_bot;
+  const double* hstat_in;
+  double* hpart;
+  int n, k, p, nx, ny, p_pad;
+  int simplex_h, grid_mode, compute_loss, write_h;
+  float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale;
+};
+struct HFinalizeArgs {
+  const double* hpart;
+  const double* colsum_gw;
+  const double* hstat_in;
+  double* hstat_out;
+  double* hist_slot;
+  int nblk, k, compute_loss;
+  float xscale;
+};
+struct WAccumArgs {
+  const void* x_pm;
+  const float* gw_s;
+  const float* h_t;
+  float* a_slab;
+  int n_pad, p, ppb;
+};
+struct WFinishArgs {
+  const float* g;
+  const float* colsum_g;
+  const float* w_old;
+  float* w_new;
+  const float* a;
+  const double* hstat;
+  const float* fixed_w;
+  const int32_t* simplex_rows;
+  float* scratch;
+  float* gw_s;
+  double* colsum_gw;
+  double* hist_slot;
+  int n, m, k, n_pad, simplex_w, update_w;
+  float log_shift, tol, rel_tol, xscale, gw_floor;
+};
+
+int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
+int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
+int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
+int launch_w_reduce(const float* slab, float* out, int nblk, int total, hipStream_t stream);
+int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
+int launch_rel_h(const float* h_old, const float* h_new, const double* hstat_new, double* hist_slot, int k, int p,
+                 int p_pad, double inv_count, float rel_tol, hipStream_t stream);
+int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
+                  int x_dtype, int n_pad, int p_pad, hipStream_t stream);
+int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream);
+int launch_dichotomy(const double* num, const double* den, int k, int p, int den_cols, double eps, double tol,
+                     int maxit, double* nu_out, int32_t* status, hipStream_t stream);
+int launch_shard_pack(const float* a, const double* hstat, const float* h_new, int k, int n_pad, int nx, int ny,
+                      int p_pad, int with_halo, void* rec, hipStream_t stream);
+int launch_shard_combine(const void* recs, int world, size_t stride, int na, float* a_out, double* hstat_out,
+                         hipStream_t stream);
+int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, hipStream_t stream);
+
+}  // namespace espm

@@ -1,0 +1,369 @@
+"""Device-side engine of the multiplicative-update loop.
+
+``MUEngine`` owns the HBM-resident data of one fit on one GPU (its share of the image when the
+pixel rows are sharded over ranks) and sequences the kernels of ``libespm_mu`` on the current
+torch stream.  PyTorch is used for device memory, streams and ``torch.distributed`` only; all
+arithmetic of the update rules runs in the HIP library (there is no CPU path).
+
+Data layout in HBM (all caller-visible arrays are plain torch tensors):
+  x_cm  (n, p_pad)   bf16|f32   channel-major X, streamed by the H-step
+  x_pm  (p, n_pad)   bf16|f32   pixel-major X, streamed by the W-step
+  h[2]  (k, p_pad)   f32        ping-pong H;  h_t (p, 8) transposed copy of the newest H
+  w[2]  (M, k)       f32        ping-pong W (M = m, or n when G is the identity)
+  gw_s  (n_pad, 8)   f32        G @ W / xscale (wave-uniform rows, read through the scalar cache)
+  a_slab (nblk_w, k, n_pad), a (k, n_pad)   partial / reduced  R H^T
+  hist  (max_iter + 2, 8) f64   per-state loss pieces and relative changes
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MUState, check, lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("espm_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible and there is "
+                           "no CPU fallback for the multiplicative-update path")
+    return torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+
+class MUEngine:
+    """One SmoothNMF problem resident on one GPU.
+
+    Parameters mirror ``multiplicative_step_h`` / ``multiplicative_step_w``
+    (espm/estimators/updates.py:6-16, :83) and the estimator attributes that feed them
+    (espm/estimators/smooth_nmf.py:325-339, :405-414).
+
+    X : (n, p) array (``layout="cm"``) or (p, n) (``layout="pm"``, hyperspy's layout); numpy or a
+        torch tensor (host or device), float32/float64.  When ``group`` is given, X is this rank's
+        block of image rows and ``shape_2d`` its local (rows, ny).
+    """
+
+    def __init__(self, X, n_components, *, layout="cm", G=None, shape_2d=None, lambda_L=0.0, mu=0,
+                 epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
+                 tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
+                 x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
+                 fix_zero_lines=True, gw_floor=1e-30):
+        self.device = require_gpu(device)
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if group is not None else 1
+        self.rank = torch.distributed.get_rank(group) if group is not None else 0
+        dev = self.device
+        k = int(n_components)
+        self.k = k
+
+        # ---- X to the device, zero lines, storage type ------------------------------------------
+        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
+        if Xd.dtype not in (torch.float32, torch.float64):
+            Xd = Xd.to(torch.float64)
+        Xd = Xd.to(dev)
+        if Xd.dim() != 2:
+            raise ValueError("X must be 2-D")
+        if layout == "pm":
+            p, n = Xd.shape
+            ch_axis, px_axis = 1, 0
+        elif layout == "cm":
+            n, p = Xd.shape
+            ch_axis, px_axis = 0, 1
+        else:
+            raise ValueError("layout must be 'cm' or 'pm'")
+        self.n, self.p = int(n), int(p)
+        self.out_dtype = np.float64 if Xd.dtype == torch.float64 else np.float32
+        if bool((Xd < 0).any()):
+            raise ValueError("Negative values in data")  # espm/estimators/base.py:528
+        if fix_zero_lines:
+            # all-zero channels / pixels become log_shift, base.py:519-528 (channel sums are global)
+            ch_sum = Xd.sum(dim=px_axis, dtype=torch.float64)
+            if group is not None:
+                torch.distributed.all_reduce(ch_sum, group=group)
+            px_sum = Xd.sum(dim=ch_axis, dtype=torch.float64)
+            zc, zp = ch_sum == 0, px_sum == 0
+            if bool(zc.any()) or bool(zp.any()):
+                Xd = Xd.clone()
+                if layout == "cm":
+                    Xd[:, zp] = log_shift
+                    Xd[zc, :] = log_shift
+                else:
+                    Xd[zp, :] = log_shift
+                    Xd[:, zc] = log_shift
+        self.sum_x = Xd.sum(dtype=torch.float64)
+        if group is not None:
+            torch.distributed.all_reduce(self.sum_x, group=group)
+        self.sum_x = float(self.sum_x)
+        if x_store == "auto":
+            exact = (Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16
+            flag = torch.tensor([1 if bool(exact) else 0], device=dev, dtype=torch.int32)
+            if group is not None:
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+            x_store = "bf16" if int(flag.item()) else "f32"
+        if x_store not in ("bf16", "f32"):
+            raise ValueError("x_store must be 'auto', 'bf16' or 'f32'")
+        self.x_store = x_store
+
+        st = MUState()
+        self.st = st
+        st.n, st.p, st.k = self.n, self.p, k
+        st.x_dtype = _lib.X_BF16 if x_store == "bf16" else _lib.X_F32
+        if shape_2d is not None:
+            nx, ny = int(shape_2d[0]), int(shape_2d[1])
+            if nx * ny != p:
+                raise ValueError(f"shape_2d {shape_2d} does not match the {p} pixels of X")
+            st.nx, st.ny, st.grid_mode = nx, ny, 1
+        else:
+            st.nx, st.ny, st.grid_mode = 0, 0, 0
+        check(lib.espm_mu_query(C.byref(st)))
+        p_total = torch.tensor([p], dtype=torch.int64, device=dev)
+        if group is not None:
+            torch.distributed.all_reduce(p_total, group=group)
+        st.p_total = int(p_total.item())
+        self.p_total = st.p_total
+
+        xt = torch.bfloat16 if x_store == "bf16" else torch.float32
+        self.x_cm = torch.empty((self.n, st.p_pad), dtype=xt, device=dev)
+        self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
+        Xd = Xd.contiguous()
+        check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
+                                 _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
+                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, _stream()))
+        torch.cuda.current_stream().synchronize()
+        del Xd
+
+        # ---- G ------------------------------------------------------------------------------------
+        if G is not None:
+            Gh = np.ascontiguousarray(np.asarray(G, dtype=np.float32))
+            if Gh.ndim != 2 or Gh.shape[0] != self.n:
+                raise ValueError(f"G must be (n={self.n}, m), got {Gh.shape}")
+            self.m = Gh.shape[1]
+            self.g = torch.from_numpy(Gh).to(dev)
+            self.colsum_g = torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)).to(dev)
+            st.m = self.m
+        else:
+            self.m, self.g, self.colsum_g = 0, None, None
+            st.m = 0
+        self.M = self.m if self.m > 0 else self.n
+
+        # ---- hyper-parameters -----------------------------------------------------------------------
+        st.simplex_h, st.simplex_w = int(bool(simplex_H)), int(bool(simplex_W))
+        st.compute_loss = int(bool(compute_loss))
+        st.lambda_l, st.sigma_l = float(lambda_L), float(sigmaL)
+        st.eps_reg, st.log_shift = float(epsilon_reg), float(log_shift)
+        st.dicotomy_tol, st.rel_tol = float(dicotomy_tol), float(tol)
+        st.xscale, st.gw_floor = float(xscale), float(gw_floor)
+        self.lambda_L, self.xscale = float(lambda_L), float(xscale)
+        mu_arr = np.asarray(mu, dtype=np.float64)
+        if mu_arr.ndim == 0 and float(mu_arr) == 0.0:
+            self.mu = None
+        else:
+            self.mu = torch.from_numpy(np.broadcast_to(mu_arr, (k,)).astype(np.float32).copy()).to(dev)
+
+        # ---- state and workspaces --------------------------------------------------------------------
+        f32 = dict(dtype=torch.float32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.w = [torch.zeros((self.M, k), **f32) for _ in range(2)]
+        self.h = [torch.ones((k, st.p_pad), **f32) for _ in range(2)]  # pad columns stay positive
+        self.h_t = torch.zeros((self.p, _lib.KP), **f32)
+        self.gw_s = torch.zeros((st.n_pad, _lib.KP), **f32)
+        self.colsum_gw = torch.zeros(_lib.KP, **f64)
+        nblk_h = (self.p + st.tile_px - 1) // st.tile_px
+        self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
+        self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
+        self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
+        self.a = torch.zeros((k, st.n_pad), **f32)
+        self.w_scratch = torch.zeros((2, self.M, k), **f32)
+        self.hist_len = int(max_iter) + 2
+        self.hist = torch.zeros((self.hist_len, _lib.HI_STRIDE), **f64)
+        self.fixed_h = self._pad_h(fixed_H) if fixed_H is not None else None
+        self.fixed_w = (torch.from_numpy(np.ascontiguousarray(np.asarray(fixed_W, dtype=np.float32))).to(dev)
+                        if fixed_W is not None else None)
+        if simplex_rows is not None:
+            mask = np.zeros(self.M, dtype=np.int32)
+            mask[np.asarray(simplex_rows)] = 1
+            self.simplex_rows = torch.from_numpy(mask).to(dev)
+            if log_shift > 0 and simplex_W and mask.sum() * log_shift >= 1:
+                raise ValueError("No solution exists!")
+        else:
+            self.simplex_rows = None
+
+        st.x_cm, st.x_pm = self.x_cm.data_ptr(), self.x_pm.data_ptr()
+        st.g = self.g.data_ptr() if self.g is not None else None
+        st.colsum_g = self.colsum_g.data_ptr() if self.colsum_g is not None else None
+        st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()
+        st.h[0], st.h[1] = self.h[0].data_ptr(), self.h[1].data_ptr()
+        st.gw_s, st.colsum_gw, st.h_t = self.gw_s.data_ptr(), self.colsum_gw.data_ptr(), self.h_t.data_ptr()
+        st.mu = self.mu.data_ptr() if self.mu is not None else None
+        st.fixed_h = self.fixed_h.data_ptr() if self.fixed_h is not None else None
+        st.fixed_w = self.fixed_w.data_ptr() if self.fixed_w is not None else None
+        st.simplex_rows = self.simplex_rows.data_ptr() if self.simplex_rows is not None else None
+        st.halo_top = st.halo_bot = None
+        st.hpart = self.hpart.data_ptr()
+        st.hstat[0], st.hstat[1] = self.hstat[0].data_ptr(), self.hstat[1].data_ptr()
+        st.a_slab, st.a, st.w_scratch = self.a_slab.data_ptr(), self.a.data_ptr(), self.w_scratch.data_ptr()
+        st.hist, st.hist_len = self.hist.data_ptr(), self.hist_len
+        st.cur, st.it = 0, 0
+
+        # ---- sharding -----------------------------------------------------------------------------------
+        if self.world > 1:
+            self.rec_bytes = int(lib.espm_mu_shard_record_bytes(C.byref(st)))
+            self.rec_send = torch.zeros(self.rec_bytes, dtype=torch.uint8, device=dev)
+            self.rec_all = torch.zeros(self.world * self.rec_bytes, dtype=torch.uint8, device=dev)
+            self.with_halo = bool(st.grid_mode and self.lambda_L != 0.0)
+
+    # ------------------------------------------------------------------------------------------------
+    def _pad_h(self, H):
+        Hh = np.asarray(H, dtype=np.float32)
+        if Hh.shape != (self.k, self.p):
+            raise ValueError(f"expected an array of shape {(self.k, self.p)}, got {Hh.shape}")
+        out = torch.full((self.k, self.st.p_pad), -1.0, dtype=torch.float32, device=self.device)
+        out[:, :self.p] = torch.from_numpy(np.ascontiguousarray(Hh)).to(self.device)
+        return out
+
+    def load_state(self, W, H):
+        """Install (W, H) as the current state: builds GW, its column sums and the statistics of H."""
+        st = self.st
+        W = np.asarray(W, dtype=np.float32)
+        H = np.asarray(H, dtype=np.float32)
+        if W.shape != (self.M, self.k):
+            raise ValueError(f"W must be {(self.M, self.k)}, got {W.shape}")
+        if H.shape != (self.k, self.p):
+            raise ValueError(f"H must be {(self.k, self.p)}, got {H.shape}")
+        st.cur, st.it = 0, 0
+        self.hist.zero_()
+        self.w[0].copy_(torch.from_numpy(np.ascontiguousarray(W)))
+        self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
+        check(lib.espm_mu_build_gw(C.byref(st), 0, _stream()))
+        check(lib.espm_mu_hstat(C.byref(st), 0, _stream()))
+        if self.world > 1:
+            self._globalize_hstat(0)
+            self._exchange_halo_only(0)
+
+    # ---- sharded helpers ---------------------------------------------------------------------------
+    def _globalize_hstat(self, which):
+        hs = self.hstat[which]
+        torch.distributed.all_reduce(hs[:_lib.HS_MAX], group=self.group)
+        torch.distributed.all_reduce(hs[_lib.HS_MAX:], op=torch.distributed.ReduceOp.MAX, group=self.group)
+
+    def _set_halo_from_records(self):
+        st, rb = self.st, self.rec_bytes
+        if not self.with_halo:
+            st.halo_top = st.halo_bot = None
+            return
+        off = self.k * st.n_pad * 4 + _lib.HS_STRIDE * 8
+        base = self.rec_all.data_ptr()
+        row = self.k * st.ny * 4
+        st.halo_top = (base + (self.rank - 1) * rb + off + row) if self.rank > 0 else None
+        st.halo_bot = (base + (self.rank + 1) * rb + off) if self.rank < self.world - 1 else None
+
+    def _exchange_halo_only(self, which):
+        """Boundary rows of h[which] to the neighbours (initial state only)."""
+        check(lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.rec_send), _stream()))
+        torch.distributed.all_gather_into_tensor(self.rec_all, self.rec_send, group=self.group)
+        self._set_halo_from_records()
+
+    # ---- one iteration, granular (stop criteria / sharded) ---------------------------------------------
+    def eval_current(self, advance_h=True):
+        """H-step from the current state: fills history slot ``it`` with the loss pieces of the current
+        state and (advance_h) leaves the new H in the other buffer."""
+        st = self.st
+        if advance_h:
+            check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+            check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+        else:
+            check(lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+
+    def finish_iteration(self):
+        """W-step with the H produced by ``eval_current`` and the bookkeeping; flips the buffers."""
+        st = self.st
+        cur, slot = st.cur, st.it
+        if slot + 1 >= self.hist_len:
+            raise ValueError("history buffer exhausted: raise max_iter")
+        s = _stream()
+        check(lib.espm_mu_w_accum(C.byref(st), s))
+        check(lib.espm_mu_w_reduce(C.byref(st), s))
+        if self.world > 1:
+            check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.rec_send), s))
+            torch.distributed.all_gather_into_tensor(self.rec_all, self.rec_send, group=self.group)
+            check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.rec_all), self.world, 1 - cur, s))
+            self._set_halo_from_records()
+        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, s))
+        check(lib.espm_mu_rel_h(C.byref(st), cur, slot + 1, s))
+        st.cur, st.it = 1 - cur, slot + 1
+
+    def iterate(self, n_iter, final_loss=True):
+        """``n_iter`` iterations without host synchronisation (no stop criterion)."""
+        st = self.st
+        if st.it + n_iter + 1 > self.hist_len:
+            raise ValueError("history buffer exhausted: raise max_iter")
+        if self.world == 1:
+            check(lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
+        else:
+            for _ in range(int(n_iter)):
+                self.eval_current(True)
+                self.finish_iteration()
+            if final_loss:
+                self.eval_current(False)
+
+    # ---- single half steps for the module-level functions ----------------------------------------------
+    def step_h_only(self):
+        st = self.st
+        check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+        check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+        return self._h_numpy(1 - st.cur)
+
+    def step_w_only(self):
+        """W update using the CURRENT H (its transposed copy is refreshed first)."""
+        st = self.st
+        cur = st.cur
+        self.h_t.zero_()
+        self.h_t[:, :self.k].copy_(self.h[cur][:, :self.p].t())
+        s = _stream()
+        check(lib.espm_mu_w_accum(C.byref(st), s))
+        check(lib.espm_mu_w_reduce(C.byref(st), s))
+        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))
+        return self.w[1 - cur].cpu().numpy()
+
+    # ---- read-back -----------------------------------------------------------------------------------------
+    def _h_numpy(self, which):
+        return self.h[which][:, :self.p].cpu().numpy()
+
+    def get_W(self):
+        return self.w[self.st.cur].cpu().numpy()
+
+    def get_H(self):
+        return self._h_numpy(self.st.cur)
+
+    def bad_count(self):
+        return float(self.hist[:self.st.it + 1, _lib.HI_BAD].sum().item())
+
+    def history(self, upto=None, average=True):
+        """Loss pieces of states 0..upto (inclusive) assembled like SmoothNMF.loss
+        (espm/estimators/smooth_nmf.py:457-475): returns dict of float64 arrays."""
+        upto = self.st.it if upto is None else upto
+        hist = self.hist[:upto + 1].clone()
+        if self.world > 1:
+            sums = hist[:, [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP, _lib.HI_BAD]].contiguous()
+            torch.distributed.all_reduce(sums, group=self.group)
+            relh = hist[:, _lib.HI_REL_H].contiguous()
+            torch.distributed.all_reduce(relh, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            hist[:, _lib.HI_KLX], hist[:, _lib.HI_REG] = sums[:, 0], sums[:, 1]
+            hist[:, _lib.HI_LAP], hist[:, _lib.HI_BAD] = sums[:, 2], sums[:, 3]
+            hist[:, _lib.HI_REL_H] = relh
+        h = hist.cpu().numpy()
+        numel = float(self.n) * float(self.p_total) if average else 1.0
+        kl = (h[:, _lib.HI_KLX] + h[:, _lib.HI_SUMY] - self.xscale * self.sum_x) / numel
+        reg = h[:, _lib.HI_REG] / numel
+        lap = 0.5 * self.lambda_L * h[:, _lib.HI_LAP] / numel
+        return dict(loss=kl + reg + lap, kl=kl, reg=reg, lap=lap, rel_W=h[:, _lib.HI_REL_W],
+                    rel_H=h[:, _lib.HI_REL_H], bad=h[:, _lib.HI_BAD])

@@ -1,0 +1,208 @@
+/*
+ * espm_mu.h - C ABI of libespm_mu.so: the SmoothNMF multiplicative-update hot path of
+ * adriente/espm, written for AMD Instinct MI355X (gfx950 / CDNA4).
+ *
+ * The reference (pure Python/numpy, no FFI of its own) has exactly one compute path worth
+ * a native boundary; the entry points below are what a binding for that path replaces.
+ * Citations are file:line in the reference repository (adriente/espm @ v1.1.3):
+ *
+ *   espm_mu_step_h        <- espm/estimators/updates.py:83-156  multiplicative_step_h (KL branch)
+ *                            + espm/estimators/dicotomy.py:4-55,111-173 (per-pixel simplex root)
+ *                            + espm/utils.py:39-76 (Laplacian, as a stencil)
+ *                            + espm/measures.py:456-504,524-548,560-577 (loss pieces of the INPUT state)
+ *   espm_mu_h_finalize    <- espm/estimators/base.py:167-207, smooth_nmf.py:457-475 (loss assembly)
+ *   espm_mu_w_accum       <- espm/estimators/updates.py:38-39,53-59 (R = X/(GWH), R H^T)
+ *   espm_mu_w_reduce      <- (new) fixed-order reduction of the per-workgroup partial R H^T slabs
+ *   espm_mu_w_finish      <- espm/estimators/updates.py:58-76 (G^T., simplex_W, clamp, fixed_W)
+ *                            + updates.py:38 / base.py:189 (GW = G @ W) + base.py:323 (rel_W)
+ *   espm_mu_rel_h         <- espm/estimators/base.py:324 (rel_H)
+ *   espm_mu_hstat         <- updates.py:139 (max_j H), updates.py:60 (sum_j H)
+ *   espm_mu_iterate       <- espm/estimators/smooth_nmf.py:284-455 (_iteration, log_surrogate)
+ *                            driven by base.py:313-394 (single GPU, no host sync)
+ *   espm_mu_shard_*       <- (new) pixel-row sharding over the GPUs of a node; no reference analogue
+ *   espm_dichotomy_simplex<- espm/estimators/dicotomy.py:4-55 (module-level function)
+ *   espm_mu_pack_x        <- base.py:243-247 (validate_data / hspy_comp transpose) as a layout step
+ *   espm_mu_laplacian     <- espm/utils.py:39-76 applied to H (H @ L), measures.py:560-577
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  All array pointers are DEVICE pointers owned by the
+ *     caller (e.g. torch tensors); the library allocates nothing that outlives a call.
+ *   - Every call only enqueues work on `stream` (a hipStream_t) and returns; no host sync.
+ *   - Return value: 0 on success, negative espm_status otherwise; espm_mu_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - X is kept twice in HBM: channel-major (n, p_pad) for the H-step and pixel-major
+ *     (p, n_pad) for the W-step, as bf16 (lossless for count data) or fp32.
+ *   - W, H, G, GW and every accumulator are fp32; loss sums are fp64.
+ */
+#ifndef ESPM_MU_H
+#define ESPM_MU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* espm_stream_t; /* hipStream_t */
+
+typedef enum espm_status {
+  ESPM_OK = 0,
+  ESPM_EINVAL = -1,       /* bad argument / shape (reference: ValueError / AssertionError) */
+  ESPM_ENOSOLUTION = -2,  /* k * log_shift >= 1 (dicotomy.py:22-23 "No solution exists!") */
+  ESPM_EHIP = -3,         /* HIP runtime error */
+  ESPM_EUNSUPPORTED = -4  /* configuration not built (k > ESPM_MAX_K) */
+} espm_status;
+
+enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1 };
+enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
+enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
+
+#define ESPM_MAX_K 8       /* components supported by the built kernels */
+#define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
+#define ESPM_PPAD 512      /* p_pad is a multiple of this */
+#define ESPM_NPAD 8        /* n_pad is a multiple of this */
+
+/* per-workgroup partial record written by the H-step (doubles) */
+#define ESPM_HP_KL 0       /* sum X*log2(X/Y) over the block (input state)            */
+#define ESPM_HP_REG 1      /* sum_k mu_k log(H_in + eps_reg)                           */
+#define ESPM_HP_LAP 2      /* sum H_in * (H_in L)                                      */
+#define ESPM_HP_BAD 3      /* count of non-finite H_out entries                        */
+#define ESPM_HP_ROWSUM 4   /* [4, 4+KP): sum_j H_out[k, j]                             */
+#define ESPM_HP_MAX 12     /* [12, 12+KP): max_j H_out[k, j]                           */
+#define ESPM_HP_STRIDE 20
+
+/* per-state statistics of one H buffer (doubles): produced by espm_mu_hstat / h_finalize */
+#define ESPM_HS_ROWSUM 0   /* [0, KP)  */
+#define ESPM_HS_MAX 8      /* [8, 16)  */
+#define ESPM_HS_STRIDE 16
+
+/* history record per evaluated state (doubles) */
+#define ESPM_HI_KLX 0      /* xscale * sum X ln(X/Y)   (local pixels)                  */
+#define ESPM_HI_REG 1      /* sum mu log(H+eps)        (local pixels)                  */
+#define ESPM_HI_LAP 2      /* sum H*(HL)               (local pixels)                  */
+#define ESPM_HI_SUMY 3     /* sum_k colsum(GW)_k * rowsum(H)_k  (uses the global rowsum in hstat) */
+#define ESPM_HI_BAD 4      /* non-finite entries produced by the step that followed     */
+#define ESPM_HI_REL_W 5    /* base.py:323 for the update that PRODUCED this state       */
+#define ESPM_HI_REL_H 6    /* base.py:324 (local max; max-reduce over ranks)            */
+#define ESPM_HI_STRIDE 8
+
+typedef struct espm_mu_state {
+  /* geometry */
+  int32_t n;        /* energy channels: rows of X                                       */
+  int32_t m;        /* columns of G; 0 means G = identity (then W is (n, k))            */
+  int32_t k;        /* components, 1..ESPM_MAX_K                                        */
+  int32_t p;        /* local pixels (= nx*ny when grid_mode = 1)                        */
+  int32_t nx, ny;   /* local image rows, row length                                     */
+  int32_t n_pad;    /* roundup(n, ESPM_NPAD)                                            */
+  int32_t p_pad;    /* roundup(p, ESPM_PPAD)                                            */
+  int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16                                         */
+  int32_t tile_px;  /* H-step pixel tile per workgroup: 64 * {1,2,4,8}, see query       */
+  int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
+  int64_t p_total;  /* pixels of the whole image over all ranks (= p on one GPU)        */
+  /* flags */
+  int32_t simplex_h, simplex_w;
+  int32_t grid_mode;        /* 0: L = identity (shape_2d None, base.py:289-291), 1: 2-D stencil */
+  int32_t compute_loss;     /* H-step also accumulates the KL term (1 log per element)  */
+  /* scalars */
+  float lambda_l, sigma_l, eps_reg, log_shift, dicotomy_tol, rel_tol;
+  float xscale;     /* X_ = xscale * X_stored (normalize=True, base.py:264-267)         */
+  float gw_floor;   /* lower clamp of GW entries, keeps X/(GW H) finite (updates.py:129-131) */
+  /* data */
+  const void* x_cm;         /* (n, p_pad) bf16|f32, zero padded                         */
+  const void* x_pm;         /* (p, n_pad) bf16|f32, zero padded                         */
+  const float* g;           /* (n, m) row-major or NULL                                  */
+  const float* colsum_g;    /* (m) or NULL                                               */
+  float* w[2];              /* (m or n, k) row-major, ping-pong                          */
+  float* gw_s;              /* (n_pad, KP): GW / xscale, pad rows = 1                    */
+  double* colsum_gw;        /* (KP): column sums of GW over real rows                    */
+  float* h[2];              /* (k, p_pad), ping-pong, pad columns must be positive       */
+  float* h_t;               /* (p, KP): transposed copy of the newest H                  */
+  const float* mu;          /* (k) or NULL                                               */
+  const float* fixed_h;     /* (k, p_pad), entries >= 0 are imposed; or NULL             */
+  const float* fixed_w;     /* (m or n, k) or NULL                                       */
+  const int32_t* simplex_rows; /* (m or n) 0/1 mask of rows under simplex_W, NULL = all  */
+  const float* halo_top;    /* (k, ny) image row above the local block or NULL           */
+  const float* halo_bot;    /* (k, ny) image row below the local block or NULL           */
+  /* workspaces */
+  double* hpart;            /* (ceil(p / tile_px), ESPM_HP_STRIDE)                       */
+  double* hstat[2];         /* (ESPM_HS_STRIDE) statistics of h[0] / h[1] (global)       */
+  float* a_slab;            /* (nblk_w, k, n_pad)                                        */
+  float* a;                 /* (k, n_pad)                                                */
+  float* w_scratch;         /* (2, m or n, k)                                            */
+  double* hist;             /* (hist_len, ESPM_HI_STRIDE), zero-initialised              */
+  int32_t hist_len;
+  int32_t cur;              /* index of the current W/H buffers (0/1), flipped by iterate */
+  int32_t it;               /* number of completed iterations = history slot of the current state */
+} espm_mu_state;
+
+const char* espm_mu_version(void);
+const char* espm_mu_last_error(void);
+
+/* Fills n_pad, p_pad, tile_px, nblk_w of `st` from n, p, k, x_dtype and the device's CU count. */
+int espm_mu_query(espm_mu_state* st);
+
+/* X (host layout, device memory) -> the two padded device layouts.  src is (n, p) when
+ * src_layout = CM or (p, n) when PM (hyperspy's layout), leading dimension ld (elements). */
+int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p,
+                   void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, espm_stream_t stream);
+
+/* statistics (row sums, row maxima) of st->h[which] into st->hstat[which] (local pixels). */
+int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream);
+
+/* gw_s, colsum_gw from g, w[which] (updates.py:107). */
+int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream);
+
+/* H update: reads h[src], writes h[1-src] and h_t, partial sums to hpart.
+ * write_h = 0 evaluates the loss pieces of the input state only. */
+int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream);
+
+/* Reduces hpart: history slot `slot` gets the loss pieces of h[src]; hstat[1-src] gets the
+ * statistics of the new H (local; the caller max/sum-reduces over ranks when sharded). */
+int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream);
+
+/* Loss pieces of the state (w[src], h[src]) into history slot `slot`; H is not updated. */
+int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t stream);
+
+/* A_slab[b] = sum over the pixels of block b of R[:, j] H[:, j]^T with R = X / (GW H), H = h_t. */
+int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream);
+/* a = sum_b a_slab[b] in fixed order. */
+int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream);
+/* W update from a, hstat[hsrc] (global row sums of the new H): reads w[src], writes w[1-src],
+ * gw_s, colsum_gw and rel_W into history slot `slot`. */
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream);
+
+/* rel_H between h[old] and h[1-old] (needs hstat[1-old] global), max-accumulated in slot. */
+int espm_mu_rel_h(const espm_mu_state* st, int old, int slot, espm_stream_t stream);
+
+/* n_iter full iterations on one GPU, no host synchronisation; updates st->cur / st->it.
+ * History slot t holds the loss pieces of state t (slot 0 = initial state) and the relative
+ * changes of the update that produced it.  A final loss-only H-step fills the last slot when
+ * final_loss != 0. */
+int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream);
+
+/* Sharded image (pixel rows split over ranks).  Per iteration every rank packs one
+ * record [A | hstat of the new H | first and last owned image row of the new H], the caller
+ * all-gathers the records (RCCL), and shard_combine sums A over ranks in fixed order, forms the
+ * global row sums / maxima in hstat[hnew].  The halo rows for the next H-step are read in place
+ * from the neighbours' records: offsets k*n_pad*4 + ESPM_HS_STRIDE*8 (+ k*ny*4 for the last row). */
+size_t espm_mu_shard_record_bytes(const espm_mu_state* st);
+int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_stream_t stream);
+int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int world, int hnew,
+                          espm_stream_t stream);
+
+/* nu (p) with sum_i max(num_ij / (nu_j + den_ij), log_shift) = 1.  num (k, p), den (k, den_cols)
+ * with den_cols in {1, p}, fp64 device arrays.  status_out (device int32): number of columns
+ * that violate the preconditions (dicotomy.py:17-19). */
+int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, int den_cols,
+                           double log_shift, double tol, int maxit, double* nu_out,
+                           int32_t* status_out, espm_stream_t stream);
+
+/* out = H @ L for the 5-point Laplacian on an (nx, ny) grid (k, nx*ny) with leading dim ld. */
+int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out,
+                      espm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESPM_MU_H */
