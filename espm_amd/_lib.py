@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (libamdhip64); it must be loaded FIRST so that libespm_mu.so binds
+# to the same runtime instance as the tensors and streams it is handed (two runtimes in one process do
+# not share devices: "no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libespm_mu.so")
 

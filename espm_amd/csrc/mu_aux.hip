@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
     nu_out[j] = NAN;
     return;
   }
-  double lo = a, hi = 2.0 * k * nmax - dmin, x = a;
+  double lo = a, hi = 2.0 * k * nmax - dmin, x = a, dxold = hi - lo;
   for (int it = 0; it < maxit; ++it) {
     double f = -1, fp = 0;
     for (int i = 0; i < k; ++i) {
@@ -133,8 +133,13 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
     }
     if (fabs(f) <= tol) break;
     if (f > 0) lo = x; else hi = x;
-    double xn = fp < 0 ? x - f / fp : (lo + hi) / 2;
-    if (!(xn > lo && xn < hi)) xn = (lo + hi) / 2;
+    double dx = fp < 0 ? -f / fp : 0.0;
+    double xn = x + dx;
+    if (!(fp < 0) || !(xn > lo && xn < hi) || fabs(dx) > 0.5 * fabs(dxold)) {
+      dx = (hi - lo) / 2;
+      xn = lo + dx;
+    }
+    dxold = dx;
     if (xn == x) break;
     x = xn;
   }

@@ -162,6 +162,7 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     return false;
   }
   T lo = a, hi = (T)(2 * k) * nmax - dmin, x = a;
+  T dxold = hi - lo;
   for (int it = 0; it < maxit; ++it) {
     T f = -1, fp = 0;
 #pragma unroll
@@ -179,8 +180,14 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     }
     if (fabs(f) <= tol) break;
     if (f > 0) lo = x; else hi = x;
-    T xn = fp < 0 ? x - f / fp : (lo + hi) / 2;
-    if (!(xn > lo && xn < hi)) xn = (lo + hi) / 2;
+    // Newton step, replaced by bisection when it leaves the bracket or stops halving the step
+    T dx = fp < 0 ? -f / fp : (T)0;
+    T xn = x + dx;
+    if (!(fp < 0) || !(xn > lo && xn < hi) || fabs(dx) > (T)0.5 * fabs(dxold)) {
+      dx = (hi - lo) / 2;
+      xn = lo + dx;
+    }
+    dxold = dx;
     if (xn == x) break;
     x = xn;
   }

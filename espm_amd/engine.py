@@ -249,6 +249,17 @@ class MUEngine:
             self._globalize_hstat(0)
             self._exchange_halo_only(0)
 
+    def set_G(self, G):
+        """Replace G (physics model refreshed it, espm/estimators/base.py:388-390) and rebuild G W."""
+        if self.m == 0:
+            raise ValueError("the engine was built with G = identity")
+        Gh = np.ascontiguousarray(np.asarray(G, dtype=np.float32))
+        if Gh.shape != (self.n, self.m):
+            raise ValueError(f"G must stay {(self.n, self.m)}, got {Gh.shape}")
+        self.g.copy_(torch.from_numpy(Gh))
+        self.colsum_g.copy_(torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)))
+        check(lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
+
     # ---- sharded helpers ---------------------------------------------------------------------------
     def _globalize_hstat(self, which):
         hs = self.hstat[which]

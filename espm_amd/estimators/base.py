@@ -1,0 +1,319 @@
+"""sklearn-style NMF estimator base with the reference's surface (espm/estimators/base.py:20-529).
+
+The fit loop of the reference (base.py:313-394) calls ``_iteration`` + ``loss`` on numpy arrays
+once per multiplicative-update iteration.  Here the loop drives a device engine
+(:class:`espm_amd.engine.MUEngine`): X, W, H stay in HBM, every iteration is a short chain of HIP
+kernels, and the loss of a state is produced by the H-step that starts the NEXT iteration (it
+forms the same G W H), so the reference's per-iteration bookkeeping costs no extra pass over X.
+Stop rules, attribute names, printed messages and return conventions follow the reference.
+"""
+from __future__ import annotations
+
+import time
+from abc import ABC, abstractmethod
+
+import numpy as np
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils.validation import check_is_fitted, validate_data
+
+from espm_amd.conf import log_shift
+from espm_amd.estimators.updates import initialize_algorithms
+from espm_amd.utils import create_laplacian_matrix, identity_laplacian, rescaled_DH
+
+
+def normalization_factor(X, nc):
+    """espm/estimators/base.py:16-18."""
+    m = np.mean(X)
+    return nc / (m * X.shape[0])
+
+
+def _is_physical_model(G):
+    return G is not None and not isinstance(G, np.ndarray) and hasattr(G, "NMF_update")
+
+
+class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
+    """Abstract NMF estimator, X (n, p) ~ G (n, m) W (m, k) H (k, p); parameters and attributes as in
+    espm/estimators/base.py:68-152."""
+
+    loss_names_ = ["KL_div_loss"]
+    const_KL_ = None
+
+    def __init__(self, n_components=2, init=None, tol=1e-4, max_iter=200, random_state=None, verbose=1, debug=False,
+                 l2=False, G=None, shape_2d=None, normalize=False, log_shift=log_shift, eval_print=10, true_D=None,
+                 true_H=None, fixed_H=None, fixed_W=None, hspy_comp=False, no_stop_criterion=False, simplex_H=False,
+                 simplex_W=True):
+        self.n_components = n_components
+        self.init = init
+        self.tol = tol
+        self.max_iter = max_iter
+        self.random_state = random_state
+        self.verbose = verbose
+        self.log_shift = log_shift
+        self.debug = debug
+        self.l2 = l2
+        self.G = G
+        self.shape_2d = shape_2d
+        self.eval_print = eval_print
+        self.true_D = true_D
+        self.true_H = true_H
+        self.fixed_H = fixed_H
+        self.fixed_W = fixed_W
+        self.hspy_comp = hspy_comp
+        self.normalize = normalize
+        self.no_stop_criterion = no_stop_criterion
+        self.simplex_H = simplex_H
+        self.simplex_W = simplex_W
+
+    def __sklearn_tags__(self):
+        tags = super().__sklearn_tags__()
+        tags.input_tags.positive_only = True
+        return tags
+
+    def _more_tags(self):
+        return {"requires_positive_X": True}
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        state = dict(state)
+        state.pop("_engine", None)  # device buffers / ctypes pointers are not picklable
+        return state
+
+    # ---- hooks implemented by the concrete estimator -------------------------------------------------
+    @abstractmethod
+    def _iteration(self, W, H):
+        pass
+
+    def _engine_kwargs(self):
+        return {}
+
+    def _detailed(self, lkl, reg, lap):
+        return [lkl]
+
+    # ---- loss -----------------------------------------------------------------------------------------
+    def _make_engine(self, X_fixed, xscale, G):
+        from espm_amd.engine import MUEngine
+
+        rows = None
+        if self.physics_model_ is not None and self.simplex_W:
+            rows = self.physics_model_.NMF_simplex()
+        return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
+                        simplex_W=self.simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
+                        fixed_W=self.fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
+                        fix_zero_lines=False, **self._engine_kwargs())
+
+    def _engine_G(self):
+        G = self.G_
+        if self._identity_G:
+            return None
+        return G
+
+    def loss(self, W, H, average=True, X=None):
+        """Loss of (W, H) (espm/estimators/base.py:167-207): generalised KL divergence of X from
+        G W H (plus the regularisers of the subclass), evaluated on the device."""
+        self.GWH_numel_ = self.G_.shape[0] * H.shape[1]
+        if self.l2:
+            raise NotImplementedError("the Frobenius loss (l2=True) is not built for the GPU path")
+        if X is None:
+            eng = self._get_engine()
+        else:
+            assert X.shape == (self.G_.shape[0], H.shape[1])
+            eng = self._make_engine(np.asarray(X), 1.0, self._engine_G())
+        eng.load_state(W, H)
+        eng.eval_current(advance_h=False)
+        h = eng.history(upto=0, average=average)
+        self.detailed_loss_ = self._detailed(float(h["kl"][0]), float(h["reg"][0]), float(h["lap"][0]))
+        return float(h["loss"][0])
+
+    def _get_engine(self):
+        eng = getattr(self, "_engine", None)
+        if eng is None:
+            check_is_fitted(self, "X_")
+            scale = getattr(self, "norm_factor_", 1.0) if self.normalize else 1.0
+            eng = self._engine = self._make_engine(self._X_fixed(), scale, self._engine_G())
+        return eng
+
+    def _X_fixed(self):
+        X = self.X_
+        if self.normalize:
+            X = X / self.norm_factor_
+        return X
+
+    # ---- fit --------------------------------------------------------------------------------------------
+    def fit_transform(self, X, y=None, W=None, H=None):
+        """Learn X ~ G W H and return G W (or H.T with ``hspy_comp``), espm/estimators/base.py:209-420."""
+        if self.hspy_comp:
+            Xv = validate_data(self, X.T, dtype=[np.float64, np.float32])
+        else:
+            Xv = validate_data(self, X, dtype=[np.float64, np.float32])
+        if self.hspy_comp is False:
+            try:  # base.py:249-259
+                import inspect
+                calframe = inspect.getouterframes(inspect.currentframe(), 2)
+                if calframe[1][3] == "decomposition" and "hyperspy" in calframe[1][1]:
+                    print("Are you calling the function decomposition from Hyperspy?\n"
+                          "If so, please set the compatibility argument 'hspy_comp' to True.\n\n"
+                          "If this argument is not set correctly, the function will not work properly!!!")
+            except Exception:
+                pass
+        if self.l2:
+            raise NotImplementedError("the Frobenius loss (l2=True) is not built for the GPU path")
+        if self.true_D is not None or self.true_H is not None:
+            raise NotImplementedError("ground-truth tracking (true_D / true_H) is outside the accelerated path")
+
+        X_fixed = self.remove_zeros_lines(Xv, self.log_shift)
+        self.const_KL_ = None
+        xscale = 1.0
+        if self.normalize:
+            self.norm_factor_ = normalization_factor(X_fixed, self.n_components)
+            self.X_ = self.norm_factor_ * X_fixed
+            xscale = float(self.norm_factor_)
+        else:
+            self.X_ = X_fixed
+
+        if _is_physical_model(self.G):
+            self.physics_model_ = self.G
+            G = self.physics_model_.NMF_update()
+        else:
+            self.physics_model_ = None
+            G = self.G
+        self._identity_G = G is None
+        self.G_, self.W_, self.H_ = initialize_algorithms(X=self.X_, G=G, W=W, H=H, n_components=self.n_components,
+                                                          init=self.init, random_state=self.random_state,
+                                                          simplex_H=self.simplex_H, simplex_W=self.simplex_W,
+                                                          physics_model=self.physics_model_)
+        if self.shape_2d is not None:
+            self.L_ = create_laplacian_matrix(*self.shape_2d)
+        else:
+            self.L_ = identity_laplacian(self.X_.shape[1])
+
+        out_dtype = self.X_.dtype
+        self._engine = eng = self._make_engine(X_fixed, xscale, None if self._identity_G else self.G_)
+        del X_fixed
+        eng.load_state(self.W_, self.H_)
+        self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]
+        self.const_KL_ = float(np.sum(self.X_ * np.log(np.maximum(self.X_, self.log_shift))) - np.sum(self.X_))
+
+        algo_start = time.time()
+        self.n_iter_ = 0
+        self._begin_fit()
+        self.losses_, self.rel_, self.detailed_losses_ = [], [], []
+        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None
+        eval_before = np.inf
+        eval_init = None
+        stop = False
+        try:
+            eng.eval_current(advance_h=True)  # loss of the initial state rides on the first H-step
+            while not stop:
+                # how many iterations may run before the host has to look at a loss value
+                if sync_each:
+                    chunk = 1
+                else:
+                    chunk = self.max_iter - self.n_iter_
+                    if self.verbose > 0:
+                        chunk = min(chunk, self.eval_print - self.n_iter_ % self.eval_print)
+                    chunk = max(chunk, 1)
+                eng.finish_iteration()
+                if chunk > 1:
+                    eng.iterate(chunk - 1, final_loss=False)
+                    eng.eval_current(advance_h=(self.n_iter_ + chunk) < self.max_iter)
+                else:
+                    last = self.n_iter_ + 1 >= self.max_iter
+                    refresh_G = self.physics_model_ is not None and (self.n_iter_ + 1) % 3 == 0
+                    eng.eval_current(advance_h=not (last or refresh_G))
+                first = self.n_iter_ + 1
+                self.n_iter_ += chunk
+                h = eng.history(upto=self.n_iter_)
+                if eval_init is None:
+                    eval_init = float(h["loss"][0])
+                for t in range(first, self.n_iter_ + 1):
+                    self.losses_.append(float(h["loss"][t]))
+                    self.detailed_losses_.append(self._detailed(float(h["kl"][t]), float(h["reg"][t]),
+                                                                float(h["lap"][t])))
+                    self.rel_.append([float(h["rel_W"][t]), float(h["rel_H"][t])])
+                eval_after = self.losses_[-1]
+                rel_W, rel_H = self.rel_[-1]
+
+                if self.n_iter_ >= self.max_iter:  # base.py:354-378
+                    print("exits because max_iteration was reached")
+                    break
+                if not self.no_stop_criterion:
+                    if max(rel_H, rel_W) < self.tol:
+                        print("exits because of relative change rel_A {} and rel_P {} < tol ".format(rel_H, rel_W))
+                        break
+                    elif abs((eval_before - eval_after) / eval_init) < self.tol:
+                        print("exits because of relative change < tol: {}".format((eval_before - eval_after) / eval_init))
+                        break
+                    elif np.isnan(eval_after):
+                        print("exit because of the presence of NaN")
+                        break
+                    elif (eval_before - eval_after) < 0:
+                        print("exit because of negative decrease {}: {}, {}".format((eval_before - eval_after),
+                                                                                     eval_before, eval_after))
+                        break
+                if self.verbose > 0 and np.mod(self.n_iter_, self.eval_print) == 0:
+                    print(f"It {self.n_iter_} / {self.max_iter}: loss {eval_after:3e},  "
+                          f"{self.n_iter_ / (time.time() - algo_start + log_shift):0.3f} it/s")
+                if self.physics_model_ is not None and self.n_iter_ % 3 == 0:  # base.py:388-392
+                    self.G_ = self.physics_model_.NMF_update(eng.get_W().astype(out_dtype))
+                    eng.set_G(self.G_)
+                    eng.eval_current(advance_h=True)
+                    eval_before = float(eng.history(upto=self.n_iter_)["loss"][self.n_iter_])
+                else:
+                    eval_before = eval_after
+        except KeyboardInterrupt:
+            pass
+
+        self.W_ = eng.get_W().astype(out_dtype)
+        self.H_ = eng.get_H().astype(out_dtype)
+        if not self.simplex_H and not self.simplex_W:
+            self.W_, self.H_ = rescaled_DH(self.W_, self.H_)  # base.py:399-400
+
+        algo_time = time.time() - algo_start
+        print(f"Stopped after {self.n_iter_} iterations in {algo_time // 60} minutes "
+              f"and {np.round(algo_time) % 60} seconds.")
+        if not self.simplex_H and not self.simplex_W:
+            self.reconstruction_err_ = self.loss(self.W_, self.H_)
+        else:
+            self.reconstruction_err_ = self.losses_[-1] if self.losses_ else self.loss(self.W_, self.H_)
+            if self.losses_:
+                self.detailed_loss_ = self.detailed_losses_[-1]
+        if self.normalize:
+            self.W_ = self.W_ / self.norm_factor_
+
+        GW = self.G_ @ self.W_
+        self.n_components_ = self.H_.shape[0]
+        if self.hspy_comp:
+            self.components_ = GW.T
+            return self.H_.T
+        self.components_ = self.H_
+        return GW
+
+    def _begin_fit(self):
+        pass
+
+    def fit(self, X, y=None, **params):
+        """Learn a NMF model for the data X (espm/estimators/base.py:422-441)."""
+        self.fit_transform(X, **params)
+        return self
+
+    def inverse_transform(self, W):
+        """G W H_ (espm/estimators/base.py:461-477)."""
+        check_is_fitted(self)
+        return self.G_ @ W @ self.H_
+
+    def get_losses(self):
+        """Structured array of the loss history (espm/estimators/base.py:479-517)."""
+        names = ["full_loss"] + self.loss_names_ + ["rel_W", "rel_H"]
+        dt = np.dtype([(elt, "float64") for elt in names])
+        rows = [(self.losses_[i],) + tuple(self.detailed_losses_[i]) + tuple(self.rel_[i])
+                for i in range(len(self.losses_))]
+        return np.array(rows, dtype=dt)
+
+    def remove_zeros_lines(self, X, epsilon):
+        """All-zero rows / columns of X become epsilon (espm/estimators/base.py:519-528)."""
+        if np.all(X >= 0):
+            new_X = X.copy()
+            new_X[:, X.sum(axis=0) == 0] = epsilon
+            new_X[X.sum(axis=1) == 0, :] = epsilon
+            return new_X
+        raise ValueError("Negative values in data")

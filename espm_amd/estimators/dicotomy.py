@@ -1,0 +1,41 @@
+"""Simplex Lagrange-multiplier root finder (espm/estimators/dicotomy.py:4-55) on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from espm_amd.conf import dicotomy_tol, log_shift, maxit_dichotomy
+
+
+def dichotomy_simplex(num, denum, log_shift=log_shift, tol=dicotomy_tol, maxit=maxit_dichotomy):
+    """Solve sum_i max(num_ij / (nu_j + denum_ij), log_shift) = 1 for every column j.
+
+    Same arguments, checks and exceptions as the reference (dicotomy.py:4-55).  The root is found
+    per column with a bracketed Newton iteration inside the reference's bracket (the reference
+    bisects all columns until the worst one meets ``tol``), so |f(nu)| <= tol holds per column.
+    """
+    import torch
+
+    from espm_amd import _lib
+    from espm_amd.engine import _ptr, _stream, require_gpu
+
+    num = np.asarray(num, dtype=np.float64)
+    denum = np.asarray(denum, dtype=np.float64)
+    assert (num >= 0).all()           # dicotomy.py:17-19
+    assert (denum >= 0).all()
+    assert (np.sum(num, axis=0) > 0).all()
+    if log_shift > 0 and denum.shape[0] * log_shift >= 1:
+        raise ValueError("No solution exists!")  # dicotomy.py:22-23
+    k, p = num.shape
+    den_cols = denum.shape[1]
+    if den_cols not in (1, p) or denum.shape[0] != k:
+        raise ValueError("denum must be (k, p) or (k, 1)")
+    dev = require_gpu()
+    d_num = torch.from_numpy(np.ascontiguousarray(num)).to(dev)
+    d_den = torch.from_numpy(np.ascontiguousarray(denum)).to(dev)
+    d_nu = torch.empty(p, dtype=torch.float64, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.espm_dichotomy_simplex(_ptr(d_num), _ptr(d_den), k, p, den_cols, float(log_shift), float(tol),
+                                               int(maxit), _ptr(d_nu), _ptr(d_status), _stream()))
+    nu = d_nu.cpu().numpy()
+    assert int(d_status.item()) == 0, "dichotomy_simplex preconditions violated on device"
+    return nu

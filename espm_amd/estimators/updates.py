@@ -1,0 +1,115 @@
+"""Multiplicative update rules with the reference's module-level signatures
+(espm/estimators/updates.py:6-16, :83, :160), running on the GPU."""
+import numpy as np
+
+from espm_amd.conf import dicotomy_tol, log_shift, sigmaL
+from espm_amd.utils import classify_laplacian
+
+
+def _as_identity(G):
+    G = np.asarray(G)
+    return G.ndim == 2 and G.shape[0] == G.shape[1] and np.array_equal(G, np.eye(G.shape[0], dtype=G.dtype))
+
+
+def _safe_inputs(G, W, H, log_shift, safe):
+    if safe:  # updates.py:20-27, :98-105
+        assert np.sum(H < -log_shift / 2) == 0
+        assert np.sum(W < -log_shift / 2) == 0
+        assert np.sum(np.asarray(G) < -log_shift / 2) == 0
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    return W, H
+
+
+def _engine(X, G, W, H, **kw):
+    from espm_amd.engine import MUEngine
+
+    X = np.asarray(X)
+    ident = _as_identity(G)
+    eng = MUEngine(X, H.shape[0], G=None if ident else np.asarray(G), fix_zero_lines=False, max_iter=1, **kw)
+    eng.load_state(W, H)
+    return eng
+
+
+def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe=True, l2=False, fixed_W=None,
+                          physics_model=None, use_bregman=False):
+    """Multiplicative step in W (espm/estimators/updates.py:6-78, KL branch)."""
+    if l2 or use_bregman:
+        raise NotImplementedError("only the KL multiplicative update (algo='log_surrogate') is built for the GPU")
+    W = np.asarray(W)
+    H = np.asarray(H)
+    W, H = _safe_inputs(G, W, H, log_shift, safe)
+    rows = physics_model.NMF_simplex() if (simplex_W and physics_model is not None) else None
+    eng = _engine(X, G, W, H, simplex_H=False, simplex_W=simplex_W, log_shift=log_shift, fixed_W=fixed_W,
+                  simplex_rows=rows)
+    out = eng.step_w_only()
+    return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
+
+
+def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
+                          dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, sigmaL=sigmaL, fixed_H=None,
+                          use_bregman=False):
+    """Multiplicative step in H (espm/estimators/updates.py:83-156, KL branch)."""
+    shape_2d = None
+    W = np.asarray(W)
+    H = np.asarray(H)
+    if not (lambda_L == 0):
+        if L is None:
+            raise ValueError("Please provide the laplacian")  # updates.py:94-95
+        kind, shape_2d = classify_laplacian(L, H.shape[1])
+    if l2 or use_bregman:
+        raise NotImplementedError("only the KL multiplicative update (algo='log_surrogate') is built for the GPU")
+    W, H = _safe_inputs(G, W, H, log_shift, safe)
+    eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, mu=mu, log_shift=log_shift,
+                  epsilon_reg=epsilon_reg, dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, shape_2d=shape_2d,
+                  sigmaL=sigmaL, fixed_H=fixed_H, compute_loss=False)
+    out = eng.step_h_only()
+    if eng.bad_count() > 0 and safe:
+        raise AssertionError("multiplicative_step_h: non-finite update or simplex preconditions violated")
+    return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
+
+
+def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_H, simplex_W, logshift=log_shift,
+                          physics_model=None):
+    """Initial G, W, H (espm/estimators/updates.py:160-223).
+
+    Host side like the reference: scikit-learn's NNDSVD / random initialisation and small
+    least-squares fits; it runs once per fit, outside the multiplicative-update loop."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+
+    if G is None:
+        skip_second = True
+        G = np.diag(np.ones(X.shape[0]).astype(X.dtype))  # updates.py:163-166 (dense identity)
+    else:
+        skip_second = False
+    if W is None:
+        if H is None:
+            D, H = _initialize_nmf(X, n_components=n_components, init=init, random_state=random_state)
+            if simplex_H:
+                H = np.nan_to_num(H, nan=1.0 / H.shape[0])
+                scale = np.sum(H, axis=0, keepdims=True)
+                H = H / scale
+                D = D * np.mean(scale)
+        else:
+            D = np.abs(np.linalg.lstsq(H.T, X.T, rcond=None)[0].T)
+        if skip_second:
+            W = D
+        elif physics_model is not None:
+            W = physics_model.NMF_initialize_W(D)
+            if simplex_W:
+                indices = physics_model.NMF_simplex()
+                W = np.nan_to_num(W, nan=1.0 / W.shape[0])
+                W[indices, :] = W[indices, :] / np.sum(W[indices, :], axis=0, keepdims=True)
+        else:
+            W = np.abs(np.linalg.lstsq(G, D, rcond=None)[0])
+            if simplex_W:
+                W = np.nan_to_num(W, nan=1.0 / W.shape[0])
+                W = W / np.sum(W, axis=0, keepdims=True)
+    elif H is None:
+        D = G @ W
+        H = np.abs(np.linalg.lstsq(D, X, rcond=None)[0])
+        if simplex_H:
+            H = H / np.sum(H, axis=0, keepdims=True)
+    W = np.maximum(W, logshift)
+    H = np.maximum(H, logshift)
+    return G, W, H

@@ -1,0 +1,216 @@
+"""GPU parity of the update rules: HIP path (through the C ABI) vs the numpy oracle and the golden
+vectors captured from the reference; plus the reference's own property tests
+(espm/tests/test_updates.py:93-249, :439-574, espm/tests/test_laplacian.py, test_measures.py:154-221)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mu_oracle as oc  # noqa: E402
+
+F32 = dict(rtol=2e-5, atol=2e-6)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from espm_amd import measures, utils
+    from espm_amd.estimators import dicotomy, updates
+    return dict(step_h=updates.multiplicative_step_h, step_w=updates.multiplicative_step_w,
+                dicho=dicotomy.dichotomy_simplex, init=updates.initialize_algorithms, measures=measures, utils=utils)
+
+
+# ------------------------------------------------------------------------------------ dichotomy
+def test_dichotomy_golden(api, golden):
+    g = golden("f1_dichotomy")
+    for i in range(int(g["n_kat"])):
+        num, den, eps, tol = g[f"kat{i}_num"], g[f"kat{i}_den"], float(g[f"kat{i}_eps"]), float(g[f"kat{i}_tol"])
+        nu = api["dicho"](num, den, eps, tol=tol)
+        np.testing.assert_allclose(nu, g[f"kat{i}_nu"], atol=4 * max(tol, 1e-12) * max(1, np.abs(g[f"kat{i}_nu"]).max()))
+    for c in range(int(g["n_rnd"])):
+        num, den, eps = g[f"rnd{c}_num"], g[f"rnd{c}_den"], float(g[f"rnd{c}_eps"])
+        nu = api["dicho"](num, den, eps, tol=0.0, maxit=100)
+        ref = g[f"rnd{c}_t0_nu"]  # reference iterated to machine precision (100 sweeps)
+        np.testing.assert_allclose(nu, ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max(), err_msg=f"case {c}")
+        f = np.sum(np.maximum(num / (den + nu), eps), axis=0) - 1
+        assert np.abs(f).max() < 1e-7
+
+
+def test_dichotomy_reference_properties(api):
+    """espm/tests/test_updates.py:93-183."""
+    rng = np.random.default_rng(1)
+    tol = 1e-8
+    num, den = rng.random((1, 1)) + 1, rng.random((1, 1))
+    assert abs(api["dicho"](num, den, 0, tol=tol) - (num - den)) < 2 * tol
+    n = 10
+    num, den = rng.random((1, n)), rng.random((1, n))
+    np.testing.assert_allclose(api["dicho"](num, den, 0, tol=tol), np.squeeze(num - den), atol=tol)
+    num, den = rng.random((n, 6)), rng.random((n, 6))
+    sol = api["dicho"](num, den, 0, tol=1e-6)
+    np.testing.assert_allclose(np.sum(num / (den + sol), axis=0), np.ones(6), atol=1e-6)
+    for den in (np.array([[1, 1, 3, 5, 4, 2]], float).T, np.array([[1, 1, 0, 5, 0, 2]], float).T):
+        num = np.array([[1, 1, 0, 0, 0, 2]], float).T
+        sol = api["dicho"](num, den, 0, tol=1e-6)
+        np.testing.assert_allclose(np.sum(num / (den + sol)), 1, atol=1e-6)
+    sol = api["dicho"](np.array([[3, 0.5]]).T, np.array([[1.0, 1]]).T, 1 / 4, tol=tol)
+    assert abs(sol - 3) < 2 * tol
+    with pytest.raises(ValueError):
+        api["dicho"](rng.random((1, n)), rng.random((1, n)), 1.1, tol=tol)
+    with pytest.raises(ValueError):
+        api["dicho"](rng.random((3, n)), rng.random((3, n)), 0.5, tol=tol)
+    num, den = rng.random((n, 6)), rng.random((n, 6))
+    sol = api["dicho"](num, den, 0.05, tol=1e-6)
+    np.testing.assert_allclose(np.sum(np.maximum(num / (den + sol), 0.05), axis=0), np.ones(6), atol=1e-6)
+    with pytest.raises(AssertionError):
+        api["dicho"](np.zeros((3, 4)), np.ones((3, 4)), 0.0)
+
+
+def test_dichotomy_twelve_decades(api):
+    """espm/tests/test_updates.py:185-249 (k=5, p=6400, scales 1e-6..1e6, with zeros and (k,1) denominators)."""
+    k, p = 5, 6400
+    span = np.logspace(-6, 6, num=17)
+    rng = np.random.default_rng(0)
+    for zeros in (False, True):
+        for den_cols in (p, 1):
+            num = rng.choice(span, (k, p)) * rng.random((k, p))
+            if zeros:
+                num[np.tile(np.arange(k), p // k), np.arange(p)] = 0
+            den = rng.choice(span, (k, den_cols)) * rng.random((k, den_cols))
+            for eps in (0.0, 0.1 / k):
+                sol = api["dicho"](num, den, eps, tol=0, maxit=100)
+                v = np.sum(np.maximum(num / (den + sol), eps), axis=0)
+                # a root next to a pole (nu ~ -den_i) is only representable to ulp(nu)/(nu + den_i) in f:
+                # the reference's own test accepts 1e-2 here
+                np.testing.assert_allclose(v, np.ones(p), atol=1e-4)
+                assert np.mean(np.abs(v - 1) < 1e-9) > 0.99
+                np.testing.assert_allclose(sol, oc.dichotomy_simplex(num, den, eps, tol=0, maxit=100), rtol=1e-5,
+                                           atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------ H step
+def test_step_h_golden_grid(api, golden):
+    g = golden("f2_step_h")
+    nx, ny = g["shape_2d"]
+    L = api["utils"].create_laplacian_matrix(nx, ny)
+    for c in range(int(g["n_cases"])):
+        t, simplex, lam, mu_on, fix_on = g[f"c{c}_cfg"]
+        t = int(t)
+        Hn = api["step_h"](g[f"in{t}_X"], g[f"in{t}_G"], g[f"in{t}_W"], g[f"in{t}_H"].copy(), simplex_H=bool(simplex),
+                           mu=g["mu_vec"] if mu_on else 0, epsilon_reg=float(g["epsilon_reg"]), lambda_L=float(lam),
+                           L=L, fixed_H=g[f"in{t}_fixed"] if fix_on else None)
+        # the reference's own multiplier is only converged to dicotomy_tol = 1e-5 (global stop rule)
+        tol = dict(rtol=3e-5, atol=3e-6) if simplex else F32
+        np.testing.assert_allclose(Hn, g[f"c{c}_H"], err_msg=f"case {c}", **tol)
+
+
+def test_step_h_golden_special(api, golden):
+    g = golden("f2_step_h")
+    nx, ny = g["shape_2d"]
+    L = api["utils"].create_laplacian_matrix(nx, ny)
+    for t in (0, 1):
+        X, G, W, H = (g[f"in{t}_{s}"] for s in ("X", "G", "W", "H"))
+        np.testing.assert_allclose(api["step_h"](X, G, W, H.copy(), simplex_H=True, mu=0.4, lambda_L=0.5, L=L, sigmaL=11.0),
+                                   g[f"smu_{t}_H"], rtol=3e-5, atol=3e-6)
+        np.testing.assert_allclose(api["step_h"](X, G, W, H.copy(), simplex_H=True, lambda_L=1.5,
+                                                 L=api["utils"].identity_laplacian(nx * ny)), g[f"lid_{t}_H"],
+                                   rtol=3e-5, atol=3e-6)
+    with pytest.raises(ValueError):
+        api["step_h"](X, G, W, H, lambda_L=1.0, L=None)
+    with pytest.raises(NotImplementedError):
+        api["step_h"](X, G, W, H, l2=True)
+
+
+def test_step_h_reference_properties(api):
+    """Fixed point, simplex, positivity, monotone decrease (espm/tests/test_updates.py:484-552)."""
+    rng = np.random.default_rng(2)
+    l, k, p, c = 26, 5, 100, 17
+    A = rng.random((k, p))
+    A = A / A.sum(axis=0, keepdims=True)
+    G, P = rng.random((l, c)), rng.random((c, k))
+    GP = G @ P
+    X = GP @ A
+    Ap = api["step_h"](X, G, P, A, simplex_H=False, mu=0, log_shift=0, epsilon_reg=1, safe=True)
+    np.testing.assert_allclose(A, Ap, atol=5e-6)
+    Ap = api["step_h"](X, G, P, A, simplex_H=True, mu=0, log_shift=0, epsilon_reg=1, safe=True)
+    np.testing.assert_allclose(A, Ap, atol=oc.DICOTOMY_TOL)
+    for _ in range(4):
+        A0 = rng.random((k, p))
+        A0 = A0 / A0.sum(axis=1, keepdims=True)
+        Ap = api["step_h"](X, G, P, A0, simplex_H=False, mu=0, log_shift=0)
+        assert (Ap > 0).all() and oc.KLdiv_loss(X, GP, A0) > oc.KLdiv_loss(X, GP, Ap)
+        mu = np.ones(k)
+        mu[0] = 0
+        Ap = api["step_h"](X, G, P, A0, simplex_H=True, mu=3 * mu, epsilon_reg=1)
+        np.testing.assert_allclose(Ap.sum(axis=0), np.ones(p), atol=oc.DICOTOMY_TOL)
+        np.testing.assert_allclose(Ap, oc.multiplicative_step_h(X, G, P, A0, simplex_H=True, mu=3 * mu), rtol=3e-5, atol=3e-6)
+        assert oc.KLdiv_loss(X, GP, A0) + oc.log_reg(A0, 3 * mu, 1) > oc.KLdiv_loss(X, GP, Ap) + oc.log_reg(A0, 3 * mu, 1)
+
+
+# ------------------------------------------------------------------------------------ W step
+def test_step_w_golden(api, golden):
+    g = golden("f3_step_w")
+    for c in range(int(g["n_cases"])):
+        t, simplex, fix_on = g[f"c{c}_cfg"]
+        X, G, W, H, fixed = (g[f"in{t}_{s}"] for s in ("X", "G", "W", "H", "fixed"))
+        Wn = api["step_w"](X, G, W.copy(), H, simplex_W=bool(simplex), fixed_W=fixed if fix_on else None)
+        np.testing.assert_allclose(Wn, g[f"c{c}_W"], rtol=3e-5, atol=1e-7, err_msg=f"case {c}")
+
+
+def test_step_w_reference_properties(api):
+    """espm/tests/test_updates.py:439-470."""
+    rng = np.random.default_rng(3)
+    l, k, p, c = 26, 5, 100, 17
+    A = rng.random((k, p))
+    A = A / A.sum(axis=1, keepdims=True)
+    G, P = rng.random((l, c)), rng.random((c, k))
+    X = G @ P @ A
+    np.testing.assert_allclose(api["step_w"](X, G, P, A, log_shift=0, simplex_W=False), P, atol=5e-6)
+    for _ in range(4):
+        P0 = rng.random((c, k))
+        Pp = api["step_w"](X, G, P0, A, simplex_W=False)
+        np.testing.assert_allclose(Pp, oc.multiplicative_step_w(X, G, P0, A), rtol=2e-5, atol=1e-7)
+        assert (Pp > 0).all() and oc.KLdiv_loss(X, G @ P0, A) > oc.KLdiv_loss(X, G @ Pp, A)
+
+
+# ------------------------------------------------------------------------------------ operators / losses
+def test_laplacian_stencil(api, golden):
+    g = golden("f4_laplacian")
+    import torch
+    from espm_amd import _lib
+    from espm_amd.engine import _ptr, _stream
+    for i, (nx, ny) in enumerate(g["shapes"]):
+        H = g[f"s{i}_H"]
+        h = torch.from_numpy(H.astype(np.float32)).cuda()
+        out = torch.empty_like(h)
+        _lib.check(_lib.lib.espm_mu_laplacian(_ptr(h), H.shape[0], int(nx), int(ny), H.shape[1], _ptr(out), _stream()))
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"s{i}_HL"], rtol=1e-5, atol=2e-6)
+        L = api["utils"].create_laplacian_matrix(nx, ny)
+        np.testing.assert_allclose(api["measures"].trace_xtLx(L, H.T), g[f"s{i}_trace"], rtol=1e-5)
+        if f"s{i}_dense" in g:
+            np.testing.assert_array_equal(np.asarray(L.todense()), g[f"s{i}_dense"])
+    L = api["utils"].create_laplacian_matrix(4, 6)  # espm/tests/test_measures.py:212-221
+    x = np.ones((4, 6))
+    assert api["measures"].trace_xtLx(L, x.ravel()) == 0
+    x[2, 3] = 2
+    np.testing.assert_allclose(api["measures"].trace_xtLx(L, x.ravel()), 4)
+
+
+def test_losses_golden(api, golden):
+    g = golden("f5_losses")
+    X, W, H, mu = g["X"], g["W"], g["H"], g["mu"]
+    m = api["measures"]
+    np.testing.assert_allclose(m.KLdiv_loss(X, W, H), g["KLdiv_loss"], rtol=2e-6)
+    np.testing.assert_allclose(m.KLdiv_loss(X, W, H, average=True), g["KLdiv_loss_avg"], rtol=2e-6)
+    np.testing.assert_allclose(m.log_reg(H, mu, 0.8), g["log_reg"], rtol=1e-10)
+    np.testing.assert_allclose(m.log_reg(H, 0.3, 1), g["log_reg_scalar"], rtol=1e-10)
+
+
+def test_initialize_algorithms_golden(api, golden):
+    g = golden("f7_init")
+    X, G = g["X"], g["G"]
+    for init in (None, "random", "nndsvd"):
+        for use_G in (False, True):
+            for simplex_H in (False, True):
+                _, W, H = api["init"](X, G if use_G else None, None, None, 3, init, 0, simplex_H, not simplex_H)
+                tag = f"{init}_{int(use_G)}_{int(simplex_H)}"
+                np.testing.assert_allclose(W, g[f"{tag}_W"], rtol=1e-9, atol=1e-14, err_msg=tag)
+                np.testing.assert_allclose(H, g[f"{tag}_H"], rtol=1e-9, atol=1e-14, err_msg=tag)
