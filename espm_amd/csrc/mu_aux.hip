@@ -101,15 +101,15 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
                                                         double* __restrict__ nu_out, int32_t* __restrict__ status) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p) return;
-  // generic-k variant of simplex_root (k is a run-time value here)
-  double a = -INFINITY, nmax = 0, dmin = INFINITY, nsum = 0;
+  // run-time-k variant of simplex_root (mu_common.hpp): shifted unknown delta = nu + d*
+  double nmax = 0, dmin_all = INFINITY, dstar = INFINITY, nsum = 0;
   bool ok = true;
   for (int i = 0; i < k; ++i) {
     const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
     ok = ok && nn >= 0 && dd >= 0;
-    if (nn > 0) a = fmax(a, nn / 2 - dd);
+    if (nn > 0) dstar = fmin(dstar, dd);
     nmax = fmax(nmax, nn);
-    dmin = fmin(dmin, dd);
+    dmin_all = fmin(dmin_all, dd);
     nsum += nn;
   }
   if (!ok || !(nsum > 0)) {
@@ -117,12 +117,17 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
     nu_out[j] = NAN;
     return;
   }
-  double lo = a, hi = 2.0 * k * nmax - dmin, x = a, dxold = hi - lo;
+  double lo = 0;
+  for (int i = 0; i < k; ++i) {
+    const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
+    if (nn > 0) lo = fmax(lo, nn / 2 - (dd - dstar));
+  }
+  double hi = 2.0 * k * nmax - dmin_all + dstar, x = lo, dxold = hi - lo;
   for (int it = 0; it < maxit; ++it) {
     double f = -1, fp = 0;
     for (int i = 0; i < k; ++i) {
       const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
-      const double inv = 1.0 / (x + dd);
+      const double inv = 1.0 / (x + (dd - dstar));
       const double t = nn > 0 ? nn * inv : 0.0;
       if (t > eps) {
         f += t;
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
     if (xn == x) break;
     x = xn;
   }
+  x -= dstar;
   nu_out[j] = x;
 }
 

@@ -130,9 +130,16 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
 
 // ---- per-column simplex multiplier ----------------------------------------------------------
 // Root of f(nu) = sum_i max(num_i / (nu + den_i), eps) - 1 inside the reference's bracket
-// (espm/estimators/dicotomy.py:29-49).  f is convex and decreasing to the right of its last
-// pole, so Newton from the left end converges monotonically; every iterate is kept inside the
-// running bisection bracket, and a plain bisection step is taken whenever Newton leaves it.
+// (espm/estimators/dicotomy.py:29-49).
+//
+// The unknown is re-parametrised as delta = nu + d*, d* = min{den_i : num_i > 0} (the last pole of
+// f sits at nu = -d*), and the shifted denominators e_i = den_i - d* >= 0 are formed once.  When the
+// simplex forces mass onto a component whose numerator is tiny (e.g. an NNDSVD zero clamped to
+// 1e-14) the root lies within ~num_i of that pole: delta ~ 1e-14 is then an ordinary fp32 number,
+// whereas nu = -d* + 1e-14 is not representable (the reference resolves it only to ulp(d*) in fp64).
+// f is convex and decreasing for delta > 0, so Newton from the left end converges monotonically;
+// iterates stay inside the running bracket and fall back to bisection when Newton leaves it or
+// stops halving its step.  Outputs delta and e[]: the update is num_i / (delta + e_i).
 // Returns false when the reference's preconditions (dicotomy.py:17-19) do not hold.
 template <typename T>
 __device__ __forceinline__ T fast_rcp(T x);
@@ -143,32 +150,40 @@ __device__ __forceinline__ double fast_rcp<double>(double x) { return 1.0 / x; }
 
 template <typename T, int K>
 __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K], int k, T eps, T tol,
-                                             int maxit, T& nu) {
-  T a = -INFINITY, nmax = 0, dmin = INFINITY, nsum = 0;
+                                             int maxit, T& delta, T (&e)[K]) {
+  T nmax = 0, dmin_all = INFINITY, dstar = INFINITY, nsum = 0;
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     if (i < k) {
       ok = ok && (num[i] >= 0) && (den[i] >= 0);
-      if (num[i] > 0) a = fmax(a, num[i] / 2 - den[i]);
+      if (num[i] > 0) dstar = fmin(dstar, den[i]);
       nmax = fmax(nmax, num[i]);
-      dmin = fmin(dmin, den[i]);
+      dmin_all = fmin(dmin_all, den[i]);
       nsum += num[i];
     }
   }
   ok = ok && (nsum > 0) && (nsum < (T)INFINITY);
   if (!ok) {
-    nu = 0;
+    delta = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) e[i] = i < k ? den[i] : (T)1;
     return false;
   }
-  T lo = a, hi = (T)(2 * k) * nmax - dmin, x = a;
-  T dxold = hi - lo;
+  T lo = 0;  // = max_i (num_i / 2 - den_i) + d*   (dicotomy.py:29-43)
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    e[i] = i < k ? den[i] - dstar : (T)1;
+    if (i < k && num[i] > 0) lo = fmax(lo, num[i] / 2 - e[i]);
+  }
+  T hi = (T)(2 * k) * nmax - dmin_all + dstar;  // dicotomy.py:49
+  T x = lo, dxold = hi - lo;
   for (int it = 0; it < maxit; ++it) {
     T f = -1, fp = 0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       if (i < k) {
-        T inv = fast_rcp<T>(x + den[i]);
+        T inv = fast_rcp<T>(x + e[i]);
         T t = num[i] > 0 ? num[i] * inv : (T)0;
         if (t > eps) {
           f += t;
@@ -191,7 +206,7 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     if (xn == x) break;
     x = xn;
   }
-  nu = x;
+  delta = x;
   return true;
 }
 

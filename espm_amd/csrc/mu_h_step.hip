@@ -138,16 +138,18 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
     if (!a.write_h) continue;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
-    float nu = 0.f;
     if (a.simplex_h) {
-      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, nu)) red[ESPM_HP_BAD] += 1.0;
+      float delta, e[K];
+      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
     }
     float ht[KP];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
-      float hn = fmaxf(nv[kk] / (dv[kk] + nu), a.log_shift);   // updates.py:152
+      float hn = fmaxf(nv[kk] / dv[kk], a.log_shift);   // updates.py:152
       if (a.fixed_h) {
         const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
         if (f >= 0.f) hn = f;                                   // updates.py:154-155

@@ -216,10 +216,10 @@ class MUEngine:
 
         # ---- sharding -----------------------------------------------------------------------------------
         if self.world > 1:
-            self.rec_bytes = int(lib.espm_mu_shard_record_bytes(C.byref(st)))
-            self.rec_send = torch.zeros(self.rec_bytes, dtype=torch.uint8, device=dev)
-            self.rec_all = torch.zeros(self.world * self.rec_bytes, dtype=torch.uint8, device=dev)
-            self.with_halo = bool(st.grid_mode and self.lambda_L != 0.0)
+            from .sharding import ShardExchange
+            self.exchange = ShardExchange(group, k, st.n_pad, st.ny, bool(st.grid_mode and self.lambda_L != 0.0), dev)
+            if self.exchange.layout.nbytes != int(lib.espm_mu_shard_record_bytes(C.byref(st))):
+                raise RuntimeError("record layout of espm_amd.sharding and libespm_mu disagree")
 
     # ------------------------------------------------------------------------------------------------
     def _pad_h(self, H):
@@ -267,20 +267,15 @@ class MUEngine:
         torch.distributed.all_reduce(hs[_lib.HS_MAX:], op=torch.distributed.ReduceOp.MAX, group=self.group)
 
     def _set_halo_from_records(self):
-        st, rb = self.st, self.rec_bytes
-        if not self.with_halo:
-            st.halo_top = st.halo_bot = None
-            return
-        off = self.k * st.n_pad * 4 + _lib.HS_STRIDE * 8
-        base = self.rec_all.data_ptr()
-        row = self.k * st.ny * 4
-        st.halo_top = (base + (self.rank - 1) * rb + off + row) if self.rank > 0 else None
-        st.halo_bot = (base + (self.rank + 1) * rb + off) if self.rank < self.world - 1 else None
+        top, bot = self.exchange.halo_offsets()
+        base = self.exchange.recv.data_ptr()
+        self.st.halo_top = base + top if top is not None else None
+        self.st.halo_bot = base + bot if bot is not None else None
 
     def _exchange_halo_only(self, which):
         """Boundary rows of h[which] to the neighbours (initial state only)."""
-        check(lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.rec_send), _stream()))
-        torch.distributed.all_gather_into_tensor(self.rec_all, self.rec_send, group=self.group)
+        check(lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.exchange.send), _stream()))
+        self.exchange.gather()
         self._set_halo_from_records()
 
     # ---- one iteration, granular (stop criteria / sharded) ---------------------------------------------
@@ -304,9 +299,9 @@ class MUEngine:
         check(lib.espm_mu_w_accum(C.byref(st), s))
         check(lib.espm_mu_w_reduce(C.byref(st), s))
         if self.world > 1:
-            check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.rec_send), s))
-            torch.distributed.all_gather_into_tensor(self.rec_all, self.rec_send, group=self.group)
-            check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.rec_all), self.world, 1 - cur, s))
+            check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
+            self.exchange.gather()
+            check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.exchange.recv), self.world, 1 - cur, s))
             self._set_halo_from_records()
         check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, s))
         check(lib.espm_mu_rel_h(C.byref(st), cur, slot + 1, s))

@@ -90,6 +90,37 @@ def dichotomy_simplex(num, denum, log_shift=LOG_SHIFT, tol=DICOTOMY_TOL, maxit=M
     return (nu, sweeps) if return_sweeps else nu
 
 
+def dichotomy_simplex_exact(num, den, log_shift=LOG_SHIFT, sweeps=200):
+    """The same root, converged and well conditioned (NOT the reference's arithmetic).
+
+    The reference bisects on nu itself; when the simplex pushes mass onto a component whose
+    numerator is tiny (an NNDSVD zero clamped to 1e-14) the root sits ~1e-11 to the right of the
+    pole nu = -den_i and fp64 resolves nu + den_i only to ulp(den_i): the reference's column sums
+    are then off by up to ~1e-2 (measured 5e-3 on tests/golden/f8_api norm_X).  Here the unknown is
+    delta = nu + min{den_i : num_i > 0}, which has full relative precision.  Used by the GPU tests as
+    the yardstick in exactly those cases.  Returns (delta, shifted denominators e) with
+    update = num / (delta + e)."""
+    num = np.asarray(num, dtype=np.float64)
+    den = np.broadcast_to(np.asarray(den, dtype=np.float64), num.shape)
+    k = num.shape[0]
+    dstar = np.where(num > 0, den, np.inf).min(axis=0)
+    e = den - dstar
+    lo = np.where(num > 0, num / 2 - e, -np.inf).max(axis=0)
+    hi = 2 * k * num.max(axis=0) - den.min(axis=0) + dstar
+
+    def f(x):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(num > 0, num / (x + e), 0.0)
+        return np.maximum(t, log_shift).sum(axis=0) - 1
+
+    for _ in range(sweeps):
+        mid = (lo + hi) / 2
+        pos = f(mid) > 0
+        lo = np.where(pos, mid, lo)
+        hi = np.where(pos, hi, mid)
+    return (lo + hi) / 2, e
+
+
 # --------------------------------------------------------------------------------------
 # Laplacian  (espm/utils.py:39-76)
 # --------------------------------------------------------------------------------------
@@ -136,8 +167,10 @@ def identity_L(p):
 # --------------------------------------------------------------------------------------
 def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT, epsilon_reg=1,
                           safe=True, dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, l2=False,
-                          sigmaL=SIGMA_L, fixed_H=None):
-    """One multiplicative H update, updates.py:83-156 (KL branch :127-132, l2 branch :109-118)."""
+                          sigmaL=SIGMA_L, fixed_H=None, exact_root=False):
+    """One multiplicative H update, updates.py:83-156 (KL branch :127-132, l2 branch :109-118).
+
+    ``exact_root`` swaps the reference's bisection for ``dichotomy_simplex_exact`` (test yardstick)."""
     if lambda_L != 0:
         if L is None:
             raise ValueError("Please provide the laplacian")  # updates.py:94-95
@@ -167,10 +200,15 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT
             num = num + lambda_L * sigmaL * maxH
             den = den + lambda_L * sigmaL * maxH + lambda_L * HL
     num = H * num
-    nu = dichotomy_simplex(num, den, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
     if safe:
         assert (den >= 0).all() and (num >= 0).all()
-    new_H = np.maximum(num / (den + nu), log_shift)
+    if simplex_H and exact_root:
+        delta, e = dichotomy_simplex_exact(num, den, log_shift)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            new_H = np.fmax(num / (delta + e), log_shift)
+    else:
+        nu = dichotomy_simplex(num, den, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
+        new_H = np.maximum(num / (den + nu), log_shift)
     if fixed_H is not None:
         keep = fixed_H >= 0
         new_H[keep] = fixed_H[keep]
@@ -325,7 +363,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         simplex_H=False, simplex_W=True, shape_2d=None, tol=1e-4, max_iter=200, init=None,
         random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
         gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
-        record_at=(), time_iterations=False):
+        record_at=(), time_iterations=False, exact_root=False):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
     SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", no linesearch).
 
@@ -358,7 +396,8 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         old_W, old_H = W_.copy(), H_.copy()
         H_ = multiplicative_step_h(X_, G_, W_, H_, simplex_H=simplex_H, mu=mu, log_shift=log_shift,
                                    epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
-                                   lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_)
+                                   lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
+                                   exact_root=exact_root)
         W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
                                    simplex_W=simplex_W, fixed_W=fixed_W)
         eval_after, det = loss(W_, H_)

@@ -1,0 +1,170 @@
+"""CPU-only checks: the C ABI loads and exports what include/espm_mu.h declares, ctypes mirrors the
+header, the host-side estimator logic (parameter coercions, API surface) matches the golden
+captures, and the product refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import mu_oracle as oc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "espm_mu.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from espm_amd import _lib
+    return _lib
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(espm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    cdll = C.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(cdll, name), f"{name} declared in espm_mu.h but not exported"
+        assert name in lib.SYMBOLS, f"{name} has no ctypes prototype in espm_amd/_lib.py"
+    assert sorted(lib.SYMBOLS) == declared
+    assert b"gfx950" in lib.lib.espm_mu_version()
+
+
+def test_header_constants_and_struct_match_ctypes(lib):
+    text = open(HEADER).read()
+    defs = dict(re.findall(r"#define\s+(ESPM_[A-Z_]+)\s+(-?\d+)", text))
+    for name, val in (("MAX_K", lib.MAX_K), ("KP", lib.KP), ("PPAD", lib.PPAD), ("NPAD", lib.NPAD),
+                      ("HP_STRIDE", lib.HP_STRIDE), ("HS_STRIDE", lib.HS_STRIDE), ("HI_STRIDE", lib.HI_STRIDE),
+                      ("HS_MAX", lib.HS_MAX), ("HI_KLX", lib.HI_KLX), ("HI_REG", lib.HI_REG), ("HI_LAP", lib.HI_LAP),
+                      ("HI_SUMY", lib.HI_SUMY), ("HI_BAD", lib.HI_BAD), ("HI_REL_W", lib.HI_REL_W),
+                      ("HI_REL_H", lib.HI_REL_H)):
+        assert int(defs["ESPM_" + name]) == val, name
+    body = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct espm_mu_state {"):text.index("} espm_mu_state;")], flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:\[\d+\])?\s*$", part.strip())[0])
+    assert names == [f[0] for f in lib.MUState._fields_]
+
+
+def test_query_layout_without_gpu(lib):
+    st = lib.MUState()
+    st.n, st.p, st.k, st.x_dtype = 2048, 512 * 512, 5, lib.X_BF16
+    assert lib.lib.espm_mu_query(C.byref(st)) == 0
+    assert (st.n_pad, st.p_pad, st.tile_px) == (2048, 262144, 512)
+    st.n, st.p = 1980, 128 * 128
+    assert lib.lib.espm_mu_query(C.byref(st)) == 0
+    assert st.n_pad == 1984 and st.p_pad == 16384 and st.tile_px == 128 and st.nblk_w >= 1
+    st.n = 0
+    assert lib.lib.espm_mu_query(C.byref(st)) == lib.EINVAL and b"must be >= 1" in lib.lib.espm_mu_last_error()
+
+
+def test_argument_errors_map_to_reference_exceptions(lib):
+    with pytest.raises(ValueError):     # dicotomy.py:22-23
+        lib.check(lib.lib.espm_dichotomy_simplex(None, None, 3, 4, 4, 0.5, 1e-5, 100, None, None, None))
+    st = lib.MUState()
+    st.n, st.p, st.k, st.x_dtype = 8, 8, 9, 0
+    lib.lib.espm_mu_query(C.byref(st))
+    st.xscale = 1.0
+    with pytest.raises(NotImplementedError):  # k > ESPM_MAX_K is refused, never silently degraded
+        lib.check(lib.lib.espm_mu_step_h(C.byref(st), 0, 1, None))
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from espm_amd.estimators import SmoothNMF
+    from espm_amd.estimators.updates import multiplicative_step_h
+    X = np.random.default_rng(0).random((6, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SmoothNMF(n_components=2, verbose=0).fit(X)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        multiplicative_step_h(X, np.eye(6), np.ones((6, 2)), np.ones((2, 8)))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "espm_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_estimator_params_and_coercions(golden, capsys):
+    from espm_amd.estimators import NMFEstimator, SmoothNMF
+    g = golden("f8_api")
+    est = SmoothNMF()
+    ours = {k: (v if isinstance(v, (int, float, str, bool, type(None))) else repr(v)) for k, v in est.get_params().items()}
+    assert ours == json.loads(str(g["default_params"]))
+    e2 = SmoothNMF(simplex_H=True, simplex_W=True, l2=True, lambda_L=-1, algo="nope", epsilon_reg=0)
+    assert dict(simplex_H=e2.simplex_H, simplex_W=e2.simplex_W, l2=e2.l2, lambda_L=e2.lambda_L, algo=e2.algo,
+                epsilon_reg=e2.epsilon_reg) == json.loads(str(g["coerced"]))
+    e3 = SmoothNMF(linesearch=True, lambda_L=0.0)
+    assert dict(lambda_L=e3.lambda_L, linesearch=e3.linesearch) == json.loads(str(g["coerced_linesearch"]))
+    assert "simplex constraint is applied to W and not to H" in capsys.readouterr().out
+    assert issubclass(SmoothNMF, NMFEstimator)
+    assert SmoothNMF.loss_names_ == ["KL_div_loss", "log_reg_loss", "Lapl_reg_loss", "gamma"]
+    from sklearn.base import clone
+    c = clone(SmoothNMF(n_components=4, lambda_L=2.0, mu=np.array([0.0, 1.0])))
+    assert c.n_components == 4 and c.lambda_L == 2.0
+
+
+def test_host_helpers_match_reference(golden):
+    from espm_amd import utils
+    from espm_amd.estimators.base import normalization_factor
+    from espm_amd.estimators.updates import initialize_algorithms
+    g4 = golden("f4_laplacian")
+    for i, (nx, ny) in enumerate(g4["shapes"]):
+        L = utils.create_laplacian_matrix(nx, ny)
+        np.testing.assert_allclose(g4[f"s{i}_H"] @ L, g4[f"s{i}_HL"], rtol=1e-12, atol=1e-14)
+        assert utils.classify_laplacian(L, nx * ny) == ("grid", (nx, ny))
+    assert utils.classify_laplacian(utils.identity_laplacian(12), 12) == ("identity", None)
+    with pytest.raises(NotImplementedError):
+        utils.classify_laplacian(2 * utils.create_laplacian_matrix(3, 4), 12)
+    g7 = golden("f7_init")
+    _, W, H = initialize_algorithms(g7["X"], g7["G"], None, None, 3, "nndsvd", 0, True, False)
+    np.testing.assert_allclose(W, g7["nndsvd_1_1_W"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(H, g7["nndsvd_1_1_H"], rtol=1e-9, atol=1e-14)
+    D, Hr = utils.rescaled_DH(g7["G"] @ g7["Wgiven_W0"] * 3.0, g7["Hgiven_H0"] / 3.0)
+    np.testing.assert_allclose(D, g7["rescaled_D"], rtol=1e-10)
+    np.testing.assert_allclose(Hr, g7["rescaled_H"], rtol=1e-10)
+    g8 = golden("f8_api")
+    np.testing.assert_allclose(normalization_factor(g8["norm_X"], 5), g8["norm_factor"], rtol=1e-12)
+
+
+def test_reference_loses_the_simplex_next_to_a_pole(golden):
+    """Documents why the HIP path solves for nu + den_min: from an NNDSVD start (zeros clamped to 1e-14) the
+    reference's first H update misses the simplex by 5e-3, the re-parametrised root by 1e-15."""
+    X = golden("f8_api")["norm_X"]
+    G, W0, H0 = oc.initialize_algorithms(X, None, None, None, 5, "nndsvd", 0, True, False)
+    ref = oc.multiplicative_step_h(X, G, W0, H0, simplex_H=True)
+    exact = oc.multiplicative_step_h(X, G, W0, H0, simplex_H=True, exact_root=True)
+    assert np.abs(ref.sum(axis=0) - 1).max() > 1e-3
+    assert np.abs(exact.sum(axis=0) - 1).max() < 1e-12
+    ok = np.abs(ref.sum(axis=0) - 1) < 1e-4      # columns where the reference is well conditioned agree
+    np.testing.assert_allclose(ref[:, ok], exact[:, ok], atol=2e-5)
+
+
+def test_synthetic_generator_is_sharding_consistent():
+    from espm_amd import synth
+    full = synth.make_problem(32, 8, 6, 3, N=50.0, seed=1)
+    part = synth.make_problem(32, 4, 6, 3, N=50.0, seed=1, row0=4, nx_total=8)
+    np.testing.assert_allclose(part["weights"], full["weights"][4 * 6:], rtol=1e-12)
+    np.testing.assert_allclose(full["weights"].sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(full["phases"].sum(axis=1), 1.0, rtol=1e-12)
+    X = synth.sample_numpy(full, seed=0)
+    assert X.shape == (32, 48) and (X >= 0).all() and X.sum() > 0

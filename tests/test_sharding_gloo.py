@@ -1,0 +1,164 @@
+"""world_size > 1 on CPU (gloo): the pixel-row sharding protocol of espm_amd.sharding.
+
+Each rank owns a block of image rows and runs the per-iteration protocol with the SAME ShardExchange
+object the GPU engine uses (record layout, one all-gather per iteration, fixed-order combine,
+neighbour halo offsets); the local arithmetic that the HIP kernels do on the GPU box is done here with
+the numpy oracle.  The sharded result must equal the single-process fit.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from espm_amd import sharding
+from oracle import mu_oracle as oc
+
+N, NX, NY, K, ITERS = 24, 9, 5, 3, 6
+LAM, MU, EPS = 1.5, 0.3, 1e-14
+
+
+def _problem():
+    rng = np.random.default_rng(11)
+    p = NX * NY
+    H = rng.random((K, p)) ** 2 + 0.05
+    H /= H.sum(axis=0, keepdims=True)
+    W = rng.random((N, K)) * 3 + 0.01
+    X = rng.poisson(W @ H * 4).astype(np.float64)
+    W0 = rng.random((N, K)) * 2 + 0.1
+    H0 = rng.random((K, p)) + 0.05
+    H0 /= H0.sum(axis=0, keepdims=True)
+    return X, W0, H0
+
+
+def _stencil_with_halo(H, nx, ny, top, bot):
+    """(H L) on a row block: rows above/below come from the neighbours' records (None = image edge)."""
+    k = H.shape[0]
+    img = H.reshape(k, nx, ny)
+    out = np.zeros_like(img)
+    out[:, 1:, :] += img[:, 1:, :] - img[:, :-1, :]
+    out[:, :-1, :] += img[:, :-1, :] - img[:, 1:, :]
+    if top is not None:
+        out[:, 0, :] += img[:, 0, :] - top
+    if bot is not None:
+        out[:, -1, :] += img[:, -1, :] - bot
+    out[:, :, 1:] += img[:, :, 1:] - img[:, :, :-1]
+    out[:, :, :-1] += img[:, :, :-1] - img[:, :, 1:]
+    return out.reshape(k, nx * ny)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, W, H0 = _problem()
+        row0, rows = sharding.split_rows(NX, world, rank)
+        sl = slice(row0 * NY, (row0 + rows) * NY)
+        Xl, H = X[:, sl], H0[:, sl].copy()
+        n_pad = (N + 7) // 8 * 8
+        ex = sharding.ShardExchange(dist.group.WORLD, K, n_pad, NY, True, "cpu")
+        lay = ex.layout
+
+        def pack(A, Hnew):
+            a, hs, top, bot = ex.record_views(ex.send)
+            a.zero_()
+            a.view(K, n_pad)[:, :N] = torch.from_numpy(A.T.astype(np.float32))      # (k, n_pad) like a_slab
+            hs.zero_()
+            hs[:K] = torch.from_numpy(Hnew.sum(axis=1))
+            hs[8:8 + K] = torch.from_numpy(Hnew.max(axis=1))
+            img = Hnew.reshape(K, rows, NY)
+            top.copy_(torch.from_numpy(img[:, 0].astype(np.float32)))
+            bot.copy_(torch.from_numpy(img[:, -1].astype(np.float32)))
+
+        def combine():
+            A = np.zeros((K, n_pad), np.float32)
+            hs = np.zeros(16)
+            for r in range(world):                                                   # fixed rank order
+                a, s, _, _ = ex.record_views(ex.recv, r)
+                A = A + a.view(K, n_pad).numpy()
+                hs[:8] += s[:8].numpy()
+                hs[8:] = np.maximum(hs[8:], s[8:].numpy())
+            return A[:, :N].T.astype(np.float64), hs
+
+        def halos():
+            t, b = ex.halo_offsets()
+            row = K * NY * 4
+            get = lambda o: ex.recv[o:o + row].view(torch.float32).view(K, NY).numpy().astype(np.float64)  # noqa: E731
+            return (get(t) if t is not None else None), (get(b) if b is not None else None)
+
+        # initial state: global statistics of H0 and the halo rows
+        pack(np.zeros((N, K)), H)
+        ex.gather()
+        _, hs = combine()
+        top, bot = halos()
+        G = np.eye(N)
+        for _ in range(ITERS):
+            GW = G @ W
+            Y = GW @ H
+            num = GW.T @ (Xl / Y)
+            den = GW.sum(axis=0)[:, None] + MU / (H + 1.0)
+            maxH = hs[8:8 + K][:, None]                                              # GLOBAL (updates.py:139)
+            HL = _stencil_with_halo(H, rows, NY, top, bot)
+            num = num + LAM * 8 * maxH
+            den = den + LAM * 8 * maxH + LAM * HL
+            num = H * num
+            delta, e = oc.dichotomy_simplex_exact(num, den, EPS)
+            Hn = np.fmax(num / (delta + e), EPS)
+            A = (Xl / (GW @ Hn)) @ Hn.T                                              # local R H^T
+            pack(A, Hn)
+            ex.gather()                                                              # ONE collective / iteration
+            Ag, hs = combine()
+            W = np.maximum(W * (G.T @ Ag) / (G.sum(axis=0)[:, None] @ hs[:K][None, :]), EPS)
+            top, bot = halos()
+            H = Hn
+        out[rank] = (W, H, lay.nbytes)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_protocol_equals_single_process(world):
+    X, W0, H0 = _problem()
+    ref = oc.fit(X, K, W=W0.copy(), H=H0.copy(), lambda_L=LAM, mu=MU, simplex_H=True, simplex_W=False,
+                 shape_2d=(NX, NY), tol=0, no_stop_criterion=True, max_iter=ITERS, exact_root=True)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    Ws = [res[r][0] for r in range(world)]
+    for Wr in Ws[1:]:
+        np.testing.assert_array_equal(Wr, Ws[0])           # replicated W is bit-identical on all ranks
+    H = np.concatenate([res[r][1] for r in range(world)], axis=1)
+    # records carry fp32 (like the device path): agreement to fp32 rounding
+    np.testing.assert_allclose(Ws[0], ref["W"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(H, ref["H"], rtol=2e-5, atol=1e-7)
+
+
+def test_record_layout_matches_the_library():
+    import __graft_entry__ as ge
+    ge.build()
+    from espm_amd import _lib
+    for n, k, ny, p in ((2048, 5, 512, 512 * 64), (1980, 8, 1024, 1024 * 128), (100, 3, 20, 400), (7, 1, 0, 1)):
+        st = _lib.MUState()
+        st.n, st.p, st.k, st.ny, st.x_dtype = n, p, k, ny, 1
+        assert _lib.lib.espm_mu_query(C.byref(st)) == 0
+        lay = sharding.record_layout(k, st.n_pad, ny)
+        assert lay.nbytes == _lib.lib.espm_mu_shard_record_bytes(C.byref(st))
+        assert lay.off_hstat % 8 == 0 and lay.off_top % 4 == 0 and lay.nbytes % 16 == 0
+
+
+def test_split_rows():
+    assert [sharding.split_rows(512, 8, r) for r in (0, 7)] == [(0, 64), (448, 64)]
+    assert [sharding.split_rows(10, 3, r) for r in range(3)] == [(0, 3), (3, 3), (6, 4)]
+    with pytest.raises(ValueError):
+        sharding.split_rows(2, 4, 0)
