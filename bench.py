@@ -152,7 +152,7 @@ def main():
     bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
     bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
     flops_it = 8.0 * N_CH * K * NX * NY
-    roofline = dict(bound="hbm", kernel="h_step_kernel<5,bf16,8,4,loss>", achieved=bytes_h / t_h_upd / 1e9,
+    roofline = dict(bound="hbm", kernel="h_step_kernel<5,bf16,...,loss>", achieved=bytes_h / t_h_upd / 1e9,
                     peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=None,
                     bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
                     w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),

@@ -22,7 +22,8 @@ X_F32, X_BF16 = 0, 1
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8
-HP_STRIDE, HS_STRIDE, HI_STRIDE = 20, 16, 8
+HP_STRIDE, HS_STRIDE, HI_STRIDE = 24, 16, 8
+WRED_SPLIT = 16
 HS_ROWSUM, HS_MAX = 0, 8
 HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = 0, 1, 2, 3, 4, 5, 6
 
@@ -42,7 +43,7 @@ class MUState(C.Structure):
         ("w", _vp * 2), ("gw_s", _vp), ("colsum_gw", _vp), ("h", _vp * 2), ("h_t", _vp),
         ("mu", _vp), ("fixed_h", _vp), ("fixed_w", _vp), ("simplex_rows", _vp),
         ("halo_top", _vp), ("halo_bot", _vp),
-        ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
+        ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a_part", _vp), ("a", _vp), ("w_scratch", _vp),
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
     ]
 
@@ -61,8 +62,7 @@ SYMBOLS = {
     "espm_mu_loss_only": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_accum": (C.c_int, [_SP, _vp]),
     "espm_mu_w_reduce": (C.c_int, [_SP, _vp]),
-    "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
-    "espm_mu_rel_h": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
+    "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_shard_record_bytes": (C.c_size_t, [_SP]),
     "espm_mu_shard_pack": (C.c_int, [_SP, C.c_int, _vp, _vp]),

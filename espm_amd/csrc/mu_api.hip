@@ -65,9 +65,9 @@ int espm_mu_query(espm_mu_state* st) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
       prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
-  // H-step: the large tile (4 waves, 16-byte loads) needs >= 2 workgroups per CU to fill the
-  // chip; otherwise the 128-pixel tile with 16 waves splitting the channel range.
-  const int big = st->x_dtype == ESPM_X_BF16 ? 512 : 256;
+  // H-step: 256-pixel tiles (4 waves) when that gives >= 2 workgroups per CU, else 128-pixel tiles
+  // with 8 waves splitting the channel range (tuned on MI355X, tools/tune).
+  const int big = 256;
   st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
   const int ychunks = st->x_dtype == ESPM_X_BF16 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
@@ -98,13 +98,14 @@ int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
   return launch_hstat(st->h[which], st->k, st->p, st->p_pad, st->hstat[which], static_cast<hipStream_t>(stream));
 }
 
-static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
+static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w, int combined) {
   WFinishArgs a;
   a.g = st->m > 0 ? st->g : nullptr;
   a.colsum_g = st->colsum_g;
   a.w_old = st->w[src];
   a.w_new = update_w ? st->w[1 - src] : st->w[src];
-  a.a = st->a;
+  a.a = combined ? st->a : st->a_part;
+  a.nsplit = combined ? 1 : ESPM_WRED_SPLIT;
   a.hstat = st->hstat[hsrc];
   a.fixed_w = st->fixed_w;
   a.simplex_rows = st->simplex_rows;
@@ -129,42 +130,14 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
 int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(which == 0 || which == 1, "which must be 0/1");
-  return launch_w_finish(finish_args(st, which, 0, -1, 0), static_cast<hipStream_t>(stream));
+  return launch_w_finish(finish_args(st, which, 0, -1, 0, 1), static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
-  HStepArgs a;
-  a.x_cm = st->x_cm;
-  a.gw_s = st->gw_s;
-  a.colsum_gw = st->colsum_gw;
-  a.h_in = st->h[src];
-  a.h_out = st->h[1 - src];
-  a.h_t = st->h_t;
-  a.mu = st->mu;
-  a.fixed_h = st->fixed_h;
-  a.halo_top = st->grid_mode ? st->halo_top : nullptr;
-  a.halo_bot = st->grid_mode ? st->halo_bot : nullptr;
-  a.hstat_in = st->hstat[src];
-  a.hpart = st->hpart;
-  a.n = st->n;
-  a.k = st->k;
-  a.p = st->p;
-  a.nx = st->nx;
-  a.ny = st->ny;
-  a.p_pad = st->p_pad;
-  a.simplex_h = st->simplex_h;
-  a.grid_mode = st->grid_mode;
-  a.compute_loss = st->compute_loss;
-  a.write_h = write_h;
-  a.lambda_l = st->lambda_l;
-  a.sigma_l = st->sigma_l;
-  a.eps_reg = st->eps_reg;
-  a.log_shift = st->log_shift;
-  a.tol = st->dicotomy_tol;
-  a.xscale = st->xscale;
-  return dispatch_h_step(a, st->x_dtype, st->tile_px, nblk_h(st), static_cast<hipStream_t>(stream));
+  return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->tile_px, nblk_h(st),
+                         static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
@@ -180,6 +153,7 @@ int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t
   a.nblk = nblk_h(st);
   a.k = st->k;
   a.compute_loss = st->compute_loss;
+  a.have_prev = st->it > 0;
   a.xscale = st->xscale;
   return launch_h_finalize(a, static_cast<hipStream_t>(stream));
 }
@@ -195,6 +169,7 @@ static int h_finalize_loss_only(const espm_mu_state* st, int src, int slot, hipS
   a.nblk = nblk_h(st);
   a.k = st->k;
   a.compute_loss = st->compute_loss;
+  a.have_prev = st->it > 0;
   a.xscale = st->xscale;
   return launch_h_finalize(a, stream);
 }
@@ -209,23 +184,15 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(st->nblk_w >= 1, "nblk_w must be >= 1");
-  WAccumArgs a;
-  a.x_pm = st->x_pm;
-  a.gw_s = st->gw_s;
-  a.h_t = st->h_t;
-  a.a_slab = st->a_slab;
-  a.n_pad = st->n_pad;
-  a.p = st->p;
-  a.ppb = (st->p + st->nblk_w - 1) / st->nblk_w;
-  return dispatch_w_accum(a, st->k, st->x_dtype, st->nblk_w, static_cast<hipStream_t>(stream));
+  return dispatch_w_accum(make_w_args(st), st->k, st->x_dtype, st->nblk_w, static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
-  return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, static_cast<hipStream_t>(stream));
+  return launch_w_reduce(st->a_slab, st->a_part, nullptr, st->nblk_w, st->k * st->n_pad, static_cast<hipStream_t>(stream));
 }
 
-int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream) {
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, int combined, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE((src == 0 || src == 1) && (hsrc == 0 || hsrc == 1), "src/hsrc must be 0/1");
   ESPM_REQUIRE(slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
@@ -234,17 +201,7 @@ int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_
     if (!st->simplex_rows && rows * (double)st->log_shift >= 1.0)
       return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
   }
-  return launch_w_finish(finish_args(st, src, hsrc, slot, 1), static_cast<hipStream_t>(stream));
-}
-
-int espm_mu_rel_h(const espm_mu_state* st, int old, int slot, espm_stream_t stream) {
-  if (int rc = check_state(st)) return rc;
-  ESPM_REQUIRE(old == 0 || old == 1, "old must be 0/1");
-  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
-  const int64_t pt = st->p_total > 0 ? st->p_total : st->p;
-  return launch_rel_h(st->h[old], st->h[1 - old], st->hstat[1 - old], st->hist + (size_t)slot * ESPM_HI_STRIDE, st->k,
-                      st->p, st->p_pad, 1.0 / ((double)st->k * (double)pt), st->rel_tol,
-                      static_cast<hipStream_t>(stream));
+  return launch_w_finish(finish_args(st, src, hsrc, slot, 1, combined), static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {
@@ -258,8 +215,7 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
     if ((rc = espm_mu_h_finalize(st, cur, slot, stream))) return rc;
     if ((rc = espm_mu_w_accum(st, stream))) return rc;
     if ((rc = espm_mu_w_reduce(st, stream))) return rc;
-    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, stream))) return rc;
-    if ((rc = espm_mu_rel_h(st, cur, slot + 1, stream))) return rc;
+    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, 0, stream))) return rc;
     st->cur = 1 - cur;
     st->it = slot + 1;
   }
@@ -293,7 +249,7 @@ int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_str
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(record && (hnew == 0 || hnew == 1), "shard_pack: bad arguments");
   const int with_halo = st->grid_mode && st->lambda_l != 0.f;
-  return launch_shard_pack(st->a, st->hstat[hnew], st->h[hnew], st->k, st->n_pad, st->nx, st->ny, st->p_pad,
+  return launch_shard_pack(st->a_part, st->hstat[hnew], st->h[hnew], st->k, st->n_pad, st->nx, st->ny, st->p_pad,
                            with_halo, record, static_cast<hipStream_t>(stream));
 }
 

@@ -70,7 +70,7 @@ int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, in
 // ---- statistics of an H buffer (one workgroup; used at initialisation only) ---------------------
 __global__ __launch_bounds__(1024) void hstat_kernel(const float* __restrict__ h, int k, int p, int p_pad,
                                                      double* __restrict__ out) {
-  __shared__ double scratch[16 * 2];
+  __shared__ double scratch[17 * 2];
   for (int kk = 0; kk < KP; ++kk) {
     double v[2] = {0.0, 0.0};
     if (kk < k) {
@@ -180,7 +180,7 @@ int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* o
 // One record per rank and iteration:  [ A (k*n_pad f32) | hstat of the new H
 // (ESPM_HS_STRIDE f64) | first owned image row of the new H (k*ny f32) | last owned row (k*ny f32) ].
 // The A block starts the record, the f64 block is 8-byte aligned because k*n_pad is a multiple of 8.
-__global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict__ a, const double* __restrict__ hstat,
+__global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict__ a /* (SPLIT, k, n_pad) partials */, const double* __restrict__ hstat,
                                                          const float* __restrict__ h_new, int k, int n_pad, int nx,
                                                          int ny, int p_pad, int with_halo, unsigned char* rec) {
   const int na = k * n_pad;
@@ -189,7 +189,12 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict
   float* rt = reinterpret_cast<float*>(rec + (size_t)na * 4 + ESPM_HS_STRIDE * 8);
   float* rb = rt + (size_t)k * ny;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-  for (int e = tid; e < na; e += nt) ra[e] = a[e];
+  for (int e = tid; e < na; e += nt) {  // second stage of the slab reduction, fixed order
+    float acc = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) acc += a[(size_t)sp * na + e];
+    ra[e] = acc;
+  }
   for (int e = tid; e < ESPM_HS_STRIDE; e += nt) rs[e] = hstat[e];
   if (with_halo) {
     for (int e = tid; e < k * ny; e += nt) {

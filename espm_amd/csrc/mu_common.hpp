@@ -104,8 +104,9 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
-// Block-wide reduction of NV doubles (sum for the first NSUM, max for the rest).  `scratch`
-// holds at least (blockDim.x / 64) * NV doubles.  Result valid in thread 0.
+// Block-wide reduction of NV doubles (sum for the first NSUM, max for the rest).  `scratch` holds at
+// least (blockDim.x / 64 + 1) * NV doubles.  Result valid in thread 0.  Stage 1: shuffles inside each
+// wave; stage 2: thread i < NV combines value i over the waves (in wave order - deterministic).
 template <int NV, int NSUM>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -116,14 +117,19 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
     for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = v[i];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    double acc = scratch[i];
     for (int w = 1; w < nw; ++w) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        double o = scratch[w * NV + i];
-        v[i] = (i < NSUM) ? v[i] + o : (o > v[i] ? o : v[i]);
-      }
+      const double o = scratch[w * NV + i];
+      acc = (i < NSUM) ? acc + o : (o > acc ? o : acc);
     }
+    scratch[nw * NV + i] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = scratch[nw * NV + i];
   }
   __syncthreads();
 }
@@ -244,7 +250,9 @@ struct HStepArgs {
   double* hpart;
   int n, k, p, nx, ny, p_pad;
   int simplex_h, grid_mode, compute_loss, write_h;
-  float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale;
+  int have_prev;     // h_out still holds the H that preceded h_in: evaluate rel_H (base.py:324)
+  float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale, rel_tol;
+  double inv_count;  // 1 / (k * p_total)
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -252,7 +260,7 @@ struct HFinalizeArgs {
   const double* hstat_in;
   double* hstat_out;
   double* hist_slot;
-  int nblk, k, compute_loss;
+  int nblk, k, compute_loss, have_prev;
   float xscale;
 };
 struct WAccumArgs {
@@ -267,7 +275,7 @@ struct WFinishArgs {
   const float* colsum_g;
   const float* w_old;
   float* w_new;
-  const float* a;
+  const float* a;       // (nsplit, k, n_pad): reduced A (nsplit = 1) or the first-stage partials
   const double* hstat;
   const float* fixed_w;
   const int32_t* simplex_rows;
@@ -275,17 +283,65 @@ struct WFinishArgs {
   float* gw_s;
   double* colsum_gw;
   double* hist_slot;
-  int n, m, k, n_pad, simplex_w, update_w;
+  int n, m, k, n_pad, simplex_w, update_w, nsplit;
   float log_shift, tol, rel_tol, xscale, gw_floor;
 };
+
+
+// argument blocks from the public state (shared by the C ABI and the tuning harness)
+inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
+  HStepArgs a;
+  a.x_cm = st->x_cm;
+  a.gw_s = st->gw_s;
+  a.colsum_gw = st->colsum_gw;
+  a.h_in = st->h[src];
+  a.h_out = st->h[1 - src];
+  a.h_t = st->h_t;
+  a.mu = st->mu;
+  a.fixed_h = st->fixed_h;
+  a.halo_top = st->grid_mode ? st->halo_top : nullptr;
+  a.halo_bot = st->grid_mode ? st->halo_bot : nullptr;
+  a.hstat_in = st->hstat[src];
+  a.hpart = st->hpart;
+  a.n = st->n;
+  a.k = st->k;
+  a.p = st->p;
+  a.nx = st->nx;
+  a.ny = st->ny;
+  a.p_pad = st->p_pad;
+  a.simplex_h = st->simplex_h;
+  a.grid_mode = st->grid_mode;
+  a.compute_loss = st->compute_loss;
+  a.write_h = write_h;
+  a.have_prev = st->it > 0;  // h[1-src] then still holds the H that preceded h[src]
+  a.rel_tol = st->rel_tol;
+  a.inv_count = 1.0 / ((double)st->k * (double)(st->p_total > 0 ? st->p_total : st->p));
+  a.lambda_l = st->lambda_l;
+  a.sigma_l = st->sigma_l;
+  a.eps_reg = st->eps_reg;
+  a.log_shift = st->log_shift;
+  a.tol = st->dicotomy_tol;
+  a.xscale = st->xscale;
+  return a;
+}
+
+inline WAccumArgs make_w_args(const espm_mu_state* st) {
+  WAccumArgs a;
+  a.x_pm = st->x_pm;
+  a.gw_s = st->gw_s;
+  a.h_t = st->h_t;
+  a.a_slab = st->a_slab;
+  a.n_pad = st->n_pad;
+  a.p = st->p;
+  a.ppb = (st->p + st->nblk_w - 1) / st->nblk_w;
+  return a;
+}
 
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
-int launch_w_reduce(const float* slab, float* out, int nblk, int total, hipStream_t stream);
+int launch_w_reduce(const float* slab, float* part, float* out, int nblk, int total, hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
-int launch_rel_h(const float* h_old, const float* h_new, const double* hstat_new, double* hist_slot, int k, int p,
-                 int p_pad, double inv_count, float rel_tol, hipStream_t stream);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                   int x_dtype, int n_pad, int p_pad, hipStream_t stream);
 int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream);

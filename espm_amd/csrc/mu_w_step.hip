@@ -9,96 +9,38 @@
 //   w_finish: numerator / denominator, optional simplex over the columns of W with the reference's
 //             global-stop bisection (dicotomy.py:111-173), clamp, fixed_W, then GW = G W for the
 //             next half step, its column sums, and rel_W (base.py:323).
-#include "mu_common.hpp"
+#include "mu_w_kernel.hpp"
 
 namespace espm {
 
-template <int K, typename XT, int CH>
-__global__ __launch_bounds__(256) void w_accum_kernel(const WAccumArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c0 = ((blockIdx.y * 4 + wave) * 64 + lane) * CH;
-  const bool active = c0 < a.n_pad;
-  constexpr int UP = 4;
-
-  float gw[CH][K];
-#pragma unroll
-  for (int i = 0; i < CH; ++i)
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) gw[i][kk] = active ? a.gw_s[(size_t)(c0 + i) * KP + kk] : 1.f;
-
-  float acc[CH][K];
-#pragma unroll
-  for (int i = 0; i < CH; ++i)
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) acc[i][kk] = 0.f;
-
-  const int j_begin = blockIdx.x * a.ppb;
-  const int j_end = min(a.p, j_begin + a.ppb);
-  const XT* xp = static_cast<const XT*>(a.x_pm) + (size_t)j_begin * a.n_pad + (active ? c0 : 0);
-  const float* ht = a.h_t + (size_t)j_begin * KP;
-
-  auto body = [&](const XVec<XT, CH>& xv, const float* hp) {
-    float hk[K];
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) hk[kk] = hp[kk];  // wave-uniform -> scalar loads
-    float x[CH];
-    xv.get(x);
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      float y = gw[i][0] * hk[0];
-#pragma unroll
-      for (int kk = 1; kk < K; ++kk) y = fmaf(gw[i][kk], hk[kk], y);
-      const float r = x[i] * __builtin_amdgcn_rcpf(y);
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) acc[i][kk] = fmaf(r, hk[kk], acc[i][kk]);
-    }
-  };
-
-  int j = j_begin;
-  for (; j + UP <= j_end; j += UP) {
-    XVec<XT, CH> xv[UP];
-#pragma unroll
-    for (int u = 0; u < UP; ++u) {
-      if (active) xv[u].load(xp + (size_t)u * a.n_pad); else xv[u].zero();
-    }
-#pragma unroll
-    for (int u = 0; u < UP; ++u) body(xv[u], ht + u * KP);
-    xp += (size_t)UP * a.n_pad;
-    ht += UP * KP;
-  }
-  for (; j < j_end; ++j) {
-    XVec<XT, CH> xv;
-    if (active) xv.load(xp); else xv.zero();
-    body(xv, ht);
-    xp += a.n_pad;
-    ht += KP;
-  }
-
-  if (active) {
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      float* dst = a.a_slab + ((size_t)blockIdx.x * K + kk) * a.n_pad + c0;
-#pragma unroll
-      for (int i = 0; i < CH; ++i) dst[i] = acc[i][kk];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void w_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+// Stage 1 of the slab reduction: grid (elements / 256, ESPM_WRED_SPLIT); split s sums the slabs
+// b = s, s + SPLIT, s + 2 SPLIT, ... in that order.  Stage 2 (the sum over the SPLIT partials, again in
+// fixed order) is done by w_finish / shard_pack when they read `a_part`.  No atomics: the result does
+// not depend on scheduling.
+__global__ __launch_bounds__(256) void w_reduce_kernel(const float* __restrict__ slab, float* __restrict__ part,
                                                         int nblk, int total) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
   if (e >= total) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nblk; b += 4) {
+  float s0 = 0.f, s1 = 0.f;
+  int b = s;
+  for (; b + ESPM_WRED_SPLIT < nblk; b += 2 * ESPM_WRED_SPLIT) {
     s0 += slab[(size_t)b * total + e];
-    s1 += slab[(size_t)(b + 1) * total + e];
-    s2 += slab[(size_t)(b + 2) * total + e];
-    s3 += slab[(size_t)(b + 3) * total + e];
+    s1 += slab[(size_t)(b + ESPM_WRED_SPLIT) * total + e];
   }
-  for (; b < nblk; ++b) s0 += slab[(size_t)b * total + e];
-  out[e] = (s0 + s1) + (s2 + s3);
+  if (b < nblk) s0 += slab[(size_t)b * total + e];
+  part[(size_t)s * total + e] = s0 + s1;
+}
+
+// Stage 2 as its own kernel (used when the reduced A must exist in memory: sharded exchange).
+__global__ __launch_bounds__(256) void w_reduce2_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                         int total) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < ESPM_WRED_SPLIT; ++s) acc += part[(size_t)s * total + e];
+  out[e] = acc;
 }
 
 // ---- W finish: one workgroup of 1024 threads --------------------------------------------------
@@ -121,8 +63,252 @@ __device__ __forceinline__ double block_max1(double v, double* scratch) {
   return bc;
 }
 
+// Register-resident variant for M <= WF_ROWS * 1024 rows (and M * k <= WF_GTA_MAX when G is given): thread t
+// owns rows t, t + 1024, ... of W and keeps their old / numerator / denominator / new entries in registers
+// across the phases (no index division, no scratch traffic); the second stage of the slab reduction
+// (sum over the `nsplit` partials, fixed order) is folded into the load of A; G^T A is formed by one wave
+// per output entry and G W' reads W' from LDS.  Same arithmetic and the same global-stop bisection as
+// w_finish_kernel below; only the data movement differs.
+constexpr int WF_GTA_MAX = 8192;
+
+__device__ __forceinline__ float load_a(const WFinishArgs& a, int kk, int c) {
+  const size_t total = (size_t)a.k * a.n_pad, idx = (size_t)kk * a.n_pad + c;
+  if (a.nsplit == ESPM_WRED_SPLIT) {  // second stage of the slab reduction: all loads in flight, fixed order
+    float v[ESPM_WRED_SPLIT];
+#pragma unroll
+    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) v[sp] = a.a[sp * total + idx];
+    float acc = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) acc += v[sp];
+    return acc;
+  }
+  float acc = 0.f;
+  for (int sp = 0; sp < a.nsplit; ++sp) acc += a.a[sp * total + idx];
+  return acc;
+}
+
+template <int KK, int WF_ROWS>
+__global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinishArgs a) {
+  constexpr int KA = KK;  // per-thread arrays are sized by the real component count (k == KK)
+  __shared__ double scratch[(WF_THREADS / 64 + 1) * 8];
+  __shared__ double s_lo[KA], s_hi[KA], s_mid[KA];
+  __shared__ int s_go;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // G given: [M*k] new W, [M*k] G^T A
+  const int M = a.m > 0 ? a.m : a.n;
+  const int k = a.k;
+  const int MK = M * k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* s_w = dyn;
+  float* s_gta = dyn + MK;
+
+  float wn[WF_ROWS][KA];
+#pragma unroll
+  for (int r = 0; r < WF_ROWS; ++r)
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) wn[r][kk] = 0.f;
+
+  if (a.update_w) {
+    if (a.g) {  // G^T A with the association G^T (R H^T), updates.py:58-59: one wave per (mm, kk)
+      for (int o = wave; o < MK; o += WF_THREADS / 64) {
+        const int mm = o / k, kk = o - mm * k;
+        float sacc = 0.f;
+        for (int c = lane; c < a.n; c += 64) sacc = fmaf(a.g[(size_t)c * a.m + mm], load_a(a, kk, c), sacc);
+        sacc = wave_sum(sacc);
+        if (lane == 0) s_gta[o] = sacc;
+      }
+      __syncthreads();
+    }
+    float rs[KA];
+#pragma unroll
+    for (int kk = 0; kk < KA; ++kk) rs[kk] = kk < k ? (float)a.hstat[ESPM_HS_ROWSUM + kk] : 0.f;
+    float wo[WF_ROWS][KA], nv[WF_ROWS][KA], dv[WF_ROWS][KA];
+    bool in_set[WF_ROWS];
+#pragma unroll
+    for (int r = 0; r < WF_ROWS; ++r) {
+      const int mm = tid + r * WF_THREADS;
+      in_set[r] = false;
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) { wo[r][kk] = 0.f; nv[r][kk] = 0.f; dv[r][kk] = 1.f; }
+      if (mm < M) {
+        in_set[r] = !a.simplex_rows || a.simplex_rows[mm];
+        const float cg = a.g ? a.colsum_g[mm] : 1.f;
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          if (kk < k) {
+            const float gta = a.g ? s_gta[mm * k + kk] : load_a(a, kk, mm);
+            wo[r][kk] = a.w_old[mm * k + kk];
+            nv[r][kk] = wo[r][kk] * gta;        // updates.py:59
+            dv[r][kk] = cg * rs[kk];            // updates.py:60
+          }
+        }
+      }
+    }
+    if (a.simplex_w) {
+      double cnt_l = 0.0;
+#pragma unroll
+      for (int r = 0; r < WF_ROWS; ++r) cnt_l += (tid + r * WF_THREADS < M && in_set[r]) ? 1.0 : 0.0;
+      const double rows = block_sum1(cnt_l, scratch);
+      double b1[KA], b2[KA], b3[KA];  // per column: max(num/2 - den), max num, max(-den)   (dicotomy.py:29-49)
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) { b1[kk] = -INFINITY; b2[kk] = 0.0; b3[kk] = -INFINITY; }
+#pragma unroll
+      for (int r = 0; r < WF_ROWS; ++r) {
+        if (tid + r * WF_THREADS < M && in_set[r]) {
+#pragma unroll
+          for (int kk = 0; kk < KA; ++kk) {
+            if (kk < k) {
+              const double nn = nv[r][kk], dd = dv[r][kk];
+              if (nn > 0) b1[kk] = fmax(b1[kk], nn / 2 - dd);
+              b2[kk] = fmax(b2[kk], nn);
+              b3[kk] = fmax(b3[kk], -dd);
+            }
+          }
+        }
+      }
+      block_reduce<KA, 0>(b1, scratch);
+      block_reduce<KA, 0>(b2, scratch);
+      block_reduce<KA, 0>(b3, scratch);
+      if (tid == 0)
+        for (int kk = 0; kk < k; ++kk) {
+          s_lo[kk] = b1[kk];
+          s_hi[kk] = rows * b2[kk] / 0.5 + b3[kk];
+        }
+      __syncthreads();
+      for (int it = 0; it <= 100; ++it) {  // dicotomy.py:146-171, global stop rule
+        if (tid < k) s_mid[tid] = (s_lo[tid] + s_hi[tid]) / 2;
+        __syncthreads();
+        double f[KA];
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) f[kk] = 0.0;
+#pragma unroll
+        for (int r = 0; r < WF_ROWS; ++r) {
+          if (tid + r * WF_THREADS < M && in_set[r]) {
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk)
+              if (kk < k) f[kk] += fmax((double)nv[r][kk] / (s_mid[kk] + (double)dv[r][kk]), (double)a.log_shift);
+          }
+        }
+        block_reduce<KA, KA>(f, scratch);
+        if (tid == 0) {
+          double worst = 0.0;
+          for (int kk = 0; kk < k; ++kk) worst = fmax(worst, fabs(f[kk] - 1.0));
+          s_go = (worst > (double)a.tol) && (it < 100);
+          if (s_go)
+            for (int kk = 0; kk < k; ++kk) {
+              if (f[kk] - 1.0 <= 0.0) s_hi[kk] = s_mid[kk]; else s_lo[kk] = s_mid[kk];
+            }
+        }
+        __syncthreads();
+        if (!s_go) break;
+      }
+    }
+    // W' = max(num / (den + nu), eps), fixed entries (updates.py:70-76); rel_W (base.py:323)
+    double sum_l = 0.0;
+#pragma unroll
+    for (int r = 0; r < WF_ROWS; ++r) {
+      const int mm = tid + r * WF_THREADS;
+      if (mm < M) {
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          if (kk < k) {
+            float den = dv[r][kk];
+            if (a.simplex_w && in_set[r]) den += (float)s_mid[kk];
+            float v = fmaxf(nv[r][kk] / den, a.log_shift);
+            if (a.fixed_w) {
+              const float fx = a.fixed_w[mm * k + kk];
+              if (fx >= 0.f) v = fx;
+            }
+            wn[r][kk] = v;
+            a.w_new[mm * k + kk] = v;
+            if (a.g) s_w[mm * k + kk] = v;
+            sum_l += (double)v;
+          }
+        }
+      }
+    }
+    const double mean_w = block_sum1(sum_l, scratch) / (double)MK;
+    double rel_l = 0.0;
+#pragma unroll
+    for (int r = 0; r < WF_ROWS; ++r) {
+      if (tid + r * WF_THREADS < M) {
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk)
+          if (kk < k)
+            rel_l = fmax(rel_l, fabs((double)wn[r][kk] - (double)wo[r][kk]) / ((double)wn[r][kk] + (double)a.rel_tol * mean_w));
+      }
+    }
+    const double rel_w = block_max1(rel_l, scratch);
+    if (tid == 0 && a.hist_slot) a.hist_slot[ESPM_HI_REL_W] = rel_w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < WF_ROWS; ++r) {
+      const int mm = tid + r * WF_THREADS;
+      if (mm < M) {
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          if (kk < k) {
+            wn[r][kk] = a.w_new[mm * k + kk];
+            if (a.g) s_w[mm * k + kk] = wn[r][kk];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // GW = G W' (updates.py:107 of the next half step), stored / xscale with a positive floor
+  double cs[KA];
+#pragma unroll
+  for (int kk = 0; kk < KA; ++kk) cs[kk] = 0.0;
+  const float inv_scale = 1.f / a.xscale;
+  auto emit_row = [&](int c, const float (&src)[KA]) {
+    float row[espm::KP];
+#pragma unroll
+    for (int kk = 0; kk < espm::KP; ++kk) row[kk] = 0.f;
+    if (c >= a.n) {
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) row[kk] = 1.f;  // padding channels: X = 0 there
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) {
+        const float v = fmaxf(src[kk], a.gw_floor);
+        cs[kk] += (double)v;
+        row[kk] = v * inv_scale;
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.gw_s + (size_t)c * espm::KP);
+    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+  };
+  if (a.g) {
+    for (int c = tid; c < a.n_pad; c += WF_THREADS) {
+      float row[KA];
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) row[kk] = 0.f;
+      if (c < a.n) {
+        for (int mm = 0; mm < a.m; ++mm) {
+          const float gv = a.g[(size_t)c * a.m + mm];
+#pragma unroll
+          for (int kk = 0; kk < KA; ++kk)
+            if (kk < k) row[kk] = fmaf(gv, s_w[mm * k + kk], row[kk]);
+        }
+      }
+      emit_row(c, row);
+    }
+  } else {  // G = identity: row c of G W' is row c of W', already in this thread's registers
+#pragma unroll
+    for (int r = 0; r < WF_ROWS; ++r) {
+      const int c = tid + r * WF_THREADS;
+      if (c < a.n_pad) emit_row(c, wn[r]);
+    }
+  }
+  block_reduce<KA, KA>(cs, scratch);
+  if (tid == 0)
+    for (int kk = 0; kk < espm::KP; ++kk) a.colsum_gw[kk] = kk < KA ? cs[kk] : 0.0;
+}
+
 __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs a) {
-  __shared__ double scratch[(WF_THREADS / 64) * 2 * KP];
+  __shared__ double scratch[(WF_THREADS / 64 + 1) * 2 * KP];
   __shared__ double s_lo[KP], s_hi[KP], s_mid[KP], s_f[KP];
   __shared__ int s_go;
   const int M = a.m > 0 ? a.m : a.n;
@@ -138,10 +324,10 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
       float gta;
       if (a.g) {
         float s = 0.f;
-        for (int c = 0; c < a.n; ++c) s = fmaf(a.g[(size_t)c * a.m + mm], a.a[(size_t)kk * a.n_pad + c], s);
+        for (int c = 0; c < a.n; ++c) s = fmaf(a.g[(size_t)c * a.m + mm], load_a(a, kk, c), s);
         gta = s;
       } else {
-        gta = a.a[(size_t)kk * a.n_pad + mm];
+        gta = load_a(a, kk, mm);
       }
       numv[e] = a.w_old[e] * gta;
       denv[e] = (a.g ? a.colsum_g[mm] : 1.f) * (float)a.hstat[ESPM_HS_ROWSUM + kk];
@@ -261,37 +447,15 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
     for (int kk = 0; kk < KP; ++kk) a.colsum_gw[kk] = cs[kk];
 }
 
-// ---- rel_H, base.py:324 ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rel_h_kernel(const float* __restrict__ h_old, const float* __restrict__ h_new,
-                                                    const double* __restrict__ hstat_new, double* hist_slot, int k,
-                                                    int p, int p_pad, double inv_count, float rel_tol) {
-  __shared__ double scratch[4];
-  double tot = 0.0;
-  for (int kk = 0; kk < k; ++kk) tot += hstat_new[ESPM_HS_ROWSUM + kk];
-  const float shift = (float)((double)rel_tol * tot * inv_count);
-  float worst = 0.f;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < p; q += gridDim.x * blockDim.x) {
-    for (int kk = 0; kk < k; ++kk) {
-      const float hn = h_new[(size_t)kk * p_pad + q], ho = h_old[(size_t)kk * p_pad + q];
-      worst = fmaxf(worst, fabsf(hn - ho) / (hn + shift));
-    }
-  }
-  double v[1] = {(double)worst};
-  block_reduce<1, 0>(v, scratch);
-  if (threadIdx.x == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(hist_slot + ESPM_HI_REL_H),
-              (unsigned long long)__double_as_longlong(v[0]));
-}
-
 // ---- dispatch -----------------------------------------------------------------------------------
 template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
   if (x_dtype == ESPM_X_BF16) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
-    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8>), grid, dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, true>), grid, dim3(256), 0, stream, args);
   } else {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 4 - 1) / (4 * 64 * 4));
-    hipLaunchKernelGGL((w_accum_kernel<K, float, 4>), grid, dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, true>), grid, dim3(256), 0, stream, args);
   }
   return check_hip(hipGetLastError(), "w_accum launch");
 }
@@ -310,23 +474,45 @@ int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipSt
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built (1..%d)", k, ESPM_MAX_K);
 }
 
-int launch_w_reduce(const float* slab, float* out, int nblk, int total, hipStream_t stream) {
-  hipLaunchKernelGGL(w_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, slab, out, nblk, total);
+int launch_w_reduce(const float* slab, float* part, float* out, int nblk, int total, hipStream_t stream) {
+  hipLaunchKernelGGL(w_reduce_kernel, dim3((total + 255) / 256, ESPM_WRED_SPLIT), dim3(256), 0, stream, slab, part,
+                     nblk, total);
+  if (out) hipLaunchKernelGGL(w_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, out, total);
   return check_hip(hipGetLastError(), "w_reduce launch");
 }
 
-int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
-  hipLaunchKernelGGL(w_finish_kernel, dim3(1), dim3(WF_THREADS), 0, stream, args);
-  return check_hip(hipGetLastError(), "w_finish launch");
+template <int KK>
+static void launch_fast(const WFinishArgs& args, int rows, size_t lds, hipStream_t stream) {
+  if (rows <= 1)
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1>), dim3(1), dim3(WF_THREADS), lds, stream, args);
+  else if (rows <= 2)
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 2>), dim3(1), dim3(WF_THREADS), lds, stream, args);
+  else
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 4>), dim3(1), dim3(WF_THREADS), lds, stream, args);
 }
 
-int launch_rel_h(const float* h_old, const float* h_new, const double* hstat_new, double* hist_slot, int k, int p,
-                 int p_pad, double inv_count, float rel_tol, hipStream_t stream) {
-  int blocks = (p + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(rel_h_kernel, dim3(blocks), dim3(256), 0, stream, h_old, h_new, hstat_new, hist_slot, k, p,
-                     p_pad, inv_count, rel_tol);
-  return check_hip(hipGetLastError(), "rel_h launch");
+int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
+  const int M = args.m > 0 ? args.m : args.n;
+  const long mk = (long)M * args.k;
+  const int span = M > args.n_pad ? M : args.n_pad;
+  const int rows = (span + WF_THREADS - 1) / WF_THREADS;
+  if (rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
+    const size_t lds = args.g ? (size_t)mk * sizeof(float) * 2 : 0;
+    switch (args.k) {
+      case 1: launch_fast<1>(args, rows, lds, stream); break;
+      case 2: launch_fast<2>(args, rows, lds, stream); break;
+      case 3: launch_fast<3>(args, rows, lds, stream); break;
+      case 4: launch_fast<4>(args, rows, lds, stream); break;
+      case 5: launch_fast<5>(args, rows, lds, stream); break;
+      case 6: launch_fast<6>(args, rows, lds, stream); break;
+      case 7: launch_fast<7>(args, rows, lds, stream); break;
+      case 8: launch_fast<8>(args, rows, lds, stream); break;
+      default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
+    }
+  } else {
+    hipLaunchKernelGGL(w_finish_kernel, dim3(1), dim3(WF_THREADS), 0, stream, args);
+  }
+  return check_hip(hipGetLastError(), "w_finish launch");
 }
 
 }  // namespace espm

@@ -181,6 +181,7 @@ class MUEngine:
         self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
         self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
         self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
+        self.a_part = torch.zeros((_lib.WRED_SPLIT, k, st.n_pad), **f32)
         self.a = torch.zeros((k, st.n_pad), **f32)
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
         self.hist_len = int(max_iter) + 2
@@ -211,6 +212,7 @@ class MUEngine:
         st.hpart = self.hpart.data_ptr()
         st.hstat[0], st.hstat[1] = self.hstat[0].data_ptr(), self.hstat[1].data_ptr()
         st.a_slab, st.a, st.w_scratch = self.a_slab.data_ptr(), self.a.data_ptr(), self.w_scratch.data_ptr()
+        st.a_part = self.a_part.data_ptr()
         st.hist, st.hist_len = self.hist.data_ptr(), self.hist_len
         st.cur, st.it = 0, 0
 
@@ -303,8 +305,7 @@ class MUEngine:
             self.exchange.gather()
             check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.exchange.recv), self.world, 1 - cur, s))
             self._set_halo_from_records()
-        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, s))
-        check(lib.espm_mu_rel_h(C.byref(st), cur, slot + 1, s))
+        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, 1 if self.world > 1 else 0, s))
         st.cur, st.it = 1 - cur, slot + 1
 
     def iterate(self, n_iter, final_loss=True):
@@ -337,7 +338,7 @@ class MUEngine:
         s = _stream()
         check(lib.espm_mu_w_accum(C.byref(st), s))
         check(lib.espm_mu_w_reduce(C.byref(st), s))
-        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))
+        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, 0, s))
         return self.w[1 - cur].cpu().numpy()
 
     # ---- read-back -----------------------------------------------------------------------------------------

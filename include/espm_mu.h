@@ -15,7 +15,7 @@
  *   espm_mu_w_reduce      <- (new) fixed-order reduction of the per-workgroup partial R H^T slabs
  *   espm_mu_w_finish      <- espm/estimators/updates.py:58-76 (G^T., simplex_W, clamp, fixed_W)
  *                            + updates.py:38 / base.py:189 (GW = G @ W) + base.py:323 (rel_W)
- *   espm_mu_rel_h         <- espm/estimators/base.py:324 (rel_H)
+ *   (rel_H, base.py:324, is produced by espm_mu_step_h / espm_mu_h_finalize of the NEXT state evaluation)
  *   espm_mu_hstat         <- updates.py:139 (max_j H), updates.py:60 (sum_j H)
  *   espm_mu_iterate       <- espm/estimators/smooth_nmf.py:284-455 (_iteration, log_surrogate)
  *                            driven by base.py:313-394 (single GPU, no host sync)
@@ -62,15 +62,19 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
+#define ESPM_WRED_SPLIT 16 /* partial sums kept by the first stage of the slab reduction */
 
-/* per-workgroup partial record written by the H-step (doubles) */
+/* per-workgroup partial record written by the H-step (doubles), stored field-major:
+ * hpart[field * nblk + block] */
 #define ESPM_HP_KL 0       /* sum X*log2(X/Y) over the block (input state)            */
 #define ESPM_HP_REG 1      /* sum_k mu_k log(H_in + eps_reg)                           */
 #define ESPM_HP_LAP 2      /* sum H_in * (H_in L)                                      */
 #define ESPM_HP_BAD 3      /* count of non-finite H_out entries                        */
 #define ESPM_HP_ROWSUM 4   /* [4, 4+KP): sum_j H_out[k, j]                             */
 #define ESPM_HP_MAX 12     /* [12, 12+KP): max_j H_out[k, j]                           */
-#define ESPM_HP_STRIDE 20
+#define ESPM_HP_RELH 20    /* max |H_in - H_prev| / (H_in + tol mean H_in) over the block (base.py:324) */
+#define ESPM_HP_NSCALAR 5  /* KL, REG, LAP, BAD, RELH                                  */
+#define ESPM_HP_STRIDE 24
 
 /* per-state statistics of one H buffer (doubles): produced by espm_mu_hstat / h_finalize */
 #define ESPM_HS_ROWSUM 0   /* [0, KP)  */
@@ -84,7 +88,8 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_HI_SUMY 3     /* sum_k colsum(GW)_k * rowsum(H)_k  (uses the global rowsum in hstat) */
 #define ESPM_HI_BAD 4      /* non-finite entries produced by the step that followed     */
 #define ESPM_HI_REL_W 5    /* base.py:323 for the update that PRODUCED this state       */
-#define ESPM_HI_REL_H 6    /* base.py:324 (local max; max-reduce over ranks)            */
+#define ESPM_HI_REL_H 6    /* base.py:324 for the update that produced this state; evaluated by the H-step that
+                              starts FROM this state (local max; max-reduce over ranks) */
 #define ESPM_HI_STRIDE 8
 
 typedef struct espm_mu_state {
@@ -125,9 +130,10 @@ typedef struct espm_mu_state {
   const float* halo_top;    /* (k, ny) image row above the local block or NULL           */
   const float* halo_bot;    /* (k, ny) image row below the local block or NULL           */
   /* workspaces */
-  double* hpart;            /* (ceil(p / tile_px), ESPM_HP_STRIDE)                       */
+  double* hpart;            /* (ESPM_HP_STRIDE, ceil(p / tile_px)) field-major              */
   double* hstat[2];         /* (ESPM_HS_STRIDE) statistics of h[0] / h[1] (global)       */
   float* a_slab;            /* (nblk_w, k, n_pad)                                        */
+  float* a_part;            /* (ESPM_WRED_SPLIT, k, n_pad) first-stage partial sums of the slabs */
   float* a;                 /* (k, n_pad)                                                */
   float* w_scratch;         /* (2, m or n, k)                                            */
   double* hist;             /* (hist_len, ESPM_HI_STRIDE), zero-initialised              */
@@ -157,8 +163,9 @@ int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream);
  * write_h = 0 evaluates the loss pieces of the input state only. */
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream);
 
-/* Reduces hpart: history slot `slot` gets the loss pieces of h[src]; hstat[1-src] gets the
- * statistics of the new H (local; the caller max/sum-reduces over ranks when sharded). */
+/* Reduces hpart: history slot `slot` gets the loss pieces of h[src] and (slot > 0) rel_H of the update
+ * that produced h[src]; hstat[1-src] gets the statistics of the new H (local; the caller max/sum-reduces
+ * over ranks when sharded). */
 int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream);
 
 /* Loss pieces of the state (w[src], h[src]) into history slot `slot`; H is not updated. */
@@ -166,14 +173,14 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 
 /* A_slab[b] = sum over the pixels of block b of R[:, j] H[:, j]^T with R = X / (GW H), H = h_t. */
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream);
-/* a = sum_b a_slab[b] in fixed order. */
+/* a_part[s] = sum of the slabs b = s, s + SPLIT, ... (first stage, fixed order); the second stage
+ * (sum over s) is folded into the consumers: w_finish (combined = 0) or shard_pack. */
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream);
-/* W update from a, hstat[hsrc] (global row sums of the new H): reads w[src], writes w[1-src],
- * gw_s, colsum_gw and rel_W into history slot `slot`. */
-int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream);
-
-/* rel_H between h[old] and h[1-old] (needs hstat[1-old] global), max-accumulated in slot. */
-int espm_mu_rel_h(const espm_mu_state* st, int old, int slot, espm_stream_t stream);
+/* W update from A and hstat[hsrc] (global row sums of the new H): reads w[src], writes w[1-src],
+ * gw_s, colsum_gw and rel_W into history slot `slot`.  combined = 0: A = sum of a_part (one GPU);
+ * combined = 1: A = `a`, the all-rank sum written by espm_mu_shard_combine. */
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, int combined,
+                     espm_stream_t stream);
 
 /* n_iter full iterations on one GPU, no host synchronisation; updates st->cur / st->it.
  * History slot t holds the loss pieces of state t (slot 0 = initial state) and the relative

@@ -64,7 +64,7 @@ def test_query_layout_without_gpu(lib):
     st = lib.MUState()
     st.n, st.p, st.k, st.x_dtype = 2048, 512 * 512, 5, lib.X_BF16
     assert lib.lib.espm_mu_query(C.byref(st)) == 0
-    assert (st.n_pad, st.p_pad, st.tile_px) == (2048, 262144, 512)
+    assert (st.n_pad, st.p_pad, st.tile_px) == (2048, 262144, 256)
     st.n, st.p = 1980, 128 * 128
     assert lib.lib.espm_mu_query(C.byref(st)) == 0
     assert st.n_pad == 1984 and st.p_pad == 16384 and st.tile_px == 128 and st.nblk_w >= 1
