@@ -23,7 +23,6 @@ SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8
 HP_STRIDE, HS_STRIDE, HI_STRIDE = 24, 16, 8
-WRED_SPLIT = 16
 HS_ROWSUM, HS_MAX = 0, 8
 HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = 0, 1, 2, 3, 4, 5, 6
 
@@ -34,7 +33,7 @@ class MUState(C.Structure):
     """struct espm_mu_state (same field order as include/espm_mu.h)."""
     _fields_ = [
         ("n", _i32), ("m", _i32), ("k", _i32), ("p", _i32), ("nx", _i32), ("ny", _i32),
-        ("n_pad", _i32), ("p_pad", _i32), ("x_dtype", _i32), ("tile_px", _i32), ("nblk_w", _i32),
+        ("n_pad", _i32), ("p_pad", _i32), ("x_dtype", _i32), ("tile_px", _i32), ("nblk_w", _i32), ("x_tile", _i32),
         ("p_total", _i64),
         ("simplex_h", _i32), ("simplex_w", _i32), ("grid_mode", _i32), ("compute_loss", _i32),
         ("lambda_l", _f32), ("sigma_l", _f32), ("eps_reg", _f32), ("log_shift", _f32),
@@ -43,7 +42,7 @@ class MUState(C.Structure):
         ("w", _vp * 2), ("gw_s", _vp), ("colsum_gw", _vp), ("h", _vp * 2), ("h_t", _vp),
         ("mu", _vp), ("fixed_h", _vp), ("fixed_w", _vp), ("simplex_rows", _vp),
         ("halo_top", _vp), ("halo_bot", _vp),
-        ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a_part", _vp), ("a", _vp), ("w_scratch", _vp),
+        ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
     ]
 
@@ -54,7 +53,7 @@ SYMBOLS = {
     "espm_mu_version": (C.c_char_p, []),
     "espm_mu_last_error": (C.c_char_p, []),
     "espm_mu_query": (C.c_int, [_SP]),
-    "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_hstat": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_build_gw": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_step_h": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
@@ -62,7 +61,7 @@ SYMBOLS = {
     "espm_mu_loss_only": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_accum": (C.c_int, [_SP, _vp]),
     "espm_mu_w_reduce": (C.c_int, [_SP, _vp]),
-    "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_shard_record_bytes": (C.c_size_t, [_SP]),
     "espm_mu_shard_pack": (C.c_int, [_SP, C.c_int, _vp, _vp]),

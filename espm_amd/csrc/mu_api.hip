@@ -36,6 +36,8 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
+  ESPM_REQUIRE(st->x_tile >= 64 && ESPM_PPAD % st->x_tile == 0 && st->x_tile % st->tile_px == 0,
+               "x_tile=%d must divide %d and be a multiple of tile_px=%d", st->x_tile, ESPM_PPAD, st->tile_px);
   ESPM_REQUIRE(st->m >= 0, "m must be >= 0");
   ESPM_REQUIRE(st->m == 0 || (st->g && st->colsum_g), "m=%d needs g and colsum_g", st->m);
   if (st->log_shift > 0.f && st->simplex_h && (double)st->k * (double)st->log_shift >= 1.0)
@@ -69,6 +71,7 @@ int espm_mu_query(espm_mu_state* st) {
   // with 8 waves splitting the channel range (tuned on MI355X, tools/tune).
   const int big = 256;
   st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
+  st->x_tile = st->tile_px;
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
   const int ychunks = st->x_dtype == ESPM_X_BF16 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
   int target = (2 * cus + ychunks - 1) / ychunks;
@@ -81,14 +84,15 @@ int espm_mu_query(espm_mu_state* st) {
 }
 
 int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                   int x_dtype, int n_pad, int p_pad, espm_stream_t stream) {
+                   int x_dtype, int n_pad, int p_pad, int x_tile, espm_stream_t stream) {
   ESPM_REQUIRE(src && x_cm && x_pm, "pack_x: NULL pointer");
   ESPM_REQUIRE(n >= 1 && p >= 1 && n_pad == roundup(n, ESPM_NPAD) && p_pad == roundup(p, ESPM_PPAD),
                "pack_x: bad shape n=%d p=%d n_pad=%d p_pad=%d", n, p, n_pad, p_pad);
   ESPM_REQUIRE(src_dtype == ESPM_SRC_F32 || src_dtype == ESPM_SRC_F64, "pack_x: bad src_dtype %d", src_dtype);
   ESPM_REQUIRE(src_layout == ESPM_LAYOUT_CM || src_layout == ESPM_LAYOUT_PM, "pack_x: bad layout %d", src_layout);
   ESPM_REQUIRE(ld >= (src_layout == ESPM_LAYOUT_CM ? p : n), "pack_x: leading dimension too small");
-  return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad,
+  ESPM_REQUIRE(x_tile >= 64 && ESPM_PPAD % x_tile == 0, "pack_x: x_tile %d must divide %d", x_tile, ESPM_PPAD);
+  return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -98,14 +102,13 @@ int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
   return launch_hstat(st->h[which], st->k, st->p, st->p_pad, st->hstat[which], static_cast<hipStream_t>(stream));
 }
 
-static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w, int combined) {
+static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
   WFinishArgs a;
   a.g = st->m > 0 ? st->g : nullptr;
   a.colsum_g = st->colsum_g;
   a.w_old = st->w[src];
   a.w_new = update_w ? st->w[1 - src] : st->w[src];
-  a.a = combined ? st->a : st->a_part;
-  a.nsplit = combined ? 1 : ESPM_WRED_SPLIT;
+  a.a = st->a;
   a.hstat = st->hstat[hsrc];
   a.fixed_w = st->fixed_w;
   a.simplex_rows = st->simplex_rows;
@@ -130,7 +133,7 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
 int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(which == 0 || which == 1, "which must be 0/1");
-  return launch_w_finish(finish_args(st, which, 0, -1, 0, 1), static_cast<hipStream_t>(stream));
+  return launch_w_finish(finish_args(st, which, 0, -1, 0), static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
@@ -140,38 +143,31 @@ int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t 
                          static_cast<hipStream_t>(stream));
 }
 
+static HFinalizeArgs finalize_args(const espm_mu_state* st, int src, int slot, bool write_hstat) {
+  HFinalizeArgs a;
+  a.hpart = st->hpart;
+  a.colsum_gw = st->colsum_gw;
+  a.hstat_in = st->hstat[src];
+  a.hstat_out = write_hstat ? st->hstat[1 - src] : nullptr;
+  a.hist_slot = st->hist + (size_t)slot * ESPM_HI_STRIDE;
+  a.nblk = nblk_h(st);
+  a.k = st->k;
+  a.compute_loss = st->compute_loss;
+  a.have_prev = st->it > 0;
+  a.xscale = st->xscale;
+  return a;
+}
+
 int espm_mu_h_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
   ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
-  HFinalizeArgs a;
-  a.hpart = st->hpart;
-  a.colsum_gw = st->colsum_gw;
-  a.hstat_in = st->hstat[src];
-  a.hstat_out = st->hstat[1 - src];
-  a.hist_slot = st->hist + (size_t)slot * ESPM_HI_STRIDE;
-  a.nblk = nblk_h(st);
-  a.k = st->k;
-  a.compute_loss = st->compute_loss;
-  a.have_prev = st->it > 0;
-  a.xscale = st->xscale;
-  return launch_h_finalize(a, static_cast<hipStream_t>(stream));
+  return launch_h_finalize(finalize_args(st, src, slot, true), static_cast<hipStream_t>(stream));
 }
 
 /* loss-only variant: does not touch hstat[1-src] */
 static int h_finalize_loss_only(const espm_mu_state* st, int src, int slot, hipStream_t stream) {
-  HFinalizeArgs a;
-  a.hpart = st->hpart;
-  a.colsum_gw = st->colsum_gw;
-  a.hstat_in = st->hstat[src];
-  a.hstat_out = nullptr;
-  a.hist_slot = st->hist + (size_t)slot * ESPM_HI_STRIDE;
-  a.nblk = nblk_h(st);
-  a.k = st->k;
-  a.compute_loss = st->compute_loss;
-  a.have_prev = st->it > 0;
-  a.xscale = st->xscale;
-  return launch_h_finalize(a, stream);
+  return launch_h_finalize(finalize_args(st, src, slot, false), stream);
 }
 
 int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
@@ -189,10 +185,10 @@ int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream) {
 
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
-  return launch_w_reduce(st->a_slab, st->a_part, nullptr, st->nblk_w, st->k * st->n_pad, static_cast<hipStream_t>(stream));
+  return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, static_cast<hipStream_t>(stream));
 }
 
-int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, int combined, espm_stream_t stream) {
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE((src == 0 || src == 1) && (hsrc == 0 || hsrc == 1), "src/hsrc must be 0/1");
   ESPM_REQUIRE(slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
@@ -201,7 +197,7 @@ int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, int c
     if (!st->simplex_rows && rows * (double)st->log_shift >= 1.0)
       return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
   }
-  return launch_w_finish(finish_args(st, src, hsrc, slot, 1, combined), static_cast<hipStream_t>(stream));
+  return launch_w_finish(finish_args(st, src, hsrc, slot, 1), static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {
@@ -212,10 +208,13 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
     const int cur = st->cur, slot = st->it;
     int rc;
     if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
-    if ((rc = espm_mu_h_finalize(st, cur, slot, stream))) return rc;
     if ((rc = espm_mu_w_accum(st, stream))) return rc;
-    if ((rc = espm_mu_w_reduce(st, stream))) return rc;
-    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, 0, stream))) return rc;
+    {  // slab reduction with the H-step's finalize riding in the same launch
+      const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
+      if ((rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, &fin, static_cast<hipStream_t>(stream))))
+        return rc;
+    }
+    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, stream))) return rc;
     st->cur = 1 - cur;
     st->it = slot + 1;
   }
@@ -249,7 +248,7 @@ int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_str
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(record && (hnew == 0 || hnew == 1), "shard_pack: bad arguments");
   const int with_halo = st->grid_mode && st->lambda_l != 0.f;
-  return launch_shard_pack(st->a_part, st->hstat[hnew], st->h[hnew], st->k, st->n_pad, st->nx, st->ny, st->p_pad,
+  return launch_shard_pack(st->a, st->hstat[hnew], st->h[hnew], st->k, st->n_pad, st->nx, st->ny, st->p_pad,
                            with_halo, record, static_cast<hipStream_t>(stream));
 }
 

@@ -21,7 +21,7 @@ __device__ __forceinline__ bf16_t to_store<bf16_t>(float v) {
 template <typename ST, typename DT>
 __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src, int src_layout, int64_t ld, int n,
                                                      int p, DT* __restrict__ x_cm, DT* __restrict__ x_pm, int n_pad,
-                                                     int p_pad) {
+                                                     int p_pad, int x_tile) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src,
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r, j = j0 + tx;
-    if (c < n && j < p_pad) x_cm[(size_t)c * p_pad + j] = to_store<DT>(tile[r][tx]);
+    if (c < n && j < p_pad)  // tile-major: [pixel block][channel][x_tile]
+      x_cm[((size_t)(j / x_tile) * n + c) * x_tile + (j % x_tile)] = to_store<DT>(tile[r][tx]);
     const int j2 = j0 + r, c2 = c0 + tx;
     if (j2 < p && c2 < n_pad) x_pm[(size_t)j2 * n_pad + c2] = to_store<DT>(tile[tx][r]);
   }
@@ -49,22 +50,22 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src,
 
 template <typename ST>
 static int pack_dispatch(const void* src, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                         int x_dtype, int n_pad, int p_pad, hipStream_t stream) {
+                         int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream) {
   dim3 grid((p_pad + 31) / 32, (n_pad + 31) / 32);
   if (x_dtype == ESPM_X_BF16)
     hipLaunchKernelGGL((pack_x_kernel<ST, bf16_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
-                       src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad);
+                       src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad, x_tile);
   else
     hipLaunchKernelGGL((pack_x_kernel<ST, float>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
-                       src_layout, ld, n, p, static_cast<float*>(x_cm), static_cast<float*>(x_pm), n_pad, p_pad);
+                       src_layout, ld, n, p, static_cast<float*>(x_cm), static_cast<float*>(x_pm), n_pad, p_pad, x_tile);
   return check_hip(hipGetLastError(), "pack_x launch");
 }
 
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                  int x_dtype, int n_pad, int p_pad, hipStream_t stream) {
+                  int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream) {
   if (src_dtype == ESPM_SRC_F64)
-    return pack_dispatch<double>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, stream);
-  return pack_dispatch<float>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, stream);
+    return pack_dispatch<double>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, stream);
+  return pack_dispatch<float>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, stream);
 }
 
 // ---- statistics of an H buffer (one workgroup; used at initialisation only) ---------------------
@@ -180,7 +181,7 @@ int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* o
 // One record per rank and iteration:  [ A (k*n_pad f32) | hstat of the new H
 // (ESPM_HS_STRIDE f64) | first owned image row of the new H (k*ny f32) | last owned row (k*ny f32) ].
 // The A block starts the record, the f64 block is 8-byte aligned because k*n_pad is a multiple of 8.
-__global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict__ a /* (SPLIT, k, n_pad) partials */, const double* __restrict__ hstat,
+__global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict__ a, const double* __restrict__ hstat,
                                                          const float* __restrict__ h_new, int k, int n_pad, int nx,
                                                          int ny, int p_pad, int with_halo, unsigned char* rec) {
   const int na = k * n_pad;
@@ -189,12 +190,7 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict
   float* rt = reinterpret_cast<float*>(rec + (size_t)na * 4 + ESPM_HS_STRIDE * 8);
   float* rb = rt + (size_t)k * ny;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-  for (int e = tid; e < na; e += nt) {  // second stage of the slab reduction, fixed order
-    float acc = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) acc += a[(size_t)sp * na + e];
-    ra[e] = acc;
-  }
+  for (int e = tid; e < na; e += nt) ra[e] = a[e];
   for (int e = tid; e < ESPM_HS_STRIDE; e += nt) rs[e] = hstat[e];
   if (with_halo) {
     for (int e = tid; e < k * ny; e += nt) {

@@ -11,6 +11,7 @@ constexpr int KP = ESPM_KP;
 constexpr int WAVE = 64;
 
 typedef uint16_t bf16_t;  // raw storage; converted with shifts (exact)
+typedef float f2 __attribute__((ext_vector_type(2)));  // pairs of fp32: v_pk_fma_f32 / v_pk_mul_f32
 
 int set_error(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
@@ -35,6 +36,12 @@ struct XVec<bf16_t, 8> {
     x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xffff0000u);
     x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xffff0000u);
   }
+  __device__ __forceinline__ void get2(f2 (&x)[4]) const {
+    x[0] = f2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+    x[1] = f2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    x[2] = f2{__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u)};
+    x[3] = f2{__uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+  }
 };
 template <>
 struct XVec<bf16_t, 4> {
@@ -45,6 +52,10 @@ struct XVec<bf16_t, 4> {
     x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
     x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
   }
+  __device__ __forceinline__ void get2(f2 (&x)[2]) const {
+    x[0] = f2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+    x[1] = f2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+  }
 };
 template <>
 struct XVec<bf16_t, 2> {
@@ -54,6 +65,9 @@ struct XVec<bf16_t, 2> {
   __device__ __forceinline__ void get(float (&x)[2]) const {
     x[0] = __uint_as_float(v << 16); x[1] = __uint_as_float(v & 0xffff0000u);
   }
+  __device__ __forceinline__ void get2(f2 (&x)[1]) const {
+    x[0] = f2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+  }
 };
 template <>
 struct XVec<float, 4> {
@@ -61,6 +75,7 @@ struct XVec<float, 4> {
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
   __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ void get(float (&x)[4]) const { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+  __device__ __forceinline__ void get2(f2 (&x)[2]) const { x[0] = f2{v.x, v.y}; x[1] = f2{v.z, v.w}; }
 };
 template <>
 struct XVec<float, 2> {
@@ -68,6 +83,7 @@ struct XVec<float, 2> {
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float2*>(p); }
   __device__ __forceinline__ void zero() { v = make_float2(0.f, 0.f); }
   __device__ __forceinline__ void get(float (&x)[2]) const { x[0] = v.x; x[1] = v.y; }
+  __device__ __forceinline__ void get2(f2 (&x)[1]) const { x[0] = f2{v.x, v.y}; }
 };
 
 template <int PX>
@@ -249,6 +265,7 @@ struct HStepArgs {
   const double* hstat_in;
   double* hpart;
   int n, k, p, nx, ny, p_pad;
+  int x_tile;        // pixel-block width of the tile-major x_cm
   int simplex_h, grid_mode, compute_loss, write_h;
   int have_prev;     // h_out still holds the H that preceded h_in: evaluate rel_H (base.py:324)
   float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale, rel_tol;
@@ -275,7 +292,7 @@ struct WFinishArgs {
   const float* colsum_g;
   const float* w_old;
   float* w_new;
-  const float* a;       // (nsplit, k, n_pad): reduced A (nsplit = 1) or the first-stage partials
+  const float* a;       // (k, n_pad): R H^T summed over the pixel blocks (and over ranks when sharded)
   const double* hstat;
   const float* fixed_w;
   const int32_t* simplex_rows;
@@ -283,9 +300,56 @@ struct WFinishArgs {
   float* gw_s;
   double* colsum_gw;
   double* hist_slot;
-  int n, m, k, n_pad, simplex_w, update_w, nsplit;
+  int n, m, k, n_pad, simplex_w, update_w;
   float log_shift, tol, rel_tol, xscale, gw_floor;
 };
+
+
+// ---- reduction of the H-step's per-workgroup records (one workgroup of 256 threads) ---------------
+__device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* scratch) {
+  // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and 4 blocks
+  // per thread are in flight at once.  Few waves on purpose: the cross-lane part costs per wave.
+  constexpr int NV = ESPM_HP_NSCALAR + 2 * KP;   // [0..3] scalar sums, [4..4+KP) row sums | [4+KP] RELH, then maxima
+  constexpr int V_RELH = 4 + KP, V_MAX = 5 + KP;
+  double v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  const size_t nb = a.nblk;
+  for (int b0 = threadIdx.x; b0 < a.nblk; b0 += 4 * 256) {
+    double t[4][ESPM_HP_RELH + 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + u * 256;
+#pragma unroll
+      for (int i = 0; i <= ESPM_HP_RELH; ++i) t[u][i] = b < a.nblk ? a.hpart[i * nb + b] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4 + KP; ++i) v[i] += t[u][i];
+      v[V_RELH] = fmax(v[V_RELH], t[u][ESPM_HP_RELH]);
+#pragma unroll
+      for (int i = 0; i < KP; ++i) v[V_MAX + i] = fmax(v[V_MAX + i], t[u][ESPM_HP_MAX + i]);
+    }
+  }
+  block_reduce<NV, 4 + KP>(v, scratch);
+  if (threadIdx.x == 0) {
+    double sumy = 0.0;
+    for (int kk = 0; kk < a.k; ++kk) sumy += a.colsum_gw[kk] * a.hstat_in[ESPM_HS_ROWSUM + kk];
+    if (a.compute_loss) a.hist_slot[ESPM_HI_KLX] = (double)a.xscale * 0.6931471805599453 * v[ESPM_HP_KL];
+    a.hist_slot[ESPM_HI_REG] = v[ESPM_HP_REG];
+    a.hist_slot[ESPM_HI_LAP] = v[ESPM_HP_LAP];
+    a.hist_slot[ESPM_HI_SUMY] = sumy;
+    a.hist_slot[ESPM_HI_BAD] = v[ESPM_HP_BAD];
+    if (a.have_prev) a.hist_slot[ESPM_HI_REL_H] = v[V_RELH];
+    if (a.hstat_out) {
+      for (int kk = 0; kk < KP; ++kk) {
+        a.hstat_out[ESPM_HS_ROWSUM + kk] = v[ESPM_HP_ROWSUM + kk];
+        a.hstat_out[ESPM_HS_MAX + kk] = v[V_MAX + kk];
+      }
+    }
+  }
+}
 
 
 // argument blocks from the public state (shared by the C ABI and the tuning harness)
@@ -309,6 +373,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.nx = st->nx;
   a.ny = st->ny;
   a.p_pad = st->p_pad;
+  a.x_tile = st->x_tile;
   a.simplex_h = st->simplex_h;
   a.grid_mode = st->grid_mode;
   a.compute_loss = st->compute_loss;
@@ -340,10 +405,11 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
-int launch_w_reduce(const float* slab, float* part, float* out, int nblk, int total, hipStream_t stream);
+int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
+                    hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                  int x_dtype, int n_pad, int p_pad, hipStream_t stream);
+                  int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream);
 int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream);
 int launch_dichotomy(const double* num, const double* den, int k, int p, int den_cols, double eps, double tol,
                      int maxit, double* nu_out, int32_t* status, hipStream_t stream);

@@ -7,8 +7,8 @@ namespace espm {
 
 // K components, XT storage type of X, PX pixels per lane (tile = 64 * PX pixels), NW waves per
 // workgroup (they split the channel range), LOSS: accumulate the KL term, U channels per load group,
-// PIPE: explicit register double buffering of the X loads and GW rows (two groups in flight).
-template <int K, typename XT, int PX, int NW, bool LOSS, int U, bool PIPE>
+// NBUF: depth of the register ring of X load groups kept in flight (0 / 1: no explicit prefetch).
+template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF>
 __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   constexpr int TP = 64 * PX;
@@ -17,94 +17,130 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   const int tile0 = blockIdx.x * TP;
   const int px0 = tile0 + lane * PX;
 
-  float h[K][PX];
+  // pixel PAIRS in fp32x2 registers: with a wave-uniform (SGPR) GW operand a plain v_fma_f32 issues at
+  // half rate on gfx950, v_pk_fma_f32 with the scalar broadcast does two FMAs in the same slot
+  // (tools/ubench/valu_rate.hip: 4.4 vs 2.3 cycles per FMA)
+  constexpr int P2 = PX / 2;
+  static_assert(PX % 2 == 0, "pixels per lane must be even");
+  f2 h[K][P2];
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) load_f32<PX>(a.h_in + (size_t)kk * a.p_pad + px0, h[kk]);
+  for (int kk = 0; kk < K; ++kk) {
+    float t[PX];
+    load_f32<PX>(a.h_in + (size_t)kk * a.p_pad + px0, t);
+#pragma unroll
+    for (int i = 0; i < P2; ++i) h[kk][i] = f2{t[2 * i], t[2 * i + 1]};
+  }
 
-  float num[K][PX];
-  float kl[PX];
+  f2 num[K][P2];
+  f2 kl[P2];
 #pragma unroll
-  for (int i = 0; i < PX; ++i) {
-    kl[i] = 0.f;
+  for (int i = 0; i < P2; ++i) {
+    kl[i] = f2{0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) num[kk][i] = 0.f;
+    for (int kk = 0; kk < K; ++kk) num[kk][i] = f2{0.f, 0.f};
   }
 
   const int chunk = (a.n + NW - 1) / NW;
   const int c_begin = min(a.n, wave * chunk);
   const int c_end = min(a.n, c_begin + chunk);
-  const XT* xbase = static_cast<const XT*>(a.x_cm) + px0;
+  // X is tile-major: x_cm[pixel block of x_tile][channel][x_tile]; a workgroup streams one contiguous
+  // region of it (sequential DRAM pages, few TLB entries) with row stride x_tile
+  const XT* xbase = static_cast<const XT*>(a.x_cm) + (size_t)(tile0 / a.x_tile) * a.n * a.x_tile + (tile0 % a.x_tile) +
+                    lane * PX;
 
   // one channel: Y = GW[c,:] H, R = X / Y, num += GW[c,:]^T R   (updates.py:127-128)
   auto channel = [&](const XVec<XT, PX>& xv, const float (&gk)[K]) {
-    float x[PX];
-    xv.get(x);
+    f2 x[P2];
+    xv.get2(x);
 #pragma unroll
-    for (int i = 0; i < PX; ++i) {
-      float y = gk[0] * h[0][i];
+    for (int i = 0; i < P2; ++i) {
+      f2 y = gk[0] * h[0][i];
 #pragma unroll
-      for (int kk = 1; kk < K; ++kk) y = fmaf(gk[kk], h[kk][i], y);
+      for (int kk = 1; kk < K; ++kk) y = gk[kk] * h[kk][i] + y;
+      const f2 inv = f2{__builtin_amdgcn_rcpf(y.x), __builtin_amdgcn_rcpf(y.y)};
       // R = X / Y; with the loss the tiny offset keeps log2(R) finite where X = 0 (0 * finite = 0) at
       // no extra cost (it rides in the fma) and is far below fp32 resolution of any non-zero R
-      const float r = LOSS ? fmaf(x[i], __builtin_amdgcn_rcpf(y), 1e-37f) : x[i] * __builtin_amdgcn_rcpf(y);
+      const f2 r = LOSS ? x[i] * inv + f2{1e-37f, 1e-37f} : x[i] * inv;
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) num[kk][i] = fmaf(gk[kk], r, num[kk][i]);
-      if constexpr (LOSS) kl[i] = fmaf(x[i], __builtin_amdgcn_logf(r), kl[i]);
+      for (int kk = 0; kk < K; ++kk) num[kk][i] = gk[kk] * r + num[kk][i];
+      if constexpr (LOSS) kl[i] = x[i] * f2{__builtin_amdgcn_logf(r.x), __builtin_amdgcn_logf(r.y)} + kl[i];
     }
   };
 
-  struct Group {
+  // Loads are issued NBUF groups of U channels ahead of their use (register ring, static indices after
+  // unrolling); the wave-uniform GW rows (scalar cache) one group ahead.  Prefetch addresses are clamped
+  // to the last full group of the wave's chunk, so no load is predicated and none leaves the chunk (a
+  // clamped re-load is simply not consumed).
+  struct XGroup {
     XVec<XT, PX> x[U];
+  };
+  struct GGroup {
     float g[U][K];
   };
-  auto load_group = [&](Group& grp, int c) {
-    const XT* xr = xbase + (size_t)c * a.p_pad;
-    const float* gr = a.gw_s + (size_t)c * KP;  // wave-uniform -> scalar loads
+  auto load_x = [&](XGroup& grp, int c) {
+    const XT* xr = xbase + (size_t)c * a.x_tile;
 #pragma unroll
-    for (int u = 0; u < U; ++u) grp.x[u].load(xr + (size_t)u * a.p_pad);
+    for (int u = 0; u < U; ++u) grp.x[u].load(xr + (size_t)u * a.x_tile);
+  };
+  auto load_g = [&](GGroup& grp, int c) {
+    const float* gr = a.gw_s + (size_t)c * KP;  // wave-uniform -> scalar loads
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) grp.g[u][kk] = gr[u * KP + kk];
   };
-  auto compute_group = [&](const Group& grp) {
+  auto compute_group = [&](const XGroup& xg, const GGroup& gg) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) channel(grp.x[u], grp.g[u]);
+    for (int u = 0; u < U; ++u) channel(xg.x[u], gg.g[u]);
   };
 
   int c = c_begin;
-  if constexpr (PIPE) {
-    // groups [c, c+U) and [c+U, c+2U) alternate between two register sets; the prefetch address is
-    // clamped to the last full group of the chunk, so no load is predicated and none leaves the
-    // wave's channel range (a clamped re-load is simply not consumed)
+  if constexpr (NBUF >= 2) {
     const int ngroups = (c_end - c_begin) / U;
     if (ngroups > 0) {
       const int c_last = c_begin + (ngroups - 1) * U;
-      Group ga, gb;
-      load_group(ga, c);
+      XGroup xs[NBUF];
+      GGroup ga, gb;
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) load_x(xs[b], min(c + b * U, c_last));
+      load_g(ga, c);
       int g = 0;
-      for (; g + 2 <= ngroups; g += 2) {
-        load_group(gb, min(c + U, c_last));
-        compute_group(ga);
-        load_group(ga, min(c + 2 * U, c_last));
-        compute_group(gb);
-        c += 2 * U;
+      // two passes over the ring per trip so that the GW double buffer (ga / gb) keeps static roles
+      for (; g + 2 * NBUF <= ngroups; g += 2 * NBUF) {
+#pragma unroll
+        for (int b = 0; b < 2 * NBUF; ++b) {
+          GGroup& cur = (b & 1) ? gb : ga;
+          GGroup& nxt = (b & 1) ? ga : gb;
+          load_g(nxt, min(c + U, c_last));
+          compute_group(xs[b % NBUF], cur);
+          load_x(xs[b % NBUF], min(c + NBUF * U, c_last));
+          c += U;
+        }
       }
-      if (g < ngroups) {
-        compute_group(ga);
-        c += U;
+      // remaining full groups: their X is already in the ring (slot (g + b) % NBUF == b since g is a
+      // multiple of NBUF); beyond the ring fall through to the plain loop below
+#pragma unroll
+      for (int b = 0; b < NBUF; ++b) {
+        if (g < ngroups) {
+          GGroup gl;
+          load_g(gl, c);
+          compute_group(xs[b], gl);
+          c += U;
+          ++g;
+        }
       }
     }
-  } else {
-    for (; c + U <= c_end; c += U) {
-      Group grp;
-      load_group(grp, c);
-      compute_group(grp);
-    }
+  }
+  for (; c + U <= c_end; c += U) {
+    XGroup xg;
+    GGroup gg;
+    load_x(xg, c);
+    load_g(gg, c);
+    compute_group(xg, gg);
   }
   for (; c < c_end; ++c) {  // remainder channels one at a time
     XVec<XT, PX> xv;
-    xv.load(xbase + (size_t)c * a.p_pad);
+    xv.load(xbase + (size_t)c * a.x_tile);
     float gk[K];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) gk[kk] = a.gw_s[(size_t)c * KP + kk];
@@ -116,7 +152,10 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   for (int kk = 0; kk < K; ++kk) {
     float* dst = smem + ((size_t)wave * K + kk) * TP + lane * PX;
 #pragma unroll
-    for (int i = 0; i < PX; ++i) dst[i] = num[kk][i];
+    for (int i = 0; i < P2; ++i) {
+      dst[2 * i] = num[kk][i].x;
+      dst[2 * i + 1] = num[kk][i].y;
+    }
   }
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
@@ -127,7 +166,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   if constexpr (LOSS) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < PX; ++i) s += kl[i];
+    for (int i = 0; i < P2; ++i) s += kl[i].x + kl[i].y;
     red[ESPM_HP_KL] = (double)s;
   }
   __syncthreads();

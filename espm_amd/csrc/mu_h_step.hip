@@ -16,77 +16,32 @@
 namespace espm {
 
 // ---- reduction of the per-workgroup records (one workgroup) ---------------------------------
-__device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* scratch) {
-  // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and 4 blocks
-  // per thread are in flight at once.  Few waves on purpose: the cross-lane part costs per wave.
-  constexpr int NV = ESPM_HP_NSCALAR + 2 * KP;   // [0..3] scalar sums, [4..4+KP) row sums | [4+KP] RELH, then maxima
-  constexpr int V_RELH = 4 + KP, V_MAX = 5 + KP;
-  double v[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = 0.0;
-  const size_t nb = a.nblk;
-  for (int b0 = threadIdx.x; b0 < a.nblk; b0 += 4 * 256) {
-    double t[4][ESPM_HP_RELH + 1];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int b = b0 + u * 256;
-#pragma unroll
-      for (int i = 0; i <= ESPM_HP_RELH; ++i) t[u][i] = b < a.nblk ? a.hpart[i * nb + b] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int i = 0; i < 4 + KP; ++i) v[i] += t[u][i];
-      v[V_RELH] = fmax(v[V_RELH], t[u][ESPM_HP_RELH]);
-#pragma unroll
-      for (int i = 0; i < KP; ++i) v[V_MAX + i] = fmax(v[V_MAX + i], t[u][ESPM_HP_MAX + i]);
-    }
-  }
-  block_reduce<NV, 4 + KP>(v, scratch);
-  if (threadIdx.x == 0) {
-    double sumy = 0.0;
-    for (int kk = 0; kk < a.k; ++kk) sumy += a.colsum_gw[kk] * a.hstat_in[ESPM_HS_ROWSUM + kk];
-    if (a.compute_loss) a.hist_slot[ESPM_HI_KLX] = (double)a.xscale * 0.6931471805599453 * v[ESPM_HP_KL];
-    a.hist_slot[ESPM_HI_REG] = v[ESPM_HP_REG];
-    a.hist_slot[ESPM_HI_LAP] = v[ESPM_HP_LAP];
-    a.hist_slot[ESPM_HI_SUMY] = sumy;
-    a.hist_slot[ESPM_HI_BAD] = v[ESPM_HP_BAD];
-    if (a.have_prev) a.hist_slot[ESPM_HI_REL_H] = v[V_RELH];
-    if (a.hstat_out) {
-      for (int kk = 0; kk < KP; ++kk) {
-        a.hstat_out[ESPM_HS_ROWSUM + kk] = v[ESPM_HP_ROWSUM + kk];
-        a.hstat_out[ESPM_HS_MAX + kk] = v[V_MAX + kk];
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) {
   __shared__ double scratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
   h_finalize_body(a, scratch);
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------
-template <int K, typename XT, int PX, int NW, int U, bool PIPE>
+template <int K, typename XT, int PX, int NW, int U, int NBUF>
 static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
   if (args.compute_loss)
-    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, true, U, PIPE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   else
-    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, false, U, PIPE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   return check_hip(hipGetLastError(), "h_step launch");
 }
 
 template <int K>
 static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
   if (x_dtype == ESPM_X_BF16) {
-    if (tile_px == 256) return launch_h<K, bf16_t, 4, 4, 4, true>(args, nblk, stream);
-    if (tile_px == 128) return launch_h<K, bf16_t, 2, 8, 8, true>(args, nblk, stream);
+    if (tile_px == 256) return launch_h<K, bf16_t, 4, 4, 8, 0>(args, nblk, stream);
+    if (tile_px == 128) return launch_h<K, bf16_t, 2, 8, 8, 2>(args, nblk, stream);
   } else {
-    if (tile_px == 256) return launch_h<K, float, 4, 4, 4, true>(args, nblk, stream);
-    if (tile_px == 128) return launch_h<K, float, 2, 8, 8, true>(args, nblk, stream);
+    if (tile_px == 256) return launch_h<K, float, 4, 4, 8, 0>(args, nblk, stream);
+    if (tile_px == 128) return launch_h<K, float, 2, 8, 8, 2>(args, nblk, stream);
   }
   return set_error(ESPM_EINVAL, "h_step: tile_px %d not available for x_dtype %d", tile_px, x_dtype);
 }

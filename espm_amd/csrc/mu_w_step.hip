@@ -13,34 +13,46 @@
 
 namespace espm {
 
-// Stage 1 of the slab reduction: grid (elements / 256, ESPM_WRED_SPLIT); split s sums the slabs
-// b = s, s + SPLIT, s + 2 SPLIT, ... in that order.  Stage 2 (the sum over the SPLIT partials, again in
-// fixed order) is done by w_finish / shard_pack when they read `a_part`.  No atomics: the result does
-// not depend on scheduling.
-__global__ __launch_bounds__(256) void w_reduce_kernel(const float* __restrict__ slab, float* __restrict__ part,
-                                                        int nblk, int total) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = blockIdx.y;
-  if (e >= total) return;
-  float s0 = 0.f, s1 = 0.f;
-  int b = s;
-  for (; b + ESPM_WRED_SPLIT < nblk; b += 2 * ESPM_WRED_SPLIT) {
-    s0 += slab[(size_t)b * total + e];
-    s1 += slab[(size_t)(b + ESPM_WRED_SPLIT) * total + e];
-  }
-  if (b < nblk) s0 += slab[(size_t)b * total + e];
-  part[(size_t)s * total + e] = s0 + s1;
-}
+// Slab reduction A = sum_b A_b in ONE pass and in a fixed order (bit-reproducible; no float atomics):
+// a workgroup owns 32 consecutive entries of A; its 256 threads are 32 entries x 8 slab groups, group g
+// sums the slabs b = g, g + 8, ... with 8 independent partial sums (loads in flight), then the 8 groups are
+// combined through LDS in group order.  One extra workgroup (when `fin` is set) reduces the H-step's
+// per-workgroup records at the same time (h_finalize_body), which saves a dependent launch per iteration.
+struct WReduceArgs {
+  const float* slab;
+  float* out;
+  int nblk, total, nred_blocks, fuse_finalize;
+  HFinalizeArgs fin;
+};
 
-// Stage 2 as its own kernel (used when the reduced A must exist in memory: sharded exchange).
-__global__ __launch_bounds__(256) void w_reduce2_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                         int total) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  float acc = 0.f;
+__global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ float s_part[8][32];
+  if ((int)blockIdx.x >= a.nred_blocks) {  // the extra workgroup
+    h_finalize_body(a.fin, fscratch);
+    return;
+  }
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + col;
+  float acc[8];
 #pragma unroll
-  for (int s = 0; s < ESPM_WRED_SPLIT; ++s) acc += part[(size_t)s * total + e];
-  out[e] = acc;
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (e < a.total) {
+    int b = grp;
+    for (; b + 56 < a.nblk; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += a.slab[(size_t)(b + 8 * u) * a.total + e];
+    }
+    for (int u = 0; b < a.nblk; b += 8, ++u) acc[u & 7] += a.slab[(size_t)b * a.total + e];
+  }
+  s_part[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (grp == 0 && e < a.total) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += s_part[g][col];
+    a.out[e] = t;
+  }
 }
 
 // ---- W finish: one workgroup of 1024 threads --------------------------------------------------
@@ -72,19 +84,7 @@ __device__ __forceinline__ double block_max1(double v, double* scratch) {
 constexpr int WF_GTA_MAX = 8192;
 
 __device__ __forceinline__ float load_a(const WFinishArgs& a, int kk, int c) {
-  const size_t total = (size_t)a.k * a.n_pad, idx = (size_t)kk * a.n_pad + c;
-  if (a.nsplit == ESPM_WRED_SPLIT) {  // second stage of the slab reduction: all loads in flight, fixed order
-    float v[ESPM_WRED_SPLIT];
-#pragma unroll
-    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) v[sp] = a.a[sp * total + idx];
-    float acc = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < ESPM_WRED_SPLIT; ++sp) acc += v[sp];
-    return acc;
-  }
-  float acc = 0.f;
-  for (int sp = 0; sp < a.nsplit; ++sp) acc += a.a[sp * total + idx];
-  return acc;
+  return a.a[(size_t)kk * a.n_pad + c];
 }
 
 template <int KK, int WF_ROWS>
@@ -452,10 +452,10 @@ template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
   if (x_dtype == ESPM_X_BF16) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
-    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, true>), grid, dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
   } else {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 4 - 1) / (4 * 64 * 4));
-    hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, true>), grid, dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, 0>), grid, dim3(256), 0, stream, args);
   }
   return check_hip(hipGetLastError(), "w_accum launch");
 }
@@ -474,10 +474,17 @@ int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipSt
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built (1..%d)", k, ESPM_MAX_K);
 }
 
-int launch_w_reduce(const float* slab, float* part, float* out, int nblk, int total, hipStream_t stream) {
-  hipLaunchKernelGGL(w_reduce_kernel, dim3((total + 255) / 256, ESPM_WRED_SPLIT), dim3(256), 0, stream, slab, part,
-                     nblk, total);
-  if (out) hipLaunchKernelGGL(w_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, part, out, total);
+int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
+                    hipStream_t stream) {
+  WReduceArgs a;
+  a.slab = slab;
+  a.out = out;
+  a.nblk = nblk;
+  a.total = total;
+  a.nred_blocks = (total + 31) / 32;
+  a.fuse_finalize = fused_finalize != nullptr;
+  if (fused_finalize) a.fin = *fused_finalize;
+  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce launch");
 }
 

@@ -6,7 +6,7 @@ torch stream.  PyTorch is used for device memory, streams and ``torch.distribute
 arithmetic of the update rules runs in the HIP library (there is no CPU path).
 
 Data layout in HBM (all caller-visible arrays are plain torch tensors):
-  x_cm  (n, p_pad)   bf16|f32   channel-major X, streamed by the H-step
+  x_cm  (p_pad/x_tile, n, x_tile) bf16|f32   X, channel-major inside pixel blocks, streamed by the H-step
   x_pm  (p, n_pad)   bf16|f32   pixel-major X, streamed by the W-step
   h[2]  (k, p_pad)   f32        ping-pong H;  h_t (p, 8) transposed copy of the newest H
   w[2]  (M, k)       f32        ping-pong W (M = m, or n when G is the identity)
@@ -56,7 +56,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -132,12 +132,14 @@ class MUEngine:
         self.p_total = st.p_total
 
         xt = torch.bfloat16 if x_store == "bf16" else torch.float32
-        self.x_cm = torch.empty((self.n, st.p_pad), dtype=xt, device=dev)
+        if x_tile is not None:
+            st.x_tile = int(x_tile)
+        self.x_cm = torch.empty((st.p_pad // st.x_tile, self.n, st.x_tile), dtype=xt, device=dev)
         self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
         Xd = Xd.contiguous()
         check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                  _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
-                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, _stream()))
+                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, _stream()))
         torch.cuda.current_stream().synchronize()
         del Xd
 
@@ -181,7 +183,6 @@ class MUEngine:
         self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
         self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
         self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
-        self.a_part = torch.zeros((_lib.WRED_SPLIT, k, st.n_pad), **f32)
         self.a = torch.zeros((k, st.n_pad), **f32)
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
         self.hist_len = int(max_iter) + 2
@@ -212,7 +213,6 @@ class MUEngine:
         st.hpart = self.hpart.data_ptr()
         st.hstat[0], st.hstat[1] = self.hstat[0].data_ptr(), self.hstat[1].data_ptr()
         st.a_slab, st.a, st.w_scratch = self.a_slab.data_ptr(), self.a.data_ptr(), self.w_scratch.data_ptr()
-        st.a_part = self.a_part.data_ptr()
         st.hist, st.hist_len = self.hist.data_ptr(), self.hist_len
         st.cur, st.it = 0, 0
 
@@ -305,7 +305,7 @@ class MUEngine:
             self.exchange.gather()
             check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.exchange.recv), self.world, 1 - cur, s))
             self._set_halo_from_records()
-        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, 1 if self.world > 1 else 0, s))
+        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, s))
         st.cur, st.it = 1 - cur, slot + 1
 
     def iterate(self, n_iter, final_loss=True):
@@ -338,7 +338,7 @@ class MUEngine:
         s = _stream()
         check(lib.espm_mu_w_accum(C.byref(st), s))
         check(lib.espm_mu_w_reduce(C.byref(st), s))
-        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, 0, s))
+        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))
         return self.w[1 - cur].cpu().numpy()
 
     # ---- read-back -----------------------------------------------------------------------------------------

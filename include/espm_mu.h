@@ -30,8 +30,9 @@
  *   - Every call only enqueues work on `stream` (a hipStream_t) and returns; no host sync.
  *   - Return value: 0 on success, negative espm_status otherwise; espm_mu_last_error() gives
  *     the message of the last failure on the calling thread.
- *   - X is kept twice in HBM: channel-major (n, p_pad) for the H-step and pixel-major
- *     (p, n_pad) for the W-step, as bf16 (lossless for count data) or fp32.
+ *   - X is kept twice in HBM: channel-major inside pixel blocks (p_pad / x_tile, n, x_tile) for the
+ *     H-step and pixel-major (p, n_pad) for the W-step, as bf16 (lossless for count data) or fp32:
+ *     both streaming kernels read one contiguous region per workgroup.
  *   - W, H, G, GW and every accumulator are fp32; loss sums are fp64.
  */
 #ifndef ESPM_MU_H
@@ -62,7 +63,6 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
-#define ESPM_WRED_SPLIT 16 /* partial sums kept by the first stage of the slab reduction */
 
 /* per-workgroup partial record written by the H-step (doubles), stored field-major:
  * hpart[field * nblk + block] */
@@ -104,6 +104,7 @@ typedef struct espm_mu_state {
   int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16                                         */
   int32_t tile_px;  /* H-step pixel tile per workgroup: 64 * {1,2,4,8}, see query       */
   int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
+  int32_t x_tile;   /* pixel-block width of the tile-major x_cm (multiple of tile_px)   */
   int64_t p_total;  /* pixels of the whole image over all ranks (= p on one GPU)        */
   /* flags */
   int32_t simplex_h, simplex_w;
@@ -114,7 +115,7 @@ typedef struct espm_mu_state {
   float xscale;     /* X_ = xscale * X_stored (normalize=True, base.py:264-267)         */
   float gw_floor;   /* lower clamp of GW entries, keeps X/(GW H) finite (updates.py:129-131) */
   /* data */
-  const void* x_cm;         /* (n, p_pad) bf16|f32, zero padded                         */
+  const void* x_cm;         /* (p_pad / x_tile, n, x_tile) bf16|f32: channel-major inside pixel blocks, zero padded */
   const void* x_pm;         /* (p, n_pad) bf16|f32, zero padded                         */
   const float* g;           /* (n, m) row-major or NULL                                  */
   const float* colsum_g;    /* (m) or NULL                                               */
@@ -133,7 +134,6 @@ typedef struct espm_mu_state {
   double* hpart;            /* (ESPM_HP_STRIDE, ceil(p / tile_px)) field-major              */
   double* hstat[2];         /* (ESPM_HS_STRIDE) statistics of h[0] / h[1] (global)       */
   float* a_slab;            /* (nblk_w, k, n_pad)                                        */
-  float* a_part;            /* (ESPM_WRED_SPLIT, k, n_pad) first-stage partial sums of the slabs */
   float* a;                 /* (k, n_pad)                                                */
   float* w_scratch;         /* (2, m or n, k)                                            */
   double* hist;             /* (hist_len, ESPM_HI_STRIDE), zero-initialised              */
@@ -145,13 +145,14 @@ typedef struct espm_mu_state {
 const char* espm_mu_version(void);
 const char* espm_mu_last_error(void);
 
-/* Fills n_pad, p_pad, tile_px, nblk_w of `st` from n, p, k, x_dtype and the device's CU count. */
+/* Fills n_pad, p_pad, tile_px, x_tile, nblk_w of `st` from n, p, k, x_dtype and the device's CU count. */
 int espm_mu_query(espm_mu_state* st);
 
 /* X (host layout, device memory) -> the two padded device layouts.  src is (n, p) when
  * src_layout = CM or (p, n) when PM (hyperspy's layout), leading dimension ld (elements). */
 int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p,
-                   void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, espm_stream_t stream);
+                   void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, int x_tile,
+                   espm_stream_t stream);
 
 /* statistics (row sums, row maxima) of st->h[which] into st->hstat[which] (local pixels). */
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream);
@@ -173,14 +174,11 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 
 /* A_slab[b] = sum over the pixels of block b of R[:, j] H[:, j]^T with R = X / (GW H), H = h_t. */
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream);
-/* a_part[s] = sum of the slabs b = s, s + SPLIT, ... (first stage, fixed order); the second stage
- * (sum over s) is folded into the consumers: w_finish (combined = 0) or shard_pack. */
+/* a = sum_b a_slab[b] in fixed order (one pass, bit-reproducible). */
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream);
-/* W update from A and hstat[hsrc] (global row sums of the new H): reads w[src], writes w[1-src],
- * gw_s, colsum_gw and rel_W into history slot `slot`.  combined = 0: A = sum of a_part (one GPU);
- * combined = 1: A = `a`, the all-rank sum written by espm_mu_shard_combine. */
-int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, int combined,
-                     espm_stream_t stream);
+/* W update from a (sharded: the all-rank sum written by espm_mu_shard_combine) and hstat[hsrc] (global
+ * row sums of the new H): reads w[src], writes w[1-src], gw_s, colsum_gw and rel_W into history slot `slot`. */
+int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream);
 
 /* n_iter full iterations on one GPU, no host synchronisation; updates st->cur / st->it.
  * History slot t holds the loss pieces of state t (slot 0 = initial state) and the relative

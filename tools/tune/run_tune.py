@@ -38,7 +38,8 @@ def main():
     prob = synth.make_problem(n, rows, ny, k, N=500.0, seed=0, nx_total=nx)
     X = synth.sample_torch(prob, "cuda", seed=1000)
     W0, H0 = synth.random_init(n, k, rows * ny, seed=0, scale=500.0 / n)
-    eng = MUEngine(X, k, layout="pm", shape_2d=(rows, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=20)
+    eng = MUEngine(X, k, layout="pm", shape_2d=(rows, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=20,
+                   x_tile=int(os.environ.get("TUNE_XTILE", 512)))
     del X
     eng.load_state(W0, H0)
     eng.iterate(3, final_loss=False)
@@ -67,10 +68,15 @@ def main():
     tile = C.c_int(0)
     bytes_h = n * p * 2 + 2 * k * p * 4
     which = os.environ.get("TUNE", "hw")
+    st.compute_loss = int(os.environ.get("TUNE_LOSS", "1"))
+    only = os.environ.get("TUNE_ONLY")
     if "h" in which:
         for rnd in range(2):
             v = 0
             while lib.tune_h_name(v):
+                if only and str(v) not in only.split(","):
+                    v += 1
+                    continue
                 rc = lib.tune_h(C.byref(st), st.cur, 1, v, C.byref(tile), s)
                 torch.cuda.synchronize()
                 assert rc == 0, rc
@@ -78,7 +84,7 @@ def main():
                 print(f"h[{v:2d}] {lib.tune_h_name(v).decode():22s} tile {tile.value:3d}: {t:7.1f} us  {bytes_h / t / 1e6:6.2f} TB/s", flush=True)
                 v += 1
     if "w" in which:
-        for nblk in (512, 1024, 256):
+        for nblk in (512, 768):
             v = 0
             while lib.tune_w_name(v):
                 rc = lib.tune_w(C.byref(st), v, nblk, s)

@@ -7,23 +7,23 @@ using namespace espm;
 
 namespace {
 
-template <int PX, int NW, int U, bool PIPE>
+template <int PX, int NW, int U, int NBUF>
 int run_h(const HStepArgs& args, int p, hipStream_t stream) {
   constexpr int K = 5;
   const int nblk = (p + 64 * PX - 1) / (64 * PX);
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   if (args.compute_loss)
-    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, true, U, PIPE>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
   else
-    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, false, U, PIPE>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
   return (int)hipGetLastError();
 }
 
-template <int UP, bool PIPE>
+template <int UP, int NBUF>
 int run_w(const WAccumArgs& args, int nblk, hipStream_t stream) {
   dim3 grid(nblk, (args.n_pad + 2047) / 2048);
-  hipLaunchKernelGGL((w_accum_kernel<5, bf16_t, 8, UP, PIPE>), grid, dim3(256), 0, stream, args);
+  hipLaunchKernelGGL((w_accum_kernel<5, bf16_t, 8, UP, NBUF>), grid, dim3(256), 0, stream, args);
   return (int)hipGetLastError();
 }
 
@@ -32,10 +32,10 @@ int run_w(const WAccumArgs& args, int nblk, hipStream_t stream) {
 extern "C" {
 
 const char* tune_h_name(int v) {
-  static const char* names[] = {"px8 nw4 u8 plain", "px8 nw4 u4 pipe", "px8 nw4 u8 pipe", "px8 nw8 u4 pipe", "px8 nw8 u8 plain",
-                                "px4 nw4 u8 plain", "px4 nw4 u8 pipe", "px4 nw4 u4 pipe", "px4 nw8 u8 pipe", "px4 nw8 u8 plain",
-                                "px2 nw16 u16 plain", "px2 nw8 u8 pipe", "px2 nw16 u8 pipe", "px4 nw16 u4 pipe", "px8 nw4 u2 pipe",
-                                "px4 nw4 u16 plain"};
+  static const char* names[] = {"px4 nw4 u4 nb2", "px4 nw4 u4 nb3", "px4 nw4 u4 nb4", "px4 nw4 u2 nb4", "px4 nw4 u2 nb6",
+                                "px4 nw4 u2 nb8", "px4 nw4 u8 nb2", "px4 nw4 u8 nb3", "px4 nw8 u4 nb3", "px4 nw8 u4 nb4",
+                                "px8 nw4 u2 nb3", "px8 nw4 u2 nb4", "px8 nw4 u4 nb3", "px2 nw8 u8 nb3", "px4 nw4 u4 nb6",
+                                "px4 nw4 u8 nb0"};
   return (v >= 0 && v < 16) ? names[v] : nullptr;
 }
 
@@ -44,29 +44,29 @@ int tune_h(const espm_mu_state* st, int src, int write_h, int v, int* tile_px, v
   HStepArgs a = make_h_args(st, src, write_h);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (v) {
-    case 0: *tile_px = 512; return run_h<8, 4, 8, false>(a, st->p, s);
-    case 1: *tile_px = 512; return run_h<8, 4, 4, true>(a, st->p, s);
-    case 2: *tile_px = 512; return run_h<8, 4, 8, true>(a, st->p, s);
-    case 3: *tile_px = 512; return run_h<8, 8, 4, true>(a, st->p, s);
-    case 4: *tile_px = 512; return run_h<8, 8, 8, false>(a, st->p, s);
-    case 5: *tile_px = 256; return run_h<4, 4, 8, false>(a, st->p, s);
-    case 6: *tile_px = 256; return run_h<4, 4, 8, true>(a, st->p, s);
-    case 7: *tile_px = 256; return run_h<4, 4, 4, true>(a, st->p, s);
-    case 8: *tile_px = 256; return run_h<4, 8, 8, true>(a, st->p, s);
-    case 9: *tile_px = 256; return run_h<4, 8, 8, false>(a, st->p, s);
-    case 10: *tile_px = 128; return run_h<2, 16, 16, false>(a, st->p, s);
-    case 11: *tile_px = 128; return run_h<2, 8, 8, true>(a, st->p, s);
-    case 12: *tile_px = 128; return run_h<2, 16, 8, true>(a, st->p, s);
-    case 13: *tile_px = 256; return run_h<4, 16, 4, true>(a, st->p, s);
-    case 14: *tile_px = 512; return run_h<8, 4, 2, true>(a, st->p, s);
-    case 15: *tile_px = 256; return run_h<4, 4, 16, false>(a, st->p, s);
+    case 0: *tile_px = 256; return run_h<4, 4, 4, 2>(a, st->p, s);
+    case 1: *tile_px = 256; return run_h<4, 4, 4, 3>(a, st->p, s);
+    case 2: *tile_px = 256; return run_h<4, 4, 4, 4>(a, st->p, s);
+    case 3: *tile_px = 256; return run_h<4, 4, 2, 4>(a, st->p, s);
+    case 4: *tile_px = 256; return run_h<4, 4, 2, 6>(a, st->p, s);
+    case 5: *tile_px = 256; return run_h<4, 4, 2, 8>(a, st->p, s);
+    case 6: *tile_px = 256; return run_h<4, 4, 8, 2>(a, st->p, s);
+    case 7: *tile_px = 256; return run_h<4, 4, 8, 3>(a, st->p, s);
+    case 8: *tile_px = 256; return run_h<4, 8, 4, 3>(a, st->p, s);
+    case 9: *tile_px = 256; return run_h<4, 8, 4, 4>(a, st->p, s);
+    case 10: *tile_px = 512; return run_h<8, 4, 2, 3>(a, st->p, s);
+    case 11: *tile_px = 512; return run_h<8, 4, 2, 4>(a, st->p, s);
+    case 12: *tile_px = 512; return run_h<8, 4, 4, 3>(a, st->p, s);
+    case 13: *tile_px = 128; return run_h<2, 8, 8, 3>(a, st->p, s);
+    case 14: *tile_px = 256; return run_h<4, 4, 4, 6>(a, st->p, s);
+    case 15: *tile_px = 256; return run_h<4, 4, 8, 0>(a, st->p, s);
   }
   return -1;
 }
 
 const char* tune_w_name(int v) {
-  static const char* names[] = {"up4 plain", "up4 pipe", "up8 plain", "up8 pipe", "up2 pipe", "up16 plain"};
-  return (v >= 0 && v < 6) ? names[v] : nullptr;
+  static const char* names[] = {"up4 nb0", "up4 nb2", "up4 nb3", "up4 nb4", "up2 nb4", "up2 nb6", "up2 nb8", "up8 nb2"};
+  return (v >= 0 && v < 8) ? names[v] : nullptr;
 }
 
 // nblk pixel blocks (a_slab must hold nblk slabs)
@@ -75,12 +75,14 @@ int tune_w(const espm_mu_state* st, int v, int nblk, void* stream) {
   a.ppb = (st->p + nblk - 1) / nblk;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (v) {
-    case 0: return run_w<4, false>(a, nblk, s);
-    case 1: return run_w<4, true>(a, nblk, s);
-    case 2: return run_w<8, false>(a, nblk, s);
-    case 3: return run_w<8, true>(a, nblk, s);
-    case 4: return run_w<2, true>(a, nblk, s);
-    case 5: return run_w<16, false>(a, nblk, s);
+    case 0: return run_w<4, 0>(a, nblk, s);
+    case 1: return run_w<4, 2>(a, nblk, s);
+    case 2: return run_w<4, 3>(a, nblk, s);
+    case 3: return run_w<4, 4>(a, nblk, s);
+    case 4: return run_w<2, 4>(a, nblk, s);
+    case 5: return run_w<2, 6>(a, nblk, s);
+    case 6: return run_w<2, 8>(a, nblk, s);
+    case 7: return run_w<8, 2>(a, nblk, s);
   }
   return -1;
 }
