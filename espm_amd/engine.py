@@ -56,7 +56,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -132,6 +132,9 @@ class MUEngine:
         self.p_total = st.p_total
 
         xt = torch.bfloat16 if x_store == "bf16" else torch.float32
+        if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
+            st.tile_px = int(tile_px)
+            st.x_tile = int(tile_px)
         if x_tile is not None:
             st.x_tile = int(x_tile)
         self.x_cm = torch.empty((st.p_pad // st.x_tile, self.n, st.x_tile), dtype=xt, device=dev)

@@ -223,3 +223,46 @@ def test_physics_model_protocol(SmoothNMF):
     from espm_amd.estimators.updates import multiplicative_step_w
     got = multiplicative_step_w(X, prob["G"], W0, est.H_, simplex_W=True, physics_model=model)
     np.testing.assert_allclose(got, ref, rtol=3e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,nx,ny,k,m", [(1980, 10, 13, 3, None), (100, 20, 20, 3, None), (333, 7, 19, 8, 17), (65, 3, 5, 1, 4),
+                                         (2050, 4, 33, 6, None)])
+def test_ragged_shapes_match_oracle(SmoothNMF, n, nx, ny, k, m):
+    """Channel counts that are not multiples of the vector width, pixel counts that do not fill a tile, k = 1..8."""
+    from espm_amd import synth
+    prob = synth.make_problem(n, nx, ny, k, N=90.0, seed=n, m=m)
+    X = synth.sample_numpy(prob, seed=n)
+    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=n, scale=0.2)
+    kw = dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False, tol=0, no_stop_criterion=True, max_iter=10)
+    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, **kw)
+    est = SmoothNMF(n_components=k, G=prob["G"], shape_2d=(nx, ny), verbose=0, **kw)
+    quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+
+
+def test_one_dimensional_spectrum_fit(SmoothNMF):
+    """The reference's 1-D fitting use (espm/datasets/eds_spim.py:228-253): p = 1, k = 1, no shape_2d,
+    fixed_H = 1, G an ndarray; and an empty-looking spectrum with all-zero channels (base.py:519-528)."""
+    rng = np.random.default_rng(5)
+    n, m = 300, 6
+    G = rng.random((n, m)) + 0.01
+    w = rng.random((m, 1)) * 5
+    x = rng.poisson(G @ w).astype(float)
+    x[50:60] = 0
+    est = SmoothNMF(n_components=1, G=G, fixed_H=np.ones((1, 1)), simplex_H=False, simplex_W=False, max_iter=50, tol=1e-9,
+                    verbose=0)
+    quiet(est.fit, x)
+    ref = oc.fit(x, 1, G=G, fixed_H=np.ones((1, 1)), simplex_H=False, simplex_W=False, max_iter=50, tol=1e-9)
+    assert est.H_.shape == (1, 1) and est.W_.shape == (m, 1) and est.n_iter_ == ref["n_iter"]
+    np.testing.assert_allclose(est.G_ @ est.W_ @ est.H_, ref["GW"] @ ref["H"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=LOSS_RTOL)
+
+
+def test_k_above_build_limit_is_refused(SmoothNMF):
+    X = np.random.default_rng(0).random((20, 30))
+    with pytest.raises(NotImplementedError):
+        quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
+    with pytest.raises(NotImplementedError):
+        quiet(SmoothNMF(n_components=2, algo="l2_surrogate", verbose=0).fit, X)

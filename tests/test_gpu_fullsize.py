@@ -1,0 +1,96 @@
+"""Headline-size checks (2048 channels x 512 x 512 pixels, k = 5, SmoothNMF simplex_H + Laplacian): the
+kernel variants the benchmark runs (256-pixel H tiles, 512-pixel-block W accumulation) are exercised at
+BASELINE.json's full size through size-independent properties and through the oracle on a pixel subset
+(an H update of a pixel depends only on its own X column, W, its 4 neighbours and the global row maxima)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mu_oracle as oc  # noqa: E402
+
+N, NX, NY, K = 2048, 512, 512, 5
+
+
+@pytest.fixture(scope="module")
+def big():
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(N, NX, NY, K, N=500.0, seed=0)
+    X = synth.sample_torch(prob, "cuda", seed=1000)                      # (p, n) counts
+    W0, H0 = synth.random_init(N, K, NX * NY, seed=0, scale=500.0 / N)
+    kw = dict(layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=8)
+    engs = {}
+    for tile in (256, 128):
+        eng = MUEngine(X, K, tile_px=tile, **kw)
+        eng.load_state(W0, H0)
+        engs[tile] = eng
+    rows = slice(200 * NY, 203 * NY)                                      # three image rows for the oracle
+    Xsub = X[rows.start - NY:rows.stop + NY].T.double().cpu().numpy()    # with one halo row each side
+    del X
+    return dict(engs=engs, W0=W0, H0=H0, Xsub=Xsub, rows=rows)
+
+
+def test_storage_is_lossless_bf16(big):
+    assert all(e.x_store == "bf16" for e in big["engs"].values())
+    assert big["engs"][256].st.tile_px == 256 and big["engs"][128].st.tile_px == 128
+
+
+def test_first_h_step_matches_oracle_on_a_pixel_subset(big):
+    eng = big["engs"][256]
+    H1 = eng.step_h_only()                                                # full-size H update, tile 256
+    W0, H0, rows = big["W0"], big["H0"], big["rows"]
+    ext = slice(rows.start - NY, rows.stop + NY)
+    # oracle on 5 image rows (3 + halo); the global row maxima enter through sigma * max_j H
+    Hsub = H0[:, ext]
+    L = oc.laplacian_matrix(5, NY)
+    GW = W0
+    Y = GW @ Hsub
+    num = GW.T @ (big["Xsub"] / Y) + 1.0 * 8 * H0.max(axis=1, keepdims=True)
+    den = GW.sum(axis=0)[:, None] + 1.0 * 8 * H0.max(axis=1, keepdims=True) + 1.0 * (Hsub @ L)
+    num = Hsub * num
+    delta, e = oc.dichotomy_simplex_exact(num, den)
+    ref = np.fmax(num / (delta + e), 1e-14)[:, NY:-NY]                    # drop the halo rows (wrong stencil there)
+    np.testing.assert_allclose(H1[:, rows], ref, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(H1.sum(axis=0), 1.0, atol=5e-6)            # simplex on every one of the 262144 pixels
+    assert (H1 >= 1e-14).all() and np.isfinite(H1).all()
+
+
+def test_kernel_variants_agree_and_loss_decreases(big):
+    out = {}
+    for tile, eng in big["engs"].items():
+        eng.load_state(big["W0"], big["H0"])
+        eng.iterate(6, final_loss=True)
+        torch.cuda.synchronize()
+        out[tile] = (eng.get_W(), eng.get_H(), eng.history())
+    (Wa, Ha, ha), (Wb, Hb, hb) = out[256], out[128]
+    np.testing.assert_allclose(Wa, Wb, rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(Ha, Hb, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ha["loss"], hb["loss"], rtol=1e-6)
+    assert np.all(np.diff(ha["loss"]) < 0)                                # monotone decrease of the full objective
+    assert ha["bad"].sum() == 0
+    np.testing.assert_allclose(Ha.sum(axis=0), 1.0, atol=5e-6)
+    # mass balance of the KL multiplicative W update: sum(GW H) == sum(X) after every W step
+    eng = big["engs"][256]
+    sum_y = float(eng.hist[6, 3].item())
+    assert abs(sum_y - eng.sum_x) / eng.sum_x < 1e-5
+
+
+def test_w_step_is_linear_in_the_pixel_blocks(big):
+    """R H^T accumulated over all pixels == sum of the accumulations over two halves (slab reduction)."""
+    import ctypes as C
+    from espm_amd import _lib
+    from espm_amd.engine import _stream
+    eng = big["engs"][256]
+    eng.load_state(big["W0"], big["H0"])
+    eng.step_h_only()
+    st = eng.st
+    s = _stream()
+    _lib.check(_lib.lib.espm_mu_w_accum(C.byref(st), s))
+    _lib.check(_lib.lib.espm_mu_w_reduce(C.byref(st), s))
+    full = eng.a.clone()
+    slabs = eng.a_slab.double().sum(dim=0)
+    np.testing.assert_allclose(full.cpu().numpy(), slabs.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    half = eng.a_slab[: st.nblk_w // 2].double().sum(dim=0) + eng.a_slab[st.nblk_w // 2:].double().sum(dim=0)
+    np.testing.assert_allclose(slabs.cpu().numpy(), half.cpu().numpy(), rtol=1e-12)
