@@ -152,8 +152,17 @@ def main():
     bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
     bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
     flops_it = 8.0 * N_CH * K * NX * NY
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, corrected as
+    # MI355X_MICROARCH.md prescribes); measured once per kernel version and committed under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_hbm_traffic.json")) as f:
+            if world == 1 and eng.x_store == "bf16":
+                traffic = json.load(f)["kernels"]["h_step"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = dict(bound="hbm", kernel="h_step_kernel<5,bf16,...,loss>", achieved=bytes_h / t_h_upd / 1e9,
-                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=None,
+                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=traffic,
                     bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
                     w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),
                     iteration=dict(algorithmic_GB=bytes_it / 1e9, hbm_frac=bytes_it * its / HBM_PEAK,
