@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--lambda-l", type=float, default=LAMBDA_L)
+    ap.add_argument("--x-store", default="auto", choices=["auto", "u8", "bf16", "f32"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,7 +101,7 @@ def main():
     H0 = H0_full[:, row0 * NY:(row0 + rows) * NY]
     total_iters = args.warmup + args.steps
     eng = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=total_iters + 40, group=group, device=device)
+                   tol=0.0, max_iter=total_iters + 40, group=group, device=device, x_store=args.x_store)
     del X
     eng.load_state(W0, H0)
 
@@ -147,7 +148,7 @@ def main():
     t_h_upd = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_step_h(C.byref(st), st.cur, 1, s)))
     t_w = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_w_accum(C.byref(st), s)))
     p_loc = eng.p
-    xbytes = 2 if eng.x_store == "bf16" else 4
+    xbytes = {"u8": 1, "bf16": 2, "f32": 4}[eng.x_store]
     bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4          # X once, H read + written
     bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
     bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
@@ -161,7 +162,7 @@ def main():
                 traffic = json.load(f)["kernels"]["h_step"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = dict(bound="hbm", kernel="h_step_kernel<5,bf16,...,loss>", achieved=bytes_h / t_h_upd / 1e9,
+    roofline = dict(bound="hbm", kernel="h_step_kernel<5,%s,...,loss>" % eng.x_store, achieved=bytes_h / t_h_upd / 1e9,
                     peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=traffic,
                     bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
                     w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libespm_mu.so")
 
 # mirrors of the header's constants
 OK, EINVAL, ENOSOLUTION, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4
-X_F32, X_BF16 = 0, 1
+X_F32, X_BF16, X_U8 = 0, 1, 2
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8

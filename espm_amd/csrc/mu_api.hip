@@ -32,7 +32,8 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE(st->n_pad == roundup(st->n, ESPM_NPAD) && st->p_pad == roundup(st->p, ESPM_PPAD),
                "n_pad/p_pad (%d, %d) do not match n, p (%d, %d); call espm_mu_query", st->n_pad, st->p_pad, st->n,
                st->p);
-  ESPM_REQUIRE(st->x_dtype == ESPM_X_F32 || st->x_dtype == ESPM_X_BF16, "bad x_dtype %d", st->x_dtype);
+  ESPM_REQUIRE(st->x_dtype == ESPM_X_F32 || st->x_dtype == ESPM_X_BF16 || st->x_dtype == ESPM_X_U8, "bad x_dtype %d",
+               st->x_dtype);
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
@@ -73,7 +74,7 @@ int espm_mu_query(espm_mu_state* st) {
   st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
   st->x_tile = st->tile_px;
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
-  const int ychunks = st->x_dtype == ESPM_X_BF16 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
+  const int ychunks = st->x_dtype != ESPM_X_F32 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
   int target = (2 * cus + ychunks - 1) / ychunks;
   int by_px = (st->p + 15) / 16;
   int nb = target < by_px ? target : by_px;

@@ -18,6 +18,9 @@ __device__ __forceinline__ bf16_t to_store<bf16_t>(float v) {
   return (bf16_t)(u >> 16);
 }
 
+template <>
+__device__ __forceinline__ uint8_t to_store<uint8_t>(float v) { return (uint8_t)(v + 0.5f); }  // exact integers
+
 template <typename ST, typename DT>
 __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src, int src_layout, int64_t ld, int n,
                                                      int p, DT* __restrict__ x_cm, DT* __restrict__ x_pm, int n_pad,
@@ -52,7 +55,10 @@ template <typename ST>
 static int pack_dispatch(const void* src, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                          int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream) {
   dim3 grid((p_pad + 31) / 32, (n_pad + 31) / 32);
-  if (x_dtype == ESPM_X_BF16)
+  if (x_dtype == ESPM_X_U8)
+    hipLaunchKernelGGL((pack_x_kernel<ST, uint8_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
+                       src_layout, ld, n, p, static_cast<uint8_t*>(x_cm), static_cast<uint8_t*>(x_pm), n_pad, p_pad, x_tile);
+  else if (x_dtype == ESPM_X_BF16)
     hipLaunchKernelGGL((pack_x_kernel<ST, bf16_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
                        src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad, x_tile);
   else

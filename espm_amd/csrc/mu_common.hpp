@@ -69,6 +69,40 @@ struct XVec<bf16_t, 2> {
     x[0] = f2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
   }
 };
+// 8-bit counts (lossless for integer data <= 255): v_cvt_f32_ubyteN widens straight from the packed dword
+__device__ __forceinline__ float ub0(uint32_t u) { return (float)(u & 0xffu); }
+__device__ __forceinline__ float ub1(uint32_t u) { return (float)((u >> 8) & 0xffu); }
+__device__ __forceinline__ float ub2(uint32_t u) { return (float)((u >> 16) & 0xffu); }
+__device__ __forceinline__ float ub3(uint32_t u) { return (float)(u >> 24); }
+template <>
+struct XVec<uint8_t, 8> {
+  uint2 v;
+  __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void zero() { v = make_uint2(0, 0); }
+  __device__ __forceinline__ void get2(f2 (&x)[4]) const {
+    x[0] = f2{ub0(v.x), ub1(v.x)};
+    x[1] = f2{ub2(v.x), ub3(v.x)};
+    x[2] = f2{ub0(v.y), ub1(v.y)};
+    x[3] = f2{ub2(v.y), ub3(v.y)};
+  }
+};
+template <>
+struct XVec<uint8_t, 4> {
+  uint32_t v;
+  __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint32_t*>(p); }
+  __device__ __forceinline__ void zero() { v = 0; }
+  __device__ __forceinline__ void get2(f2 (&x)[2]) const {
+    x[0] = f2{ub0(v), ub1(v)};
+    x[1] = f2{ub2(v), ub3(v)};
+  }
+};
+template <>
+struct XVec<uint8_t, 2> {
+  uint16_t v;
+  __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint16_t*>(p); }
+  __device__ __forceinline__ void zero() { v = 0; }
+  __device__ __forceinline__ void get2(f2 (&x)[1]) const { x[0] = f2{ub0(v), ub1(v)}; }
+};
 template <>
 struct XVec<float, 4> {
   float4 v;

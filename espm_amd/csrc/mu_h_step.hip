@@ -36,7 +36,10 @@ static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
 
 template <int K>
 static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
-  if (x_dtype == ESPM_X_BF16) {
+  if (x_dtype == ESPM_X_U8) {
+    if (tile_px == 256) return launch_h<K, uint8_t, 4, 4, 8, 0>(args, nblk, stream);
+    if (tile_px == 128) return launch_h<K, uint8_t, 2, 8, 8, 2>(args, nblk, stream);
+  } else if (x_dtype == ESPM_X_BF16) {
     if (tile_px == 256) return launch_h<K, bf16_t, 4, 4, 8, 0>(args, nblk, stream);
     if (tile_px == 128) return launch_h<K, bf16_t, 2, 8, 8, 2>(args, nblk, stream);
   } else {

@@ -450,7 +450,10 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
 // ---- dispatch -----------------------------------------------------------------------------------
 template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
-  if (x_dtype == ESPM_X_BF16) {
+  if (x_dtype == ESPM_X_U8) {
+    dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
+    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
+  } else if (x_dtype == ESPM_X_BF16) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
     hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
   } else {

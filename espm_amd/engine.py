@@ -6,8 +6,8 @@ torch stream.  PyTorch is used for device memory, streams and ``torch.distribute
 arithmetic of the update rules runs in the HIP library (there is no CPU path).
 
 Data layout in HBM (all caller-visible arrays are plain torch tensors):
-  x_cm  (p_pad/x_tile, n, x_tile) bf16|f32   X, channel-major inside pixel blocks, streamed by the H-step
-  x_pm  (p, n_pad)   bf16|f32   pixel-major X, streamed by the W-step
+  x_cm  (p_pad/x_tile, n, x_tile) u8|bf16|f32   X, channel-major inside pixel blocks, streamed by the H-step
+  x_pm  (p, n_pad)   u8|bf16|f32   pixel-major X, streamed by the W-step
   h[2]  (k, p_pad)   f32        ping-pong H;  h_t (p, 8) transposed copy of the newest H
   w[2]  (M, k)       f32        ping-pong W (M = m, or n when G is the identity)
   gw_s  (n_pad, 8)   f32        G @ W / xscale (wave-uniform rows, read through the scalar cache)
@@ -104,19 +104,23 @@ class MUEngine:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
         if x_store == "auto":
+            # u8: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
+            # which is not an integer: such data keep the bf16 store and the reference's exact semantics
+            is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
             exact = (Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16
-            flag = torch.tensor([1 if bool(exact) else 0], device=dev, dtype=torch.int32)
+            code = 2 if bool(is_count) else (1 if bool(exact) else 0)
+            flag = torch.tensor([code], device=dev, dtype=torch.int32)
             if group is not None:
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
-            x_store = "bf16" if int(flag.item()) else "f32"
-        if x_store not in ("bf16", "f32"):
-            raise ValueError("x_store must be 'auto', 'bf16' or 'f32'")
+            x_store = ("f32", "bf16", "u8")[int(flag.item())]
+        if x_store not in ("u8", "bf16", "f32"):
+            raise ValueError("x_store must be 'auto', 'u8', 'bf16' or 'f32'")
         self.x_store = x_store
 
         st = MUState()
         self.st = st
         st.n, st.p, st.k = self.n, self.p, k
-        st.x_dtype = _lib.X_BF16 if x_store == "bf16" else _lib.X_F32
+        st.x_dtype = {"u8": _lib.X_U8, "bf16": _lib.X_BF16, "f32": _lib.X_F32}[x_store]
         if shape_2d is not None:
             nx, ny = int(shape_2d[0]), int(shape_2d[1])
             if nx * ny != p:
@@ -131,7 +135,7 @@ class MUEngine:
         st.p_total = int(p_total.item())
         self.p_total = st.p_total
 
-        xt = torch.bfloat16 if x_store == "bf16" else torch.float32
+        xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
         if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
             st.tile_px = int(tile_px)
             st.x_tile = int(tile_px)

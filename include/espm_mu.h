@@ -55,7 +55,7 @@ typedef enum espm_status {
   ESPM_EUNSUPPORTED = -4  /* configuration not built (k > ESPM_MAX_K) */
 } espm_status;
 
-enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1 };
+enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1, ESPM_X_U8 = 2 /* integer counts <= 255 */ };
 enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
 enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
 
@@ -101,7 +101,7 @@ typedef struct espm_mu_state {
   int32_t nx, ny;   /* local image rows, row length                                     */
   int32_t n_pad;    /* roundup(n, ESPM_NPAD)                                            */
   int32_t p_pad;    /* roundup(p, ESPM_PPAD)                                            */
-  int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16                                         */
+  int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16 | ESPM_X_U8                             */
   int32_t tile_px;  /* H-step pixel tile per workgroup: 64 * {1,2,4,8}, see query       */
   int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
   int32_t x_tile;   /* pixel-block width of the tile-major x_cm (multiple of tile_px)   */

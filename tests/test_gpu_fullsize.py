@@ -22,8 +22,8 @@ def big():
     W0, H0 = synth.random_init(N, K, NX * NY, seed=0, scale=500.0 / N)
     kw = dict(layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=8)
     engs = {}
-    for tile in (256, 128):
-        eng = MUEngine(X, K, tile_px=tile, **kw)
+    for tile, store in ((256, "auto"), (128, "auto"), ("bf16", "bf16")):
+        eng = MUEngine(X, K, tile_px=tile if isinstance(tile, int) else 256, x_store=store, **kw)
         eng.load_state(W0, H0)
         engs[tile] = eng
     rows = slice(200 * NY, 203 * NY)                                      # three image rows for the oracle
@@ -32,9 +32,13 @@ def big():
     return dict(engs=engs, W0=W0, H0=H0, Xsub=Xsub, rows=rows)
 
 
-def test_storage_is_lossless_bf16(big):
-    assert all(e.x_store == "bf16" for e in big["engs"].values())
+def test_storage_is_lossless(big):
+    """Counts <= 255 are stored as 8-bit integers (auto), bf16 on request: both are exact for this data."""
+    assert big["engs"][256].x_store == "u8" and big["engs"][128].x_store == "u8" and big["engs"]["bf16"].x_store == "bf16"
     assert big["engs"][256].st.tile_px == 256 and big["engs"][128].st.tile_px == 128
+    a = big["engs"][256].x_pm[:4096].float()
+    b = big["engs"]["bf16"].x_pm[:4096].float()
+    assert torch.equal(a, b)
 
 
 def test_first_h_step_matches_oracle_on_a_pixel_subset(big):
@@ -65,6 +69,10 @@ def test_kernel_variants_agree_and_loss_decreases(big):
         torch.cuda.synchronize()
         out[tile] = (eng.get_W(), eng.get_H(), eng.history())
     (Wa, Ha, ha), (Wb, Hb, hb) = out[256], out[128]
+    Wc, Hc, hc = out["bf16"]
+    np.testing.assert_allclose(Wa, Wc, rtol=1e-6, atol=1e-10)          # u8 and bf16 stores hold the same numbers
+    np.testing.assert_allclose(Ha, Hc, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(ha["loss"], hc["loss"], rtol=1e-9)
     np.testing.assert_allclose(Wa, Wb, rtol=2e-5, atol=1e-8)
     np.testing.assert_allclose(Ha, Hb, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(ha["loss"], hb["loss"], rtol=1e-6)
