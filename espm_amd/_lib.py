@@ -33,13 +33,13 @@ class MUState(C.Structure):
     """struct espm_mu_state (same field order as include/espm_mu.h)."""
     _fields_ = [
         ("n", _i32), ("m", _i32), ("k", _i32), ("p", _i32), ("nx", _i32), ("ny", _i32),
-        ("n_pad", _i32), ("p_pad", _i32), ("x_dtype", _i32), ("tile_px", _i32), ("nblk_w", _i32), ("x_tile", _i32),
+        ("n_pad", _i32), ("p_pad", _i32), ("x_dtype", _i32), ("tile_px", _i32), ("nblk_w", _i32), ("x_tile", _i32), ("n_cm", _i32), ("h_variant", _i32),
         ("p_total", _i64),
         ("simplex_h", _i32), ("simplex_w", _i32), ("grid_mode", _i32), ("compute_loss", _i32),
         ("lambda_l", _f32), ("sigma_l", _f32), ("eps_reg", _f32), ("log_shift", _f32),
         ("dicotomy_tol", _f32), ("rel_tol", _f32), ("xscale", _f32), ("gw_floor", _f32),
         ("x_cm", _vp), ("x_pm", _vp), ("g", _vp), ("colsum_g", _vp),
-        ("w", _vp * 2), ("gw_s", _vp), ("colsum_gw", _vp), ("h", _vp * 2), ("h_t", _vp),
+        ("w", _vp * 2), ("gw_s", _vp), ("colsum_gw", _vp), ("gw_a", _vp), ("gw_p", _vp), ("h", _vp * 2), ("h_t", _vp),
         ("mu", _vp), ("fixed_h", _vp), ("fixed_w", _vp), ("simplex_rows", _vp),
         ("halo_top", _vp), ("halo_bot", _vp),
         ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
@@ -53,7 +53,7 @@ SYMBOLS = {
     "espm_mu_version": (C.c_char_p, []),
     "espm_mu_last_error": (C.c_char_p, []),
     "espm_mu_query": (C.c_int, [_SP]),
-    "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_hstat": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_build_gw": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_step_h": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),

@@ -37,6 +37,9 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
+  ESPM_REQUIRE(st->n_cm == roundup(st->n, ESPM_NCM), "n_cm must be roundup(n, %d)", ESPM_NCM);
+  ESPM_REQUIRE(st->h_variant == 0 || (st->gw_a && st->gw_p && st->tile_px == 128 && st->x_dtype != ESPM_X_F32),
+               "h_variant 1 needs gw_a, gw_p, tile_px = 128 and a 1- or 2-byte X store");
   ESPM_REQUIRE(st->x_tile >= 64 && ESPM_PPAD % st->x_tile == 0 && st->x_tile % st->tile_px == 0,
                "x_tile=%d must divide %d and be a multiple of tile_px=%d", st->x_tile, ESPM_PPAD, st->tile_px);
   ESPM_REQUIRE(st->m >= 0, "m must be >= 0");
@@ -73,6 +76,8 @@ int espm_mu_query(espm_mu_state* st) {
   const int big = 256;
   st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
   st->x_tile = st->tile_px;
+  st->n_cm = roundup(st->n, ESPM_NCM);
+  st->h_variant = 0;
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
   const int ychunks = st->x_dtype != ESPM_X_F32 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
   int target = (2 * cus + ychunks - 1) / ychunks;
@@ -85,7 +90,7 @@ int espm_mu_query(espm_mu_state* st) {
 }
 
 int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                   int x_dtype, int n_pad, int p_pad, int x_tile, espm_stream_t stream) {
+                   int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, espm_stream_t stream) {
   ESPM_REQUIRE(src && x_cm && x_pm, "pack_x: NULL pointer");
   ESPM_REQUIRE(n >= 1 && p >= 1 && n_pad == roundup(n, ESPM_NPAD) && p_pad == roundup(p, ESPM_PPAD),
                "pack_x: bad shape n=%d p=%d n_pad=%d p_pad=%d", n, p, n_pad, p_pad);
@@ -93,7 +98,8 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
   ESPM_REQUIRE(src_layout == ESPM_LAYOUT_CM || src_layout == ESPM_LAYOUT_PM, "pack_x: bad layout %d", src_layout);
   ESPM_REQUIRE(ld >= (src_layout == ESPM_LAYOUT_CM ? p : n), "pack_x: leading dimension too small");
   ESPM_REQUIRE(x_tile >= 64 && ESPM_PPAD % x_tile == 0, "pack_x: x_tile %d must divide %d", x_tile, ESPM_PPAD);
-  return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile,
+  ESPM_REQUIRE(n_cm == roundup(n, ESPM_NCM), "pack_x: n_cm must be roundup(n, %d)", ESPM_NCM);
+  return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, n_cm,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -116,6 +122,9 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.scratch = st->w_scratch;
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
+  a.gw_a = st->h_variant ? st->gw_a : nullptr;  // only the matrix-core H-step consumes these
+  a.gw_p = st->h_variant ? st->gw_p : nullptr;
+  a.n_cm = st->n_cm;
   a.hist_slot = (slot >= 0 && st->hist) ? st->hist + (size_t)slot * ESPM_HI_STRIDE : nullptr;
   a.n = st->n;
   a.m = st->m;
@@ -140,7 +149,7 @@ int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
-  return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->tile_px, nblk_h(st),
+  return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->h_variant ? -128 : st->tile_px, nblk_h(st),
                          static_cast<hipStream_t>(stream));
 }
 

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint8_t to_store<uint8_t>(float v) { return (uint8_t)
 template <typename ST, typename DT>
 __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src, int src_layout, int64_t ld, int n,
                                                      int p, DT* __restrict__ x_cm, DT* __restrict__ x_pm, int n_pad,
-                                                     int p_pad, int x_tile) {
+                                                     int p_pad, int x_tile, int n_cm) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src,
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r, j = j0 + tx;
-    if (c < n && j < p_pad)  // tile-major: [pixel block][channel][x_tile]
-      x_cm[((size_t)(j / x_tile) * n + c) * x_tile + (j % x_tile)] = to_store<DT>(tile[r][tx]);
+    if (c < n_cm && j < p_pad)  // tile-major: [pixel block][channel row, zero padded to n_cm][x_tile]
+      x_cm[((size_t)(j / x_tile) * n_cm + c) * x_tile + (j % x_tile)] = to_store<DT>(tile[r][tx]);
     const int j2 = j0 + r, c2 = c0 + tx;
     if (j2 < p && c2 < n_pad) x_pm[(size_t)j2 * n_pad + c2] = to_store<DT>(tile[tx][r]);
   }
@@ -53,25 +53,25 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src,
 
 template <typename ST>
 static int pack_dispatch(const void* src, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                         int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream) {
-  dim3 grid((p_pad + 31) / 32, (n_pad + 31) / 32);
+                         int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream) {
+  dim3 grid((p_pad + 31) / 32, (n_cm + 31) / 32);
   if (x_dtype == ESPM_X_U8)
     hipLaunchKernelGGL((pack_x_kernel<ST, uint8_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
-                       src_layout, ld, n, p, static_cast<uint8_t*>(x_cm), static_cast<uint8_t*>(x_pm), n_pad, p_pad, x_tile);
+                       src_layout, ld, n, p, static_cast<uint8_t*>(x_cm), static_cast<uint8_t*>(x_pm), n_pad, p_pad, x_tile, n_cm);
   else if (x_dtype == ESPM_X_BF16)
     hipLaunchKernelGGL((pack_x_kernel<ST, bf16_t>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
-                       src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad, x_tile);
+                       src_layout, ld, n, p, static_cast<bf16_t*>(x_cm), static_cast<bf16_t*>(x_pm), n_pad, p_pad, x_tile, n_cm);
   else
     hipLaunchKernelGGL((pack_x_kernel<ST, float>), grid, dim3(256), 0, stream, static_cast<const ST*>(src),
-                       src_layout, ld, n, p, static_cast<float*>(x_cm), static_cast<float*>(x_pm), n_pad, p_pad, x_tile);
+                       src_layout, ld, n, p, static_cast<float*>(x_cm), static_cast<float*>(x_pm), n_pad, p_pad, x_tile, n_cm);
   return check_hip(hipGetLastError(), "pack_x launch");
 }
 
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
-                  int x_dtype, int n_pad, int p_pad, int x_tile, hipStream_t stream) {
+                  int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream) {
   if (src_dtype == ESPM_SRC_F64)
-    return pack_dispatch<double>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, stream);
-  return pack_dispatch<float>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, stream);
+    return pack_dispatch<double>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, n_cm, stream);
+  return pack_dispatch<float>(src, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, n_cm, stream);
 }
 
 // ---- statistics of an H buffer (one workgroup; used at initialisation only) ---------------------

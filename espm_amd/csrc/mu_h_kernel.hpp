@@ -5,6 +5,125 @@
 
 namespace espm {
 
+// Epilogue shared by the H-step kernels: `smem` holds `nparts` partial numerators [part][K][TP] (written by
+// the caller, not yet synchronised); one thread per pixel adds the regularisation terms, solves the simplex
+// multiplier, clamps, writes H', H'^T and the per-workgroup record.  kl_lane = this lane's part of
+// sum X log2(X / Y).
+template <int K>
+__device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane) {
+  constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
+  double red[NRED];
+#pragma unroll
+  for (int i = 0; i < NRED; ++i) red[i] = 0.0;
+  // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
+  constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
+  red[ESPM_HP_KL] = (double)kl_lane;
+  __syncthreads();
+
+  // ---- epilogue: one thread per pixel -------------------------------------------------------
+  const float ls = a.lambda_l * a.sigma_l;
+  float rel_shift = 0.f;
+  if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
+    double tot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) tot += a.hstat_in[ESPM_HS_ROWSUM + kk];
+    rel_shift = (float)((double)a.rel_tol * tot * a.inv_count);
+  }
+  for (int jj = threadIdx.x; jj < TP; jj += (int)blockDim.x) {
+    const int q = tile0 + jj;
+    if (q >= a.p) continue;
+    float hin[K], nv[K], dv[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      float s = 0.f;
+      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * K + kk) * TP + jj];
+      hin[kk] = a.h_in[(size_t)kk * a.p_pad + q];
+      nv[kk] = s * a.xscale;
+      dv[kk] = (float)a.colsum_gw[kk];
+    }
+    if (a.have_prev) {
+      // rel_H of the update that produced h_in: the other buffer still holds the previous H
+      // (each thread reads its own entries before overwriting them below), base.py:324
+      float worst = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const float hp = a.h_out[(size_t)kk * a.p_pad + q];
+        worst = fmaxf(worst, fabsf(hin[kk] - hp) / (hin[kk] + rel_shift));
+      }
+      red[R_RELH] = fmax(red[R_RELH], (double)worst);
+    }
+    if (a.mu) {
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const float m = a.mu[kk];
+        dv[kk] += m / (hin[kk] + a.eps_reg);                          // updates.py:134-137
+        red[ESPM_HP_REG] += (double)(m * logf(hin[kk] + a.eps_reg));  // measures.py:543-548
+      }
+    }
+    if (a.lambda_l != 0.f) {
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const float hl = a.grid_mode
+                             ? stencil_hl(a.h_in + (size_t)kk * a.p_pad,
+                                          a.halo_top ? a.halo_top + (size_t)kk * a.ny : nullptr,
+                                          a.halo_bot ? a.halo_bot + (size_t)kk * a.ny : nullptr, q, a.nx, a.ny,
+                                          hin[kk])
+                             : hin[kk];
+        const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
+        nv[kk] += ls * mh;                                      // updates.py:140
+        dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
+        red[ESPM_HP_LAP] += (double)(hin[kk] * hl);             // measures.py:574-577
+      }
+    }
+    if (!a.write_h) continue;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
+    if (a.simplex_h) {
+      float delta, e[K];
+      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
+    }
+    float ht[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      float hn = fmaxf(nv[kk] / dv[kk], a.log_shift);          // updates.py:152
+      if (a.fixed_h) {
+        const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
+        if (f >= 0.f) hn = f;                                   // updates.py:154-155
+      }
+      if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;            // NaN or inf
+      a.h_out[(size_t)kk * a.p_pad + q] = hn;
+      ht[kk] = hn;
+      red[R_ROWSUM + kk] += (double)hn;
+      red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+    }
+    float4* dst = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
+    dst[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
+    dst[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+  }
+
+  __syncthreads();  // smem is reused as reduction scratch
+  block_reduce<NRED, R_RELH>(red, reinterpret_cast<double*>(smem));
+  if (threadIdx.x == 0) {
+    // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
+    double* out = a.hpart + blockIdx.x;
+    const size_t nb = gridDim.x;
+    out[ESPM_HP_KL * nb] = red[ESPM_HP_KL];
+    out[ESPM_HP_REG * nb] = red[ESPM_HP_REG];
+    out[ESPM_HP_LAP * nb] = red[ESPM_HP_LAP];
+    out[ESPM_HP_BAD * nb] = red[ESPM_HP_BAD];
+    out[ESPM_HP_RELH * nb] = red[R_RELH];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      out[(ESPM_HP_ROWSUM + kk) * nb] = kk < K ? red[R_ROWSUM + kk] : 0.0;
+      out[(ESPM_HP_MAX + kk) * nb] = kk < K ? red[R_MAX + kk] : 0.0;
+    }
+  }
+}
+
 // K components, XT storage type of X, PX pixels per lane (tile = 64 * PX pixels), NW waves per
 // workgroup (they split the channel range), LOSS: accumulate the KL term, U channels per load group,
 // NBUF: depth of the register ring of X load groups kept in flight (0 / 1: no explicit prefetch).
@@ -45,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   const int c_end = min(a.n, c_begin + chunk);
   // X is tile-major: x_cm[pixel block of x_tile][channel][x_tile]; a workgroup streams one contiguous
   // region of it (sequential DRAM pages, few TLB entries) with row stride x_tile
-  const XT* xbase = static_cast<const XT*>(a.x_cm) + (size_t)(tile0 / a.x_tile) * a.n * a.x_tile + (tile0 % a.x_tile) +
+  const XT* xbase = static_cast<const XT*>(a.x_cm) + (size_t)(tile0 / a.x_tile) * a.n_cm * a.x_tile + (tile0 % a.x_tile) +
                     lane * PX;
 
   // one channel: Y = GW[c,:] H, R = X / Y, num += GW[c,:]^T R   (updates.py:127-128)
@@ -157,122 +276,12 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
       dst[2 * i + 1] = num[kk][i].y;
     }
   }
-  constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
-  double red[NRED];
-#pragma unroll
-  for (int i = 0; i < NRED; ++i) red[i] = 0.0;
-  // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
-  constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
+  float kl_lane = 0.f;
   if constexpr (LOSS) {
-    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < P2; ++i) s += kl[i].x + kl[i].y;
-    red[ESPM_HP_KL] = (double)s;
+    for (int i = 0; i < P2; ++i) kl_lane += kl[i].x + kl[i].y;
   }
-  __syncthreads();
-
-  // ---- epilogue: one thread per pixel -------------------------------------------------------
-  const float ls = a.lambda_l * a.sigma_l;
-  float rel_shift = 0.f;
-  if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
-    double tot = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) tot += a.hstat_in[ESPM_HS_ROWSUM + kk];
-    rel_shift = (float)((double)a.rel_tol * tot * a.inv_count);
-  }
-  for (int jj = threadIdx.x; jj < TP; jj += NW * 64) {
-    const int q = tile0 + jj;
-    if (q >= a.p) continue;
-    float hin[K], nv[K], dv[K];
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      float s = 0.f;
-      for (int w = 0; w < NW; ++w) s += smem[((size_t)w * K + kk) * TP + jj];
-      hin[kk] = a.h_in[(size_t)kk * a.p_pad + q];
-      nv[kk] = s * a.xscale;
-      dv[kk] = (float)a.colsum_gw[kk];
-    }
-    if (a.have_prev) {
-      // rel_H of the update that produced h_in: the other buffer still holds the previous H
-      // (each thread reads its own entries before overwriting them below), base.py:324
-      float worst = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        const float hp = a.h_out[(size_t)kk * a.p_pad + q];
-        worst = fmaxf(worst, fabsf(hin[kk] - hp) / (hin[kk] + rel_shift));
-      }
-      red[R_RELH] = fmax(red[R_RELH], (double)worst);
-    }
-    if (a.mu) {
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        const float m = a.mu[kk];
-        dv[kk] += m / (hin[kk] + a.eps_reg);                          // updates.py:134-137
-        red[ESPM_HP_REG] += (double)(m * logf(hin[kk] + a.eps_reg));  // measures.py:543-548
-      }
-    }
-    if (a.lambda_l != 0.f) {
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        const float hl = a.grid_mode
-                             ? stencil_hl(a.h_in + (size_t)kk * a.p_pad,
-                                          a.halo_top ? a.halo_top + (size_t)kk * a.ny : nullptr,
-                                          a.halo_bot ? a.halo_bot + (size_t)kk * a.ny : nullptr, q, a.nx, a.ny,
-                                          hin[kk])
-                             : hin[kk];
-        const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
-        nv[kk] += ls * mh;                                      // updates.py:140
-        dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
-        red[ESPM_HP_LAP] += (double)(hin[kk] * hl);             // measures.py:574-577
-      }
-    }
-    if (!a.write_h) continue;
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
-    if (a.simplex_h) {
-      float delta, e[K];
-      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.0;
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
-    }
-    float ht[KP];
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      float hn = fmaxf(nv[kk] / dv[kk], a.log_shift);          // updates.py:152
-      if (a.fixed_h) {
-        const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
-        if (f >= 0.f) hn = f;                                   // updates.py:154-155
-      }
-      if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;            // NaN or inf
-      a.h_out[(size_t)kk * a.p_pad + q] = hn;
-      ht[kk] = hn;
-      red[R_ROWSUM + kk] += (double)hn;
-      red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
-    }
-    float4* dst = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
-    dst[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
-    dst[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
-  }
-
-  __syncthreads();  // smem is reused as reduction scratch
-  block_reduce<NRED, R_RELH>(red, reinterpret_cast<double*>(smem));
-  if (threadIdx.x == 0) {
-    // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
-    double* out = a.hpart + blockIdx.x;
-    const size_t nb = gridDim.x;
-    out[ESPM_HP_KL * nb] = red[ESPM_HP_KL];
-    out[ESPM_HP_REG * nb] = red[ESPM_HP_REG];
-    out[ESPM_HP_LAP * nb] = red[ESPM_HP_LAP];
-    out[ESPM_HP_BAD * nb] = red[ESPM_HP_BAD];
-    out[ESPM_HP_RELH * nb] = red[R_RELH];
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk) {
-      out[(ESPM_HP_ROWSUM + kk) * nb] = kk < K ? red[R_ROWSUM + kk] : 0.0;
-      out[(ESPM_HP_MAX + kk) * nb] = kk < K ? red[R_MAX + kk] : 0.0;
-    }
-  }
+  h_epilogue<K>(a, smem, NW, TP, tile0, kl_lane);
 }
 
 }  // namespace espm

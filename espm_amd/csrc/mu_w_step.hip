@@ -276,12 +276,40 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         row[kk] = v * inv_scale;
       }
     }
-    float4* dst = reinterpret_cast<float4*>(a.gw_s + (size_t)c * espm::KP);
-    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+    if (c < a.n_pad) {
+      float4* dst = reinterpret_cast<float4*>(a.gw_s + (size_t)c * espm::KP);
+      dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+      dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+    }
+    if (a.gw_p) {  // operands of the matrix-core H-step: channel pairs and A fragments of the bf16 splits
+      float rv[KA];
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) {
+        rv[kk] = row[kk];
+        a.gw_p[(size_t)(c >> 1) * 2 * KA + 2 * kk + (c & 1)] = row[kk];
+      }
+      constexpr int NMF = MfmaCount<KA>::value;
+      uint16_t slots[32 * NMF];
+      build_slots<KA, NMF>(rv, 0, slots);
+      uint4* ga = reinterpret_cast<uint4*>(a.gw_a);
+      const int blk = c >> 4, rr = c & 15;
+#pragma unroll
+      for (int m = 0; m < NMF; ++m)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int s0 = 32 * m + 8 * gq;
+          uint4 v;
+          v.x = slots[s0] | ((uint32_t)slots[s0 + 1] << 16);
+          v.y = slots[s0 + 2] | ((uint32_t)slots[s0 + 3] << 16);
+          v.z = slots[s0 + 4] | ((uint32_t)slots[s0 + 5] << 16);
+          v.w = slots[s0 + 6] | ((uint32_t)slots[s0 + 7] << 16);
+          ga[((size_t)blk * NMF + m) * 64 + gq * 16 + rr] = v;
+        }
+    }
   };
+  const int n_rows = a.gw_p ? a.n_cm : a.n_pad;
   if (a.g) {
-    for (int c = tid; c < a.n_pad; c += WF_THREADS) {
+    for (int c = tid; c < n_rows; c += WF_THREADS) {
       float row[KA];
 #pragma unroll
       for (int kk = 0; kk < KA; ++kk) row[kk] = 0.f;
@@ -299,7 +327,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
       const int c = tid + r * WF_THREADS;
-      if (c < a.n_pad) emit_row(c, wn[r]);
+      if (c < n_rows) emit_row(c, wn[r]);
     }
   }
   block_reduce<KA, KA>(cs, scratch);
@@ -452,7 +480,7 @@ template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
   if (x_dtype == ESPM_X_U8) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
-    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
+    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, 8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
   } else if (x_dtype == ESPM_X_BF16) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
     hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
@@ -504,7 +532,7 @@ static void launch_fast(const WFinishArgs& args, int rows, size_t lds, hipStream
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int M = args.m > 0 ? args.m : args.n;
   const long mk = (long)M * args.k;
-  const int span = M > args.n_pad ? M : args.n_pad;
+  const int span = M > args.n_cm ? M : args.n_cm;
   const int rows = (span + WF_THREADS - 1) / WF_THREADS;
   if (rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
     const size_t lds = args.g ? (size_t)mk * sizeof(float) * 2 : 0;
@@ -520,6 +548,7 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
       default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
     }
   } else {
+    if (args.gw_p) return set_error(ESPM_EUNSUPPORTED, "matrix-core H-step operands need M, n <= 4096 rows");
     hipLaunchKernelGGL(w_finish_kernel, dim3(1), dim3(WF_THREADS), 0, stream, args);
   }
   return check_hip(hipGetLastError(), "w_finish launch");

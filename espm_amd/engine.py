@@ -17,6 +17,7 @@ Data layout in HBM (all caller-visible arrays are plain torch tensors):
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -56,7 +57,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -136,17 +137,22 @@ class MUEngine:
         self.p_total = st.p_total
 
         xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
+        if h_variant is None:
+            h_variant = int(os.environ.get("ESPM_H_VARIANT", "0"))
+        if h_variant and x_store in ("u8", "bf16"):  # Y = GW H on the matrix cores: 128-pixel tiles
+            st.h_variant = 1
+            tile_px = 128
         if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
             st.tile_px = int(tile_px)
             st.x_tile = int(tile_px)
         if x_tile is not None:
             st.x_tile = int(x_tile)
-        self.x_cm = torch.empty((st.p_pad // st.x_tile, self.n, st.x_tile), dtype=xt, device=dev)
+        self.x_cm = torch.empty((st.p_pad // st.x_tile, st.n_cm, st.x_tile), dtype=xt, device=dev)
         self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
         Xd = Xd.contiguous()
         check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                  _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
-                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, _stream()))
+                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, st.n_cm, _stream()))
         torch.cuda.current_stream().synchronize()
         del Xd
 
@@ -186,6 +192,9 @@ class MUEngine:
         self.h_t = torch.zeros((self.p, _lib.KP), **f32)
         self.gw_s = torch.zeros((st.n_pad, _lib.KP), **f32)
         self.colsum_gw = torch.zeros(_lib.KP, **f64)
+        nmf = (6 * k + 31) // 32
+        self.gw_a = torch.zeros((st.n_cm // 16, nmf, 64, 8), dtype=torch.bfloat16, device=dev)
+        self.gw_p = torch.zeros((st.n_cm // 2, k, 2), **f32)
         nblk_h = (self.p + st.tile_px - 1) // st.tile_px
         self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
         self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
@@ -212,6 +221,7 @@ class MUEngine:
         st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()
         st.h[0], st.h[1] = self.h[0].data_ptr(), self.h[1].data_ptr()
         st.gw_s, st.colsum_gw, st.h_t = self.gw_s.data_ptr(), self.colsum_gw.data_ptr(), self.h_t.data_ptr()
+        st.gw_a, st.gw_p = self.gw_a.data_ptr(), self.gw_p.data_ptr()
         st.mu = self.mu.data_ptr() if self.mu is not None else None
         st.fixed_h = self.fixed_h.data_ptr() if self.fixed_h is not None else None
         st.fixed_w = self.fixed_w.data_ptr() if self.fixed_w is not None else None

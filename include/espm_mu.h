@@ -63,6 +63,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
+#define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
 
 /* per-workgroup partial record written by the H-step (doubles), stored field-major:
  * hpart[field * nblk + block] */
@@ -105,6 +106,8 @@ typedef struct espm_mu_state {
   int32_t tile_px;  /* H-step pixel tile per workgroup: 64 * {1,2,4,8}, see query       */
   int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
   int32_t x_tile;   /* pixel-block width of the tile-major x_cm (multiple of tile_px)   */
+  int32_t n_cm;     /* roundup(n, ESPM_NCM): channel rows per pixel block of x_cm       */
+  int32_t h_variant; /* 0: fp32 VALU H-step, 1: Y = GW H on the matrix cores (tile_px = 128) */
   int64_t p_total;  /* pixels of the whole image over all ranks (= p on one GPU)        */
   /* flags */
   int32_t simplex_h, simplex_w;
@@ -115,13 +118,15 @@ typedef struct espm_mu_state {
   float xscale;     /* X_ = xscale * X_stored (normalize=True, base.py:264-267)         */
   float gw_floor;   /* lower clamp of GW entries, keeps X/(GW H) finite (updates.py:129-131) */
   /* data */
-  const void* x_cm;         /* (p_pad / x_tile, n, x_tile) bf16|f32: channel-major inside pixel blocks, zero padded */
+  const void* x_cm;         /* (p_pad / x_tile, n_cm, x_tile) u8|bf16|f32: channel-major inside pixel blocks, zero padded */
   const void* x_pm;         /* (p, n_pad) bf16|f32, zero padded                         */
   const float* g;           /* (n, m) row-major or NULL                                  */
   const float* colsum_g;    /* (m) or NULL                                               */
   float* w[2];              /* (m or n, k) row-major, ping-pong                          */
   float* gw_s;              /* (n_pad, KP): GW / xscale, pad rows = 1                    */
   double* colsum_gw;        /* (KP): column sums of GW over real rows                    */
+  void* gw_a;               /* (n_cm / 16, NMF, 64, 8) bf16: MFMA A fragments of the 3-way bf16 split of gw_s, NMF = ceil(6k/32) */
+  float* gw_p;              /* (n_cm / 2, k, 2): gw_s as channel pairs for v_pk_fma_f32   */
   float* h[2];              /* (k, p_pad), ping-pong, pad columns must be positive       */
   float* h_t;               /* (p, KP): transposed copy of the newest H                  */
   const float* mu;          /* (k) or NULL                                               */
@@ -151,7 +156,7 @@ int espm_mu_query(espm_mu_state* st);
 /* X (host layout, device memory) -> the two padded device layouts.  src is (n, p) when
  * src_layout = CM or (p, n) when PM (hyperspy's layout), leading dimension ld (elements). */
 int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p,
-                   void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, int x_tile,
+                   void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm,
                    espm_stream_t stream);
 
 /* statistics (row sums, row maxima) of st->h[which] into st->hstat[which] (local pixels). */

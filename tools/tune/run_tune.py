@@ -13,12 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build():
     csrc = os.path.join(ROOT, "espm_amd", "csrc")
-    out = os.path.join(HERE, "libespm_tune.so")
+    u8 = os.environ.get("TUNE_XT", "bf16") == "u8"
+    out = os.path.join(HERE, "libespm_tune_u8.so" if u8 else "libespm_tune.so")
     srcs = [os.path.join(csrc, f) for f in ("mu_api.hip", "mu_h_step.hip", "mu_w_step.hip", "mu_aux.hip")] + [os.path.join(HERE, "tune.hip")]
     newest = max(os.path.getmtime(f) for f in srcs + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".hpp")])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", out, os.path.join(HERE, "tune.hip")])
+                               "-I", os.path.join(ROOT, "include"), "-I", csrc, "-o", out, os.path.join(HERE, "tune.hip")] + (["-DTUNE_U8"] if u8 else []))
     return out
 
 
@@ -39,7 +40,7 @@ def main():
     X = synth.sample_torch(prob, "cuda", seed=1000)
     W0, H0 = synth.random_init(n, k, rows * ny, seed=0, scale=500.0 / n)
     eng = MUEngine(X, k, layout="pm", shape_2d=(rows, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=20,
-                   x_tile=int(os.environ.get("TUNE_XTILE", 512)))
+                   x_tile=int(os.environ.get("TUNE_XTILE", 512)), x_store=os.environ.get("TUNE_XT", "bf16"))
     del X
     eng.load_state(W0, H0)
     eng.iterate(3, final_loss=False)
@@ -66,7 +67,7 @@ def main():
 
     s = _stream()
     tile = C.c_int(0)
-    bytes_h = n * p * 2 + 2 * k * p * 4
+    bytes_h = n * p * (1 if os.environ.get('TUNE_XT') == 'u8' else 2) + 2 * k * p * 4
     which = os.environ.get("TUNE", "hw")
     st.compute_loss = int(os.environ.get("TUNE_LOSS", "1"))
     only = os.environ.get("TUNE_ONLY")

@@ -5,6 +5,12 @@
 
 using namespace espm;
 
+#ifdef TUNE_U8
+typedef uint8_t xt_t;
+#else
+typedef bf16_t xt_t;
+#endif
+
 namespace {
 
 template <int PX, int NW, int U, int NBUF>
@@ -14,16 +20,16 @@ int run_h(const HStepArgs& args, int p, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   if (args.compute_loss)
-    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, xt_t, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
   else
-    hipLaunchKernelGGL((h_step_kernel<K, bf16_t, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, xt_t, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
   return (int)hipGetLastError();
 }
 
 template <int UP, int NBUF>
 int run_w(const WAccumArgs& args, int nblk, hipStream_t stream) {
   dim3 grid(nblk, (args.n_pad + 2047) / 2048);
-  hipLaunchKernelGGL((w_accum_kernel<5, bf16_t, 8, UP, NBUF>), grid, dim3(256), 0, stream, args);
+  hipLaunchKernelGGL((w_accum_kernel<5, xt_t, 8, UP, NBUF>), grid, dim3(256), 0, stream, args);
   return (int)hipGetLastError();
 }
 
