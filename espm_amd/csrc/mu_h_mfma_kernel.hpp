@@ -109,9 +109,6 @@ __global__ __launch_bounds__(NW * 64) void h_step_mfma_kernel(const HStepArgs a)
       for (int m = 0; m < NMF; ++m) y[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             b.af[m], __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + (size_t)(16 * t) * BROW + 32 * m)), y[t], 0, 0, 0);
     }
-#ifdef ESPM_MFMA_NOPS
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     // pixel pairs (2u, 2u + 1) of one channel share an fp32x2 register: adjacent elements of the X row, the
     // matching Y entries are gathered from two accumulator tiles by the accumulator reads themselves
     auto channel = [&](auto ic) {
@@ -123,11 +120,22 @@ __global__ __launch_bounds__(NW * 64) void h_step_mfma_kernel(const HStepArgs a)
         constexpr int u = decltype(uc)::value;
         const f2 yy = f2{y[2 * u][i], y[2 * u + 1][i]};
         const f2 xx = f2{b.xr[i].template elem<2 * u>(), b.xr[i].template elem<2 * u + 1>()};
-        const f2 inv = f2{__builtin_amdgcn_rcpf(yy.x), __builtin_amdgcn_rcpf(yy.y)};
+        // In-place reciprocals (source = destination register).  v_accvgpr_read_b32 is NOT ordered against the
+        // operand read of an earlier transcendental op: with two waves on a SIMD the compiler's
+        //   v_rcp_f32 v72, v55 ... v_accvgpr_read_b32 v55, a8
+        // let the accumulator read overwrite v55 before the rcp had read lanes 48-63 of it (measured: wrong
+        // numerators for g = 3, even pixels only, non-deterministic; DESIGN.md "matrix-core variant").  With
+        // source = destination the next writer is ordered behind the rcp's own result write.
+        f2 inv = yy;
+        asm("v_rcp_f32_e32 %0, %0\n\tv_rcp_f32_e32 %1, %1\n\ts_nop 0" : "+v"(inv.x), "+v"(inv.y));
         const f2 r = LOSS ? xx * inv + f2{1e-37f, 1e-37f} : xx * inv;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) acc[kk][u] = gv[kk] * r + acc[kk][u];
-        if constexpr (LOSS) kl = xx * f2{__builtin_amdgcn_logf(r.x), __builtin_amdgcn_logf(r.y)} + kl;
+        if constexpr (LOSS) {
+          f2 lg = r;  // r is dead after the accumulation above: log in place, same ordering argument as for rcp
+          asm("v_log_f32_e32 %0, %0\n\tv_log_f32_e32 %1, %1\n\ts_nop 0" : "+v"(lg.x), "+v"(lg.y));
+          kl = xx * lg + kl;
+        }
       };
       pixel_pair(std::integral_constant<int, 0>{});
       pixel_pair(std::integral_constant<int, 1>{});
@@ -146,9 +154,6 @@ __global__ __launch_bounds__(NW * 64) void h_step_mfma_kernel(const HStepArgs a)
     Blk b;
     load_blk(b, blk);
     compute_blk(b);
-#ifdef ESPM_DBG_LOOPSYNC
-    __syncthreads();
-#endif
   }
 
   __syncthreads();  // every wave is done with the H-split image: smem is reused for the partial numerators

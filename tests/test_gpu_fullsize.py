@@ -44,6 +44,8 @@ def test_storage_is_lossless(big):
 def test_first_h_step_matches_oracle_on_a_pixel_subset(big):
     eng = big["engs"][256]
     H1 = eng.step_h_only()                                                # full-size H update, tile 256
+    eng.load_state(big["W0"], big["H0"])
+    assert np.array_equal(H1, eng.step_h_only())                          # bitwise reproducible run to run
     W0, H0, rows = big["W0"], big["H0"], big["rows"]
     ext = slice(rows.start - NY, rows.stop + NY)
     # oracle on 5 image rows (3 + halo); the global row maxima enter through sigma * max_j H
@@ -120,3 +122,7 @@ def test_matrix_core_h_step_variant(big):
     np.testing.assert_allclose(eng.get_H(), ref.get_H(), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(eng.get_W(), ref.get_W(), rtol=2e-5, atol=1e-8)
     np.testing.assert_allclose(eng.history()["loss"], ref.history()["loss"], rtol=1e-6)
+    H4 = eng.get_H()
+    eng.load_state(big["W0"], big["H0"])
+    eng.iterate(4, final_loss=True)
+    assert np.array_equal(H4, eng.get_H())                                # and bitwise reproducible (see the rcp note)
