@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--lambda-l", type=float, default=LAMBDA_L)
-    ap.add_argument("--x-store", default="auto", choices=["auto", "u8", "bf16", "f32"])
+    ap.add_argument("--x-store", default="auto", choices=["auto", "ell", "u8", "bf16", "f32"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,10 +148,21 @@ def main():
     t_h_upd = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_step_h(C.byref(st), st.cur, 1, s)))
     t_w = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_w_accum(C.byref(st), s)))
     p_loc = eng.p
-    xbytes = {"u8": 1, "bf16": 2, "f32": 4}[eng.x_store]
-    bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4          # X once, H read + written
-    bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
-    bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
+    if eng.x_store == "ell":
+        # sparse count store: 16 bits per non-zero entry of X (list padding is overhead, not algorithmic work);
+        # the H-step also reads the per-pixel loss constant
+        e_h, e_w = eng.ell["entries_h"], eng.ell["entries_w"]
+        bytes_h = 2 * e_h + 2 * K * p_loc * 4 + p_loc * 4        # lists once, H read + written, sum x log2 x
+        bytes_w = 2 * e_w + K * p_loc * 4                        # lists once, H read
+        nnz = torch.tensor([float(eng.ell["nnz"])], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(nnz)
+        bytes_it = 2 * float(nnz.item()) + 2 * K * NX * NY * 4   # SURVEY 8(d) with X = its non-zero entries, once
+    else:
+        xbytes = {"u8": 1, "bf16": 2, "f32": 4}[eng.x_store]
+        bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4          # X once, H read + written
+        bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
+        bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
     flops_it = 8.0 * N_CH * K * NX * NY
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, corrected as
     # MI355X_MICROARCH.md prescribes); measured once per kernel version and committed under profiles/
@@ -162,7 +173,7 @@ def main():
                 traffic = json.load(f)["kernels"]["h_step"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = dict(bound="hbm", kernel="h_step_kernel<5,%s,...,loss>" % eng.x_store, achieved=bytes_h / t_h_upd / 1e9,
+    roofline = dict(bound="hbm", kernel=("h_step_ell_kernel<5,loss>" if eng.x_store == "ell" else "h_step_kernel<5,%s,...,loss>" % eng.x_store), achieved=bytes_h / t_h_upd / 1e9,
                     peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=traffic,
                     bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
                     w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("ESPM_MU_LIB", os.path.join(_HERE, "lib", "libespm_mu.
 
 # mirrors of the header's constants
 OK, EINVAL, ENOSOLUTION, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4
-X_F32, X_BF16, X_U8 = 0, 1, 2
+X_F32, X_BF16, X_U8, X_ELL = 0, 1, 2, 3
+ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = 512, 1024, 10, 144 * 1024
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8
@@ -44,6 +45,8 @@ class MUState(C.Structure):
         ("halo_top", _vp), ("halo_bot", _vp),
         ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
+        ("ell_h", _vp), ("ell_h_off", _vp), ("ell_xlx", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
+        ("ell_cbits", _i32), ("n_cg", _i32),
     ]
 
 

@@ -32,8 +32,15 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE(st->n_pad == roundup(st->n, ESPM_NPAD) && st->p_pad == roundup(st->p, ESPM_PPAD),
                "n_pad/p_pad (%d, %d) do not match n, p (%d, %d); call espm_mu_query", st->n_pad, st->p_pad, st->n,
                st->p);
-  ESPM_REQUIRE(st->x_dtype == ESPM_X_F32 || st->x_dtype == ESPM_X_BF16 || st->x_dtype == ESPM_X_U8, "bad x_dtype %d",
-               st->x_dtype);
+  ESPM_REQUIRE(st->x_dtype >= ESPM_X_F32 && st->x_dtype <= ESPM_X_ELL, "bad x_dtype %d", st->x_dtype);
+  if (st->x_dtype == ESPM_X_ELL) {
+    ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_xlx && st->ell_w && st->ell_w_off && st->chan_perm,
+                 "the sparse count store needs ell_h, ell_h_off, ell_xlx, ell_w, ell_w_off and chan_perm");
+    ESPM_REQUIRE(st->tile_px == ESPM_ELL_TILE && st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB &&
+                     st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
+                 "sparse count store: tile_px must be %d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
+                 ESPM_ELL_TILE, ESPM_ELL_PB);
+  }
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
@@ -78,6 +85,15 @@ int espm_mu_query(espm_mu_state* st) {
   st->x_tile = st->tile_px;
   st->n_cm = roundup(st->n, ESPM_NCM);
   st->h_variant = 0;
+  st->n_cg = (st->n + 63) / 64;
+  if (st->x_dtype == ESPM_X_ELL) {  // sparse count store: fixed decomposition (mu_ell_kernel.hpp)
+    st->tile_px = st->x_tile = ESPM_ELL_TILE;
+    st->nblk_w = (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB;
+    st->ell_cbits = 1;
+    while ((1 << st->ell_cbits) < st->n) ++st->ell_cbits;
+    if (st->ell_cbits > 14) return set_error(ESPM_EUNSUPPORTED, "sparse count store: n=%d needs more than 14 index bits", st->n);
+    return ESPM_OK;
+  }
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
   const int ychunks = st->x_dtype != ESPM_X_F32 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
   int target = (2 * cus + ychunks - 1) / ychunks;
@@ -149,6 +165,7 @@ int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  if (st->x_dtype == ESPM_X_ELL) return launch_h_ell(make_h_args(st, src, write_h), nblk_h(st), static_cast<hipStream_t>(stream));
   return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->h_variant ? -128 : st->tile_px, nblk_h(st),
                          static_cast<hipStream_t>(stream));
 }
@@ -190,6 +207,7 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(st->nblk_w >= 1, "nblk_w must be >= 1");
+  if (st->x_dtype == ESPM_X_ELL) return launch_w_ell(make_w_args(st), st->k, st->nblk_w, static_cast<hipStream_t>(stream));
   return dispatch_w_accum(make_w_args(st), st->k, st->x_dtype, st->nblk_w, static_cast<hipStream_t>(stream));
 }
 

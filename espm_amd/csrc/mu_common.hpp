@@ -355,6 +355,11 @@ struct HStepArgs {
   int have_prev;     // h_out still holds the H that preceded h_in: evaluate rel_H (base.py:324)
   float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale, rel_tol;
   double inv_count;  // 1 / (k * p_total)
+  // sparse count store (mu_ell_kernel.hpp)
+  const uint32_t* ell;
+  const int32_t* ell_off;
+  const float* ell_xlx;
+  int ell_bits, n_pad;
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -371,6 +376,11 @@ struct WAccumArgs {
   const float* h_t;
   float* a_slab;
   int n_pad, p, ppb;
+  // sparse count store (mu_ell_kernel.hpp)
+  const uint32_t* ell;
+  const int32_t* ell_off;
+  const int32_t* chan_perm;
+  int n_cg;
 };
 struct WFinishArgs {
   const float* g;
@@ -477,6 +487,11 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.log_shift = st->log_shift;
   a.tol = st->dicotomy_tol;
   a.xscale = st->xscale;
+  a.ell = st->ell_h;
+  a.ell_off = st->ell_h_off;
+  a.ell_xlx = st->ell_xlx;
+  a.ell_bits = st->ell_cbits;
+  a.n_pad = st->n_pad;
   return a;
 }
 
@@ -489,11 +504,17 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
   a.n_pad = st->n_pad;
   a.p = st->p;
   a.ppb = (st->p + st->nblk_w - 1) / st->nblk_w;
+  a.ell = st->ell_w;
+  a.ell_off = st->ell_w_off;
+  a.chan_perm = st->chan_perm;
+  a.n_cg = st->n_cg;
   return a;
 }
 
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
+int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
+int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
                     hipStream_t stream);

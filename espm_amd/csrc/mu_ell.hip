@@ -1,0 +1,71 @@
+// Launchers of the sparse count store kernels (mu_ell_kernel.hpp).
+#include "mu_ell_kernel.hpp"
+
+namespace espm {
+
+// dynamic LDS above 64 KB has to be granted per kernel (once)
+template <typename KernelT>
+static int allow_lds(KernelT kern, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return ESPM_OK;
+  if (bytes > ESPM_ELL_LDS_MAX) return set_error(ESPM_EUNSUPPORTED, "%s: %zu bytes of LDS exceed %d", what, bytes, ESPM_ELL_LDS_MAX);
+  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), what);
+}
+
+template <int K>
+static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
+  constexpr int UNR = 4;
+  const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float);
+  if (red > part) part = red;
+  const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
+  if (args.compute_loss) {
+    if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR>, bytes, "h_step (ell)")) return rc;
+    hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+  } else {
+    if (int rc = allow_lds(h_step_ell_kernel<K, false, UNR>, bytes, "h_step (ell)")) return rc;
+    hipLaunchKernelGGL((h_step_ell_kernel<K, false, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+  }
+  return check_hip(hipGetLastError(), "h_step (ell) launch");
+}
+
+int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
+  ESPM_REQUIRE(args.ell && args.ell_off && args.ell_xlx, "h_step: the sparse store needs ell_h, ell_h_off, ell_xlx");
+  ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
+  switch (args.k) {
+    case 1: return launch_h_ell_k<1>(args, nblk, stream);
+    case 2: return launch_h_ell_k<2>(args, nblk, stream);
+    case 3: return launch_h_ell_k<3>(args, nblk, stream);
+    case 4: return launch_h_ell_k<4>(args, nblk, stream);
+    case 5: return launch_h_ell_k<5>(args, nblk, stream);
+    case 6: return launch_h_ell_k<6>(args, nblk, stream);
+    case 7: return launch_h_ell_k<7>(args, nblk, stream);
+    case 8: return launch_h_ell_k<8>(args, nblk, stream);
+  }
+  return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built", args.k);
+}
+
+template <int K>
+static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) {
+  constexpr int UNR = 4;
+  const size_t bytes = (size_t)ESPM_ELL_PB * EllTab<K>::FLOATS * sizeof(float);
+  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk), dim3(ESPM_ELL_PB), bytes, stream, args);
+  return check_hip(hipGetLastError(), "w_accum (ell) launch");
+}
+
+int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
+  ESPM_REQUIRE(args.ell && args.ell_off && args.chan_perm && args.n_cg >= 1, "w_accum: the sparse store needs ell_w, ell_w_off, chan_perm");
+  ESPM_REQUIRE(nblk == (args.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB, "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, ESPM_ELL_PB);
+  switch (k) {
+    case 1: return launch_w_ell_k<1>(args, nblk, stream);
+    case 2: return launch_w_ell_k<2>(args, nblk, stream);
+    case 3: return launch_w_ell_k<3>(args, nblk, stream);
+    case 4: return launch_w_ell_k<4>(args, nblk, stream);
+    case 5: return launch_w_ell_k<5>(args, nblk, stream);
+    case 6: return launch_w_ell_k<6>(args, nblk, stream);
+    case 7: return launch_w_ell_k<7>(args, nblk, stream);
+    case 8: return launch_w_ell_k<8>(args, nblk, stream);
+  }
+  return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built", k);
+}
+
+}  // namespace espm

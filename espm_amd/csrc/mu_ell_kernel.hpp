@@ -1,0 +1,202 @@
+// Kernels of the sparse count store (x_dtype = ESPM_X_ELL, include/espm_mu.h).
+//
+// Spectrum images are Poisson counts: at the headline size (500 counts per pixel over 2048 channels) 80 % of
+// the entries of X are zero, and a zero entry contributes nothing to either update (R = X / Y is zero there,
+// and X ln(X / Y) too) - the dense kernels spend four fifths of their vector-ALU time, which is what bounds
+// them, on those zeros.  Here only the non-zero entries are stored and processed, 16 bits each:
+//
+//   H-step: lists BY PIXEL.  A lane owns one pixel, so H[:, pixel] and the numerator of that pixel live in
+//           registers and nothing is reduced across lanes; per entry the lane gathers the GW row of the
+//           entry's channel from a table in LDS.  entry = count << cbits | channel.
+//   W-step: lists BY CHANNEL inside blocks of 1024 pixels.  A lane owns one channel (GW row and the R H^T
+//           accumulator in registers) and gathers H[:, pixel] of the entry from a table of the block's
+//           H columns in LDS.  entry = count << pbits | pixel-in-block.  Channels are visited in order of
+//           decreasing total count (chan_perm), so the 64 lists of a wave have about the same length.
+//
+// Both lists are "ELL" slabs: the j-th entries of the 64 lanes of a wave are adjacent in memory (one
+// coalesced 256-byte row carries entries 2r and 2r+1 of each lane), padded with zero entries (count 0) to the
+// longest list of the 64.  A count that does not fit its field is stored as several entries of the same
+// channel / pixel - which is why the loss term is accumulated as  sum x log2 Y  against the precomputed
+// per-pixel constant  sum x log2 x,  not as  sum x log2(x / Y).
+//
+// Bounds: the lists are read once per launch at HBM rate; per entry the LDS serves one 16- or
+// 20..32-byte gather, which is the second limit (random rows: ~3-way bank conflicts inside a 16-lane group).
+#pragma once
+#include "mu_h_kernel.hpp"
+
+namespace espm {
+
+// LDS table of rows of K floats: components 0..3 as float4 (ds_read_b128 at a 16-byte stride: the 16 lanes of
+// a read group spread over all 16 bank quads), components 4.. in a second array of 1, 2 or 4 floats per row.
+template <int K>
+struct EllTab {
+  static constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : 4));
+  static constexpr int FLOATS = 4 + WB;
+  // row r from 8 consecutive floats (the KP-strided gw_s / h_t rows)
+  static __device__ __forceinline__ void put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
+    reinterpret_cast<float4*>(tab)[r] = lo;
+    float* tb = tab + 4 * (size_t)rows;
+    if constexpr (WB == 1) tb[r] = hi.x;
+    if constexpr (WB == 2) reinterpret_cast<float2*>(tb)[r] = make_float2(hi.x, hi.y);
+    if constexpr (WB == 4) reinterpret_cast<float4*>(tb)[r] = hi;
+  }
+  static __device__ __forceinline__ void get(const float* tab, int rows, uint32_t r, float (&g)[K]) {
+    const float4 lo = reinterpret_cast<const float4*>(tab)[r];
+    const float l[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+    for (int i = 0; i < (K < 4 ? K : 4); ++i) g[i] = l[i];
+    const float* tb = tab + 4 * (size_t)rows;
+    if constexpr (WB == 1) g[4] = tb[r];
+    if constexpr (WB == 2) {
+      const float2 v = reinterpret_cast<const float2*>(tb)[r];
+      g[4] = v.x;
+      g[5] = v.y;
+    }
+    if constexpr (WB == 4) {
+      const float4 v = reinterpret_cast<const float4*>(tb)[r];
+      const float h[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 4; i < K; ++i) g[i] = h[i - 4];
+    }
+  }
+};
+
+// Walks the `len` dwords (two 16-bit entries each) of this lane's list; `row` points at the lane's first
+// dword, consecutive dwords are 64 apart.  UNR dwords are requested one batch ahead of their use and the
+// 2 UNR table gathers of a batch are issued together.  body(index, count, table row) consumes one entry.
+template <int K, int UNR, typename Body>
+__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, const float* tab, int tab_rows, int idx_bits,
+                                         Body body) {
+  const uint32_t mask = (1u << idx_bits) - 1u;
+  auto batch = [&](const uint32_t (&e)[UNR]) {
+    float g[2 * UNR][K];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      EllTab<K>::get(tab, tab_rows, e[u] & mask, g[2 * u]);
+      EllTab<K>::get(tab, tab_rows, (e[u] >> 16) & mask, g[2 * u + 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      body((float)((e[u] & 0xffffu) >> idx_bits), g[2 * u]);
+      body((float)(e[u] >> (16 + idx_bits)), g[2 * u + 1]);
+    }
+  };
+  int j = 0;
+  if (len >= UNR) {
+    uint32_t e[UNR], en[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
+    for (; j + UNR <= len; j += UNR) {
+      const int jn = min(j + UNR, len - UNR);  // the last batch re-requests itself (no branch, no overrun)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) en[u] = row[(size_t)(jn + u) * 64];
+      batch(e);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) e[u] = en[u];
+    }
+  }
+  for (; j < len; ++j) {
+    const uint32_t v = row[(size_t)j * 64];
+    float g0[K], g1[K];
+    EllTab<K>::get(tab, tab_rows, v & mask, g0);
+    EllTab<K>::get(tab, tab_rows, (v >> 16) & mask, g1);
+    body((float)((v & 0xffffu) >> idx_bits), g0);
+    body((float)(v >> (16 + idx_bits)), g1);
+  }
+}
+
+// ---- H-step --------------------------------------------------------------------------------------
+// One workgroup = 512 pixels = 8 waves, one 64-pixel group per wave.  updates.py:127-132 restricted to the
+// non-zero entries of X; the per-pixel epilogue (regularisers, simplex, clamp, statistics) is h_epilogue.
+template <int K, bool LOSS, int UNR>
+__global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepArgs a) {
+  constexpr int TP = ESPM_ELL_TILE;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tab = smem;                                          // [n_pad] rows of GW
+  float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [K][TP] numerators, then reduction scratch
+  for (int r = threadIdx.x; r < a.n_pad; r += TP) {
+    const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
+    EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile0 = blockIdx.x * TP;
+  const int grp = tile0 / 64 + wave;
+  const int px = tile0 + wave * 64 + lane;  // < p_pad (a multiple of TP); pad pixels have empty lists
+
+  float hk[K], acc[K];
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) {
+    hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
+    acc[kk] = 0.f;
+  }
+  float xlogy = 0.f;
+  const int beg = a.ell_off[grp], end = a.ell_off[grp + 1];
+  ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
+    float y = g[0] * hk[0];
+#pragma unroll
+    for (int kk = 1; kk < K; ++kk) y = fmaf(g[kk], hk[kk], y);
+    const float r = x * __builtin_amdgcn_rcpf(y);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(g[kk], r, acc[kk]);
+    if constexpr (LOSS) xlogy = fmaf(x, __builtin_amdgcn_logf(y), xlogy);
+  });
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) part[kk * TP + wave * 64 + lane] = acc[kk];
+  // sum x log2(x / Y) of this pixel = (sum x log2 x) - (sum x log2 Y)
+  const float kl = LOSS ? a.ell_xlx[px] - xlogy : 0.f;
+  h_epilogue<K>(a, part, 1, TP, tile0, kl);
+}
+
+// ---- W accumulation ---------------------------------------------------------------------------------
+// One workgroup = one block of 1024 pixels, 16 waves; a wave handles 64 channels (one per lane) at a time.
+// Channel groups are in order of decreasing total count: wave w takes groups w, 31 - w, 32 + w, ... so the
+// waves of a workgroup carry about the same number of entries.  updates.py:38-39, :53, :59.
+template <int K, int UNR>
+__global__ __launch_bounds__(ESPM_ELL_PB) void w_accum_ell_kernel(const WAccumArgs a) {
+  constexpr int PB = ESPM_ELL_PB, NW = PB / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tab = smem;  // [PB] columns of H
+  const int b = blockIdx.x;
+  {
+    const int q = b * PB + (int)threadIdx.x;
+    float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // pixels past the end: never referenced by an entry with a count
+    if (q < a.p) {
+      const float4* src = reinterpret_cast<const float4*>(a.h_t + (size_t)q * KP);
+      lo = src[0];
+      hi = src[1];
+    }
+    EllTab<K>::put(tab, PB, threadIdx.x, lo, hi);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int t = 0; t * NW < a.n_cg; ++t) {
+    const int cg = t * NW + ((t & 1) ? NW - 1 - wave : wave);
+    if (cg >= a.n_cg) continue;
+    const int c = a.chan_perm[cg * 64 + lane];
+    const float* gsrc = a.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
+    float gw[K], acc[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      gw[kk] = gsrc[kk];
+      acc[kk] = 0.f;
+    }
+    const int beg = a.ell_off[(size_t)b * a.n_cg + cg], end = a.ell_off[(size_t)b * a.n_cg + cg + 1];
+    ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, PB, ESPM_ELL_PBITS, [&](float x, const float (&h)[K]) {
+      float y = gw[0] * h[0];
+#pragma unroll
+      for (int kk = 1; kk < K; ++kk) y = fmaf(gw[kk], h[kk], y);
+      const float r = x * __builtin_amdgcn_rcpf(y);
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(r, h[kk], acc[kk]);
+    });
+    if (c >= 0) {
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) a.a_slab[((size_t)b * K + kk) * a.n_pad + c] = acc[kk];
+    }
+  }
+}
+
+}  // namespace espm

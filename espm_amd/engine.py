@@ -25,6 +25,9 @@ import torch
 from . import _lib
 from ._lib import MUState, check, lib
 
+# the sparse count store is chosen (x_store='auto') when at most this fraction of X is non-zero
+ELL_MAX_DENSITY = 0.35
+
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
@@ -104,24 +107,35 @@ class MUEngine:
         if group is not None:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
-        if x_store == "auto":
-            # u8: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
-            # which is not an integer: such data keep the bf16 store and the reference's exact semantics
+        if x_store in ("auto", "ell"):
+            # u8 / ell: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
+            # which is not an integer: such data keep the bf16 store and the reference's exact semantics.
+            # ell (non-zero entries only) when at most ELL_MAX_DENSITY of the entries are non-zero and the GW table
+            # fits in LDS; the decision is taken jointly by all ranks.
             is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
             exact = (Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16
             code = 2 if bool(is_count) else (1 if bool(exact) else 0)
+            if code == 2:
+                from . import ell as _ell
+                n_pad8 = (self.n + 7) // 8 * 8
+                fits = self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
+                sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
+                if fits and (sparse or x_store == "ell"):
+                    code = 3
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
             if group is not None:
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
-            x_store = ("f32", "bf16", "u8")[int(flag.item())]
-        if x_store not in ("u8", "bf16", "f32"):
-            raise ValueError("x_store must be 'auto', 'u8', 'bf16' or 'f32'")
+            if x_store == "ell" and int(flag.item()) != 3:
+                raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS")
+            x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
+        if x_store not in ("u8", "bf16", "f32", "ell"):
+            raise ValueError("x_store must be 'auto', 'ell', 'u8', 'bf16' or 'f32'")
         self.x_store = x_store
 
         st = MUState()
         self.st = st
         st.n, st.p, st.k = self.n, self.p, k
-        st.x_dtype = {"u8": _lib.X_U8, "bf16": _lib.X_BF16, "f32": _lib.X_F32}[x_store]
+        st.x_dtype = {"u8": _lib.X_U8, "bf16": _lib.X_BF16, "f32": _lib.X_F32, "ell": _lib.X_ELL}[x_store]
         if shape_2d is not None:
             nx, ny = int(shape_2d[0]), int(shape_2d[1])
             if nx * ny != p:
@@ -136,23 +150,32 @@ class MUEngine:
         st.p_total = int(p_total.item())
         self.p_total = st.p_total
 
-        xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
         if h_variant is None:
             h_variant = int(os.environ.get("ESPM_H_VARIANT", "0"))
-        if h_variant and x_store in ("u8", "bf16"):  # Y = GW H on the matrix cores: 128-pixel tiles
-            st.h_variant = 1
-            tile_px = 128
-        if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
-            st.tile_px = int(tile_px)
-            st.x_tile = int(tile_px)
-        if x_tile is not None:
-            st.x_tile = int(x_tile)
-        self.x_cm = torch.empty((st.p_pad // st.x_tile, st.n_cm, st.x_tile), dtype=xt, device=dev)
-        self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
-        Xd = Xd.contiguous()
-        check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
-                                 _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
-                                 _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, st.n_cm, _stream()))
+        self.ell = None
+        if x_store == "ell":
+            from . import ell as _ell
+            self.x_cm = self.x_pm = None
+            self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits)
+            assert self.ell["n_cg"] == st.n_cg and self.ell["nblk_w"] == st.nblk_w
+            self.x_bytes = 4 * (self.ell["ell_h"].numel() + self.ell["ell_w"].numel())
+        else:
+            xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
+            if h_variant and x_store in ("u8", "bf16"):  # Y = GW H on the matrix cores: 128-pixel tiles
+                st.h_variant = 1
+                tile_px = 128
+            if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
+                st.tile_px = int(tile_px)
+                st.x_tile = int(tile_px)
+            if x_tile is not None:
+                st.x_tile = int(x_tile)
+            self.x_cm = torch.empty((st.p_pad // st.x_tile, st.n_cm, st.x_tile), dtype=xt, device=dev)
+            self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
+            Xd = Xd.contiguous()
+            check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
+                                     _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
+                                     _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, st.n_cm, _stream()))
+            self.x_bytes = self.x_cm.numel() * self.x_cm.element_size() + self.x_pm.numel() * self.x_pm.element_size()
         torch.cuda.current_stream().synchronize()
         del Xd
 
@@ -215,7 +238,12 @@ class MUEngine:
         else:
             self.simplex_rows = None
 
-        st.x_cm, st.x_pm = self.x_cm.data_ptr(), self.x_pm.data_ptr()
+        if self.ell is None:
+            st.x_cm, st.x_pm = self.x_cm.data_ptr(), self.x_pm.data_ptr()
+        else:
+            st.x_cm = st.x_pm = None
+            st.ell_h, st.ell_h_off, st.ell_xlx = (self.ell[key].data_ptr() for key in ("ell_h", "ell_h_off", "xlx"))
+            st.ell_w, st.ell_w_off, st.chan_perm = (self.ell[key].data_ptr() for key in ("ell_w", "ell_w_off", "chan_perm"))
         st.g = self.g.data_ptr() if self.g is not None else None
         st.colsum_g = self.colsum_g.data_ptr() if self.colsum_g is not None else None
         st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()

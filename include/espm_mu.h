@@ -55,7 +55,8 @@ typedef enum espm_status {
   ESPM_EUNSUPPORTED = -4  /* configuration not built (k > ESPM_MAX_K) */
 } espm_status;
 
-enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1, ESPM_X_U8 = 2 /* integer counts <= 255 */ };
+enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1, ESPM_X_U8 = 2 /* integer counts <= 255 */,
+       ESPM_X_ELL = 3 /* integer counts, non-zero entries only (sparse count store, below) */ };
 enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
 enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
 
@@ -63,6 +64,10 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
+#define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
+#define ESPM_ELL_PB 1024   /* sparse store: pixels per block of the W accumulation                          */
+#define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
+#define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
 
 /* per-workgroup partial record written by the H-step (doubles), stored field-major:
@@ -102,7 +107,7 @@ typedef struct espm_mu_state {
   int32_t nx, ny;   /* local image rows, row length                                     */
   int32_t n_pad;    /* roundup(n, ESPM_NPAD)                                            */
   int32_t p_pad;    /* roundup(p, ESPM_PPAD)                                            */
-  int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16 | ESPM_X_U8                             */
+  int32_t x_dtype;  /* ESPM_X_F32 | ESPM_X_BF16 | ESPM_X_U8 | ESPM_X_ELL                */
   int32_t tile_px;  /* H-step pixel tile per workgroup: 64 * {1,2,4,8}, see query       */
   int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
   int32_t x_tile;   /* pixel-block width of the tile-major x_cm (multiple of tile_px)   */
@@ -145,6 +150,24 @@ typedef struct espm_mu_state {
   int32_t hist_len;
   int32_t cur;              /* index of the current W/H buffers (0/1), flipped by iterate */
   int32_t it;               /* number of completed iterations = history slot of the current state */
+  /* Sparse count store (x_dtype = ESPM_X_ELL; x_cm / x_pm are then unused and may be NULL).  Only the non-zero
+   * entries of X are kept, 16 bits each, as lists padded to the longest of 64 ("ELL"): the entries 2r and 2r+1
+   * of the 64 lists of a wave form row r of 64 dwords (low half first), value 0 = padding.  A count that
+   * exceeds its field is split over several entries with the same index.
+   *   H-step: one list per pixel, 64 consecutive pixels per wave; entry = count << ell_cbits | channel;
+   *           rows [ell_h_off[g], ell_h_off[g+1]) belong to pixels 64 g .. 64 g + 63.
+   *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); the 64 lists of a wave are the channels
+   *           chan_perm[64 cg .. 64 cg + 63] (channels in order of decreasing total count, -1 = none);
+   *           entry = count << ESPM_ELL_PBITS | pixel - block start; rows
+   *           [ell_w_off[b * n_cg + cg], ell_w_off[b * n_cg + cg + 1]).  nblk_w = ceil(p / ESPM_ELL_PB). */
+  const uint32_t* ell_h;    /* (rows_h, 64) */
+  const int32_t* ell_h_off; /* (p_pad / 64 + 1) */
+  const float* ell_xlx;     /* (p_pad): sum over channels of x log2 x per pixel (the loss constant, base.py:200) */
+  const uint32_t* ell_w;    /* (rows_w, 64) */
+  const int32_t* ell_w_off; /* (nblk_w * n_cg + 1) */
+  const int32_t* chan_perm; /* (64 * n_cg) */
+  int32_t ell_cbits;        /* index bits of an H-step entry: 2^ell_cbits >= n, <= 14 */
+  int32_t n_cg;             /* channel groups: ceil(n / 64) */
 } espm_mu_state;
 
 const char* espm_mu_version(void);

@@ -1,0 +1,67 @@
+"""The sparse count store (include/espm_mu.h, x_dtype = ESPM_X_ELL) built by espm_amd.ell decodes back to X.
+
+CPU only: the builder is torch tensor plumbing and runs on host tensors too; the kernels that read the lists
+are exercised by the gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from espm_amd import _lib, ell
+
+
+def decode(store, p, n, p_pad, cbits):
+    PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
+    eh = store["ell_h"].numpy().astype(np.int64) & 0xFFFFFFFF
+    off = store["ell_h_off"].numpy()
+    Xh = np.zeros((p_pad, n), dtype=np.int64)
+    for g in range(p_pad // 64):
+        rows = eh[off[g] * 64:off[g + 1] * 64].reshape(-1, 64)
+        for half in (0, 1):
+            ent = (rows >> (16 * half)) & 0xFFFF
+            cnt, c = ent >> cbits, ent & ((1 << cbits) - 1)
+            for lane in range(64):
+                np.add.at(Xh[g * 64 + lane], c[:, lane], cnt[:, lane])
+    ew = store["ell_w"].numpy().astype(np.int64) & 0xFFFFFFFF
+    woff = store["ell_w_off"].numpy()
+    perm = store["chan_perm"].numpy()
+    n_cg = store["n_cg"]
+    Xw = np.zeros((store["nblk_w"] * PB, n), dtype=np.int64)
+    for b in range(store["nblk_w"]):
+        for cg in range(n_cg):
+            rows = ew[woff[b * n_cg + cg] * 64:woff[b * n_cg + cg + 1] * 64].reshape(-1, 64)
+            for half in (0, 1):
+                ent = (rows >> (16 * half)) & 0xFFFF
+                cnt, pl = ent >> PBITS, ent & (PB - 1)
+                for lane in range(64):
+                    c = perm[cg * 64 + lane]
+                    if c < 0:
+                        assert not cnt[:, lane].any()
+                        continue
+                    np.add.at(Xw[b * PB:(b + 1) * PB, c], pl[:, lane], cnt[:, lane])
+    return Xh, Xw
+
+
+@pytest.mark.parametrize("n,p,rate,big", [(100, 400, 0.3, False), (1980, 1300, 0.2, True), (70, 2049, 1.5, True)])
+def test_lists_decode_to_x(n, p, rate, big):
+    rng = np.random.default_rng(n + p)
+    X = rng.poisson(rate * rng.uniform(0.1, 2.0, size=(1, n)), size=(p, n)).astype(np.float32)
+    if big:  # counts beyond the count field of an entry are split over several entries
+        X[rng.integers(0, p, 40), rng.integers(0, n, 40)] = rng.integers(32, 256, 40)
+    cbits = max(1, int(np.ceil(np.log2(n))))
+    p_pad = (p + 511) // 512 * 512
+    store = ell.build(torch.from_numpy(X), p_pad, cbits, chunk=512)
+    assert store["nnz"] == int((X != 0).sum())
+    Xh, Xw = decode(store, p, n, p_pad, cbits)
+    assert np.array_equal(Xh[:p], X.astype(np.int64)) and not Xh[p:].any()
+    assert np.array_equal(Xw[:p], X.astype(np.int64)) and not Xw[p:].any()
+    # the loss constant: sum x log2 x per pixel
+    ref = (X.astype(np.float64) * np.log2(np.maximum(X, 1.0))).sum(axis=1)
+    np.testing.assert_allclose(store["xlx"].numpy()[:p], ref, rtol=1e-6)
+    # channels in order of decreasing entry count, every channel exactly once
+    perm = store["chan_perm"].numpy()
+    assert sorted(perm[perm >= 0].tolist()) == list(range(n))
+    # lists are padded to the longest of 64 only: rows of a group = ceil(max entries / 2)
+    xmax = (1 << (16 - cbits)) - 1
+    ent = np.ceil(X / xmax).sum(axis=1)
+    ent = np.concatenate([ent, np.zeros(p_pad - p)]).reshape(-1, 64).max(axis=1)
+    assert np.array_equal(np.diff(store["ell_h_off"].numpy()), (ent + 1) // 2)

@@ -1,0 +1,211 @@
+// Prototype 2: sparse H-step numerator with one PIXEL PER LANE (no cross-lane reductions).
+//
+// ELL by 64-pixel group: entry j of the 64 pixels of a group is one coalesced 256-byte row;
+// entry = (byte offset of the GW row in the LDS table) | count << 16.  Per entry a lane gathers its GW row
+// (K floats, 24-byte stride: three ds_read_b64) and accumulates the numerator of ITS pixel in registers.
+// Question: is the LDS gather fast enough to beat the dense VALU kernel (213 us at 2048 x 512 x 512, k = 5)?
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 sparse_h2.hip -o sparse_h2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+
+constexpr int K = 5, KS = 6;  // KS: floats per LDS row (24 bytes: 3 x b64)
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int UNR, bool LOSS, int NT, int LAY>
+__global__ __launch_bounds__(NT) void sparse_h2(const uint32_t* __restrict__ ell, const int* __restrict__ goff,
+                                                 const float* __restrict__ gw /* [n][KS] */, const float* __restrict__ h /* [K][p] */,
+                                                 float* __restrict__ num /* [K][p] */, float* __restrict__ klout, int n, int p,
+                                                 int groups_per_wave) {
+  extern __shared__ float gwl[];  // LAY 0: [n][KS]; LAY 1: [n][4] then [n] (fifth component)
+  if (LAY == 0) {
+    for (int i = threadIdx.x; i < n * KS / 2; i += NT)
+      reinterpret_cast<float2*>(gwl)[i] = reinterpret_cast<const float2*>(gw)[i];
+  } else {
+    for (int c = threadIdx.x; c < n; c += NT) {
+      const float* src = gw + (size_t)c * KS;
+      reinterpret_cast<float4*>(gwl)[c] = make_float4(src[0], src[1], src[2], src[3]);
+      gwl[4 * n + c] = src[4];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g0 = (blockIdx.x * (NT / 64) + wave) * groups_per_wave;
+  const char* tab = reinterpret_cast<const char*>(gwl);
+  for (int g = g0; g < g0 + groups_per_wave; ++g) {
+    const int px = g * 64 + lane;
+    if (g * 64 >= p) break;
+    float hk[K], acc[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) { hk[kk] = h[(size_t)kk * p + px]; acc[kk] = 0.f; }
+    float kl = 0.f;
+    const int beg = goff[g], end = goff[g + 1];  // in rows of 64 entries
+    const uint32_t* row = ell + (size_t)beg * 64 + lane;
+    const int len = end - beg;
+    const float2* tab2 = reinterpret_cast<const float2*>(gwl);
+    const float4* tab4 = reinterpret_cast<const float4*>(gwl);
+    const float* tab1 = gwl + 4 * n;
+    struct GRow { float g[K]; };
+    auto gather = [&](uint32_t e, GRow& gr) {
+      const uint32_t c = e & 0xffffu;
+      if (LAY == 0) {
+        const float2 a = tab2[3 * c], b = tab2[3 * c + 1], cc = tab2[3 * c + 2];
+        gr.g[0] = a.x; gr.g[1] = a.y; gr.g[2] = b.x; gr.g[3] = b.y; gr.g[4] = cc.x;
+      } else {
+        const float4 a = tab4[c];
+        gr.g[0] = a.x; gr.g[1] = a.y; gr.g[2] = a.z; gr.g[3] = a.w; gr.g[4] = tab1[c];
+      }
+    };
+    auto compute = [&](uint32_t e, const GRow& gr) {
+      const float x = (float)((e >> 16) & 0xffu);
+      float y = gr.g[0] * hk[0];
+#pragma unroll
+      for (int kk = 1; kk < K; ++kk) y = fmaf(gr.g[kk], hk[kk], y);
+      const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(gr.g[kk], r, acc[kk]);
+      if (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+    };
+    auto process = [&](uint32_t e) { GRow gr; gather(e, gr); compute(e, gr); };
+    int j = 0;
+    if (len >= UNR) {
+      uint32_t e[UNR], en[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
+      for (; j + UNR <= len; j += UNR) {
+        // request the next batch of entries (clamped to the last full batch) before working on this one
+        const int jn = min(j + UNR, len - UNR);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) en[u] = row[(size_t)(jn + u) * 64];
+        GRow gr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) gather(e[u], gr[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) compute(e[u], gr[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) e[u] = en[u];
+      }
+    }
+    for (; j < len; ++j) process(row[(size_t)j * 64]);
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) num[(size_t)kk * p + px] = acc[kk];
+    if (LOSS) klout[px] = kl;
+  }
+}
+
+static inline uint64_t rng(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+int main(int argc, char** argv) {
+  const int n = 2048, nx = argc > 1 ? atoi(argv[1]) : 512, ny = nx, p = nx * ny;
+  const double counts = argc > 2 ? atof(argv[2]) : 500.0;
+  // spectrum: smooth background + a few peaks, normalised; per-pixel rates = counts * mix of two spectra
+  std::vector<double> s1(n), s2(n);
+  double t1 = 0, t2 = 0;
+  for (int c = 0; c < n; ++c) {
+    const double u = (double)c / n;
+    s1[c] = 0.3 * exp(-2 * u) + exp(-0.5 * pow((u - 0.2) / 0.02, 2)) + 0.7 * exp(-0.5 * pow((u - 0.55) / 0.03, 2));
+    s2[c] = 0.3 * exp(-3 * u) + exp(-0.5 * pow((u - 0.35) / 0.025, 2)) + 0.5 * exp(-0.5 * pow((u - 0.8) / 0.04, 2));
+    t1 += s1[c]; t2 += s2[c];
+  }
+  for (int c = 0; c < n; ++c) { s1[c] /= t1; s2[c] /= t2; }
+  // Poisson sampling by thinning: P(x = 0) = exp(-rate); counts drawn 1 + small extra
+  std::vector<std::vector<uint32_t>> lists(p);
+  uint64_t seed = 88172645463325252ull;
+  size_t nnz = 0;
+  std::vector<uint32_t> thr1(n), thr2(n);
+  for (int q = 0; q < p; ++q) {
+    const double w = 0.5 + 0.5 * sin(0.02 * (q / ny)) * cos(0.03 * (q % ny));
+    auto& L = lists[q];
+    L.reserve(512);
+    for (int c = 0; c < n; ++c) {
+      const double rate = counts * (w * s1[c] + (1 - w) * s2[c]);
+      const double u = (rng(seed) >> 11) * (1.0 / 9007199254740992.0);
+      double pk = exp(-rate), cum = pk;
+      int x = 0;
+      while (u > cum && x < 255) { ++x; pk *= rate / x; cum += pk; }
+      if (x) L.push_back((uint32_t)c | ((uint32_t)x << 16));
+    }
+    nnz += L.size();
+  }
+  const int ngroups = p / 64;
+  std::vector<int> goff(ngroups + 1, 0);
+  for (int g = 0; g < ngroups; ++g) {
+    size_t m = 0;
+    for (int l = 0; l < 64; ++l) m = std::max(m, lists[g * 64 + l].size());
+    goff[g + 1] = goff[g] + (int)m;
+  }
+  const size_t rows = goff[ngroups];
+  printf("n %d p %d counts %.0f: nnz %zu (density %.3f), ELL rows %zu (padding %.3f), ELL bytes %.1f MB\n", n, p, counts, nnz,
+         (double)nnz / ((double)n * p), rows, (double)rows * 64 / nnz, rows * 256 / 1e6);
+  std::vector<uint32_t> ell(rows * 64, 0u);
+  for (int g = 0; g < ngroups; ++g)
+    for (int l = 0; l < 64; ++l) {
+      const auto& L = lists[g * 64 + l];
+      for (size_t j = 0; j < L.size(); ++j) ell[((size_t)goff[g] + j) * 64 + l] = L[j];
+    }
+  std::vector<float> gw((size_t)n * KS, 0.f), h((size_t)K * p);
+  for (int c = 0; c < n; ++c)
+    for (int kk = 0; kk < K; ++kk) gw[(size_t)c * KS + kk] = (float)(s1[c] * (0.5 + 0.1 * kk) + s2[c] * (0.6 - 0.1 * kk)) * 500.f;
+  for (size_t i = 0; i < h.size(); ++i) h[i] = 0.1f + 0.2f * ((rng(seed) >> 40) * (1.f / 16777216.f));
+
+  uint32_t* d_ell; int* d_goff; float *d_gw, *d_h, *d_num, *d_kl;
+  CK(hipMalloc(&d_ell, ell.size() * 4)); CK(hipMalloc(&d_goff, goff.size() * 4));
+  CK(hipMalloc(&d_gw, gw.size() * 4)); CK(hipMalloc(&d_h, h.size() * 4));
+  CK(hipMalloc(&d_num, h.size() * 4)); CK(hipMalloc(&d_kl, (size_t)p * 4));
+  CK(hipMemcpy(d_ell, ell.data(), ell.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_goff, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_gw, gw.data(), gw.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_h, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  const size_t lds = (size_t)n * KS * 4;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](auto kern, const char* name, int gpw, int nt) {
+    const int wpb = nt / 64;
+    const int nwg = (ngroups + wpb * gpw - 1) / (wpb * gpw);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(nt), lds, 0, d_ell, d_goff, d_gw, d_h, d_num, d_kl, n, p, gpw);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 50;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(nt), lds, 0, d_ell, d_goff, d_gw, d_h, d_num, d_kl, n, p, gpw);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s nt %4d gpw %d wgs %5d: %8.1f us  (%.1f cycles/row/SIMD at 2.4 GHz)\n", name, nt, gpw, nwg, ms * 1000 / reps,
+           ms * 1e-3 / reps * 2.4e9 * 1024 / rows);
+  };
+  for (int gpw : {1}) {
+    run(sparse_h2<8, true, 512, 0>, "unr8 loss b64x3", gpw, 512);
+    run(sparse_h2<8, true, 1024, 0>, "unr8 loss b64x3", gpw, 1024);
+    run(sparse_h2<16, true, 1024, 0>, "unr16 loss b64x3", gpw, 1024);
+    run(sparse_h2<4, true, 1024, 1>, "unr4 loss b128+b32", gpw, 1024);
+    run(sparse_h2<8, true, 512, 1>, "unr8 loss b128+b32", gpw, 512);
+    run(sparse_h2<8, true, 1024, 1>, "unr8 loss b128+b32", gpw, 1024);
+    run(sparse_h2<16, true, 1024, 1>, "unr16 loss b128+b32", gpw, 1024);
+    run(sparse_h2<8, false, 1024, 1>, "unr8 noloss b128+b32", gpw, 1024);
+  }
+  // check a few pixels against the host
+  std::vector<float> numh(h.size());
+  CK(hipMemcpy(numh.data(), d_num, h.size() * 4, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (int q : {0, 63, 64, 12345, p - 1}) {
+    double ref[K] = {0};
+    for (uint32_t e : lists[q]) {
+      const int c = (e & 0xffff);
+      const double x = (e >> 16) & 0xff;
+      double y = 0;
+      for (int kk = 0; kk < K; ++kk) y += (double)gw[(size_t)c * KS + kk] * h[(size_t)kk * p + q];
+      for (int kk = 0; kk < K; ++kk) ref[kk] += gw[(size_t)c * KS + kk] * x / y;
+    }
+    for (int kk = 0; kk < K; ++kk) worst = std::max(worst, fabs(numh[(size_t)kk * p + q] - ref[kk]) / fabs(ref[kk]));
+  }
+  printf("max rel err vs host on 5 pixels: %.3g\n", worst);
+  return 0;
+}
