@@ -45,7 +45,7 @@ class MUState(C.Structure):
         ("halo_top", _vp), ("halo_bot", _vp),
         ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
-        ("ell_h", _vp), ("ell_h_off", _vp), ("ell_xlx", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
+        ("ell_h", _vp), ("ell_h_off", _vp), ("ell_klc", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
         ("ell_cbits", _i32), ("n_cg", _i32),
     ]
 

@@ -34,8 +34,8 @@ static int check_state(const espm_mu_state* st) {
                st->p);
   ESPM_REQUIRE(st->x_dtype >= ESPM_X_F32 && st->x_dtype <= ESPM_X_ELL, "bad x_dtype %d", st->x_dtype);
   if (st->x_dtype == ESPM_X_ELL) {
-    ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_xlx && st->ell_w && st->ell_w_off && st->chan_perm,
-                 "the sparse count store needs ell_h, ell_h_off, ell_xlx, ell_w, ell_w_off and chan_perm");
+    ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_klc && st->ell_w && st->ell_w_off && st->chan_perm,
+                 "the sparse count store needs ell_h, ell_h_off, ell_klc, ell_w, ell_w_off and chan_perm");
     ESPM_REQUIRE(st->tile_px == ESPM_ELL_TILE && st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB &&
                      st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
                  "sparse count store: tile_px must be %d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",

@@ -358,7 +358,7 @@ struct HStepArgs {
   // sparse count store (mu_ell_kernel.hpp)
   const uint32_t* ell;
   const int32_t* ell_off;
-  const float* ell_xlx;
+  const float* ell_klc;
   int ell_bits, n_pad;
 };
 struct HFinalizeArgs {
@@ -489,7 +489,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.xscale = st->xscale;
   a.ell = st->ell_h;
   a.ell_off = st->ell_h_off;
-  a.ell_xlx = st->ell_xlx;
+  a.ell_klc = st->ell_klc;
   a.ell_bits = st->ell_cbits;
   a.n_pad = st->n_pad;
   return a;

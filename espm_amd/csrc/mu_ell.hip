@@ -29,7 +29,7 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
 }
 
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
-  ESPM_REQUIRE(args.ell && args.ell_off && args.ell_xlx, "h_step: the sparse store needs ell_h, ell_h_off, ell_xlx");
+  ESPM_REQUIRE(args.ell && args.ell_off && args.ell_klc, "h_step: the sparse store needs ell_h, ell_h_off, ell_klc");
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {
     case 1: return launch_h_ell_k<1>(args, nblk, stream);

@@ -15,9 +15,9 @@
 //
 // Both lists are "ELL" slabs: the j-th entries of the 64 lanes of a wave are adjacent in memory (one
 // coalesced 256-byte row carries entries 2r and 2r+1 of each lane), padded with zero entries (count 0) to the
-// longest list of the 64.  A count that does not fit its field is stored as several entries of the same
-// channel / pixel - which is why the loss term is accumulated as  sum x log2 Y  against the precomputed
-// per-pixel constant  sum x log2 x,  not as  sum x log2(x / Y).
+// longest list of the 64.  A count that does not fit its field is stored as several entries x_i of the same
+// channel / pixel; the loss term is accumulated per entry as x_i log2(x_i / Y) (well conditioned, like the dense
+// kernels) and the per-pixel constant  sum x log2 x - sum_i x_i log2 x_i  of the split counts is added at the end.
 //
 // Bounds: the lists are read once per launch at HBM rate; per entry the LDS serves one 16- or
 // 20..32-byte gather, which is the second limit (random rows: ~3-way bank conflicts inside a 16-lane group).
@@ -131,22 +131,21 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
     hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
     acc[kk] = 0.f;
   }
-  float xlogy = 0.f;
+  float kl = 0.f;
   const int beg = a.ell_off[grp], end = a.ell_off[grp + 1];
   ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
     float y = g[0] * hk[0];
 #pragma unroll
     for (int kk = 1; kk < K; ++kk) y = fmaf(g[kk], hk[kk], y);
-    const float r = x * __builtin_amdgcn_rcpf(y);
+    // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+    const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(g[kk], r, acc[kk]);
-    if constexpr (LOSS) xlogy = fmaf(x, __builtin_amdgcn_logf(y), xlogy);
+    if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
   });
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) part[kk * TP + wave * 64 + lane] = acc[kk];
-  // sum x log2(x / Y) of this pixel = (sum x log2 x) - (sum x log2 Y)
-  const float kl = LOSS ? a.ell_xlx[px] - xlogy : 0.f;
-  h_epilogue<K>(a, part, 1, TP, tile0, kl);
+  h_epilogue<K>(a, part, 1, TP, tile0, LOSS ? kl + a.ell_klc[px] : 0.f);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ def count_entries(Xpm, xmax_h, xmax_w, chunk=16384):
 def build(Xpm, p_pad, cbits, chunk=16384):
     """Xpm: (p, n) non-negative integer-valued tensor on the device (any float dtype).
 
-    Returns a dict of device tensors: ell_h (int32 dwords), ell_h_off (int32), xlx (float32, p_pad), ell_w,
+    Returns a dict of device tensors: ell_h (int32 dwords), ell_h_off (int32), klc (float32, p_pad), ell_w,
     ell_w_off, chan_perm (int32, 64 * n_cg), and the python ints n_cg, nblk_w, nnz, entries_h, entries_w."""
     dev = Xpm.device
     p, n = Xpm.shape
@@ -88,12 +88,17 @@ def build(Xpm, p_pad, cbits, chunk=16384):
         raise ValueError("sparse count store: H lists exceed 2^31 dwords")
     ell_h = torch.zeros(max(rows_h, 1) * 64, **i32)
     ell_h16 = ell_h.view(torch.int16)
-    xlx = torch.zeros(p_pad, dtype=torch.float32, device=dev)
+    klc = torch.zeros(p_pad, dtype=torch.float32, device=dev)
+    xm = float(xmax_h)
     for q0 in range(0, p, chunk):
         blk = Xpm[q0:q0 + chunk]
         xi = blk.to(torch.int64)
         xd = blk.to(torch.float64)
-        xlx[q0:q0 + blk.shape[0]] = (xd * torch.log2(xd.clamp_min(1.0))).sum(dim=1).to(torch.float32)
+        # loss correction of the split counts: x log2 x - sum over the entries x_i of x_i log2 x_i
+        nfull = torch.ceil(xd / xm).clamp_min(1.0) - 1.0
+        rest = xd - nfull * xm
+        klc[q0:q0 + blk.shape[0]] = (xd * torch.log2(xd.clamp_min(1.0)) - nfull * xm * float(torch.log2(torch.tensor(xm)))
+                                     - rest * torch.log2(rest.clamp_min(1.0))).sum(dim=1).to(torch.float32)
         nz = xi.nonzero(as_tuple=False)                       # sorted by pixel, then channel
         if nz.numel() == 0:
             continue
@@ -142,7 +147,7 @@ def build(Xpm, p_pad, cbits, chunk=16384):
         dword = (w_off[b * n_cg + (slot >> 6)] + (j >> 1)) * 64 + (slot & 63)
         _store16(ell_w16, dword, j & 1, (val << PBITS) | pl)
 
-    return dict(ell_h=ell_h, ell_h_off=h_off.to(torch.int32), xlx=xlx, ell_w=ell_w, ell_w_off=w_off.to(torch.int32),
+    return dict(ell_h=ell_h, ell_h_off=h_off.to(torch.int32), klc=klc, ell_w=ell_w, ell_w_off=w_off.to(torch.int32),
                 chan_perm=chan_perm.to(torch.int32), n_cg=n_cg, nblk_w=nblk_w, nnz=nnz,
                 entries_h=int(per_px.sum()), entries_w=int(per_ch.sum()), rows_h=rows_h, rows_w=rows_w)
 

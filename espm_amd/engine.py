@@ -107,6 +107,8 @@ class MUEngine:
         if group is not None:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
+        if h_variant is None:
+            h_variant = int(os.environ.get("ESPM_H_VARIANT", "0"))
         if x_store in ("auto", "ell"):
             # u8 / ell: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
             # which is not an integer: such data keep the bf16 store and the reference's exact semantics.
@@ -120,7 +122,7 @@ class MUEngine:
                 n_pad8 = (self.n + 7) // 8 * 8
                 fits = self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
                 sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
-                if fits and (sparse or x_store == "ell"):
+                if fits and (x_store == "ell" or (sparse and not h_variant)):
                     code = 3
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
             if group is not None:
@@ -150,8 +152,6 @@ class MUEngine:
         st.p_total = int(p_total.item())
         self.p_total = st.p_total
 
-        if h_variant is None:
-            h_variant = int(os.environ.get("ESPM_H_VARIANT", "0"))
         self.ell = None
         if x_store == "ell":
             from . import ell as _ell
@@ -242,7 +242,7 @@ class MUEngine:
             st.x_cm, st.x_pm = self.x_cm.data_ptr(), self.x_pm.data_ptr()
         else:
             st.x_cm = st.x_pm = None
-            st.ell_h, st.ell_h_off, st.ell_xlx = (self.ell[key].data_ptr() for key in ("ell_h", "ell_h_off", "xlx"))
+            st.ell_h, st.ell_h_off, st.ell_klc = (self.ell[key].data_ptr() for key in ("ell_h", "ell_h_off", "klc"))
             st.ell_w, st.ell_w_off, st.chan_perm = (self.ell[key].data_ptr() for key in ("ell_w", "ell_w_off", "chan_perm"))
         st.g = self.g.data_ptr() if self.g is not None else None
         st.colsum_g = self.colsum_g.data_ptr() if self.colsum_g is not None else None

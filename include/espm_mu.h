@@ -153,7 +153,8 @@ typedef struct espm_mu_state {
   /* Sparse count store (x_dtype = ESPM_X_ELL; x_cm / x_pm are then unused and may be NULL).  Only the non-zero
    * entries of X are kept, 16 bits each, as lists padded to the longest of 64 ("ELL"): the entries 2r and 2r+1
    * of the 64 lists of a wave form row r of 64 dwords (low half first), value 0 = padding.  A count that
-   * exceeds its field is split over several entries with the same index.
+   * exceeds its field is split over several entries with the same index (the kernels evaluate the loss term
+   * x_i log2(x_i / Y) per entry; ell_klc restores sum x log2(x / Y) for split counts).
    *   H-step: one list per pixel, 64 consecutive pixels per wave; entry = count << ell_cbits | channel;
    *           rows [ell_h_off[g], ell_h_off[g+1]) belong to pixels 64 g .. 64 g + 63.
    *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); the 64 lists of a wave are the channels
@@ -162,7 +163,8 @@ typedef struct espm_mu_state {
    *           [ell_w_off[b * n_cg + cg], ell_w_off[b * n_cg + cg + 1]).  nblk_w = ceil(p / ESPM_ELL_PB). */
   const uint32_t* ell_h;    /* (rows_h, 64) */
   const int32_t* ell_h_off; /* (p_pad / 64 + 1) */
-  const float* ell_xlx;     /* (p_pad): sum over channels of x log2 x per pixel (the loss constant, base.py:200) */
+  const float* ell_klc;     /* (p_pad): loss correction of split counts per pixel: sum over the elements of
+                               x log2 x minus the sum over their entries x_i of x_i log2 x_i (0 without splits) */
   const uint32_t* ell_w;    /* (rows_w, 64) */
   const int32_t* ell_w_off; /* (nblk_w * n_cg + 1) */
   const int32_t* chan_perm; /* (64 * n_cg) */

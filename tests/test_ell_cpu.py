@@ -54,14 +54,18 @@ def test_lists_decode_to_x(n, p, rate, big):
     Xh, Xw = decode(store, p, n, p_pad, cbits)
     assert np.array_equal(Xh[:p], X.astype(np.int64)) and not Xh[p:].any()
     assert np.array_equal(Xw[:p], X.astype(np.int64)) and not Xw[p:].any()
-    # the loss constant: sum x log2 x per pixel
-    ref = (X.astype(np.float64) * np.log2(np.maximum(X, 1.0))).sum(axis=1)
-    np.testing.assert_allclose(store["xlx"].numpy()[:p], ref, rtol=1e-6)
+    # loss correction of the split counts: sum x log2 x - sum over the entries of x_i log2 x_i, per pixel
+    xmax = (1 << (16 - cbits)) - 1
+    lg = lambda v: v * np.log2(np.maximum(v, 1.0))
+    Xd = X.astype(np.float64)
+    nfull = np.maximum(np.ceil(Xd / xmax), 1.0) - 1.0
+    ref = (lg(Xd) - nfull * lg(np.float64(xmax)) - lg(Xd - nfull * xmax)).sum(axis=1)
+    np.testing.assert_allclose(store["klc"].numpy()[:p], ref, rtol=1e-6, atol=1e-6)
+    assert (ref > 0).any() == bool((X > xmax).any())
     # channels in order of decreasing entry count, every channel exactly once
     perm = store["chan_perm"].numpy()
     assert sorted(perm[perm >= 0].tolist()) == list(range(n))
     # lists are padded to the longest of 64 only: rows of a group = ceil(max entries / 2)
-    xmax = (1 << (16 - cbits)) - 1
     ent = np.ceil(X / xmax).sum(axis=1)
     ent = np.concatenate([ent, np.zeros(p_pad - p)]).reshape(-1, 64).max(axis=1)
     assert np.array_equal(np.diff(store["ell_h_off"].numpy()), (ent + 1) // 2)

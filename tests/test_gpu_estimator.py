@@ -266,6 +266,62 @@ def test_matrix_core_variant_matches_oracle(n, nx, ny, k, m):
     assert h["bad"].sum() == 0
 
 
+@pytest.mark.parametrize("store", ["ell", "u8"])
+@pytest.mark.parametrize("n,nx,ny,k,m,counts,hot,kw", [
+    (64, 12, 10, 5, None, 90.0, 0, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),
+    (333, 7, 19, 8, 17, 90.0, 0, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),    # G given, k = 8
+    (1980, 33, 31, 3, None, 500.0, 0, dict(lambda_L=0.0, simplex_H=True, simplex_W=False)),           # BASELINE config 2 shape, 1023 pixels
+    (2050, 4, 33, 6, None, 300.0, 40, dict(lambda_L=1.0, simplex_H=False, simplex_W=True)),           # 12 index bits: counts > 15 are split
+    (50, 5, 6, 2, None, 150.0, 25, dict(lambda_L=0.3, simplex_H=True, simplex_W=False)),              # counts > 63: split in the W lists
+    (100, 40, 30, 2, None, 20.0, 0, dict(lambda_L=0.5, mu=0.1, simplex_H=True, simplex_W=False)),     # very sparse, two W blocks
+    (70, 5, 6, 7, None, 40.0, 0, dict(lambda_L=0.0, simplex_H=True, simplex_W=False)),
+])
+def test_count_stores_match_oracle(store, n, nx, ny, k, m, counts, hot, kw):
+    """The sparse count store (x_store='ell': non-zero entries only) and the dense 8-bit store against the fp64
+    oracle: ragged channel / pixel counts, every k, G given, counts that need several entries, fixed_H."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(n, nx, ny, k, N=counts, seed=n, m=m)
+    X = np.minimum(synth.sample_numpy(prob, seed=n), 255.0)
+    if hot:  # a few bright entries whose counts do not fit the count field of one entry
+        rng = np.random.default_rng(n)
+        X[rng.integers(0, n, hot), rng.integers(0, nx * ny, hot)] = rng.integers(70, 256, hot)
+    X[X.sum(axis=1) == 0, 0] = 1.0  # the count stores take strictly integer data: no all-zero lines (base.py:519-528)
+    X[0, X.sum(axis=0) == 0] = 1.0
+    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=n, scale=0.2)
+    fixed_H = None
+    if k >= 2 and not kw.get("simplex_H"):
+        fixed_H = -np.ones((k, nx * ny))
+        fixed_H[0, ::3] = 0.25
+    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                 max_iter=6, tol=0, fixed_H=fixed_H, **kw)
+    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=6, tol=0, x_store=store, fixed_H=fixed_H, **kw)
+    assert eng.x_store == store
+    eng.load_state(W0, H0)
+    eng.iterate(6, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
+
+
+def test_sparse_store_is_chosen_for_sparse_counts_only():
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(128, 8, 8, 2, N=30.0, seed=1)
+    X = synth.sample_numpy(prob, seed=1)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    assert MUEngine(X, 2, shape_2d=(8, 8)).x_store == "ell"            # ~20 % non-zero
+    assert MUEngine(X + 1.0, 2, shape_2d=(8, 8)).x_store == "u8"       # dense counts
+    assert MUEngine(X * 0.5, 2, shape_2d=(8, 8)).x_store == "bf16"     # not integer
+    with pytest.raises(ValueError):
+        MUEngine(X * 0.5, 2, shape_2d=(8, 8), x_store="ell")
+
+
 def test_one_dimensional_spectrum_fit(SmoothNMF):
     """The reference's 1-D fitting use (espm/datasets/eds_spim.py:228-253): p = 1, k = 1, no shape_2d,
     fixed_H = 1, G an ndarray; and an empty-looking spectrum with all-zero channels (base.py:519-528)."""

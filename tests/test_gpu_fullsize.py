@@ -1,5 +1,6 @@
 """Headline-size checks (2048 channels x 512 x 512 pixels, k = 5, SmoothNMF simplex_H + Laplacian): the
-kernel variants the benchmark runs (256-pixel H tiles, 512-pixel-block W accumulation) are exercised at
+kernel variants the benchmark runs (the sparse count store it selects by default, and the dense u8 / bf16
+stores with 256- and 128-pixel H tiles) are exercised at
 BASELINE.json's full size through size-independent properties and through the oracle on a pixel subset
 (an H update of a pixel depends only on its own X column, W, its 4 neighbours and the global row maxima)."""
 import numpy as np
@@ -22,8 +23,8 @@ def big():
     W0, H0 = synth.random_init(N, K, NX * NY, seed=0, scale=500.0 / N)
     kw = dict(layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=8)
     engs = {}
-    for tile, store in ((256, "auto"), (128, "auto"), ("bf16", "bf16")):
-        eng = MUEngine(X, K, tile_px=tile if isinstance(tile, int) else 256, x_store=store, **kw)
+    for tile, store in ((256, "u8"), (128, "u8"), ("bf16", "bf16"), ("ell", "auto")):
+        eng = MUEngine(X, K, tile_px=tile if isinstance(tile, int) else None, x_store=store, **kw)
         eng.load_state(W0, H0)
         engs[tile] = eng
     rows = slice(200 * NY, 203 * NY)                                      # three image rows for the oracle
@@ -35,14 +36,17 @@ def big():
 def test_storage_is_lossless(big):
     """Counts <= 255 are stored as 8-bit integers (auto), bf16 on request: both are exact for this data."""
     assert big["engs"][256].x_store == "u8" and big["engs"][128].x_store == "u8" and big["engs"]["bf16"].x_store == "bf16"
+    assert big["engs"]["ell"].x_store == "ell"                              # auto: 20 % of the counts are non-zero
     assert big["engs"][256].st.tile_px == 256 and big["engs"][128].st.tile_px == 128
     a = big["engs"][256].x_pm[:4096].float()
     b = big["engs"]["bf16"].x_pm[:4096].float()
     assert torch.equal(a, b)
 
 
-def test_first_h_step_matches_oracle_on_a_pixel_subset(big):
-    eng = big["engs"][256]
+@pytest.mark.parametrize("which", [256, "ell"])
+def test_first_h_step_matches_oracle_on_a_pixel_subset(big, which):
+    eng = big["engs"][which]
+    eng.load_state(big["W0"], big["H0"])
     H1 = eng.step_h_only()                                                # full-size H update, tile 256
     eng.load_state(big["W0"], big["H0"])
     assert np.array_equal(H1, eng.step_h_only())                          # bitwise reproducible run to run
@@ -72,6 +76,13 @@ def test_kernel_variants_agree_and_loss_decreases(big):
         out[tile] = (eng.get_W(), eng.get_H(), eng.history())
     (Wa, Ha, ha), (Wb, Hb, hb) = out[256], out[128]
     Wc, Hc, hc = out["bf16"]
+    We, He, he = out["ell"]
+    np.testing.assert_allclose(Wa, We, rtol=2e-5, atol=1e-8)            # sparse count store: other summation order
+    np.testing.assert_allclose(Ha, He, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ha["loss"], he["loss"], rtol=1e-6)
+    np.testing.assert_allclose(ha["rel_W"], he["rel_W"], rtol=1e-4)
+    np.testing.assert_allclose(ha["rel_H"], he["rel_H"], rtol=1e-3)
+    assert he["bad"].sum() == 0
     np.testing.assert_allclose(Wa, Wc, rtol=1e-6, atol=1e-10)          # u8 and bf16 stores hold the same numbers
     np.testing.assert_allclose(Ha, Hc, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(ha["loss"], hc["loss"], rtol=1e-9)
