@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 Metric (BASELINE.json): MU iterations / second on the 2048-channel x (512*512)-pixel X, k = 5,
-SmoothNMF with simplex on H and Laplacian smoothness (lambda = 1), bf16-stored counts, fp32
-arithmetic.  One "step" = one full iteration (H update + W update + the loss of the state and
+SmoothNMF with simplex on H and Laplacian smoothness (lambda = 1), fp32 arithmetic; the counts are
+held in the store the engine selects for them (--x-store auto: the sparse count store, 16 bits per non-zero
+entry; u8 / bf16 / f32 are the dense stores).  One "step" = one full iteration (H update + W update + the loss of the state and
 the relative changes the reference book-keeps every iteration, espm/estimators/base.py:316-351).
 With N > 1 the image rows are sharded over the ranks (strong scaling: same total problem).
 
@@ -32,7 +33,7 @@ BF16_PEAK = 2.5e15      # dense bf16 MFMA FLOP/s (spec)
 VALU_F32_PEAK = 157.3e12
 
 
-def cpu_baseline(prob, rows=16, iters=4):
+def cpu_baseline(prob, rows=64, iters=4):
     """Oracle (numpy fp64, reference op sequence incl. the dense identity G) on the first `rows`
     image rows; time scales linearly with pixels, so it/s(full) = it/s(crop) * crop / full."""
     from oracle import mu_oracle as oc
@@ -158,19 +159,20 @@ def main():
         if world > 1:
             torch.distributed.all_reduce(nnz)
         bytes_it = 2 * float(nnz.item()) + 2 * K * NX * NY * 4   # SURVEY 8(d) with X = its non-zero entries, once
+        flops_it = 8.0 * K * float(nnz.item())                   # four products restricted to the non-zero entries
     else:
         xbytes = {"u8": 1, "bf16": 2, "f32": 4}[eng.x_store]
         bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4          # X once, H read + written
         bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
         bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
-    flops_it = 8.0 * N_CH * K * NX * NY
+        flops_it = 8.0 * N_CH * K * NX * NY
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, corrected as
     # MI355X_MICROARCH.md prescribes); measured once per kernel version and committed under profiles/
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01b_hbm_traffic.json")) as f:
-            if world == 1 and eng.x_store == "bf16":
-                traffic = json.load(f)["kernels"]["h_step"]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            if world == 1:
+                traffic = json.load(f)["stores"][eng.x_store]["h_step"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     roofline = dict(bound="hbm", kernel=("h_step_ell_kernel<5,loss>" if eng.x_store == "ell" else "h_step_kernel<5,%s,...,loss>" % eng.x_store), achieved=bytes_h / t_h_upd / 1e9,

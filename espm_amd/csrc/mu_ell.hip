@@ -1,6 +1,13 @@
 // Launchers of the sparse count store kernels (mu_ell_kernel.hpp).
 #include "mu_ell_kernel.hpp"
 
+#ifndef ESPM_ELL_UNR_H
+#define ESPM_ELL_UNR_H 4
+#endif
+#ifndef ESPM_ELL_UNR_W
+#define ESPM_ELL_UNR_W 4
+#endif
+
 namespace espm {
 
 // dynamic LDS above 64 KB has to be granted per kernel (once)
@@ -13,7 +20,7 @@ static int allow_lds(KernelT kern, size_t bytes, const char* what) {
 
 template <int K>
 static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
-  constexpr int UNR = 4;
+  constexpr int UNR = ESPM_ELL_UNR_H;
   const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float);
   if (red > part) part = red;
@@ -46,9 +53,9 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
 
 template <int K>
 static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) {
-  constexpr int UNR = 4;
+  constexpr int UNR = ESPM_ELL_UNR_W;
   const size_t bytes = (size_t)ESPM_ELL_PB * EllTab<K>::FLOATS * sizeof(float);
-  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk), dim3(ESPM_ELL_PB), bytes, stream, args);
+  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk), dim3(ESPM_ELL_WTHREADS), bytes, stream, args);
   return check_hip(hipGetLastError(), "w_accum (ell) launch");
 }
 

@@ -61,6 +61,32 @@ struct EllTab {
   }
 };
 
+// y = sum_k g[k] h[k] and acc[k] += g[k] r with component PAIRS in fp32x2 registers (v_pk_fma_f32: the float4
+// of a gathered row already sits in two aligned register pairs), an odd last component as a scalar FMA.
+template <int K>
+__device__ __forceinline__ float ell_dot(const float (&g)[K], const float (&h)[K]) {
+  if constexpr (K == 1) {
+    return g[0] * h[0];
+  } else {
+    f2 s = f2{g[0], g[1]} * f2{h[0], h[1]};
+#pragma unroll
+    for (int q = 1; q < K / 2; ++q) s = f2{g[2 * q], g[2 * q + 1]} * f2{h[2 * q], h[2 * q + 1]} + s;
+    float y = s.x + s.y;
+    if constexpr (K & 1) y = fmaf(g[K - 1], h[K - 1], y);
+    return y;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ell_axpy(float (&acc)[K], const float (&g)[K], float r) {
+#pragma unroll
+  for (int q = 0; q < K / 2; ++q) {
+    const f2 t = f2{g[2 * q], g[2 * q + 1]} * r + f2{acc[2 * q], acc[2 * q + 1]};
+    acc[2 * q] = t.x;
+    acc[2 * q + 1] = t.y;
+  }
+  if constexpr (K & 1) acc[K - 1] = fmaf(g[K - 1], r, acc[K - 1]);
+}
+
 // Walks the `len` dwords (two 16-bit entries each) of this lane's list; `row` points at the lane's first
 // dword, consecutive dwords are 64 apart.  UNR dwords are requested one batch ahead of their use and the
 // 2 UNR table gathers of a batch are issued together.  body(index, count, table row) consumes one entry.
@@ -134,13 +160,10 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
   float kl = 0.f;
   const int beg = a.ell_off[grp], end = a.ell_off[grp + 1];
   ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
-    float y = g[0] * hk[0];
-#pragma unroll
-    for (int kk = 1; kk < K; ++kk) y = fmaf(g[kk], hk[kk], y);
+    const float y = ell_dot<K>(g, hk);
     // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
     const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(g[kk], r, acc[kk]);
+    ell_axpy<K>(acc, g, r);
     if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
   });
 #pragma unroll
@@ -149,16 +172,16 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------
-// One workgroup = one block of 1024 pixels, 16 waves; a wave handles 64 channels (one per lane) at a time.
+// One workgroup (16 waves) = one block of ESPM_ELL_PB = 1024 pixels; a wave handles 64 channels (one per lane) at a time.
 // Channel groups are in order of decreasing total count: wave w takes groups w, 31 - w, 32 + w, ... so the
 // waves of a workgroup carry about the same number of entries.  updates.py:38-39, :53, :59.
 template <int K, int UNR>
-__global__ __launch_bounds__(ESPM_ELL_PB) void w_accum_ell_kernel(const WAccumArgs a) {
-  constexpr int PB = ESPM_ELL_PB, NW = PB / 64;
+__global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WAccumArgs a) {
+  constexpr int PB = ESPM_ELL_PB, NW = ESPM_ELL_WTHREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;  // [PB] columns of H
   const int b = blockIdx.x;
-  {
+  if ((int)threadIdx.x < PB) {
     const int q = b * PB + (int)threadIdx.x;
     float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // pixels past the end: never referenced by an entry with a count
     if (q < a.p) {
@@ -184,12 +207,8 @@ __global__ __launch_bounds__(ESPM_ELL_PB) void w_accum_ell_kernel(const WAccumAr
     }
     const int beg = a.ell_off[(size_t)b * a.n_cg + cg], end = a.ell_off[(size_t)b * a.n_cg + cg + 1];
     ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, PB, ESPM_ELL_PBITS, [&](float x, const float (&h)[K]) {
-      float y = gw[0] * h[0];
-#pragma unroll
-      for (int kk = 1; kk < K; ++kk) y = fmaf(gw[kk], h[kk], y);
-      const float r = x * __builtin_amdgcn_rcpf(y);
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) acc[kk] = fmaf(r, h[kk], acc[kk]);
+      const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
+      ell_axpy<K>(acc, h, r);
     });
     if (c >= 0) {
 #pragma unroll

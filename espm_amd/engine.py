@@ -6,6 +6,8 @@ torch stream.  PyTorch is used for device memory, streams and ``torch.distribute
 arithmetic of the update rules runs in the HIP library (there is no CPU path).
 
 Data layout in HBM (all caller-visible arrays are plain torch tensors):
+  ell   sparse count store (x_store "ell"): 16-bit lists of the non-zero entries, by pixel for the H-step and by
+        (1024-pixel block, channel) for the W-step (espm_amd/ell.py, include/espm_mu.h); or the dense stores
   x_cm  (p_pad/x_tile, n, x_tile) u8|bf16|f32   X, channel-major inside pixel blocks, streamed by the H-step
   x_pm  (p, n_pad)   u8|bf16|f32   pixel-major X, streamed by the W-step
   h[2]  (k, p_pad)   f32        ping-pong H;  h_t (p, 8) transposed copy of the newest H

@@ -67,6 +67,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
 #define ESPM_ELL_PB 1024   /* sparse store: pixels per block of the W accumulation                          */
 #define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
+#define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
 

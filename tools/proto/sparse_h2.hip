@@ -134,6 +134,27 @@ int main(int argc, char** argv) {
     }
     nnz += L.size();
   }
+  if (argc > 3 && atoi(argv[3])) {
+    // bank-aware order: at step j lane l reads a row whose bank quad (c mod 16) is (l + j) mod 16 where possible
+    for (int q = 0; q < p; ++q) {
+      auto& L = lists[q];
+      const int l = q & 63;
+      std::vector<std::vector<uint32_t>> cls(16);
+      for (uint32_t e : L) cls[((e & 0xffff) - l) & 15].push_back(e);
+      std::vector<uint32_t> out;
+      out.reserve(L.size());
+      size_t r = 0;
+      bool any = true;
+      while (any) {
+        any = false;
+        for (int b = 0; b < 16; ++b)
+          if (r < cls[b].size()) { out.push_back(cls[b][r]); any = true; }
+        ++r;
+      }
+      L.swap(out);
+    }
+    printf("bank-aware entry order\n");
+  }
   const int ngroups = p / 64;
   std::vector<int> goff(ngroups + 1, 0);
   for (int g = 0; g < ngroups; ++g) {
@@ -182,14 +203,10 @@ int main(int argc, char** argv) {
            ms * 1e-3 / reps * 2.4e9 * 1024 / rows);
   };
   for (int gpw : {1}) {
-    run(sparse_h2<8, true, 512, 0>, "unr8 loss b64x3", gpw, 512);
-    run(sparse_h2<8, true, 1024, 0>, "unr8 loss b64x3", gpw, 1024);
-    run(sparse_h2<16, true, 1024, 0>, "unr16 loss b64x3", gpw, 1024);
     run(sparse_h2<4, true, 1024, 1>, "unr4 loss b128+b32", gpw, 1024);
     run(sparse_h2<8, true, 512, 1>, "unr8 loss b128+b32", gpw, 512);
     run(sparse_h2<8, true, 1024, 1>, "unr8 loss b128+b32", gpw, 1024);
     run(sparse_h2<16, true, 1024, 1>, "unr16 loss b128+b32", gpw, 1024);
-    run(sparse_h2<8, false, 1024, 1>, "unr8 noloss b128+b32", gpw, 1024);
   }
   // check a few pixels against the host
   std::vector<float> numh(h.size());
