@@ -36,9 +36,9 @@ static int check_state(const espm_mu_state* st) {
   if (st->x_dtype == ESPM_X_ELL) {
     ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_klc && st->ell_w && st->ell_w_off && st->chan_perm,
                  "the sparse count store needs ell_h, ell_h_off, ell_klc, ell_w, ell_w_off and chan_perm");
-    ESPM_REQUIRE(st->tile_px == ESPM_ELL_TILE && st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB &&
-                     st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
-                 "sparse count store: tile_px must be %d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
+    ESPM_REQUIRE((st->tile_px == 64 || st->tile_px == 128 || st->tile_px == 256 || st->tile_px == ESPM_ELL_TILE) &&
+                     st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
+                 "sparse count store: tile_px must be 64..%d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
                  ESPM_ELL_TILE, ESPM_ELL_PB);
   }
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
@@ -87,7 +87,11 @@ int espm_mu_query(espm_mu_state* st) {
   st->h_variant = 0;
   st->n_cg = (st->n + 63) / 64;
   if (st->x_dtype == ESPM_X_ELL) {  // sparse count store: fixed decomposition (mu_ell_kernel.hpp)
-    st->tile_px = st->x_tile = ESPM_ELL_TILE;
+    // H-step: 512 pixels per workgroup (8 waves, one 64-pixel list group each); smaller images split every group
+    // over 2, 4 or 8 waves so that about two workgroups per CU remain
+    st->tile_px = ESPM_ELL_TILE;
+    while (st->tile_px > 64 && (st->p + st->tile_px - 1) / st->tile_px < 2 * cus) st->tile_px /= 2;
+    st->x_tile = st->tile_px;
     st->nblk_w = (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB;
     st->ell_cbits = 1;
     while ((1 << st->ell_cbits) < st->n) ++st->ell_cbits;

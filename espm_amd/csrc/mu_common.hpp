@@ -360,6 +360,7 @@ struct HStepArgs {
   const int32_t* ell_off;
   const float* ell_klc;
   int ell_bits, n_pad;
+  int ell_tp;        // pixels per workgroup of the sparse H-step (= tile_px: 64, 128, 256 or 512)
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -491,6 +492,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.ell_off = st->ell_h_off;
   a.ell_klc = st->ell_klc;
   a.ell_bits = st->ell_cbits;
+  a.ell_tp = st->tile_px;
   a.n_pad = st->n_pad;
   return a;
 }

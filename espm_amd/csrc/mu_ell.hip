@@ -22,7 +22,7 @@ template <int K>
 static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
   constexpr int UNR = ESPM_ELL_UNR_H;
   const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
-  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float);
+  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float);  // [nsplit][K][tile_px]: K * 512 floats whatever the split
   if (red > part) part = red;
   const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
   if (args.compute_loss) {
@@ -37,6 +37,7 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
 
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell && args.ell_off && args.ell_klc, "h_step: the sparse store needs ell_h, ell_h_off, ell_klc");
+  ESPM_REQUIRE(args.ell_tp == 64 || args.ell_tp == 128 || args.ell_tp == 256 || args.ell_tp == 512, "h_step: sparse store tile_px=%d must be 64, 128, 256 or 512", args.ell_tp);
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {
     case 1: return launch_h_ell_k<1>(args, nblk, stream);
@@ -51,11 +52,31 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
   return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built", args.k);
 }
 
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+              ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 template <int K>
 static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) {
   constexpr int UNR = ESPM_ELL_UNR_W;
+  // one workgroup per pixel block while the blocks alone cover the chip; otherwise the channel groups of a
+  // block are dealt to `csplit` workgroups, each with as many waves (<= 16) as it has groups (two per wave
+  // when csplit = 1: heavy / light pairing)
+  int csplit = 1;
+  while (nblk * csplit < device_cus() && csplit * 2 <= args.n_cg) csplit *= 2;
+  const int mine = (args.n_cg + csplit - 1) / csplit;
+  int nw = csplit == 1 ? (mine + 1) / 2 : mine;
+  if (nw > ESPM_ELL_WTHREADS / 64) nw = ESPM_ELL_WTHREADS / 64;
+  if (nw < 1) nw = 1;
   const size_t bytes = (size_t)ESPM_ELL_PB * EllTab<K>::FLOATS * sizeof(float);
-  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk), dim3(ESPM_ELL_WTHREADS), bytes, stream, args);
+  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk, csplit), dim3(64 * nw), bytes, stream, args);
   return check_hip(hipGetLastError(), "w_accum (ell) launch");
 }
 

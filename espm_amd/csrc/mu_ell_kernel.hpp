@@ -132,24 +132,31 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, const flo
 }
 
 // ---- H-step --------------------------------------------------------------------------------------
-// One workgroup = 512 pixels = 8 waves, one 64-pixel group per wave.  updates.py:127-132 restricted to the
-// non-zero entries of X; the per-pixel epilogue (regularisers, simplex, clamp, statistics) is h_epilogue.
+// One workgroup = 8 waves = TP = 512 / nsplit pixels: every 64-pixel list group is walked by `nsplit` waves,
+// each taking a contiguous slice of its rows (nsplit = 1 at the headline size; small images use 2, 4 or 8 so
+// that the grid still covers the chip).  updates.py:127-132 restricted to the non-zero entries of X; the
+// per-pixel epilogue (regularisers, simplex, clamp, statistics) is h_epilogue, which sums the nsplit partial
+// numerators.
 template <int K, bool LOSS, int UNR>
 __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepArgs a) {
-  constexpr int TP = ESPM_ELL_TILE;
+  constexpr int NT = ESPM_ELL_TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;                                          // [n_pad] rows of GW
-  float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [K][TP] numerators, then reduction scratch
-  for (int r = threadIdx.x; r < a.n_pad; r += TP) {
+  float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [nsplit][K][TP] numerators, then reduction scratch
+  for (int r = threadIdx.x; r < a.n_pad; r += NT) {
     const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
     EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int TP = a.ell_tp;             // pixels of this workgroup: 64 * (8 / nsplit)
+  const int gpw = TP >> 6;             // list groups per workgroup
+  const int nsplit = (NT / 64) / gpw;
+  const int gi = wave % gpw, si = wave / gpw;
   const int tile0 = blockIdx.x * TP;
-  const int grp = tile0 / 64 + wave;
-  const int px = tile0 + wave * 64 + lane;  // < p_pad (a multiple of TP); pad pixels have empty lists
+  const int grp = tile0 / 64 + gi;
+  const int px = tile0 + gi * 64 + lane;  // < p_pad (a multiple of 512); pad pixels have empty lists
 
   float hk[K], acc[K];
 #pragma unroll
@@ -158,8 +165,9 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
     acc[kk] = 0.f;
   }
   float kl = 0.f;
-  const int beg = a.ell_off[grp], end = a.ell_off[grp + 1];
-  ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
+  const int beg = a.ell_off[grp], len = a.ell_off[grp + 1] - beg;
+  const int r0 = (int)((long)len * si / nsplit), r1 = (int)((long)len * (si + 1) / nsplit);
+  ell_walk<K, UNR>(a.ell + (size_t)(beg + r0) * 64 + lane, r1 - r0, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
     const float y = ell_dot<K>(g, hk);
     // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
     const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
@@ -167,36 +175,42 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
     if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
   });
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) part[kk * TP + wave * 64 + lane] = acc[kk];
-  h_epilogue<K>(a, part, 1, TP, tile0, LOSS ? kl + a.ell_klc[px] : 0.f);
+  for (int kk = 0; kk < K; ++kk) part[((size_t)si * K + kk) * TP + gi * 64 + lane] = acc[kk];
+  if (LOSS && si == 0) kl += a.ell_klc[px];
+  h_epilogue<K>(a, part, nsplit, TP, tile0, LOSS ? kl : 0.f);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------
-// One workgroup (16 waves) = one block of ESPM_ELL_PB = 1024 pixels; a wave handles 64 channels (one per lane) at a time.
-// Channel groups are in order of decreasing total count: wave w takes groups w, 31 - w, 32 + w, ... so the
-// waves of a workgroup carry about the same number of entries.  updates.py:38-39, :53, :59.
+// Workgroup (b, y) = pixel block b (ESPM_ELL_PB = 1024 pixels) x the channel groups cg = y, y + csplit, ...
+// (csplit = gridDim.y; 1 at the headline size, more for small images so that the grid covers the chip).
+// A wave handles 64 channels (one per lane) at a time.  Channel groups are in order of decreasing total
+// count: with nw waves, wave w takes the workgroup's groups w, 2 nw - 1 - w, 2 nw + w, ... so the waves carry
+// about the same number of entries.  updates.py:38-39, :53, :59.
 template <int K, int UNR>
 __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WAccumArgs a) {
-  constexpr int PB = ESPM_ELL_PB, NW = ESPM_ELL_WTHREADS / 64;
+  constexpr int PB = ESPM_ELL_PB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;  // [PB] columns of H
-  const int b = blockIdx.x;
-  if ((int)threadIdx.x < PB) {
-    const int q = b * PB + (int)threadIdx.x;
+  const int b = blockIdx.x, y = blockIdx.y, csplit = gridDim.y;
+  const int nw = (int)blockDim.x >> 6;
+  for (int r = threadIdx.x; r < PB; r += (int)blockDim.x) {
+    const int q = b * PB + r;
     float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // pixels past the end: never referenced by an entry with a count
     if (q < a.p) {
       const float4* src = reinterpret_cast<const float4*>(a.h_t + (size_t)q * KP);
       lo = src[0];
       hi = src[1];
     }
-    EllTab<K>::put(tab, PB, threadIdx.x, lo, hi);
+    EllTab<K>::put(tab, PB, r, lo, hi);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int t = 0; t * NW < a.n_cg; ++t) {
-    const int cg = t * NW + ((t & 1) ? NW - 1 - wave : wave);
-    if (cg >= a.n_cg) continue;
+  const int mine = (a.n_cg - y + csplit - 1) / csplit;  // channel groups of this workgroup
+  for (int t = 0; t * nw < mine; ++t) {
+    const int i = t * nw + ((t & 1) ? nw - 1 - wave : wave);
+    if (i >= mine) continue;
+    const int cg = i * csplit + y;
     const int c = a.chan_perm[cg * 64 + lane];
     const float* gsrc = a.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
