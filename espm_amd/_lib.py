@@ -57,6 +57,9 @@ SYMBOLS = {
     "espm_mu_last_error": (C.c_char_p, []),
     "espm_mu_query": (C.c_int, [_SP]),
     "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "espm_mu_ell_count": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_plan": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_fill": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_hstat": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_build_gw": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_step_h": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),

@@ -111,7 +111,7 @@ int espm_mu_query(espm_mu_state* st) {
 
 int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                    int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, espm_stream_t stream) {
-  ESPM_REQUIRE(src && x_cm && x_pm, "pack_x: NULL pointer");
+  ESPM_REQUIRE(src && x_pm, "pack_x: NULL pointer");  // x_cm may be NULL (sparse store ingest needs x_pm only)
   ESPM_REQUIRE(n >= 1 && p >= 1 && n_pad == roundup(n, ESPM_NPAD) && p_pad == roundup(p, ESPM_PPAD),
                "pack_x: bad shape n=%d p=%d n_pad=%d p_pad=%d", n, p, n_pad, p_pad);
   ESPM_REQUIRE(src_dtype == ESPM_SRC_F32 || src_dtype == ESPM_SRC_F64, "pack_x: bad src_dtype %d", src_dtype);
@@ -121,6 +121,40 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
   ESPM_REQUIRE(n_cm == roundup(n, ESPM_NCM), "pack_x: n_cm must be roundup(n, %d)", ESPM_NCM);
   return launch_pack_x(src, src_dtype, src_layout, ld, n, p, x_cm, x_pm, x_dtype, n_pad, p_pad, x_tile, n_cm,
                        static_cast<hipStream_t>(stream));
+}
+
+static int check_ell_geometry(const espm_mu_state* st) {
+  ESPM_REQUIRE(st != nullptr, "state is NULL");
+  ESPM_REQUIRE(st->x_dtype == ESPM_X_ELL && st->n >= 1 && st->p >= 1 && st->n_pad == roundup(st->n, ESPM_NPAD) &&
+                   st->p_pad == roundup(st->p, ESPM_PPAD) && st->n_cg == (st->n + 63) / 64 &&
+                   st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->ell_cbits >= 1 && st->ell_cbits <= 14 &&
+                   (1 << st->ell_cbits) >= st->n,
+               "sparse store builder: set x_dtype = ESPM_X_ELL and call espm_mu_query first");
+  return ESPM_OK;
+}
+
+int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
+                      espm_stream_t stream) {
+  if (int rc = check_ell_geometry(st)) return rc;
+  ESPM_REQUIRE(x_pm_u8 && cnt_px && cnt_bc && ell_klc, "ell_count: NULL pointer");
+  return launch_ell_count(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
+                          st->nblk_w, cnt_px, cnt_bc, ell_klc, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
+                     int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream) {
+  if (int rc = check_ell_geometry(st)) return rc;
+  ESPM_REQUIRE(cnt_px && cnt_bc && chan_perm && ell_h_off && ell_w_off && rows, "ell_plan: NULL pointer");
+  return launch_ell_plan(cnt_px, cnt_bc, st->n, st->n_cg, st->nblk_w, st->p_pad / 64, chan_perm, ell_h_off, ell_w_off,
+                         reinterpret_cast<long long*>(rows), static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* ell_h_off,
+                     const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, espm_stream_t stream) {
+  if (int rc = check_ell_geometry(st)) return rc;
+  ESPM_REQUIRE(x_pm_u8 && chan_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
+  return launch_ell_fill(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
+                         st->nblk_w, chan_perm, ell_h_off, ell_w_off, ell_h, ell_w, static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {

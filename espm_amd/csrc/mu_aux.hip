@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const ST* __restrict__ src,
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int c = c0 + r, j = j0 + tx;
-    if (c < n_cm && j < p_pad)  // tile-major: [pixel block][channel row, zero padded to n_cm][x_tile]
+    if (x_cm && c < n_cm && j < p_pad)  // tile-major: [pixel block][channel row, zero padded to n_cm][x_tile]
       x_cm[((size_t)(j / x_tile) * n_cm + c) * x_tile + (j % x_tile)] = to_store<DT>(tile[r][tx]);
     const int j2 = j0 + r, c2 = c0 + tx;
     if (j2 < p && c2 < n_pad) x_pm[(size_t)j2 * n_pad + c2] = to_store<DT>(tile[tx][r]);

@@ -516,6 +516,13 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
+int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);
+int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int ngrp, int32_t* chan_perm,
+                    int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+                    const int32_t* chan_perm, const int32_t* h_off, const int32_t* w_off, uint32_t* ell_h, uint32_t* ell_w,
+                    hipStream_t stream);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,

@@ -1,0 +1,207 @@
+// Builder of the sparse count store (include/espm_mu.h, x_dtype = ESPM_X_ELL) from the dense pixel-major
+// 8-bit store that espm_mu_pack_x writes.  One-time work per fit (a few ms at the headline size), written for
+// clarity: every list has ONE owner lane that walks its pixels / channels in order, so no cross-lane
+// bookkeeping is needed and the lists come out in ascending index order.
+//
+//   espm_mu_ell_count : entries per pixel list, entries per (pixel block, channel) list, the loss constant
+//   espm_mu_ell_plan  : channel order (decreasing total count), row offsets of both list sets, row totals
+//   espm_mu_ell_fill  : the entries
+#include "mu_common.hpp"
+
+namespace espm {
+
+__device__ __forceinline__ int ell_reps(int x, int xmax) { return (x + xmax - 1) / xmax; }
+
+// lane = pixel: walks the pixel's row of the (p, n_pad) 8-bit matrix
+__global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
+                                                          int xmax, int32_t* __restrict__ cnt_px, float* __restrict__ klc) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= p_pad) return;
+  int cnt = 0;
+  double corr = 0.0;
+  if (q < p) {
+    const uint8_t* row = x_pm + (size_t)q * n_pad;
+    const double lxm = (double)xmax * log2((double)xmax);
+    for (int c = 0; c < n; ++c) {
+      const int x = row[c];
+      if (x == 0) continue;
+      const int r = ell_reps(x, xmax);
+      cnt += r;
+      if (r > 1) {  // x log2 x - sum over its entries of x_i log2 x_i
+        const int rest = x - (r - 1) * xmax;
+        corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
+      }
+    }
+  }
+  cnt_px[q] = cnt;
+  klc[q] = (float)corr;
+}
+
+// lane = channel: walks the pixels of one block
+__global__ __launch_bounds__(256) void ell_count_w_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int ncol,
+                                                          int xmax, int32_t* __restrict__ cnt_bc) {
+  const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= ncol) return;
+  int cnt = 0;
+  if (c < n) {
+    const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
+    for (int q = q0; q < q1; ++q) {
+      const int x = x_pm[(size_t)q * n_pad + c];
+      if (x) cnt += ell_reps(x, xmax);
+    }
+  }
+  cnt_bc[(size_t)b * ncol + c] = cnt;
+}
+
+// exclusive scan of `count` values produced by f(i) into out[0..count], one workgroup of 1024 threads
+template <typename F>
+__device__ void block_scan_rows(int count, int32_t* out, long long* total, long long* s_sums, F f) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int chunk = (count + nt - 1) / nt;
+  const int i0 = min(count, t * chunk), i1 = min(count, i0 + chunk);
+  long long s = 0;
+  for (int i = i0; i < i1; ++i) s += f(i);
+  s_sums[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int i = 0; i < nt; ++i) {
+      const long long v = s_sums[i];
+      s_sums[i] = run;
+      run += v;
+    }
+    *total = run;
+    out[count] = (int32_t)(run < 0x7fffffffLL ? run : 0x7fffffffLL);
+  }
+  __syncthreads();
+  long long run = s_sums[t];
+  for (int i = i0; i < i1; ++i) {
+    out[i] = (int32_t)(run < 0x7fffffffLL ? run : 0x7fffffffLL);
+    run += f(i);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void ell_plan_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc, int n,
+                                                        int n_cg, int nblk, int ngrp, int32_t* __restrict__ chan_perm,
+                                                        int32_t* __restrict__ h_off, int32_t* __restrict__ w_off,
+                                                        long long* __restrict__ rows) {
+  extern __shared__ long long s_buf[];  // [1024] scan sums, then [n] channel totals (as uint32)
+  long long* s_sums = s_buf;
+  uint32_t* tot = reinterpret_cast<uint32_t*>(s_buf + 1024);
+  const int ncol = n_cg * 64;
+  // channel totals, then the stable order by decreasing total (same as torch.argsort(descending, stable))
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    uint32_t s = 0;
+    for (int b = 0; b < nblk; ++b) s += (uint32_t)cnt_bc[(size_t)b * ncol + c];
+    tot[c] = s;
+  }
+  for (int s = n + threadIdx.x; s < ncol; s += blockDim.x) chan_perm[s] = -1;
+  __syncthreads();
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    const uint32_t mine = tot[c];
+    int rank = 0;
+    for (int o = 0; o < n; ++o) {
+      const uint32_t v = tot[o];
+      rank += (v > mine) || (v == mine && o < c);
+    }
+    chan_perm[rank] = c;
+  }
+  __syncthreads();
+  // H lists: rows of group g = ceil(max entries of its 64 pixels / 2)
+  block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g) {
+    int m = 0;
+    for (int l = 0; l < 64; ++l) m = max(m, cnt_px[g * 64 + l]);
+    return (long long)((m + 1) / 2);
+  });
+  // W lists: rows of (block, channel group) = ceil(max entries of its 64 channels / 2)
+  block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i) {
+    const int b = i / n_cg, cg = i - b * n_cg;
+    int m = 0;
+    for (int l = 0; l < 64; ++l) {
+      const int c = chan_perm[cg * 64 + l];
+      if (c >= 0) m = max(m, cnt_bc[(size_t)b * ncol + c]);
+    }
+    return (long long)((m + 1) / 2);
+  });
+}
+
+__device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, int lane, uint32_t entry) {
+  base16[((row0 + (size_t)(j >> 1)) * 64 + lane) * 2 + (j & 1)] = (uint16_t)entry;
+}
+
+// lane = pixel (a wave = one 64-pixel list group)
+__global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
+                                                         int cbits, const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= p) return;
+  const int xmax = (1 << (16 - cbits)) - 1;
+  uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_h);
+  const size_t row0 = (size_t)h_off[q >> 6];
+  const int lane = q & 63;
+  const uint8_t* row = x_pm + (size_t)q * n_pad;
+  int j = 0;
+  for (int c = 0; c < n; ++c) {
+    int x = row[c];
+    while (x > 0) {
+      const int v = x > xmax ? xmax : x;
+      ell_put(base16, row0, j++, lane, ((uint32_t)v << cbits) | (uint32_t)c);
+      x -= v;
+    }
+  }
+}
+
+// lane = channel slot (a wave = one channel group of one pixel block)
+__global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg,
+                                                        const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
+                                                        uint32_t* __restrict__ ell_w) {
+  const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
+  const int c = chan_perm[cg * 64 + lane];
+  if (c < 0) return;
+  constexpr int xmax = (1 << (16 - ESPM_ELL_PBITS)) - 1;
+  uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_w);
+  const size_t row0 = (size_t)w_off[(size_t)b * n_cg + cg];
+  const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
+  int j = 0;
+  for (int q = q0; q < q1; ++q) {
+    int x = x_pm[(size_t)q * n_pad + c];
+    while (x > 0) {
+      const int v = x > xmax ? xmax : x;
+      ell_put(base16, row0, j++, lane, ((uint32_t)v << ESPM_ELL_PBITS) | (uint32_t)(q - q0));
+      x -= v;
+    }
+  }
+}
+
+int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
+  const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ESPM_ELL_PBITS)) - 1;
+  hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
+                     cnt_px, klc);
+  hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p,
+                     n_cg * 64, xmax_w, cnt_bc);
+  return check_hip(hipGetLastError(), "ell_count launch");
+}
+
+int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int ngrp, int32_t* chan_perm,
+                    int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream) {
+  const size_t lds = 1024 * sizeof(long long) + (size_t)n * sizeof(uint32_t);
+  if (lds > 64 * 1024) {
+    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ell_plan_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "ell_plan"))
+      return rc;
+  }
+  hipLaunchKernelGGL(ell_plan_kernel, dim3(1), dim3(1024), lds, stream, cnt_px, cnt_bc, n, n_cg, nblk, ngrp, chan_perm, h_off,
+                     w_off, rows);
+  return check_hip(hipGetLastError(), "ell_plan launch");
+}
+
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+                    const int32_t* chan_perm, const int32_t* h_off, const int32_t* w_off, uint32_t* ell_h, uint32_t* ell_w,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, h_off, ell_h);
+  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, n_cg), dim3(64), 0, stream, x_pm, n_pad, p, n_cg, chan_perm, w_off, ell_w);
+  return check_hip(hipGetLastError(), "ell_fill launch");
+}
+
+}  // namespace espm

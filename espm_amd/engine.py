@@ -158,7 +158,10 @@ class MUEngine:
         if x_store == "ell":
             from . import ell as _ell
             self.x_cm = self.x_pm = None
-            self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits)
+            if os.environ.get("ESPM_ELL_BUILDER", "hip") == "torch":  # the tensor-op builder (tests cross-check the two)
+                self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits)
+            else:
+                self.ell = self._build_ell(Xd.contiguous(), layout)
             assert self.ell["n_cg"] == st.n_cg and self.ell["nblk_w"] == st.nblk_w
             self.x_bytes = 4 * (self.ell["ell_h"].numel() + self.ell["ell_w"].numel())
         else:
@@ -271,6 +274,38 @@ class MUEngine:
                 raise RuntimeError("record layout of espm_amd.sharding and libespm_mu disagree")
 
     # ------------------------------------------------------------------------------------------------
+    def _build_ell(self, Xd, layout):
+        """Sparse count store through the C ABI: dense 8-bit pixel-major copy (espm_mu_pack_x) -> espm_mu_ell_count /
+        _plan / _fill.  Same result as espm_amd.ell.build (tests/test_gpu_updates.py::test_ell_builders_agree)."""
+        st, dev = self.st, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        x8 = torch.empty((self.p, st.n_pad), dtype=torch.uint8, device=dev)
+        check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
+                                 _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
+                                 None, _ptr(x8), _lib.X_U8, st.n_pad, st.p_pad, _lib.PPAD, st.n_cm, _stream()))
+        cnt_px = torch.empty(st.p_pad, **i32)
+        cnt_bc = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
+        klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
+        check(lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
+        chan_perm = torch.empty(st.n_cg * 64, **i32)
+        h_off = torch.empty(st.p_pad // 64 + 1, **i32)
+        w_off = torch.empty(st.nblk_w * st.n_cg + 1, **i32)
+        rows = torch.zeros(2, dtype=torch.int64, device=dev)
+        check(lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(h_off), _ptr(w_off),
+                                   _ptr(rows), _stream()))
+        rows_h, rows_w = (int(v) for v in rows.cpu())
+        if max(rows_h, rows_w) * 64 >= 2 ** 31:
+            raise ValueError("sparse count store: the lists exceed 2^31 dwords")
+        ell_h = torch.zeros(max(rows_h, 1) * 64, **i32)
+        ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
+        check(lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(h_off), _ptr(w_off), _ptr(ell_h), _ptr(ell_w),
+                                   _stream()))
+        nnz = int((x8[:, :self.n] != 0).sum())
+        torch.cuda.current_stream().synchronize()
+        return dict(ell_h=ell_h, ell_h_off=h_off, klc=klc, ell_w=ell_w, ell_w_off=w_off, chan_perm=chan_perm, n_cg=st.n_cg,
+                    nblk_w=st.nblk_w, nnz=nnz, entries_h=int(cnt_px.sum()), entries_w=int(cnt_bc.sum()), rows_h=rows_h,
+                    rows_w=rows_w)
+
     def _pad_h(self, H):
         Hh = np.asarray(H, dtype=np.float32)
         if Hh.shape != (self.k, self.p):

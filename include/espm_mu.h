@@ -185,6 +185,22 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
                    void* x_cm, void* x_pm, int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm,
                    espm_stream_t stream);
 
+/* Sparse count store (x_dtype = ESPM_X_ELL) from the dense pixel-major 8-bit matrix x_pm_u8 (p, n_pad) that
+ * espm_mu_pack_x writes for x_dtype = ESPM_X_U8 (its x_cm argument may be NULL then).  `st` needs n, p, x_dtype =
+ * ESPM_X_ELL and espm_mu_query.  Three steps, all buffers caller-allocated:
+ *   count: cnt_px (p_pad) entries of each pixel's H-step list; cnt_bc (nblk_w, 64 n_cg) entries of each (pixel
+ *          block, channel) W-step list (natural channel order); ell_klc (p_pad).
+ *   plan : chan_perm (64 n_cg), ell_h_off (p_pad / 64 + 1), ell_w_off (nblk_w n_cg + 1) and rows[2] (device):
+ *          rows of 64 dwords of the H-step and of the W-step lists.  The caller reads rows[] back, checks
+ *          64 rows < 2^31 and allocates ell_h (rows[0], 64) and ell_w (rows[1], 64), ZERO-initialised.
+ *   fill : writes the entries.  The dense x_pm_u8 can be released afterwards. */
+int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
+                      espm_stream_t stream);
+int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
+                     int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream);
+int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* ell_h_off,
+                     const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, espm_stream_t stream);
+
 /* statistics (row sums, row maxima) of st->h[which] into st->hstat[which] (local pixels). */
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream);
 

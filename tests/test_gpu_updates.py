@@ -214,3 +214,30 @@ def test_initialize_algorithms_golden(api, golden):
                 tag = f"{init}_{int(use_G)}_{int(simplex_H)}"
                 np.testing.assert_allclose(W, g[f"{tag}_W"], rtol=1e-9, atol=1e-14, err_msg=tag)
                 np.testing.assert_allclose(H, g[f"{tag}_H"], rtol=1e-9, atol=1e-14, err_msg=tag)
+
+
+@pytest.mark.parametrize("n,nx,ny,layout", [(100, 20, 20, "cm"), (1980, 33, 31, "pm"), (2050, 40, 30, "cm"), (70, 64, 33, "pm")])
+def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
+    """The C-ABI builder of the sparse count store (espm_mu_ell_count / _plan / _fill) and the tensor-op builder
+    espm_amd.ell.build (decoded back to X on the CPU by tests/test_ell_cpu.py) produce identical lists."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(n, nx, ny, 3, N=0.25 * n, seed=n)
+    X = np.minimum(synth.sample_numpy(prob, seed=n), 255.0)
+    rng = np.random.default_rng(n)
+    X[rng.integers(0, n, 50), rng.integers(0, nx * ny, 50)] = rng.integers(20, 256, 50)   # counts that need several entries
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    Xin = X if layout == "cm" else np.ascontiguousarray(X.T)
+    stores = {}
+    for builder in ("hip", "torch"):
+        monkeypatch.setenv("ESPM_ELL_BUILDER", builder)
+        eng = MUEngine(Xin, 3, layout=layout, shape_2d=(nx, ny), x_store="ell")
+        stores[builder] = eng.ell
+    a, b = stores["hip"], stores["torch"]
+    for key in ("ell_h_off", "ell_w_off", "chan_perm", "ell_h", "ell_w"):
+        assert torch.equal(a[key].cpu(), b[key].cpu()), key
+    for key in ("nnz", "entries_h", "entries_w", "rows_h", "rows_w", "n_cg", "nblk_w"):
+        assert a[key] == b[key], key
+    np.testing.assert_allclose(a["klc"].cpu().numpy(), b["klc"].cpu().numpy(), rtol=1e-6, atol=1e-6)
