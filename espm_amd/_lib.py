@@ -46,7 +46,7 @@ class MUState(C.Structure):
         ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
         ("ell_h", _vp), ("ell_h_off", _vp), ("ell_klc", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
-        ("ell_cbits", _i32), ("n_cg", _i32),
+        ("ell_cbits", _i32), ("n_cg", _i32), ("pix_perm", _vp),
     ]
 
 
@@ -58,8 +58,8 @@ SYMBOLS = {
     "espm_mu_query": (C.c_int, [_SP]),
     "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_ell_count": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp]),
-    "espm_mu_ell_plan": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "espm_mu_ell_fill": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_plan": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_fill": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_hstat": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_build_gw": (C.c_int, [_SP, C.c_int, _vp]),
     "espm_mu_step_h": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),

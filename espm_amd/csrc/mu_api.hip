@@ -34,8 +34,8 @@ static int check_state(const espm_mu_state* st) {
                st->p);
   ESPM_REQUIRE(st->x_dtype >= ESPM_X_F32 && st->x_dtype <= ESPM_X_ELL, "bad x_dtype %d", st->x_dtype);
   if (st->x_dtype == ESPM_X_ELL) {
-    ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_klc && st->ell_w && st->ell_w_off && st->chan_perm,
-                 "the sparse count store needs ell_h, ell_h_off, ell_klc, ell_w, ell_w_off and chan_perm");
+    ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_klc && st->ell_w && st->ell_w_off && st->chan_perm && st->pix_perm,
+                 "the sparse count store needs ell_h, ell_h_off, ell_klc, ell_w, ell_w_off, chan_perm and pix_perm");
     ESPM_REQUIRE((st->tile_px == 64 || st->tile_px == 128 || st->tile_px == 256 || st->tile_px == ESPM_ELL_TILE) &&
                      st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
                  "sparse count store: tile_px must be 64..%d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
@@ -128,7 +128,8 @@ static int check_ell_geometry(const espm_mu_state* st) {
   ESPM_REQUIRE(st->x_dtype == ESPM_X_ELL && st->n >= 1 && st->p >= 1 && st->n_pad == roundup(st->n, ESPM_NPAD) &&
                    st->p_pad == roundup(st->p, ESPM_PPAD) && st->n_cg == (st->n + 63) / 64 &&
                    st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->ell_cbits >= 1 && st->ell_cbits <= 14 &&
-                   (1 << st->ell_cbits) >= st->n,
+                   (1 << st->ell_cbits) >= st->n &&
+                   (st->tile_px == 64 || st->tile_px == 128 || st->tile_px == 256 || st->tile_px == ESPM_ELL_TILE),
                "sparse store builder: set x_dtype = ESPM_X_ELL and call espm_mu_query first");
   return ESPM_OK;
 }
@@ -142,19 +143,21 @@ int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt
 }
 
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
-                     int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream) {
+                     int32_t* pix_perm, int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream) {
   if (int rc = check_ell_geometry(st)) return rc;
-  ESPM_REQUIRE(cnt_px && cnt_bc && chan_perm && ell_h_off && ell_w_off && rows, "ell_plan: NULL pointer");
-  return launch_ell_plan(cnt_px, cnt_bc, st->n, st->n_cg, st->nblk_w, st->p_pad / 64, chan_perm, ell_h_off, ell_w_off,
-                         reinterpret_cast<long long*>(rows), static_cast<hipStream_t>(stream));
+  ESPM_REQUIRE(cnt_px && cnt_bc && chan_perm && pix_perm && ell_h_off && ell_w_off && rows, "ell_plan: NULL pointer");
+  return launch_ell_plan(cnt_px, cnt_bc, st->n, st->n_cg, st->nblk_w, st->p_pad, st->tile_px, chan_perm, pix_perm, ell_h_off,
+                         ell_w_off, reinterpret_cast<long long*>(rows), static_cast<hipStream_t>(stream));
 }
 
-int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* ell_h_off,
-                     const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, espm_stream_t stream) {
+int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,
+                     const int32_t* ell_h_off, const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w,
+                     espm_stream_t stream) {
   if (int rc = check_ell_geometry(st)) return rc;
-  ESPM_REQUIRE(x_pm_u8 && chan_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
+  ESPM_REQUIRE(x_pm_u8 && chan_perm && pix_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
   return launch_ell_fill(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
-                         st->nblk_w, chan_perm, ell_h_off, ell_w_off, ell_h, ell_w, static_cast<hipStream_t>(stream));
+                         st->nblk_w, st->tile_px, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w,
+                         static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {

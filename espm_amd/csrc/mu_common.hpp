@@ -359,6 +359,7 @@ struct HStepArgs {
   const uint32_t* ell;
   const int32_t* ell_off;
   const float* ell_klc;
+  const int32_t* ell_pix;
   int ell_bits, n_pad;
   int ell_tp;        // pixels per workgroup of the sparse H-step (= tile_px: 64, 128, 256 or 512)
 };
@@ -491,6 +492,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.ell = st->ell_h;
   a.ell_off = st->ell_h_off;
   a.ell_klc = st->ell_klc;
+  a.ell_pix = st->pix_perm;
   a.ell_bits = st->ell_cbits;
   a.ell_tp = st->tile_px;
   a.n_pad = st->n_pad;
@@ -518,11 +520,11 @@ int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);
-int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int ngrp, int32_t* chan_perm,
-                    int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
-int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
-                    const int32_t* chan_perm, const int32_t* h_off, const int32_t* w_off, uint32_t* ell_h, uint32_t* ell_w,
-                    hipStream_t stream);
+int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
+                    int32_t* chan_perm, int32_t* pix_perm, int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win,
+                    const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,

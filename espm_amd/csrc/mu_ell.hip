@@ -36,7 +36,7 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
 }
 
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
-  ESPM_REQUIRE(args.ell && args.ell_off && args.ell_klc, "h_step: the sparse store needs ell_h, ell_h_off, ell_klc");
+  ESPM_REQUIRE(args.ell && args.ell_off && args.ell_klc && args.ell_pix, "h_step: the sparse store needs ell_h, ell_h_off, ell_klc, pix_perm");
   ESPM_REQUIRE(args.ell_tp == 64 || args.ell_tp == 128 || args.ell_tp == 256 || args.ell_tp == 512, "h_step: sparse store tile_px=%d must be 64, 128, 256 or 512", args.ell_tp);
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {

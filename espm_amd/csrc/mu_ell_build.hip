@@ -4,7 +4,7 @@
 // bookkeeping is needed and the lists come out in ascending index order.
 //
 //   espm_mu_ell_count : entries per pixel list, entries per (pixel block, channel) list, the loss constant
-//   espm_mu_ell_plan  : channel order (decreasing total count), row offsets of both list sets, row totals
+//   espm_mu_ell_plan  : list orders (channels per pixel block, pixels per window: decreasing length), row offsets, row totals
 //   espm_mu_ell_fill  : the entries
 #include "mu_common.hpp"
 
@@ -82,44 +82,53 @@ __device__ void block_scan_rows(int count, int32_t* out, long long* total, long 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void ell_plan_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc, int n,
-                                                        int n_cg, int nblk, int ngrp, int32_t* __restrict__ chan_perm,
-                                                        int32_t* __restrict__ h_off, int32_t* __restrict__ w_off,
-                                                        long long* __restrict__ rows) {
-  extern __shared__ long long s_buf[];  // [1024] scan sums, then [n] channel totals (as uint32)
-  long long* s_sums = s_buf;
-  uint32_t* tot = reinterpret_cast<uint32_t*>(s_buf + 1024);
+// Orders by decreasing list length (stable: ties keep the lower index first - what torch.argsort(descending=True,
+// stable=True) gives).  Workgroups [0, nblk): the channels of pixel block b -> chan_perm[b]; workgroups
+// [nblk, nblk + nwin): the pixels of window w -> pix_perm.
+__global__ __launch_bounds__(1024) void ell_order_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc, int n,
+                                                         int n_cg, int nblk, int win, int32_t* __restrict__ chan_perm,
+                                                         int32_t* __restrict__ pix_perm) {
+  extern __shared__ int32_t s_cnt[];  // [max(n, win)]
   const int ncol = n_cg * 64;
-  // channel totals, then the stable order by decreasing total (same as torch.argsort(descending, stable))
-  for (int c = threadIdx.x; c < n; c += blockDim.x) {
-    uint32_t s = 0;
-    for (int b = 0; b < nblk; ++b) s += (uint32_t)cnt_bc[(size_t)b * ncol + c];
-    tot[c] = s;
-  }
-  for (int s = n + threadIdx.x; s < ncol; s += blockDim.x) chan_perm[s] = -1;
+  const bool chan = (int)blockIdx.x < nblk;
+  const int count = chan ? n : win;
+  const int32_t* src = chan ? cnt_bc + (size_t)blockIdx.x * ncol : cnt_px + (size_t)(blockIdx.x - nblk) * win;
+  int32_t* dst = chan ? chan_perm + (size_t)blockIdx.x * ncol : pix_perm + (size_t)(blockIdx.x - nblk) * win;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s_cnt[i] = src[i];
+  if (chan)
+    for (int s = n + threadIdx.x; s < ncol; s += blockDim.x) dst[s] = -1;
   __syncthreads();
-  for (int c = threadIdx.x; c < n; c += blockDim.x) {
-    const uint32_t mine = tot[c];
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const int mine = s_cnt[i];
     int rank = 0;
-    for (int o = 0; o < n; ++o) {
-      const uint32_t v = tot[o];
-      rank += (v > mine) || (v == mine && o < c);
+    for (int o = 0; o < count; ++o) {
+      const int v = s_cnt[o];
+      rank += (v > mine) || (v == mine && o < i);
     }
-    chan_perm[rank] = c;
+    dst[rank] = i;
   }
-  __syncthreads();
-  // H lists: rows of group g = ceil(max entries of its 64 pixels / 2)
+}
+
+__global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc,
+                                                           int n_cg, int nblk, int ngrp, int win,
+                                                           const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ pix_perm,
+                                                           int32_t* __restrict__ h_off, int32_t* __restrict__ w_off,
+                                                           long long* __restrict__ rows) {
+  __shared__ long long s_sums[1024];
+  const int ncol = n_cg * 64;
+  // H lists: rows of slot group g = ceil(max entries of its 64 slots / 2)
   block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g) {
+    const int w0 = (g * 64) / win * win;
     int m = 0;
-    for (int l = 0; l < 64; ++l) m = max(m, cnt_px[g * 64 + l]);
+    for (int l = 0; l < 64; ++l) m = max(m, cnt_px[w0 + pix_perm[g * 64 + l]]);
     return (long long)((m + 1) / 2);
   });
   // W lists: rows of (block, channel group) = ceil(max entries of its 64 channels / 2)
   block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i) {
-    const int b = i / n_cg, cg = i - b * n_cg;
+    const int b = i / n_cg;
     int m = 0;
     for (int l = 0; l < 64; ++l) {
-      const int c = chan_perm[cg * 64 + l];
+      const int c = chan_perm[(size_t)i * 64 + l];
       if (c >= 0) m = max(m, cnt_bc[(size_t)b * ncol + c]);
     }
     return (long long)((m + 1) / 2);
@@ -130,15 +139,18 @@ __device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, in
   base16[((row0 + (size_t)(j >> 1)) * 64 + lane) * 2 + (j & 1)] = (uint16_t)entry;
 }
 
-// lane = pixel (a wave = one 64-pixel list group)
+// lane = list slot (a wave = one group of 64 slots); slot -> pixel through pix_perm
 __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
-                                                         int cbits, const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
+                                                         int cbits, int win, const int32_t* __restrict__ pix_perm,
+                                                         const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= p_pad) return;
+  const int q = slot / win * win + pix_perm[slot];
   if (q >= p) return;
   const int xmax = (1 << (16 - cbits)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_h);
-  const size_t row0 = (size_t)h_off[q >> 6];
-  const int lane = q & 63;
+  const size_t row0 = (size_t)h_off[slot >> 6];
+  const int lane = slot & 63;
   const uint8_t* row = x_pm + (size_t)q * n_pad;
   int j = 0;
   for (int c = 0; c < n; ++c) {
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
                                                         uint32_t* __restrict__ ell_w) {
   const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
-  const int c = chan_perm[cg * 64 + lane];
+  const int c = chan_perm[((size_t)b * n_cg + cg) * 64 + lane];
   if (c < 0) return;
   constexpr int xmax = (1 << (16 - ESPM_ELL_PBITS)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_w);
@@ -183,23 +195,26 @@ int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, in
   return check_hip(hipGetLastError(), "ell_count launch");
 }
 
-int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int ngrp, int32_t* chan_perm,
-                    int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream) {
-  const size_t lds = 1024 * sizeof(long long) + (size_t)n * sizeof(uint32_t);
+int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
+                    int32_t* chan_perm, int32_t* pix_perm, int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream) {
+  const size_t lds = (size_t)(n > win ? n : win) * sizeof(int32_t);
   if (lds > 64 * 1024) {
-    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ell_plan_kernel),
+    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ell_order_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "ell_plan"))
       return rc;
   }
-  hipLaunchKernelGGL(ell_plan_kernel, dim3(1), dim3(1024), lds, stream, cnt_px, cnt_bc, n, n_cg, nblk, ngrp, chan_perm, h_off,
-                     w_off, rows);
+  hipLaunchKernelGGL(ell_order_kernel, dim3(nblk + p_pad / win), dim3(1024), lds, stream, cnt_px, cnt_bc, n, n_cg, nblk, win,
+                     chan_perm, pix_perm);
+  hipLaunchKernelGGL(ell_offsets_kernel, dim3(1), dim3(1024), 0, stream, cnt_px, cnt_bc, n_cg, nblk, p_pad / 64, win, chan_perm,
+                     pix_perm, h_off, w_off, rows);
   return check_hip(hipGetLastError(), "ell_plan launch");
 }
 
-int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
-                    const int32_t* chan_perm, const int32_t* h_off, const int32_t* w_off, uint32_t* ell_h, uint32_t* ell_w,
-                    hipStream_t stream) {
-  hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, h_off, ell_h);
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win,
+                    const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream) {
+  hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
+                     pix_perm, h_off, ell_h);
   hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, n_cg), dim3(64), 0, stream, x_pm, n_pad, p, n_cg, chan_perm, w_off, ell_w);
   return check_hip(hipGetLastError(), "ell_fill launch");
 }

@@ -10,8 +10,10 @@
 //           entry's channel from a table in LDS.  entry = count << cbits | channel.
 //   W-step: lists BY CHANNEL inside blocks of 1024 pixels.  A lane owns one channel (GW row and the R H^T
 //           accumulator in registers) and gathers H[:, pixel] of the entry from a table of the block's
-//           H columns in LDS.  entry = count << pbits | pixel-in-block.  Channels are visited in order of
-//           decreasing total count (chan_perm), so the 64 lists of a wave have about the same length.
+//           H columns in LDS.  entry = count << pbits | pixel-in-block.
+//   In both sets the 64 lists of a wave are neighbours in the order of decreasing list length (pixels inside
+//   the workgroup's window: pix_perm; channels inside the pixel block: chan_perm), so they have about the same
+//   length and the padding stays at a few per cent.
 //
 // Both lists are "ELL" slabs: the j-th entries of the 64 lanes of a wave are adjacent in memory (one
 // coalesced 256-byte row carries entries 2r and 2r+1 of each lane), padded with zero entries (count 0) to the
@@ -156,7 +158,9 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
   const int gi = wave % gpw, si = wave / gpw;
   const int tile0 = blockIdx.x * TP;
   const int grp = tile0 / 64 + gi;
-  const int px = tile0 + gi * 64 + lane;  // < p_pad (a multiple of 512); pad pixels have empty lists
+  // the lists of a window are ordered by length: slot -> pixel of the window (pad pixels have empty lists)
+  const int lp = a.ell_pix[tile0 + gi * 64 + lane];
+  const int px = tile0 + lp;  // < p_pad (a multiple of 512)
 
   float hk[K], acc[K];
 #pragma unroll
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
     if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
   });
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) part[((size_t)si * K + kk) * TP + gi * 64 + lane] = acc[kk];
+  for (int kk = 0; kk < K; ++kk) part[((size_t)si * K + kk) * TP + lp] = acc[kk];
   if (LOSS && si == 0) kl += a.ell_klc[px];
   h_epilogue<K>(a, part, nsplit, TP, tile0, LOSS ? kl : 0.f);
 }
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WA
     const int i = t * nw + ((t & 1) ? nw - 1 - wave : wave);
     if (i >= mine) continue;
     const int cg = i * csplit + y;
-    const int c = a.chan_perm[cg * 64 + lane];
+    const int c = a.chan_perm[((size_t)b * a.n_cg + cg) * 64 + lane];
     const float* gsrc = a.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
 #pragma unroll

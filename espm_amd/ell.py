@@ -5,10 +5,11 @@ the iteration loop; the kernels that consume them are in espm_amd/csrc/mu_ell_ke
 
 Layout (see the header for the authoritative description): 16-bit entries, two per dword, the dwords of the
 64 lists of a wave interleaved ("ELL" rows of 64 dwords); value 0 pads a list to the longest of its 64.
-  H-step lists: one per pixel, entry = count << cbits | channel, ascending channel.
+  H-step lists: one per pixel, entry = count << cbits | channel, ascending channel; inside every window of
+                ``tile_px`` pixels the lists are ordered by decreasing length (``pix_perm``: slot -> pixel offset).
   W-step lists: one per (block of 1024 pixels, channel), entry = count << 10 | pixel - block start, ascending
-                pixel; the channels of a wave are 64 consecutive entries of ``chan_perm`` (channels sorted by
-                decreasing number of entries).
+                pixel; the channels of a wave are 64 consecutive entries of ``chan_perm[block]`` (the block's
+                channels by decreasing list length).
 A count larger than its field is split over several entries.
 """
 from __future__ import annotations
@@ -59,11 +60,12 @@ def count_entries(Xpm, xmax_h, xmax_w, chunk=16384):
     return per_px, per_ch, nnz
 
 
-def build(Xpm, p_pad, cbits, chunk=16384):
+def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
     """Xpm: (p, n) non-negative integer-valued tensor on the device (any float dtype).
 
-    Returns a dict of device tensors: ell_h (int32 dwords), ell_h_off (int32), klc (float32, p_pad), ell_w,
-    ell_w_off, chan_perm (int32, 64 * n_cg), and the python ints n_cg, nblk_w, nnz, entries_h, entries_w."""
+    Returns a dict of device tensors: ell_h (int32 dwords), ell_h_off (int32), klc (float32, p_pad), pix_perm (int32,
+    p_pad), ell_w, ell_w_off, chan_perm (int32, nblk_w x 64 n_cg), and the python ints n_cg, nblk_w, nnz, entries_h,
+    entries_w, rows_h, rows_w."""
     dev = Xpm.device
     p, n = Xpm.shape
     PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
@@ -79,7 +81,13 @@ def build(Xpm, p_pad, cbits, chunk=16384):
     ngrp = p_pad // 64
     cnt_pad = torch.zeros(p_pad, dtype=torch.int64, device=dev)
     cnt_pad[:p] = per_px
-    glen = cnt_pad.view(ngrp, 64).max(dim=1).values          # entries of the longest list of each group
+    # inside every window of tile_px pixels: slots by decreasing list length (stable)
+    pix_perm = torch.argsort(cnt_pad.view(-1, tile_px), dim=1, descending=True, stable=True)     # slot -> pixel offset
+    win0 = (torch.arange(p_pad, device=dev) // tile_px) * tile_px
+    slot_pixel = win0 + pix_perm.reshape(-1)                     # global slot -> global pixel
+    slot_of = torch.empty(p_pad, dtype=torch.int64, device=dev)
+    slot_of[slot_pixel] = torch.arange(p_pad, device=dev)       # global pixel -> global slot
+    glen = cnt_pad[slot_pixel].view(ngrp, 64).max(dim=1).values  # entries of the longest list of each slot group
     grows = (glen + 1) // 2                                    # dword rows
     h_off = torch.zeros(ngrp + 1, dtype=torch.int64, device=dev)
     h_off[1:] = torch.cumsum(grows, 0)
@@ -108,22 +116,22 @@ def build(Xpm, p_pad, cbits, chunk=16384):
         cnt = per_px[q0:q0 + blk.shape[0]]
         start = torch.cumsum(cnt, 0) - cnt                    # first entry of each pixel of the chunk
         j = torch.arange(q.numel(), device=dev) - start[q]    # position in the pixel's list
-        pix = q + q0
-        dword = (h_off[pix >> 6] + (j >> 1)) * 64 + (pix & 63)
+        slot = slot_of[q + q0]
+        dword = (h_off[slot >> 6] + (j >> 1)) * 64 + (slot & 63)
         _store16(ell_h16, dword, j & 1, (val << cbits) | c)
 
     # ---- W lists ---------------------------------------------------------------------------------------
-    order = torch.argsort(per_ch, descending=True, stable=True)
-    chan_perm = torch.full((n_cg * 64,), -1, dtype=torch.int64, device=dev)
-    chan_perm[:n] = order
-    slot_of = torch.empty(n, dtype=torch.int64, device=dev)
-    slot_of[order] = torch.arange(n, device=dev)
-    # pass 1: entries per (block, channel) -> rows per (block, channel group)
-    cnt_bc = torch.zeros((nblk_w, n_cg * 64), dtype=torch.int64, device=dev)
+    # pass 1: entries per (block, channel); inside every block the channels by decreasing list length (stable)
+    cnt_bc = torch.zeros((nblk_w, n), dtype=torch.int64, device=dev)
     for b in range(nblk_w):
         xi = Xpm[b * PB:(b + 1) * PB].to(torch.int32)
-        cnt_bc[b, :n] = _split_counts(xi, xmax_w).sum(dim=0).to(torch.int64)[order]
-    wrows = (cnt_bc.view(nblk_w, n_cg, 64).max(dim=2).values + 1) // 2
+        cnt_bc[b] = _split_counts(xi, xmax_w).sum(dim=0).to(torch.int64)
+    order = torch.argsort(cnt_bc, dim=1, descending=True, stable=True)     # (nblk_w, n): slot -> channel
+    chan_perm = torch.full((nblk_w, n_cg * 64), -1, dtype=torch.int64, device=dev)
+    chan_perm[:, :n] = order
+    cnt_slot = torch.zeros((nblk_w, n_cg * 64), dtype=torch.int64, device=dev)
+    cnt_slot[:, :n] = torch.gather(cnt_bc, 1, order)
+    wrows = (cnt_slot.view(nblk_w, n_cg, 64).max(dim=2).values + 1) // 2
     w_off = torch.zeros(nblk_w * n_cg + 1, dtype=torch.int64, device=dev)
     w_off[1:] = torch.cumsum(wrows.reshape(-1), 0)
     rows_w = int(w_off[-1])
@@ -139,15 +147,16 @@ def build(Xpm, p_pad, cbits, chunk=16384):
         c, pl = nz[:, 0], nz[:, 1]
         x = xt[c, pl]
         c, pl, val = _expand(c, pl, x, _split_counts(x, xmax_w), xmax_w)
-        cnt = torch.zeros(n, dtype=torch.int64, device=dev)
-        cnt[order] = cnt_bc[b, :n]                            # entries per channel (natural order)
+        cnt = cnt_bc[b]                                       # entries per channel (natural order)
         start = torch.cumsum(cnt, 0) - cnt
         j = torch.arange(c.numel(), device=dev) - start[c]
-        slot = slot_of[c]
+        slot_of_c = torch.empty(n, dtype=torch.int64, device=dev)
+        slot_of_c[order[b]] = torch.arange(n, device=dev)
+        slot = slot_of_c[c]
         dword = (w_off[b * n_cg + (slot >> 6)] + (j >> 1)) * 64 + (slot & 63)
         _store16(ell_w16, dword, j & 1, (val << PBITS) | pl)
 
-    return dict(ell_h=ell_h, ell_h_off=h_off.to(torch.int32), klc=klc, ell_w=ell_w, ell_w_off=w_off.to(torch.int32),
+    return dict(ell_h=ell_h, ell_h_off=h_off.to(torch.int32), klc=klc, pix_perm=pix_perm.reshape(-1).to(torch.int32), ell_w=ell_w, ell_w_off=w_off.to(torch.int32),
                 chan_perm=chan_perm.to(torch.int32), n_cg=n_cg, nblk_w=nblk_w, nnz=nnz,
                 entries_h=int(per_px.sum()), entries_w=int(per_ch.sum()), rows_h=rows_h, rows_w=rows_w)
 

@@ -159,7 +159,7 @@ class MUEngine:
             from . import ell as _ell
             self.x_cm = self.x_pm = None
             if os.environ.get("ESPM_ELL_BUILDER", "hip") == "torch":  # the tensor-op builder (tests cross-check the two)
-                self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits)
+                self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits, st.tile_px)
             else:
                 self.ell = self._build_ell(Xd.contiguous(), layout)
             assert self.ell["n_cg"] == st.n_cg and self.ell["nblk_w"] == st.nblk_w
@@ -249,6 +249,7 @@ class MUEngine:
             st.x_cm = st.x_pm = None
             st.ell_h, st.ell_h_off, st.ell_klc = (self.ell[key].data_ptr() for key in ("ell_h", "ell_h_off", "klc"))
             st.ell_w, st.ell_w_off, st.chan_perm = (self.ell[key].data_ptr() for key in ("ell_w", "ell_w_off", "chan_perm"))
+            st.pix_perm = self.ell["pix_perm"].data_ptr()
         st.g = self.g.data_ptr() if self.g is not None else None
         st.colsum_g = self.colsum_g.data_ptr() if self.colsum_g is not None else None
         st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()
@@ -287,22 +288,23 @@ class MUEngine:
         cnt_bc = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
         klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
         check(lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
-        chan_perm = torch.empty(st.n_cg * 64, **i32)
+        chan_perm = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
+        pix_perm = torch.empty(st.p_pad, **i32)
         h_off = torch.empty(st.p_pad // 64 + 1, **i32)
         w_off = torch.empty(st.nblk_w * st.n_cg + 1, **i32)
         rows = torch.zeros(2, dtype=torch.int64, device=dev)
-        check(lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(h_off), _ptr(w_off),
-                                   _ptr(rows), _stream()))
+        check(lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off),
+                                   _ptr(w_off), _ptr(rows), _stream()))
         rows_h, rows_w = (int(v) for v in rows.cpu())
         if max(rows_h, rows_w) * 64 >= 2 ** 31:
             raise ValueError("sparse count store: the lists exceed 2^31 dwords")
         ell_h = torch.zeros(max(rows_h, 1) * 64, **i32)
         ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
-        check(lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(h_off), _ptr(w_off), _ptr(ell_h), _ptr(ell_w),
-                                   _stream()))
+        check(lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
+                                   _ptr(ell_h), _ptr(ell_w), _stream()))
         nnz = int((x8[:, :self.n] != 0).sum())
         torch.cuda.current_stream().synchronize()
-        return dict(ell_h=ell_h, ell_h_off=h_off, klc=klc, ell_w=ell_w, ell_w_off=w_off, chan_perm=chan_perm, n_cg=st.n_cg,
+        return dict(ell_h=ell_h, ell_h_off=h_off, klc=klc, pix_perm=pix_perm, ell_w=ell_w, ell_w_off=w_off, chan_perm=chan_perm, n_cg=st.n_cg,
                     nblk_w=st.nblk_w, nnz=nnz, entries_h=int(cnt_px.sum()), entries_w=int(cnt_bc.sum()), rows_h=rows_h,
                     rows_w=rows_w)
 

@@ -156,11 +156,14 @@ typedef struct espm_mu_state {
    * of the 64 lists of a wave form row r of 64 dwords (low half first), value 0 = padding.  A count that
    * exceeds its field is split over several entries with the same index (the kernels evaluate the loss term
    * x_i log2(x_i / Y) per entry; ell_klc restores sum x log2(x / Y) for split counts).
-   *   H-step: one list per pixel, 64 consecutive pixels per wave; entry = count << ell_cbits | channel;
-   *           rows [ell_h_off[g], ell_h_off[g+1]) belong to pixels 64 g .. 64 g + 63.
-   *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); the 64 lists of a wave are the channels
-   *           chan_perm[64 cg .. 64 cg + 63] (channels in order of decreasing total count, -1 = none);
-   *           entry = count << ESPM_ELL_PBITS | pixel - block start; rows
+   *   H-step: one list per pixel; entry = count << ell_cbits | channel.  Inside every window of tile_px pixels
+   *           (the pixels of one H-step workgroup) the lists are ordered by decreasing length: slot s of the
+   *           window starting at pixel w0 is pixel w0 + pix_perm[w0 + s], and the 64 lists of a wave are 64
+   *           consecutive slots, so they have about the same length (little padding).  Rows
+   *           [ell_h_off[g], ell_h_off[g+1]) belong to slots 64 g .. 64 g + 63.
+   *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); inside block b the 64 lists of a wave are
+   *           the channels chan_perm[b][64 cg .. 64 cg + 63] (the block's channels by decreasing list length,
+   *           -1 = none); entry = count << ESPM_ELL_PBITS | pixel - block start; rows
    *           [ell_w_off[b * n_cg + cg], ell_w_off[b * n_cg + cg + 1]).  nblk_w = ceil(p / ESPM_ELL_PB). */
   const uint32_t* ell_h;    /* (rows_h, 64) */
   const int32_t* ell_h_off; /* (p_pad / 64 + 1) */
@@ -168,9 +171,10 @@ typedef struct espm_mu_state {
                                x log2 x minus the sum over their entries x_i of x_i log2 x_i (0 without splits) */
   const uint32_t* ell_w;    /* (rows_w, 64) */
   const int32_t* ell_w_off; /* (nblk_w * n_cg + 1) */
-  const int32_t* chan_perm; /* (64 * n_cg) */
+  const int32_t* chan_perm; /* (nblk_w, 64 * n_cg) */
   int32_t ell_cbits;        /* index bits of an H-step entry: 2^ell_cbits >= n, <= 14 */
   int32_t n_cg;             /* channel groups: ceil(n / 64) */
+  const int32_t* pix_perm;  /* (p_pad): slot -> pixel offset inside its tile_px window (H-step lists) */
 } espm_mu_state;
 
 const char* espm_mu_version(void);
@@ -190,16 +194,18 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
  * ESPM_X_ELL and espm_mu_query.  Three steps, all buffers caller-allocated:
  *   count: cnt_px (p_pad) entries of each pixel's H-step list; cnt_bc (nblk_w, 64 n_cg) entries of each (pixel
  *          block, channel) W-step list (natural channel order); ell_klc (p_pad).
- *   plan : chan_perm (64 n_cg), ell_h_off (p_pad / 64 + 1), ell_w_off (nblk_w n_cg + 1) and rows[2] (device):
+ *   plan : chan_perm (nblk_w, 64 n_cg), pix_perm (p_pad; windows of st->tile_px pixels), ell_h_off (p_pad / 64 + 1),
+ *          ell_w_off (nblk_w n_cg + 1) and rows[2] (device):
  *          rows of 64 dwords of the H-step and of the W-step lists.  The caller reads rows[] back, checks
  *          64 rows < 2^31 and allocates ell_h (rows[0], 64) and ell_w (rows[1], 64), ZERO-initialised.
  *   fill : writes the entries.  The dense x_pm_u8 can be released afterwards. */
 int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
                       espm_stream_t stream);
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
-                     int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream);
-int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* ell_h_off,
-                     const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, espm_stream_t stream);
+                     int32_t* pix_perm, int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream);
+int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,
+                     const int32_t* ell_h_off, const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w,
+                     espm_stream_t stream);
 
 /* statistics (row sums, row maxima) of st->h[which] into st->hstat[which] (local pixels). */
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream);

@@ -9,22 +9,25 @@ import torch
 from espm_amd import _lib, ell
 
 
-def decode(store, p, n, p_pad, cbits):
+def decode(store, p, n, p_pad, cbits, tile_px):
     PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
     eh = store["ell_h"].numpy().astype(np.int64) & 0xFFFFFFFF
     off = store["ell_h_off"].numpy()
     Xh = np.zeros((p_pad, n), dtype=np.int64)
+    pix = store["pix_perm"].numpy()
     for g in range(p_pad // 64):
         rows = eh[off[g] * 64:off[g + 1] * 64].reshape(-1, 64)
         for half in (0, 1):
             ent = (rows >> (16 * half)) & 0xFFFF
             cnt, c = ent >> cbits, ent & ((1 << cbits) - 1)
             for lane in range(64):
-                np.add.at(Xh[g * 64 + lane], c[:, lane], cnt[:, lane])
+                slot = g * 64 + lane
+                np.add.at(Xh[slot // tile_px * tile_px + pix[slot]], c[:, lane], cnt[:, lane])
     ew = store["ell_w"].numpy().astype(np.int64) & 0xFFFFFFFF
     woff = store["ell_w_off"].numpy()
     perm = store["chan_perm"].numpy()
     n_cg = store["n_cg"]
+    assert perm.shape == (store["nblk_w"], n_cg * 64)
     Xw = np.zeros((store["nblk_w"] * PB, n), dtype=np.int64)
     for b in range(store["nblk_w"]):
         for cg in range(n_cg):
@@ -33,7 +36,7 @@ def decode(store, p, n, p_pad, cbits):
                 ent = (rows >> (16 * half)) & 0xFFFF
                 cnt, pl = ent >> PBITS, ent & (PB - 1)
                 for lane in range(64):
-                    c = perm[cg * 64 + lane]
+                    c = perm[b, cg * 64 + lane]
                     if c < 0:
                         assert not cnt[:, lane].any()
                         continue
@@ -41,17 +44,17 @@ def decode(store, p, n, p_pad, cbits):
     return Xh, Xw
 
 
-@pytest.mark.parametrize("n,p,rate,big", [(100, 400, 0.3, False), (1980, 1300, 0.2, True), (70, 2049, 1.5, True)])
-def test_lists_decode_to_x(n, p, rate, big):
+@pytest.mark.parametrize("n,p,rate,big,tile_px", [(100, 400, 0.3, False, 64), (1980, 1300, 0.2, True, 512), (70, 2049, 1.5, True, 128)])
+def test_lists_decode_to_x(n, p, rate, big, tile_px):
     rng = np.random.default_rng(n + p)
     X = rng.poisson(rate * rng.uniform(0.1, 2.0, size=(1, n)), size=(p, n)).astype(np.float32)
     if big:  # counts beyond the count field of an entry are split over several entries
         X[rng.integers(0, p, 40), rng.integers(0, n, 40)] = rng.integers(32, 256, 40)
     cbits = max(1, int(np.ceil(np.log2(n))))
     p_pad = (p + 511) // 512 * 512
-    store = ell.build(torch.from_numpy(X), p_pad, cbits, chunk=512)
+    store = ell.build(torch.from_numpy(X), p_pad, cbits, tile_px, chunk=512)
     assert store["nnz"] == int((X != 0).sum())
-    Xh, Xw = decode(store, p, n, p_pad, cbits)
+    Xh, Xw = decode(store, p, n, p_pad, cbits, tile_px)
     assert np.array_equal(Xh[:p], X.astype(np.int64)) and not Xh[p:].any()
     assert np.array_equal(Xw[:p], X.astype(np.int64)) and not Xw[p:].any()
     # loss correction of the split counts: sum x log2 x - sum over the entries of x_i log2 x_i, per pixel
@@ -62,10 +65,19 @@ def test_lists_decode_to_x(n, p, rate, big):
     ref = (lg(Xd) - nfull * lg(np.float64(xmax)) - lg(Xd - nfull * xmax)).sum(axis=1)
     np.testing.assert_allclose(store["klc"].numpy()[:p], ref, rtol=1e-6, atol=1e-6)
     assert (ref > 0).any() == bool((X > xmax).any())
-    # channels in order of decreasing entry count, every channel exactly once
+    # channels of every block in order of decreasing list length, every channel exactly once
     perm = store["chan_perm"].numpy()
-    assert sorted(perm[perm >= 0].tolist()) == list(range(n))
-    # lists are padded to the longest of 64 only: rows of a group = ceil(max entries / 2)
+    xmax_w = (1 << (16 - _lib.ELL_PBITS)) - 1
+    for b in range(store["nblk_w"]):
+        row = perm[b][perm[b] >= 0]
+        assert sorted(row.tolist()) == list(range(n))
+        ent_c = np.ceil(X[b * _lib.ELL_PB:(b + 1) * _lib.ELL_PB] / xmax_w).sum(axis=0)
+        assert (np.diff(ent_c[row]) <= 0).all()
+    # pixels of every window in order of decreasing list length; lists padded to the longest of their 64 slots only
     ent = np.ceil(X / xmax).sum(axis=1)
-    ent = np.concatenate([ent, np.zeros(p_pad - p)]).reshape(-1, 64).max(axis=1)
-    assert np.array_equal(np.diff(store["ell_h_off"].numpy()), (ent + 1) // 2)
+    ent = np.concatenate([ent, np.zeros(p_pad - p)])
+    pix = store["pix_perm"].numpy().reshape(-1, tile_px)
+    assert (np.sort(pix, axis=1) == np.arange(tile_px)).all()
+    ent_slot = np.take_along_axis(ent.reshape(-1, tile_px), pix, axis=1)
+    assert (np.diff(ent_slot, axis=1) <= 0).all()
+    assert np.array_equal(np.diff(store["ell_h_off"].numpy()), (ent_slot.reshape(-1, 64).max(axis=1) + 1) // 2)

@@ -236,7 +236,7 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
         eng = MUEngine(Xin, 3, layout=layout, shape_2d=(nx, ny), x_store="ell")
         stores[builder] = eng.ell
     a, b = stores["hip"], stores["torch"]
-    for key in ("ell_h_off", "ell_w_off", "chan_perm", "ell_h", "ell_w"):
+    for key in ("ell_h_off", "ell_w_off", "chan_perm", "pix_perm", "ell_h", "ell_w"):
         assert torch.equal(a[key].cpu(), b[key].cpu()), key
     for key in ("nnz", "entries_h", "entries_w", "rows_h", "rows_w", "n_cg", "nblk_w"):
         assert a[key] == b[key], key
