@@ -177,7 +177,7 @@ def main():
         pass
     roofline = dict(bound="hbm", kernel=("h_step_ell_kernel<5,loss>" if eng.x_store == "ell" else "h_step_kernel<5,%s,...,loss>" % eng.x_store), achieved=bytes_h / t_h_upd / 1e9,
                     peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=traffic,
-                    bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
+                    bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3, launch_ms_loss_only=t_h * 1e3,
                     w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),
                     iteration=dict(algorithmic_GB=bytes_it / 1e9, hbm_frac=bytes_it * its / HBM_PEAK,
                                    valu_f32_frac=flops_it * its / VALU_F32_PEAK,

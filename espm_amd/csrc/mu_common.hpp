@@ -281,7 +281,9 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     if (i < k && num[i] > 0) lo = fmax(lo, num[i] / 2 - e[i]);
   }
   T hi = (T)(2 * k) * nmax - dmin_all + dstar;  // dicotomy.py:49
-  T x = lo, dxold = hi - lo;
+  // start at nu = 0 (delta = d*) when that lies inside the bracket: multiplicative updates sit close to their
+  // fixed point, where sum_i num_i / den_i is already ~1; the safeguards below handle either side of the root
+  T x = fmax(lo, fmin(dstar, hi)), dxold = hi - lo;
   for (int it = 0; it < maxit; ++it) {
     T f = -1, fp = 0;
 #pragma unroll
