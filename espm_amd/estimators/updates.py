@@ -69,12 +69,24 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
     return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
 
 
+def _initial_factors(X, n_components, init, random_state, sklearn_init):
+    from espm_amd import init_device
+
+    nndsvd = init in (None, "nndsvd", "nndsvda", "nndsvdar") and n_components <= min(X.shape)
+    if nndsvd and X.size >= init_device.DEVICE_INIT_MIN_SIZE:
+        import torch
+        if torch.cuda.is_available():
+            return init_device.initialize_nmf_device(X, n_components, init=init, random_state=random_state)
+    return sklearn_init(X, n_components=n_components, init=init, random_state=random_state)
+
+
 def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_H, simplex_W, logshift=log_shift,
                           physics_model=None):
     """Initial G, W, H (espm/estimators/updates.py:160-223).
 
-    Host side like the reference: scikit-learn's NNDSVD / random initialisation and small
-    least-squares fits; it runs once per fit, outside the multiplicative-update loop."""
+    Like the reference: scikit-learn's NNDSVD / random initialisation and small least-squares fits, once per
+    fit, outside the multiplicative-update loop.  For a large X the NNDSVD's sixteen passes over X run on the
+    GPU (espm_amd/init_device.py: same algorithm, same random stream, result equal to scikit-learn's to rounding)."""
     from sklearn.decomposition._nmf import _initialize_nmf
 
     if G is None:
@@ -84,7 +96,7 @@ def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_
         skip_second = False
     if W is None:
         if H is None:
-            D, H = _initialize_nmf(X, n_components=n_components, init=init, random_state=random_state)
+            D, H = _initial_factors(X, n_components, init, random_state, _initialize_nmf)
             if simplex_H:
                 H = np.nan_to_num(H, nan=1.0 / H.shape[0])
                 scale = np.sum(H, axis=0, keepdims=True)

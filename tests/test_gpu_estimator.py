@@ -322,6 +322,33 @@ def test_sparse_store_is_chosen_for_sparse_counts_only():
         MUEngine(X * 0.5, 2, shape_2d=(8, 8), x_store="ell")
 
 
+@pytest.mark.parametrize("n,p,k,init,dtype", [(300, 20000, 4, None, np.float64), (2100, 2400, 5, "nndsvd", np.float64),
+                                               (256, 17000, 3, "nndsvdar", np.float32), (6000, 700, 6, "nndsvda", np.float64)])
+def test_device_nndsvd_matches_sklearn(n, p, k, init, dtype):
+    """espm_amd.init_device (randomized SVD passes over X on the GPU) against scikit-learn's _initialize_nmf, which
+    the reference calls (espm/estimators/updates.py:179): same random stream, same algorithm, equal to rounding -
+    for a wide X (transposed inside the randomized SVD), a tall one, fp32 input and every NNDSVD variant."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+    from espm_amd import init_device
+    from espm_amd.estimators.updates import initialize_algorithms
+    rng = np.random.default_rng(n)
+    W = rng.random((n, k)) ** 3
+    H = rng.random((k, p)) ** 2
+    X = rng.poisson(3.0 * W @ H).astype(dtype)
+    assert X.size >= init_device.DEVICE_INIT_MIN_SIZE
+    Wr, Hr = _initialize_nmf(X, n_components=k, init=init, random_state=7)
+    Wd, Hd = init_device.initialize_nmf_device(X, k, init=init, random_state=7)
+    tol = 2e-4 if dtype == np.float32 else 1e-8
+    np.testing.assert_allclose(Wd, Wr, rtol=tol, atol=tol * np.abs(Wr).max())
+    np.testing.assert_allclose(Hd, Hr, rtol=tol, atol=tol * np.abs(Hr).max())
+    assert Wd.dtype == Wr.dtype and Hd.dtype == Hr.dtype
+    # and through the module-level entry point the estimators use
+    G, W0, H0 = initialize_algorithms(X, None, None, None, k, init, 7, True, False)
+    scale = Hr.sum(axis=0, keepdims=True)
+    np.testing.assert_allclose(H0, np.maximum(Hr / scale, 1e-14), rtol=10 * tol, atol=tol)
+    np.testing.assert_allclose(W0, np.maximum(Wr * scale.mean(), 1e-14), rtol=10 * tol, atol=tol * np.abs(Wr).max())
+
+
 def test_one_dimensional_spectrum_fit(SmoothNMF):
     """The reference's 1-D fitting use (espm/datasets/eds_spim.py:228-253): p = 1, k = 1, no shape_2d,
     fixed_H = 1, G an ndarray; and an empty-looking spectrum with all-zero channels (base.py:519-528)."""
