@@ -27,6 +27,10 @@ def normalization_factor(X, nc):
     return nc / (m * X.shape[0])
 
 
+# X with at least this many entries is uploaded once and prepared on the device (see fit_transform)
+_DEVICE_PREP_MIN_SIZE = 4_000_000
+
+
 def _is_physical_model(G):
     return G is not None and not isinstance(G, np.ndarray) and hasattr(G, "NMF_update")
 
@@ -160,15 +164,45 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         if self.true_D is not None or self.true_H is not None:
             raise NotImplementedError("ground-truth tracking (true_D / true_H) is outside the accelerated path")
 
-        X_fixed = self.remove_zeros_lines(Xv, self.log_shift)
+        # Large X: ONE upload; the passes the reference makes over X on the host before the loop (sign check, zero
+        # lines base.py:519-528, mean for normalize, const_KL_ base.py:200-201, the NNDSVD's products) run on that
+        # device copy, which then feeds the engine.  Small X: the host path, like the reference.
+        Xd = None
+        if Xv.size >= _DEVICE_PREP_MIN_SIZE:
+            import torch
+            if torch.cuda.is_available():
+                Xd = torch.from_numpy(np.ascontiguousarray(Xv)).to(f"cuda:{torch.cuda.current_device()}")
         self.const_KL_ = None
         xscale = 1.0
+        if Xd is None:
+            X_fixed = self.remove_zeros_lines(Xv, self.log_shift)
+            mean_x = None
+        else:
+            if bool((Xd < 0).any()):
+                raise ValueError("Negative values in data")
+            zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
+            if bool(zp.any()) or bool(zc.any()):
+                X_fixed = Xv.copy()
+                X_fixed[:, zp.cpu().numpy()] = self.log_shift
+                X_fixed[zc.cpu().numpy(), :] = self.log_shift
+                Xd[:, zp] = self.log_shift
+                Xd[zc, :] = self.log_shift
+            else:
+                X_fixed = Xv
+            mean_x = float(Xd.mean(dtype=torch.float64))
         if self.normalize:
-            self.norm_factor_ = normalization_factor(X_fixed, self.n_components)
+            self.norm_factor_ = (normalization_factor(X_fixed, self.n_components) if mean_x is None
+                                 else self.n_components / (mean_x * X_fixed.shape[0]))
             self.X_ = self.norm_factor_ * X_fixed
             xscale = float(self.norm_factor_)
         else:
             self.X_ = X_fixed
+        X_init_dev = None
+        if Xd is not None:
+            X_init_dev = Xd * xscale if self.normalize else Xd
+            xs = X_init_dev.to(torch.float64) if X_init_dev.dtype != torch.float64 else X_init_dev
+            self._const_KL_dev = float((xs * torch.log(xs.clamp_min(self.log_shift))).sum() - xs.sum())
+            del xs
 
         if _is_physical_model(self.G):
             self.physics_model_ = self.G
@@ -180,18 +214,22 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self.G_, self.W_, self.H_ = initialize_algorithms(X=self.X_, G=G, W=W, H=H, n_components=self.n_components,
                                                           init=self.init, random_state=self.random_state,
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,
-                                                          physics_model=self.physics_model_)
+                                                          physics_model=self.physics_model_, X_device=X_init_dev)
+        del X_init_dev
         if self.shape_2d is not None:
             self.L_ = create_laplacian_matrix(*self.shape_2d)
         else:
             self.L_ = identity_laplacian(self.X_.shape[1])
 
         out_dtype = self.X_.dtype
-        self._engine = eng = self._make_engine(X_fixed, xscale, None if self._identity_G else self.G_)
-        del X_fixed
+        self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd, xscale, None if self._identity_G else self.G_)
+        del X_fixed, Xd
         eng.load_state(self.W_, self.H_)
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]
-        self.const_KL_ = float(np.sum(self.X_ * np.log(np.maximum(self.X_, self.log_shift))) - np.sum(self.X_))
+        self.const_KL_ = (getattr(self, "_const_KL_dev", None) if Xv.size >= _DEVICE_PREP_MIN_SIZE else None)
+        if self.const_KL_ is None:
+            self.const_KL_ = float(np.sum(self.X_ * np.log(np.maximum(self.X_, self.log_shift))) - np.sum(self.X_))
+        self._const_KL_dev = None
 
         algo_start = time.time()
         self.n_iter_ = 0

@@ -69,19 +69,20 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
     return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
 
 
-def _initial_factors(X, n_components, init, random_state, sklearn_init):
+def _initial_factors(X, n_components, init, random_state, sklearn_init, X_device=None):
     from espm_amd import init_device
 
     nndsvd = init in (None, "nndsvd", "nndsvda", "nndsvdar") and n_components <= min(X.shape)
     if nndsvd and X.size >= init_device.DEVICE_INIT_MIN_SIZE:
         import torch
         if torch.cuda.is_available():
-            return init_device.initialize_nmf_device(X, n_components, init=init, random_state=random_state)
+            return init_device.initialize_nmf_device(X, n_components, init=init, random_state=random_state,
+                                                     X_device=X_device)
     return sklearn_init(X, n_components=n_components, init=init, random_state=random_state)
 
 
 def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_H, simplex_W, logshift=log_shift,
-                          physics_model=None):
+                          physics_model=None, X_device=None):
     """Initial G, W, H (espm/estimators/updates.py:160-223).
 
     Like the reference: scikit-learn's NNDSVD / random initialisation and small least-squares fits, once per
@@ -96,7 +97,7 @@ def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_
         skip_second = False
     if W is None:
         if H is None:
-            D, H = _initial_factors(X, n_components, init, random_state, _initialize_nmf)
+            D, H = _initial_factors(X, n_components, init, random_state, _initialize_nmf, X_device)
             if simplex_H:
                 H = np.nan_to_num(H, nan=1.0 / H.shape[0])
                 scale = np.sum(H, axis=0, keepdims=True)

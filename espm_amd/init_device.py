@@ -71,13 +71,14 @@ def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     return U[:, :n_components], s[:n_components], Vt[:n_components, :]
 
 
-def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None):
+def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None):
     """sklearn.decomposition._nmf._initialize_nmf for the NNDSVD family with the passes over X on the GPU.
 
-    X: (n_samples, n_features) numpy array, fp32 or fp64 (kept in its dtype, like scikit-learn)."""
+    X: (n_samples, n_features) numpy array, fp32 or fp64 (kept in its dtype, like scikit-learn); X_device: the same
+    matrix already on the GPU (then X is only consulted for its shape and dtype)."""
     from sklearn.utils import check_random_state
 
-    if (X < 0).any():
+    if X_device is None and (X < 0).any():
         raise ValueError("Negative values in data passed to NMF initialization")
     n_samples, n_features = X.shape
     if init is None:
@@ -86,8 +87,11 @@ def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-
         raise ValueError(f"initialize_nmf_device handles the NNDSVD family, got init={init!r}")
     if n_components > min(n_samples, n_features):
         raise ValueError("init = '{}' can only be used when n_components <= min(n_samples, n_features)".format(init))
-    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-    Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+    if X_device is not None:
+        Xd = X_device
+    else:
+        dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
     U, S, V = randomized_svd_device(Xd, n_components, random_state)
     avg = float(Xd.mean(dtype=torch.float64)) if init != "nndsvd" else 0.0
     del Xd
