@@ -67,6 +67,7 @@ SYMBOLS = {
     "espm_mu_loss_only": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_accum": (C.c_int, [_SP, _vp]),
     "espm_mu_w_reduce": (C.c_int, [_SP, _vp]),
+    "espm_mu_w_reduce_finalize": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_shard_record_bytes": (C.c_size_t, [_SP]),

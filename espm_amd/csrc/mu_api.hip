@@ -257,6 +257,14 @@ int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
   return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, static_cast<hipStream_t>(stream));
 }
 
+int espm_mu_w_reduce_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  const HFinalizeArgs fin = finalize_args(st, src, slot, true);
+  return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, &fin, static_cast<hipStream_t>(stream));
+}
+
 int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE((src == 0 || src == 1) && (hsrc == 0 || hsrc == 1), "src/hsrc must be 0/1");

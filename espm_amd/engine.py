@@ -326,6 +326,7 @@ class MUEngine:
         if H.shape != (self.k, self.p):
             raise ValueError(f"H must be {(self.k, self.p)}, got {H.shape}")
         st.cur, st.it = 0, 0
+        self._pending_finalize = None
         self.hist.zero_()
         self.w[0].copy_(torch.from_numpy(np.ascontiguousarray(W)))
         self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
@@ -339,6 +340,7 @@ class MUEngine:
         """Replace G (physics model refreshed it, espm/estimators/base.py:388-390) and rebuild G W."""
         if self.m == 0:
             raise ValueError("the engine was built with G = identity")
+        self._flush_finalize()
         Gh = np.ascontiguousarray(np.asarray(G, dtype=np.float32))
         if Gh.shape != (self.n, self.m):
             raise ValueError(f"G must stay {(self.n, self.m)}, got {Gh.shape}")
@@ -367,13 +369,23 @@ class MUEngine:
     # ---- one iteration, granular (stop criteria / sharded) ---------------------------------------------
     def eval_current(self, advance_h=True):
         """H-step from the current state: fills history slot ``it`` with the loss pieces of the current
-        state and (advance_h) leaves the new H in the other buffer."""
+        state and (advance_h) leaves the new H in the other buffer.
+
+        With advance_h the reduction of the H-step's records is deferred: ``finish_iteration`` folds it into its
+        slab-reduction launch; any other consumer (``history``, ``step_*_only``, ...) flushes it first."""
         st = self.st
+        self._flush_finalize()
         if advance_h:
             check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
-            check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+            self._pending_finalize = (st.cur, st.it)
         else:
             check(lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+
+    def _flush_finalize(self):
+        pend = getattr(self, "_pending_finalize", None)
+        if pend is not None:
+            self._pending_finalize = None
+            check(lib.espm_mu_h_finalize(C.byref(self.st), pend[0], pend[1], _stream()))
 
     def finish_iteration(self):
         """W-step with the H produced by ``eval_current`` and the bookkeeping; flips the buffers."""
@@ -383,7 +395,12 @@ class MUEngine:
             raise ValueError("history buffer exhausted: raise max_iter")
         s = _stream()
         check(lib.espm_mu_w_accum(C.byref(st), s))
-        check(lib.espm_mu_w_reduce(C.byref(st), s))
+        if getattr(self, "_pending_finalize", None) == (cur, slot):
+            self._pending_finalize = None
+            check(lib.espm_mu_w_reduce_finalize(C.byref(st), cur, slot, s))
+        else:
+            self._flush_finalize()
+            check(lib.espm_mu_w_reduce(C.byref(st), s))
         if self.world > 1:
             check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
             self.exchange.gather()
@@ -397,6 +414,7 @@ class MUEngine:
         st = self.st
         if st.it + n_iter + 1 > self.hist_len:
             raise ValueError("history buffer exhausted: raise max_iter")
+        self._flush_finalize()
         if self.world == 1:
             check(lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
         else:
@@ -409,6 +427,7 @@ class MUEngine:
     # ---- single half steps for the module-level functions ----------------------------------------------
     def step_h_only(self):
         st = self.st
+        self._flush_finalize()
         check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
         check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
         return self._h_numpy(1 - st.cur)
@@ -417,6 +436,7 @@ class MUEngine:
         """W update using the CURRENT H (its transposed copy is refreshed first)."""
         st = self.st
         cur = st.cur
+        self._flush_finalize()
         self.h_t.zero_()
         self.h_t[:, :self.k].copy_(self.h[cur][:, :self.p].t())
         s = _stream()
@@ -436,12 +456,14 @@ class MUEngine:
         return self._h_numpy(self.st.cur)
 
     def bad_count(self):
+        self._flush_finalize()
         return float(self.hist[:self.st.it + 1, _lib.HI_BAD].sum().item())
 
     def history(self, upto=None, average=True):
         """Loss pieces of states 0..upto (inclusive) assembled like SmoothNMF.loss
         (espm/estimators/smooth_nmf.py:457-475): returns dict of float64 arrays."""
         upto = self.st.it if upto is None else upto
+        self._flush_finalize()
         hist = self.hist[:upto + 1].clone()
         if self.world > 1:
             sums = hist[:, [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP, _lib.HI_BAD]].contiguous()

@@ -229,6 +229,10 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream);
 /* a = sum_b a_slab[b] in fixed order (one pass, bit-reproducible). */
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream);
+/* espm_mu_w_reduce and espm_mu_h_finalize(st, src, slot) in ONE launch (the reduction of the H-step's records
+ * rides in an extra workgroup): for callers that sequence the half-steps themselves, after espm_mu_step_h(src, 1)
+ * and espm_mu_w_accum. */
+int espm_mu_w_reduce_finalize(const espm_mu_state* st, int src, int slot, espm_stream_t stream);
 /* W update from a (sharded: the all-rank sum written by espm_mu_shard_combine) and hstat[hsrc] (global
  * row sums of the new H): reads w[src], writes w[1-src], gw_s, colsum_gw and rel_W into history slot `slot`. */
 int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream);
