@@ -169,6 +169,7 @@ int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
 static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
   WFinishArgs a;
   a.g = st->m > 0 ? st->g : nullptr;
+  a.g_t = st->m > 0 ? st->g_t : nullptr;
   a.colsum_g = st->colsum_g;
   a.w_old = st->w[src];
   a.w_new = update_w ? st->w[1 - src] : st->w[src];

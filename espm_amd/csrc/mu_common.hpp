@@ -388,6 +388,7 @@ struct WAccumArgs {
 };
 struct WFinishArgs {
   const float* g;
+  const float* g_t;     // (m, n_pad) transposed copy of g or null
   const float* colsum_g;
   const float* w_old;
   float* w_new;

@@ -82,6 +82,19 @@ __device__ __forceinline__ double block_max1(double v, double* scratch) {
 // per output entry and G W' reads W' from LDS.  Same arithmetic and the same global-stop bisection as
 // w_finish_kernel below; only the data movement differs.
 constexpr int WF_GTA_MAX = 8192;
+constexpr int WF_GTA_PAR = 512;  // M * k up to which G^T A uses the all-threads path (16 x M k floats of LDS)
+
+// One step of a packed butterfly sum over the lanes of a wave: of the first N values a lane keeps one half
+// (the upper one when `up`) and adds the partner's copy of that half, which the partner sends instead of keeping.
+template <int N>
+__device__ __forceinline__ void butterfly_half(float (&v)[32], bool up, int off) {
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const float send = up ? v[j] : v[N / 2 + j];
+    const float keep = up ? v[N / 2 + j] : v[j];
+    v[j] = keep + __shfl_xor(send, off, 64);
+  }
+}
 
 __device__ __forceinline__ float load_a(const WFinishArgs& a, int kk, int c) {
   return a.a[(size_t)kk * a.n_pad + c];
@@ -108,7 +121,62 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     for (int kk = 0; kk < KA; ++kk) wn[r][kk] = 0.f;
 
   if (a.update_w) {
-    if (a.g) {  // G^T A with the association G^T (R H^T), updates.py:58-59: one wave per (mm, kk)
+    if (a.g && a.g_t && MK <= WF_GTA_PAR) {
+      // G^T A with the association G^T (R H^T), updates.py:58-59, with every thread busy: thread = channel
+      // (its k entries of A in registers), G^T rows read coalesced, the products of a wave summed across its lanes
+      // and the per-wave partials by the workgroup.  s_part lives behind s_gta.
+      float* s_part = s_gta + MK;  // [WF_THREADS / 64][MK]
+      float av[WF_ROWS][KA];
+#pragma unroll
+      for (int r = 0; r < WF_ROWS; ++r) {
+        const int c = tid + r * WF_THREADS;
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) av[r][kk] = (kk < k && c < a.n) ? load_a(a, kk, c) : 0.f;
+      }
+      // Batches of 4 rows of G^T: 32 (row, component) products per lane, summed over the 64 lanes by a packed
+      // butterfly - in every step a lane hands the half of its values it does not keep to its partner - which
+      // takes 32 cross-lane moves instead of 6 x 32 (the moves, on one CU, are what bounds this phase).
+      constexpr int MB = 4, KB8 = 8;
+      for (int m0 = 0; m0 < a.m; m0 += MB) {
+        float gv[MB][WF_ROWS];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const int mm = m0 + b < a.m ? m0 + b : a.m - 1;
+#pragma unroll
+          for (int r = 0; r < WF_ROWS; ++r) {
+            const int c = tid + r * WF_THREADS;
+            gv[b][r] = c < a.n ? a.g_t[(size_t)mm * a.n_pad + c] : 0.f;
+          }
+        }
+        float v[MB * KB8];
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+          for (int kk = 0; kk < KB8; ++kk) {
+            float t = 0.f;
+            if (kk < KA) {
+#pragma unroll
+              for (int r = 0; r < WF_ROWS; ++r) t = fmaf(gv[b][r], av[r][kk < KA ? kk : 0], t);
+            }
+            v[b * KB8 + kk] = t;
+          }
+        butterfly_half<32>(v, (lane & 32) != 0, 32);
+        butterfly_half<16>(v, (lane & 16) != 0, 16);
+        butterfly_half<8>(v, (lane & 8) != 0, 8);
+        butterfly_half<4>(v, (lane & 4) != 0, 4);
+        butterfly_half<2>(v, (lane & 2) != 0, 2);
+        const float total = v[0] + __shfl_xor(v[0], 1, 64);
+        const int idx = (lane >> 1) & 31, b = idx >> 3, kk = idx & 7;  // the (row, component) this lane pair ended up with
+        if (!(lane & 1) && m0 + b < a.m && kk < k) s_part[wave * MK + (m0 + b) * k + kk] = total;
+      }
+      __syncthreads();
+      for (int o = tid; o < MK; o += WF_THREADS) {
+        float t = 0.f;
+        for (int w = 0; w < WF_THREADS / 64; ++w) t += s_part[w * MK + o];
+        s_gta[o] = t;
+      }
+      __syncthreads();
+    } else if (a.g) {  // no transposed copy: one wave per (mm, kk), G read with a stride of m
       for (int o = wave; o < MK; o += WF_THREADS / 64) {
         const int mm = o / k, kk = o - mm * k;
         float sacc = 0.f;
@@ -314,11 +382,22 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
 #pragma unroll
       for (int kk = 0; kk < KA; ++kk) row[kk] = 0.f;
       if (c < a.n) {
-        for (int mm = 0; mm < a.m; ++mm) {
-          const float gv = a.g[(size_t)c * a.m + mm];
+        constexpr int MB = 8;  // entries of the G row requested together
+        for (int m0 = 0; m0 < a.m; m0 += MB) {
+          float gv[MB];
 #pragma unroll
-          for (int kk = 0; kk < KA; ++kk)
-            if (kk < k) row[kk] = fmaf(gv, s_w[mm * k + kk], row[kk]);
+          for (int b = 0; b < MB; ++b) {
+            const int mm = m0 + b < a.m ? m0 + b : a.m - 1;
+            gv[b] = a.g_t ? a.g_t[(size_t)mm * a.n_pad + c] : a.g[(size_t)c * a.m + mm];
+          }
+#pragma unroll
+          for (int b = 0; b < MB; ++b) {
+            if (m0 + b < a.m) {
+#pragma unroll
+              for (int kk = 0; kk < KA; ++kk)
+                if (kk < k) row[kk] = fmaf(gv[b], s_w[(m0 + b) * k + kk], row[kk]);
+            }
+          }
         }
       }
       emit_row(c, row);
@@ -535,7 +614,7 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int span = M > args.n_cm ? M : args.n_cm;
   const int rows = (span + WF_THREADS - 1) / WF_THREADS;
   if (rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
-    const size_t lds = args.g ? (size_t)mk * sizeof(float) * 2 : 0;
+    const size_t lds = args.g ? (size_t)mk * sizeof(float) * (2 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0)) : 0;
     switch (args.k) {
       case 1: launch_fast<1>(args, rows, lds, stream); break;
       case 2: launch_fast<2>(args, rows, lds, stream); break;

@@ -191,10 +191,12 @@ class MUEngine:
                 raise ValueError(f"G must be (n={self.n}, m), got {Gh.shape}")
             self.m = Gh.shape[1]
             self.g = torch.from_numpy(Gh).to(dev)
+            self.g_t = torch.zeros((self.m, st.n_pad), dtype=torch.float32, device=dev)   # coalesced reads in the W finish
+            self.g_t[:, :self.n] = self.g.t()
             self.colsum_g = torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)).to(dev)
             st.m = self.m
         else:
-            self.m, self.g, self.colsum_g = 0, None, None
+            self.m, self.g, self.colsum_g, self.g_t = 0, None, None, None
             st.m = 0
         self.M = self.m if self.m > 0 else self.n
 
@@ -251,6 +253,7 @@ class MUEngine:
             st.ell_w, st.ell_w_off, st.chan_perm = (self.ell[key].data_ptr() for key in ("ell_w", "ell_w_off", "chan_perm"))
             st.pix_perm = self.ell["pix_perm"].data_ptr()
         st.g = self.g.data_ptr() if self.g is not None else None
+        st.g_t = self.g_t.data_ptr() if self.g_t is not None else None
         st.colsum_g = self.colsum_g.data_ptr() if self.colsum_g is not None else None
         st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()
         st.h[0], st.h[1] = self.h[0].data_ptr(), self.h[1].data_ptr()
@@ -345,6 +348,7 @@ class MUEngine:
         if Gh.shape != (self.n, self.m):
             raise ValueError(f"G must stay {(self.n, self.m)}, got {Gh.shape}")
         self.g.copy_(torch.from_numpy(Gh))
+        self.g_t[:, :self.n] = self.g.t()
         self.colsum_g.copy_(torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)))
         check(lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
 

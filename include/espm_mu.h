@@ -175,6 +175,8 @@ typedef struct espm_mu_state {
   int32_t ell_cbits;        /* index bits of an H-step entry: 2^ell_cbits >= n, <= 14 */
   int32_t n_cg;             /* channel groups: ceil(n / 64) */
   const int32_t* pix_perm;  /* (p_pad): slot -> pixel offset inside its tile_px window (H-step lists) */
+  const float* g_t;         /* optional (m, n_pad): G transposed, zero padded; the W finish then reads G with
+                               coalesced loads (NULL: it reads g with a stride of m) */
 } espm_mu_state;
 
 const char* espm_mu_version(void);
