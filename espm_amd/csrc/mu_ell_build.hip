@@ -3,9 +3,12 @@
 // clarity: every list has ONE owner lane that walks its pixels / channels in order, so no cross-lane
 // bookkeeping is needed and the lists come out in ascending index order.
 //
-//   espm_mu_ell_count : entries per pixel list, entries per (pixel block, channel) list, the loss constant
-//   espm_mu_ell_plan  : list orders (channels per pixel block, pixels per window: decreasing length), row offsets, row totals
-//   espm_mu_ell_fill  : the entries
+//   espm_mu_ell_count : entries and unit elements (count 1) per pixel list and per (pixel block, channel) list, the loss constant
+//   espm_mu_ell_plan  : list orders (channels per pixel block, pixels per window: decreasing length), row offsets
+//                       (two per group: first unit row, first general row), row totals
+//   espm_mu_ell_fill  : the entries.  Unit rows of a group: ESPM_ELL_UNIT_ROWS * floor(min over its 64 lists of the
+//                       unit elements / (2 ESPM_ELL_UNIT_ROWS)); a list's first 2 * (unit rows) elements with
+//                       count 1 go there as index << 4, everything else to the general rows.
 #include "mu_common.hpp"
 
 namespace espm {
@@ -14,10 +17,11 @@ __device__ __forceinline__ int ell_reps(int x, int xmax) { return (x + xmax - 1)
 
 // lane = pixel: walks the pixel's row of the (p, n_pad) 8-bit matrix
 __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
-                                                          int xmax, int32_t* __restrict__ cnt_px, float* __restrict__ klc) {
+                                                          int xmax, int unit_ok, int32_t* __restrict__ cnt_px,
+                                                          float* __restrict__ klc) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= p_pad) return;
-  int cnt = 0;
+  int cnt = 0, ones = 0;
   double corr = 0.0;
   if (q < p) {
     const uint8_t* row = x_pm + (size_t)q * n_pad;
@@ -27,6 +31,7 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
       if (x == 0) continue;
       const int r = ell_reps(x, xmax);
       cnt += r;
+      ones += x == 1;
       if (r > 1) {  // x log2 x - sum over its entries of x_i log2 x_i
         const int rest = x - (r - 1) * xmax;
         corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
@@ -34,6 +39,7 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
     }
   }
   cnt_px[q] = cnt;
+  cnt_px[p_pad + q] = unit_ok ? ones : 0;
   klc[q] = (float)corr;
 }
 
@@ -42,25 +48,30 @@ __global__ __launch_bounds__(256) void ell_count_w_kernel(const uint8_t* __restr
                                                           int xmax, int32_t* __restrict__ cnt_bc) {
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= ncol) return;
-  int cnt = 0;
+  int cnt = 0, ones = 0;
   if (c < n) {
     const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
     for (int q = q0; q < q1; ++q) {
       const int x = x_pm[(size_t)q * n_pad + c];
       if (x) cnt += ell_reps(x, xmax);
+      ones += x == 1;
     }
   }
   cnt_bc[(size_t)b * ncol + c] = cnt;
+  cnt_bc[((size_t)gridDim.x + b) * ncol + c] = ones;
 }
 
-// exclusive scan of `count` values produced by f(i) into out[0..count], one workgroup of 1024 threads
+// Row offsets of `count` list groups, one workgroup of 1024 threads: f(i, unit) returns the rows of group i and sets
+// the unit rows among them; out[2 i] = first (unit) row, out[2 i + 1] = first general row, out[2 count] = all rows.
 template <typename F>
 __device__ void block_scan_rows(int count, int32_t* out, long long* total, long long* s_sums, F f) {
   const int t = threadIdx.x, nt = blockDim.x;
   const int chunk = (count + nt - 1) / nt;
   const int i0 = min(count, t * chunk), i1 = min(count, i0 + chunk);
+  auto clamp31 = [](long long v) { return (int32_t)(v < 0x7fffffffLL ? v : 0x7fffffffLL); };
   long long s = 0;
-  for (int i = i0; i < i1; ++i) s += f(i);
+  int unit = 0;
+  for (int i = i0; i < i1; ++i) s += f(i, unit);
   s_sums[t] = s;
   __syncthreads();
   if (t == 0) {
@@ -71,13 +82,15 @@ __device__ void block_scan_rows(int count, int32_t* out, long long* total, long 
       run += v;
     }
     *total = run;
-    out[count] = (int32_t)(run < 0x7fffffffLL ? run : 0x7fffffffLL);
+    out[2 * count] = clamp31(run);
   }
   __syncthreads();
   long long run = s_sums[t];
   for (int i = i0; i < i1; ++i) {
-    out[i] = (int32_t)(run < 0x7fffffffLL ? run : 0x7fffffffLL);
-    run += f(i);
+    const long long rows = f(i, unit);
+    out[2 * i] = clamp31(run);
+    out[2 * i + 1] = clamp31(run + unit);
+    run += rows;
   }
   __syncthreads();
 }
@@ -109,29 +122,44 @@ __global__ __launch_bounds__(1024) void ell_order_kernel(const int32_t* __restri
   }
 }
 
+// rows of a group whose longest list has m entries and whose poorest list has u unit elements
+__device__ __forceinline__ long long ell_group_rows(int m, int u, int& unit) {
+  unit = u / (2 * ESPM_ELL_UNIT_ROWS) * ESPM_ELL_UNIT_ROWS;
+  return (long long)unit + (m - 2 * unit + 1) / 2;
+}
+
 __global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc,
                                                            int n_cg, int nblk, int ngrp, int win,
                                                            const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ pix_perm,
                                                            int32_t* __restrict__ h_off, int32_t* __restrict__ w_off,
                                                            long long* __restrict__ rows) {
   __shared__ long long s_sums[1024];
-  const int ncol = n_cg * 64;
-  // H lists: rows of slot group g = ceil(max entries of its 64 slots / 2)
-  block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g) {
+  const int ncol = n_cg * 64, p_pad = ngrp * 64;
+  // H lists of slot group g
+  block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g, int& unit) {
     const int w0 = (g * 64) / win * win;
-    int m = 0;
-    for (int l = 0; l < 64; ++l) m = max(m, cnt_px[w0 + pix_perm[g * 64 + l]]);
-    return (long long)((m + 1) / 2);
+    int m = 0, u = 0x7fffffff;
+    for (int l = 0; l < 64; ++l) {
+      const int q = w0 + pix_perm[g * 64 + l];
+      m = max(m, cnt_px[q]);
+      u = min(u, cnt_px[p_pad + q]);
+    }
+    return ell_group_rows(m, u, unit);
   });
-  // W lists: rows of (block, channel group) = ceil(max entries of its 64 channels / 2)
-  block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i) {
+  // W lists of (block, channel group)
+  block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i, int& unit) {
     const int b = i / n_cg;
-    int m = 0;
+    int m = 0, u = 0x7fffffff;
     for (int l = 0; l < 64; ++l) {
       const int c = chan_perm[(size_t)i * 64 + l];
-      if (c >= 0) m = max(m, cnt_bc[(size_t)b * ncol + c]);
+      if (c >= 0) {
+        m = max(m, cnt_bc[(size_t)b * ncol + c]);
+        u = min(u, cnt_bc[((size_t)nblk + b) * ncol + c]);
+      } else {
+        u = 0;
+      }
     }
-    return (long long)((m + 1) / 2);
+    return ell_group_rows(m, u, unit);
   });
 }
 
@@ -149,15 +177,20 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
   if (q >= p) return;
   const int xmax = (1 << (16 - cbits)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_h);
-  const size_t row0 = (size_t)h_off[slot >> 6];
+  const size_t row0 = (size_t)h_off[2 * (slot >> 6)], row1 = (size_t)h_off[2 * (slot >> 6) + 1];
+  const int units = 2 * (int)(row1 - row0);
   const int lane = slot & 63;
   const uint8_t* row = x_pm + (size_t)q * n_pad;
-  int j = 0;
+  int j = 0, ju = 0;
   for (int c = 0; c < n; ++c) {
     int x = row[c];
+    if (x == 1 && ju < units) {
+      ell_put(base16, row0, ju++, lane, (uint32_t)c << 4);
+      continue;
+    }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;
-      ell_put(base16, row0, j++, lane, ((uint32_t)v << cbits) | (uint32_t)c);
+      ell_put(base16, row1, j++, lane, ((uint32_t)v << cbits) | (uint32_t)c);
       x -= v;
     }
   }
@@ -172,14 +205,19 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
   if (c < 0) return;
   constexpr int xmax = (1 << (16 - ESPM_ELL_PBITS)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_w);
-  const size_t row0 = (size_t)w_off[(size_t)b * n_cg + cg];
+  const size_t row0 = (size_t)w_off[2 * ((size_t)b * n_cg + cg)], row1 = (size_t)w_off[2 * ((size_t)b * n_cg + cg) + 1];
+  const int units = 2 * (int)(row1 - row0);
   const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
-  int j = 0;
+  int j = 0, ju = 0;
   for (int q = q0; q < q1; ++q) {
     int x = x_pm[(size_t)q * n_pad + c];
+    if (x == 1 && ju < units) {
+      ell_put(base16, row0, ju++, lane, (uint32_t)(q - q0) << 4);
+      continue;
+    }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;
-      ell_put(base16, row0, j++, lane, ((uint32_t)v << ESPM_ELL_PBITS) | (uint32_t)(q - q0));
+      ell_put(base16, row1, j++, lane, ((uint32_t)v << ESPM_ELL_PBITS) | (uint32_t)(q - q0));
       x -= v;
     }
   }
@@ -188,8 +226,9 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
   const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ESPM_ELL_PBITS)) - 1;
+  // a unit entry holds index << 4 in 16 bits
   hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
-                     cnt_px, klc);
+                     n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc);
   hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p,
                      n_cg * 64, xmax_w, cnt_bc);
   return check_hip(hipGetLastError(), "ell_count launch");

@@ -21,6 +21,13 @@
 // channel / pixel; the loss term is accumulated per entry as x_i log2(x_i / Y) (well conditioned, like the dense
 // kernels) and the per-pixel constant  sum x log2 x - sum_i x_i log2 x_i  of the split counts is added at the end.
 //
+// Nine in ten non-zero entries of a count image are ONES.  The rows of a 64-list group therefore come in two
+// segments: first the UNIT rows - every lane holds an entry with count 1 in every position, stored as the byte
+// offset of its table row (index << 4), no count field, no padding: two vector instructions decode an entry,
+// x = 1 drops the multiply and the padding guard - then the general rows described above, which take the rest
+// (counts > 1, the ones beyond the shortest run of ones among the 64 lanes, padding).  The offsets array has
+// two words per group: [first unit row, first general row], and the end of the last group.
+//
 // Bounds: the lists are read once per launch at HBM rate; per entry the LDS serves one 16- or
 // 20..32-byte gather, which is the second limit (random rows: ~3-way bank conflicts inside a 16-lane group).
 #pragma once
@@ -30,35 +37,65 @@ namespace espm {
 
 // LDS table of rows of K floats: components 0..3 as float4 (ds_read_b128 at a 16-byte stride: the 16 lanes of
 // a read group spread over all 16 bank quads), components 4.. in a second array of 1, 2 or 4 floats per row.
+// The second array comes FIRST: with the table at the start of the workgroup's LDS a unit entry (byte offset of
+// the float4 row) addresses it as entry >> 2 (or >> 1, >> 0) without adding a base.
+typedef float lds_v4f __attribute__((ext_vector_type(4)));
+typedef float lds_v2f __attribute__((ext_vector_type(2)));
+#define ESPM_LDS(T) __attribute__((address_space(3))) const T*
+__device__ __forceinline__ uint32_t lds_address(const float* ptr) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)ptr;
+}
+// The kernels below have no static LDS, so their dynamic LDS (the table) starts at address 0; the unit-entry
+// decode relies on it and every kernel checks it once.
+__device__ __forceinline__ void ell_table_at_lds_zero(const float* tab) {
+  if (lds_address(tab) != 0u) __builtin_trap();
+}
 template <int K>
 struct EllTab {
   static constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : 4));
   static constexpr int FLOATS = 4 + WB;
+  static __device__ __forceinline__ const float* quad(const float* tab, int rows) { return tab + (size_t)WB * rows; }
   // row r from 8 consecutive floats (the KP-strided gw_s / h_t rows)
   static __device__ __forceinline__ void put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
-    reinterpret_cast<float4*>(tab)[r] = lo;
-    float* tb = tab + 4 * (size_t)rows;
-    if constexpr (WB == 1) tb[r] = hi.x;
-    if constexpr (WB == 2) reinterpret_cast<float2*>(tb)[r] = make_float2(hi.x, hi.y);
-    if constexpr (WB == 4) reinterpret_cast<float4*>(tb)[r] = hi;
+    reinterpret_cast<float4*>(tab + (size_t)WB * rows)[r] = lo;
+    if constexpr (WB == 1) tab[r] = hi.x;
+    if constexpr (WB == 2) reinterpret_cast<float2*>(tab)[r] = make_float2(hi.x, hi.y);
+    if constexpr (WB == 4) reinterpret_cast<float4*>(tab)[r] = hi;
   }
   static __device__ __forceinline__ void get(const float* tab, int rows, uint32_t r, float (&g)[K]) {
-    const float4 lo = reinterpret_cast<const float4*>(tab)[r];
+    const float4 lo = reinterpret_cast<const float4*>(quad(tab, rows))[r];
     const float l[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
     for (int i = 0; i < (K < 4 ? K : 4); ++i) g[i] = l[i];
-    const float* tb = tab + 4 * (size_t)rows;
-    if constexpr (WB == 1) g[4] = tb[r];
+    if constexpr (WB == 1) g[4] = tab[r];
     if constexpr (WB == 2) {
-      const float2 v = reinterpret_cast<const float2*>(tb)[r];
+      const float2 v = reinterpret_cast<const float2*>(tab)[r];
       g[4] = v.x;
       g[5] = v.y;
     }
     if constexpr (WB == 4) {
-      const float4 v = reinterpret_cast<const float4*>(tb)[r];
+      const float4 v = reinterpret_cast<const float4*>(tab)[r];
       const float h[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int i = 4; i < K; ++i) g[i] = h[i - 4];
+    }
+  }
+  // unit entry: off = 16 * row.  The table sits at LDS address 0 (ell_table_at_lds_zero), lds_q = LDS address of its
+  // float4 part: the address of the second array is a shift of the entry, with no base to add.
+  static __device__ __forceinline__ void get_unit(uint32_t lds_q, uint32_t off, float (&g)[K]) {
+    const lds_v4f lo = *(ESPM_LDS(lds_v4f))(lds_q + off);
+#pragma unroll
+    for (int i = 0; i < (K < 4 ? K : 4); ++i) g[i] = lo[i];
+    if constexpr (WB == 1) g[4] = *(ESPM_LDS(float))(off >> 2);
+    if constexpr (WB == 2) {
+      const lds_v2f v = *(ESPM_LDS(lds_v2f))(off >> 1);
+      g[4] = v[0];
+      g[5] = v[1];
+    }
+    if constexpr (WB == 4) {
+      const lds_v4f v = *(ESPM_LDS(lds_v4f))(off);
+#pragma unroll
+      for (int i = 4; i < K; ++i) g[i] = v[i - 4];
     }
   }
 };
@@ -91,23 +128,19 @@ __device__ __forceinline__ void ell_axpy(float (&acc)[K], const float (&g)[K], f
 
 // Walks the `len` dwords (two 16-bit entries each) of this lane's list; `row` points at the lane's first
 // dword, consecutive dwords are 64 apart.  UNR dwords are requested one batch ahead of their use and the
-// 2 UNR table gathers of a batch are issued together.  body(index, count, table row) consumes one entry.
-template <int K, int UNR, typename Body>
-__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, const float* tab, int tab_rows, int idx_bits,
-                                         Body body) {
-  const uint32_t mask = (1u << idx_bits) - 1u;
+// 2 UNR table gathers of a batch are issued together.  get(dword, half, g) gathers the table row of entry
+// `half` of the dword into g and returns the entry's count; body(count, g) consumes one entry.
+template <int K, int UNR, typename Get, typename Body>
+__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body) {
   auto batch = [&](const uint32_t (&e)[UNR]) {
-    float g[2 * UNR][K];
+    float g[2 * UNR][K], x[2 * UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      EllTab<K>::get(tab, tab_rows, e[u] & mask, g[2 * u]);
-      EllTab<K>::get(tab, tab_rows, (e[u] >> 16) & mask, g[2 * u + 1]);
+      x[2 * u] = get(e[u], 0, g[2 * u]);
+      x[2 * u + 1] = get(e[u], 1, g[2 * u + 1]);
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      body((float)((e[u] & 0xffffu) >> idx_bits), g[2 * u]);
-      body((float)(e[u] >> (16 + idx_bits)), g[2 * u + 1]);
-    }
+    for (int u = 0; u < 2 * UNR; ++u) body(x[u], g[u]);
   };
   int j = 0;
   if (len >= UNR) {
@@ -126,12 +159,34 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, const flo
   for (; j < len; ++j) {
     const uint32_t v = row[(size_t)j * 64];
     float g0[K], g1[K];
-    EllTab<K>::get(tab, tab_rows, v & mask, g0);
-    EllTab<K>::get(tab, tab_rows, (v >> 16) & mask, g1);
-    body((float)((v & 0xffffu) >> idx_bits), g0);
-    body((float)(v >> (16 + idx_bits)), g1);
+    const float x0 = get(v, 0, g0), x1 = get(v, 1, g1);
+    body(x0, g0);
+    body(x1, g1);
   }
 }
+// general entries: count << idx_bits | index
+template <int K>
+struct EllGet {
+  const float* tab;
+  int rows, idx_bits;
+  uint32_t mask;
+  __device__ __forceinline__ EllGet(const float* t, int r, int bits) : tab(t), rows(r), idx_bits(bits), mask((1u << bits) - 1u) {}
+  __device__ __forceinline__ float operator()(uint32_t e, int half, float (&g)[K]) const {
+    const uint32_t v = half ? e >> 16 : e & 0xffffu;
+    EllTab<K>::get(tab, rows, v & mask, g);
+    return (float)(v >> idx_bits);
+  }
+};
+// unit entries: byte offset of the float4 row, count 1
+template <int K>
+struct EllGetUnit {
+  uint32_t lds_q;
+  __device__ __forceinline__ EllGetUnit(int rows) : lds_q((uint32_t)(EllTab<K>::WB * rows) * 4u) {}
+  __device__ __forceinline__ float operator()(uint32_t e, int half, float (&g)[K]) const {
+    EllTab<K>::get_unit(lds_q, half ? e >> 16 : e & 0xffffu, g);
+    return 1.f;
+  }
+};
 
 // ---- H-step --------------------------------------------------------------------------------------
 // One workgroup = 8 waves = TP = 512 / nsplit pixels: every 64-pixel list group is walked by `nsplit` waves,
@@ -144,6 +199,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
   constexpr int NT = ESPM_ELL_TILE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;                                          // [n_pad] rows of GW
+  ell_table_at_lds_zero(tab);
   float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [nsplit][K][TP] numerators, then reduction scratch
   for (int r = threadIdx.x; r < a.n_pad; r += NT) {
     const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
@@ -169,15 +225,27 @@ __global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepAr
     acc[kk] = 0.f;
   }
   float kl = 0.f;
-  const int beg = a.ell_off[grp], len = a.ell_off[grp + 1] - beg;
+  // rows [beg, mid): unit entries, [mid, end): general entries; this wave takes rows [r0, r1) of the group
+  const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg, len = a.ell_off[2 * grp + 2] - beg;
   const int r0 = (int)((long)len * si / nsplit), r1 = (int)((long)len * (si + 1) / nsplit);
-  ell_walk<K, UNR>(a.ell + (size_t)(beg + r0) * 64 + lane, r1 - r0, tab, a.n_pad, a.ell_bits, [&](float x, const float (&g)[K]) {
-    const float y = ell_dot<K>(g, hk);
-    // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
-    const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-    ell_axpy<K>(acc, g, r);
-    if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-  });
+  const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
+  if (r0 < mid) {
+    ell_walk<K, UNR>(lrow + (size_t)r0 * 64, min(r1, mid) - r0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
+      const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+      ell_axpy<K>(acc, g, r);
+      if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
+    });
+  }
+  if (r1 > mid) {
+    const int g0 = max(r0, mid);
+    ell_walk<K, UNR>(lrow + (size_t)g0 * 64, r1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
+      const float y = ell_dot<K>(g, hk);
+      // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+      const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+      ell_axpy<K>(acc, g, r);
+      if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+    });
+  }
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) part[((size_t)si * K + kk) * TP + lp] = acc[kk];
   if (LOSS && si == 0) kl += a.ell_klc[px];
@@ -195,6 +263,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WA
   constexpr int PB = ESPM_ELL_PB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;  // [PB] columns of H
+  ell_table_at_lds_zero(tab);
   const int b = blockIdx.x, y = blockIdx.y, csplit = gridDim.y;
   const int nw = (int)blockDim.x >> 6;
   for (int r = threadIdx.x; r < PB; r += (int)blockDim.x) {
@@ -223,8 +292,13 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WA
       gw[kk] = gsrc[kk];
       acc[kk] = 0.f;
     }
-    const int beg = a.ell_off[(size_t)b * a.n_cg + cg], end = a.ell_off[(size_t)b * a.n_cg + cg + 1];
-    ell_walk<K, UNR>(a.ell + (size_t)beg * 64 + lane, end - beg, tab, PB, ESPM_ELL_PBITS, [&](float x, const float (&h)[K]) {
+    const int32_t* off = a.ell_off + 2 * ((size_t)b * a.n_cg + cg);
+    const int beg = off[0], mid = off[1], end = off[2];
+    const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
+    ell_walk<K, UNR>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+      ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
+    });
+    ell_walk<K, UNR>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, ESPM_ELL_PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });

@@ -11,6 +11,9 @@ Layout (see the header for the authoritative description): 16-bit entries, two p
                 pixel; the channels of a wave are 64 consecutive entries of ``chan_perm[block]`` (the block's
                 channels by decreasing list length).
 A count larger than its field is split over several entries.
+Every list group (64 lists) starts with UNIT rows: entries with count 1 stored as index << 4, in every lane and
+position, as many as the group's poorest list has ones (rounded down to a multiple of 2 ELL_UNIT_ROWS entries); the
+general rows (count << bits | index) follow.  The offsets carry two words per group.
 """
 from __future__ import annotations
 
@@ -47,17 +50,68 @@ def _store16(ell16, dword, half, value):
 
 
 def count_entries(Xpm, xmax_h, xmax_w, chunk=16384):
-    """(entries per pixel for the H lists, entries per channel for the W lists, non-zeros) of the (p, n) image."""
+    """(entries per pixel of the H lists, elements equal to 1 per pixel, entries per channel of the W lists,
+    non-zeros) of the (p, n) image."""
     p, n = Xpm.shape
     per_px = torch.empty(p, dtype=torch.int64, device=Xpm.device)
+    ones_px = torch.empty(p, dtype=torch.int64, device=Xpm.device)
     per_ch = torch.zeros(n, dtype=torch.int64, device=Xpm.device)
     nnz = 0
     for q0 in range(0, p, chunk):
         xi = Xpm[q0:q0 + chunk].to(torch.int32)
         per_px[q0:q0 + chunk] = _split_counts(xi, xmax_h).sum(dim=1)
+        ones_px[q0:q0 + chunk] = (xi == 1).sum(dim=1)
         per_ch += _split_counts(xi, xmax_w).sum(dim=0)
         nnz += int((xi != 0).sum())
-    return per_px, per_ch, nnz
+    return per_px, ones_px, per_ch, nnz
+
+
+def _group_rows(longest, fewest_ones):
+    """(unit rows, general rows) of list groups whose longest list has `longest` entries and whose poorest list
+    has `fewest_ones` elements equal to 1 (espm_mu.h: UNIT rows)."""
+    ub = _lib.ELL_UNIT_ROWS
+    unit = fewest_ones // (2 * ub) * ub
+    return unit, (longest - 2 * unit + 1) // 2
+
+
+def _offsets(unit, general):
+    """[first unit row, first general row] per group and the end of the last group."""
+    rows = unit + general
+    first = torch.cumsum(rows, 0) - rows
+    off = torch.empty(2 * rows.numel() + 1, dtype=torch.int64, device=rows.device)
+    off[0:-1:2] = first
+    off[1::2] = first + unit
+    off[-1] = rows.sum()
+    return off
+
+
+def _scatter_lists(ell16, major, minor, x, n_major, unit_cap, row_unit, row_general, lane, xmax, idx_bits):
+    """Writes the entries of the elements (major, minor, x) - sorted by major, then minor; x > 0 - of n_major lists.
+
+    List i may place its first unit_cap[i] elements equal to 1 into the unit rows that start at row_unit[i] (as
+    minor << 4); everything else goes to the general rows from row_general[i] (as count << idx_bits | minor, counts
+    above xmax split); lane[i] is the list's lane."""
+    dev = x.device
+    if x.numel() == 0:
+        return
+    is_one = (x == 1).to(torch.int64)
+    nz_per = torch.bincount(major, minlength=n_major)
+    first_el = torch.cumsum(nz_per, 0) - nz_per                   # first element of each list
+    ones_before = torch.cumsum(is_one, 0) - is_one
+    rank_one = ones_before - ones_before[first_el.clamp_max(x.numel() - 1)][major]   # rank among the list's ones
+    in_unit = (is_one == 1) & (rank_one < unit_cap[major])
+    mu, ju = major[in_unit], rank_one[in_unit]
+    _store16(ell16, (row_unit[mu] + (ju >> 1)) * 64 + lane[mu], ju & 1, minor[in_unit] << 4)
+    rest = ~in_unit
+    mg, cg, xg = major[rest], minor[rest], x[rest]
+    if mg.numel() == 0:
+        return
+    reps = _split_counts(xg, xmax)
+    mg, cg, val = _expand(mg, cg, xg, reps, xmax)
+    ent_per = torch.bincount(mg, minlength=n_major)
+    first_ent = torch.cumsum(ent_per, 0) - ent_per
+    j = torch.arange(mg.numel(), device=dev) - first_ent[mg]
+    _store16(ell16, (row_general[mg] + (j >> 1)) * 64 + lane[mg], j & 1, (val << idx_bits) | cg)
 
 
 def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
@@ -65,7 +119,7 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
 
     Returns a dict of device tensors: ell_h (int32 dwords), ell_h_off (int32), klc (float32, p_pad), pix_perm (int32,
     p_pad), ell_w, ell_w_off, chan_perm (int32, nblk_w x 64 n_cg), and the python ints n_cg, nblk_w, nnz, entries_h,
-    entries_w, rows_h, rows_w."""
+    entries_w, rows_h, rows_w, unit_rows_h, unit_rows_w."""
     dev = Xpm.device
     p, n = Xpm.shape
     PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
@@ -75,12 +129,16 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
     nblk_w = (p + PB - 1) // PB
     i32 = dict(dtype=torch.int32, device=dev)
 
-    per_px, per_ch, nnz = count_entries(Xpm, xmax_h, xmax_w, chunk)
+    per_px, ones_px, per_ch, nnz = count_entries(Xpm, xmax_h, xmax_w, chunk)
+    if n > _lib.ELL_UNIT_MAX_N:       # index << 4 must fit 16 bits
+        ones_px = torch.zeros_like(ones_px)
 
     # ---- H lists ---------------------------------------------------------------------------------------
     ngrp = p_pad // 64
     cnt_pad = torch.zeros(p_pad, dtype=torch.int64, device=dev)
     cnt_pad[:p] = per_px
+    ones_pad = torch.zeros(p_pad, dtype=torch.int64, device=dev)
+    ones_pad[:p] = ones_px
     # inside every window of tile_px pixels: slots by decreasing list length (stable)
     pix_perm = torch.argsort(cnt_pad.view(-1, tile_px), dim=1, descending=True, stable=True)     # slot -> pixel offset
     win0 = (torch.arange(p_pad, device=dev) // tile_px) * tile_px
@@ -88,9 +146,9 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
     slot_of = torch.empty(p_pad, dtype=torch.int64, device=dev)
     slot_of[slot_pixel] = torch.arange(p_pad, device=dev)       # global pixel -> global slot
     glen = cnt_pad[slot_pixel].view(ngrp, 64).max(dim=1).values  # entries of the longest list of each slot group
-    grows = (glen + 1) // 2                                    # dword rows
-    h_off = torch.zeros(ngrp + 1, dtype=torch.int64, device=dev)
-    h_off[1:] = torch.cumsum(grows, 0)
+    gones = ones_pad[slot_pixel].view(ngrp, 64).min(dim=1).values
+    gunit, ggen = _group_rows(glen, gones)
+    h_off = _offsets(gunit, ggen)
     rows_h = int(h_off[-1])
     if rows_h * 64 >= 2 ** 31:
         raise ValueError("sparse count store: H lists exceed 2^31 dwords")
@@ -98,6 +156,7 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
     ell_h16 = ell_h.view(torch.int16)
     klc = torch.zeros(p_pad, dtype=torch.float32, device=dev)
     xm = float(xmax_h)
+    grp_of_px = slot_of >> 6                                   # pixel -> slot group
     for q0 in range(0, p, chunk):
         blk = Xpm[q0:q0 + chunk]
         xi = blk.to(torch.int64)
@@ -111,29 +170,27 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
         if nz.numel() == 0:
             continue
         q, c = nz[:, 0], nz[:, 1]
-        x = xi[q, c]
-        q, c, val = _expand(q, c, x, _split_counts(x, xmax_h), xmax_h)
-        cnt = per_px[q0:q0 + blk.shape[0]]
-        start = torch.cumsum(cnt, 0) - cnt                    # first entry of each pixel of the chunk
-        j = torch.arange(q.numel(), device=dev) - start[q]    # position in the pixel's list
-        slot = slot_of[q + q0]
-        dword = (h_off[slot >> 6] + (j >> 1)) * 64 + (slot & 63)
-        _store16(ell_h16, dword, j & 1, (val << cbits) | c)
+        g = grp_of_px[q0:q0 + blk.shape[0]]
+        _scatter_lists(ell_h16, q, c, xi[q, c], blk.shape[0], 2 * gunit[g], h_off[2 * g], h_off[2 * g + 1],
+                       slot_of[q0:q0 + blk.shape[0]] & 63, xmax_h, cbits)
 
     # ---- W lists ---------------------------------------------------------------------------------------
-    # pass 1: entries per (block, channel); inside every block the channels by decreasing list length (stable)
+    # pass 1: entries and ones per (block, channel); inside every block the channels by decreasing list length (stable)
     cnt_bc = torch.zeros((nblk_w, n), dtype=torch.int64, device=dev)
+    ones_bc = torch.zeros((nblk_w, n), dtype=torch.int64, device=dev)
     for b in range(nblk_w):
         xi = Xpm[b * PB:(b + 1) * PB].to(torch.int32)
         cnt_bc[b] = _split_counts(xi, xmax_w).sum(dim=0).to(torch.int64)
+        ones_bc[b] = (xi == 1).sum(dim=0)
     order = torch.argsort(cnt_bc, dim=1, descending=True, stable=True)     # (nblk_w, n): slot -> channel
     chan_perm = torch.full((nblk_w, n_cg * 64), -1, dtype=torch.int64, device=dev)
     chan_perm[:, :n] = order
     cnt_slot = torch.zeros((nblk_w, n_cg * 64), dtype=torch.int64, device=dev)
     cnt_slot[:, :n] = torch.gather(cnt_bc, 1, order)
-    wrows = (cnt_slot.view(nblk_w, n_cg, 64).max(dim=2).values + 1) // 2
-    w_off = torch.zeros(nblk_w * n_cg + 1, dtype=torch.int64, device=dev)
-    w_off[1:] = torch.cumsum(wrows.reshape(-1), 0)
+    ones_slot = torch.zeros((nblk_w, n_cg * 64), dtype=torch.int64, device=dev)   # a slot without a channel has no ones
+    ones_slot[:, :n] = torch.gather(ones_bc, 1, order)
+    wunit, wgen = _group_rows(cnt_slot.view(nblk_w, n_cg, 64).max(dim=2).values, ones_slot.view(nblk_w, n_cg, 64).min(dim=2).values)
+    w_off = _offsets(wunit.reshape(-1), wgen.reshape(-1))
     rows_w = int(w_off[-1])
     if rows_w * 64 >= 2 ** 31:
         raise ValueError("sparse count store: W lists exceed 2^31 dwords")
@@ -145,20 +202,16 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
         if nz.numel() == 0:
             continue
         c, pl = nz[:, 0], nz[:, 1]
-        x = xt[c, pl]
-        c, pl, val = _expand(c, pl, x, _split_counts(x, xmax_w), xmax_w)
-        cnt = cnt_bc[b]                                       # entries per channel (natural order)
-        start = torch.cumsum(cnt, 0) - cnt
-        j = torch.arange(c.numel(), device=dev) - start[c]
         slot_of_c = torch.empty(n, dtype=torch.int64, device=dev)
         slot_of_c[order[b]] = torch.arange(n, device=dev)
-        slot = slot_of_c[c]
-        dword = (w_off[b * n_cg + (slot >> 6)] + (j >> 1)) * 64 + (slot & 63)
-        _store16(ell_w16, dword, j & 1, (val << PBITS) | pl)
+        g = b * n_cg + (slot_of_c >> 6)                        # channel -> list group
+        _scatter_lists(ell_w16, c, pl, xt[c, pl], n, 2 * wunit.reshape(-1)[g], w_off[2 * g], w_off[2 * g + 1], slot_of_c & 63,
+                       xmax_w, PBITS)
 
     return dict(ell_h=ell_h, ell_h_off=h_off.to(torch.int32), klc=klc, pix_perm=pix_perm.reshape(-1).to(torch.int32), ell_w=ell_w, ell_w_off=w_off.to(torch.int32),
                 chan_perm=chan_perm.to(torch.int32), n_cg=n_cg, nblk_w=nblk_w, nnz=nnz,
-                entries_h=int(per_px.sum()), entries_w=int(per_ch.sum()), rows_h=rows_h, rows_w=rows_w)
+                entries_h=int(per_px.sum()), entries_w=int(per_ch.sum()), rows_h=rows_h, rows_w=rows_w,
+                unit_rows_h=int(gunit.sum()), unit_rows_w=int(wunit.sum()))
 
 
 def lds_bytes_h(n_pad, k):

@@ -287,14 +287,14 @@ class MUEngine:
         check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                  _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
                                  None, _ptr(x8), _lib.X_U8, st.n_pad, st.p_pad, _lib.PPAD, st.n_cm, _stream()))
-        cnt_px = torch.empty(st.p_pad, **i32)
-        cnt_bc = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
+        cnt_px = torch.empty((2, st.p_pad), **i32)                    # entries, elements equal to 1
+        cnt_bc = torch.empty((2, st.nblk_w, st.n_cg * 64), **i32)
         klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
         check(lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
         chan_perm = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
         pix_perm = torch.empty(st.p_pad, **i32)
-        h_off = torch.empty(st.p_pad // 64 + 1, **i32)
-        w_off = torch.empty(st.nblk_w * st.n_cg + 1, **i32)
+        h_off = torch.empty(2 * (st.p_pad // 64) + 1, **i32)          # per group: first unit row, first general row
+        w_off = torch.empty(2 * st.nblk_w * st.n_cg + 1, **i32)
         rows = torch.zeros(2, dtype=torch.int64, device=dev)
         check(lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off),
                                    _ptr(w_off), _ptr(rows), _stream()))
@@ -308,8 +308,9 @@ class MUEngine:
         nnz = int((x8[:, :self.n] != 0).sum())
         torch.cuda.current_stream().synchronize()
         return dict(ell_h=ell_h, ell_h_off=h_off, klc=klc, pix_perm=pix_perm, ell_w=ell_w, ell_w_off=w_off, chan_perm=chan_perm, n_cg=st.n_cg,
-                    nblk_w=st.nblk_w, nnz=nnz, entries_h=int(cnt_px.sum()), entries_w=int(cnt_bc.sum()), rows_h=rows_h,
-                    rows_w=rows_w)
+                    nblk_w=st.nblk_w, nnz=nnz, entries_h=int(cnt_px[0].sum()), entries_w=int(cnt_bc[0].sum()), rows_h=rows_h,
+                    rows_w=rows_w, unit_rows_h=int((h_off[1::2] - h_off[0:-1:2]).sum()),
+                    unit_rows_w=int((w_off[1::2] - w_off[0:-1:2]).sum()))
 
     def _pad_h(self, H):
         Hh = np.asarray(H, dtype=np.float32)

@@ -67,6 +67,8 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
 #define ESPM_ELL_PB 1024   /* sparse store: pixels per block of the W accumulation                          */
 #define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
+#define ESPM_ELL_UNIT_ROWS 4 /* sparse store: the unit rows of a list group are a multiple of this             */
+#define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
@@ -160,17 +162,24 @@ typedef struct espm_mu_state {
    *           (the pixels of one H-step workgroup) the lists are ordered by decreasing length: slot s of the
    *           window starting at pixel w0 is pixel w0 + pix_perm[w0 + s], and the 64 lists of a wave are 64
    *           consecutive slots, so they have about the same length (little padding).  Rows
-   *           [ell_h_off[g], ell_h_off[g+1]) belong to slots 64 g .. 64 g + 63.
+   *           [ell_h_off[2 g], ell_h_off[2 g + 2]) belong to slots 64 g .. 64 g + 63.
    *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); inside block b the 64 lists of a wave are
    *           the channels chan_perm[b][64 cg .. 64 cg + 63] (the block's channels by decreasing list length,
    *           -1 = none); entry = count << ESPM_ELL_PBITS | pixel - block start; rows
-   *           [ell_w_off[b * n_cg + cg], ell_w_off[b * n_cg + cg + 1]).  nblk_w = ceil(p / ESPM_ELL_PB). */
+   *           [ell_w_off[2 i], ell_w_off[2 i + 2]) with i = b * n_cg + cg.  nblk_w = ceil(p / ESPM_ELL_PB).
+   *   UNIT rows: most non-zero entries of a count image are ones.  The first rows [off[2 i], off[2 i + 1]) of
+   *           a group hold only entries with count 1, in EVERY lane and position (no padding), stored without a
+   *           count as index << 4 (the byte offset of a 16-byte table row): u = min over the 64 lists of their
+   *           elements equal to 1, unit rows = ESPM_ELL_UNIT_ROWS * floor(u / (2 ESPM_ELL_UNIT_ROWS)); a list's
+   *           first 2 * (unit rows) ones (ascending index) go there, all its other elements to the general rows
+   *           [off[2 i + 1], off[2 i + 2]) in the count << bits | index form.  H-step lists have unit rows only
+   *           when n <= ESPM_ELL_UNIT_MAX_N. */
   const uint32_t* ell_h;    /* (rows_h, 64) */
-  const int32_t* ell_h_off; /* (p_pad / 64 + 1) */
+  const int32_t* ell_h_off; /* (2 p_pad / 64 + 1) */
   const float* ell_klc;     /* (p_pad): loss correction of split counts per pixel: sum over the elements of
                                x log2 x minus the sum over their entries x_i of x_i log2 x_i (0 without splits) */
   const uint32_t* ell_w;    /* (rows_w, 64) */
-  const int32_t* ell_w_off; /* (nblk_w * n_cg + 1) */
+  const int32_t* ell_w_off; /* (2 nblk_w * n_cg + 1) */
   const int32_t* chan_perm; /* (nblk_w, 64 * n_cg) */
   int32_t ell_cbits;        /* index bits of an H-step entry: 2^ell_cbits >= n, <= 14 */
   int32_t n_cg;             /* channel groups: ceil(n / 64) */
@@ -194,10 +203,10 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
 /* Sparse count store (x_dtype = ESPM_X_ELL) from the dense pixel-major 8-bit matrix x_pm_u8 (p, n_pad) that
  * espm_mu_pack_x writes for x_dtype = ESPM_X_U8 (its x_cm argument may be NULL then).  `st` needs n, p, x_dtype =
  * ESPM_X_ELL and espm_mu_query.  Three steps, all buffers caller-allocated:
- *   count: cnt_px (p_pad) entries of each pixel's H-step list; cnt_bc (nblk_w, 64 n_cg) entries of each (pixel
- *          block, channel) W-step list (natural channel order); ell_klc (p_pad).
- *   plan : chan_perm (nblk_w, 64 n_cg), pix_perm (p_pad; windows of st->tile_px pixels), ell_h_off (p_pad / 64 + 1),
- *          ell_w_off (nblk_w n_cg + 1) and rows[2] (device):
+ *   count: cnt_px (2, p_pad) entries of each pixel's H-step list, then its elements equal to 1; cnt_bc (2, nblk_w,
+ *          64 n_cg) the same for each (pixel block, channel) W-step list (natural channel order); ell_klc (p_pad).
+ *   plan : chan_perm (nblk_w, 64 n_cg), pix_perm (p_pad; windows of st->tile_px pixels), ell_h_off (2 p_pad / 64 + 1),
+ *          ell_w_off (2 nblk_w n_cg + 1) and rows[2] (device):
  *          rows of 64 dwords of the H-step and of the W-step lists.  The caller reads rows[] back, checks
  *          64 rows < 2^31 and allocates ell_h (rows[0], 64) and ell_w (rows[1], 64), ZERO-initialised.
  *   fill : writes the entries.  The dense x_pm_u8 can be released afterwards. */

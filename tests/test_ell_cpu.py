@@ -9,39 +9,50 @@ import torch
 from espm_amd import _lib, ell
 
 
+def _decode_group(X_rows, words, off, i, bits, row_of_lane):
+    """Adds the entries of list group i (unit rows, then general rows) to X_rows[row_of_lane(lane)][index].
+    Returns the group's (unit rows, general rows)."""
+    unit = words[off[2 * i] * 64:off[2 * i + 1] * 64].reshape(-1, 64)
+    gen = words[off[2 * i + 1] * 64:off[2 * i + 2] * 64].reshape(-1, 64)
+    for half in (0, 1):
+        u = (unit >> (16 * half)) & 0xFFFF
+        assert not (u & 15).any()                      # index << 4, count 1 implied
+        ent = (gen >> (16 * half)) & 0xFFFF
+        cnt, idx = ent >> bits, ent & ((1 << bits) - 1)
+        for lane in range(64):
+            tgt = row_of_lane(lane)
+            if tgt is None:
+                assert not cnt[:, lane].any() and unit.shape[0] == 0
+                continue
+            np.add.at(tgt, u[:, lane] >> 4, 1)
+            np.add.at(tgt, idx[:, lane], cnt[:, lane])
+    return unit.shape[0], gen.shape[0]
+
+
 def decode(store, p, n, p_pad, cbits, tile_px):
     PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
     eh = store["ell_h"].numpy().astype(np.int64) & 0xFFFFFFFF
     off = store["ell_h_off"].numpy()
+    assert off.shape == (2 * (p_pad // 64) + 1,)
     Xh = np.zeros((p_pad, n), dtype=np.int64)
     pix = store["pix_perm"].numpy()
+    rows_h = []
     for g in range(p_pad // 64):
-        rows = eh[off[g] * 64:off[g + 1] * 64].reshape(-1, 64)
-        for half in (0, 1):
-            ent = (rows >> (16 * half)) & 0xFFFF
-            cnt, c = ent >> cbits, ent & ((1 << cbits) - 1)
-            for lane in range(64):
-                slot = g * 64 + lane
-                np.add.at(Xh[slot // tile_px * tile_px + pix[slot]], c[:, lane], cnt[:, lane])
+        rows_h.append(_decode_group(None, eh, off, g, cbits,
+                                    lambda lane: Xh[(g * 64 + lane) // tile_px * tile_px + pix[g * 64 + lane]]))
     ew = store["ell_w"].numpy().astype(np.int64) & 0xFFFFFFFF
     woff = store["ell_w_off"].numpy()
     perm = store["chan_perm"].numpy()
     n_cg = store["n_cg"]
-    assert perm.shape == (store["nblk_w"], n_cg * 64)
-    Xw = np.zeros((store["nblk_w"] * PB, n), dtype=np.int64)
+    assert perm.shape == (store["nblk_w"], n_cg * 64) and woff.shape == (2 * store["nblk_w"] * n_cg + 1,)
+    XwT = np.zeros((store["nblk_w"], n, PB), dtype=np.int64)   # [block][channel][pixel of the block]
+    rows_w = []
     for b in range(store["nblk_w"]):
         for cg in range(n_cg):
-            rows = ew[woff[b * n_cg + cg] * 64:woff[b * n_cg + cg + 1] * 64].reshape(-1, 64)
-            for half in (0, 1):
-                ent = (rows >> (16 * half)) & 0xFFFF
-                cnt, pl = ent >> PBITS, ent & (PB - 1)
-                for lane in range(64):
-                    c = perm[b, cg * 64 + lane]
-                    if c < 0:
-                        assert not cnt[:, lane].any()
-                        continue
-                    np.add.at(Xw[b * PB:(b + 1) * PB, c], pl[:, lane], cnt[:, lane])
-    return Xh, Xw
+            rows_w.append(_decode_group(None, ew, woff, b * n_cg + cg, PBITS,
+                                        lambda lane: XwT[b, perm[b, cg * 64 + lane]] if perm[b, cg * 64 + lane] >= 0 else None))
+    Xw = XwT.transpose(0, 2, 1).reshape(store["nblk_w"] * PB, n)
+    return Xh, Xw, np.array(rows_h), np.array(rows_w)
 
 
 @pytest.mark.parametrize("n,p,rate,big,tile_px", [(100, 400, 0.3, False, 64), (1980, 1300, 0.2, True, 512), (70, 2049, 1.5, True, 128)])
@@ -54,7 +65,7 @@ def test_lists_decode_to_x(n, p, rate, big, tile_px):
     p_pad = (p + 511) // 512 * 512
     store = ell.build(torch.from_numpy(X), p_pad, cbits, tile_px, chunk=512)
     assert store["nnz"] == int((X != 0).sum())
-    Xh, Xw = decode(store, p, n, p_pad, cbits, tile_px)
+    Xh, Xw, rows_h, rows_w = decode(store, p, n, p_pad, cbits, tile_px)
     assert np.array_equal(Xh[:p], X.astype(np.int64)) and not Xh[p:].any()
     assert np.array_equal(Xw[:p], X.astype(np.int64)) and not Xw[p:].any()
     # loss correction of the split counts: sum x log2 x - sum over the entries of x_i log2 x_i, per pixel
@@ -80,4 +91,16 @@ def test_lists_decode_to_x(n, p, rate, big, tile_px):
     assert (np.sort(pix, axis=1) == np.arange(tile_px)).all()
     ent_slot = np.take_along_axis(ent.reshape(-1, tile_px), pix, axis=1)
     assert (np.diff(ent_slot, axis=1) <= 0).all()
-    assert np.array_equal(np.diff(store["ell_h_off"].numpy()), (ent_slot.reshape(-1, 64).max(axis=1) + 1) // 2)
+    # unit rows: as many entries as the poorest of the 64 lists has ones, in whole batches of ELL_UNIT_ROWS rows;
+    # general rows: what is left of the longest list
+    ub = _lib.ELL_UNIT_ROWS
+    ones = np.concatenate([(X == 1).sum(axis=1), np.zeros(p_pad - p, dtype=np.int64)])
+    ones_slot = np.take_along_axis(ones.reshape(-1, tile_px), pix, axis=1).reshape(-1, 64)
+    unit = ones_slot.min(axis=1) // (2 * ub) * ub
+    assert np.array_equal(rows_h[:, 0], unit)
+    assert np.array_equal(rows_h[:, 1], (ent_slot.reshape(-1, 64).max(axis=1) - 2 * unit + 1) // 2)
+    assert store["unit_rows_h"] == unit.sum() and store["rows_h"] == rows_h.sum()
+    assert store["unit_rows_w"] == rows_w[:, 0].sum() and store["rows_w"] == rows_w.sum()
+    assert (rows_w[:, 0] % ub == 0).all()
+    if rate < 1.0 and p >= 1024:
+        assert unit.sum() > 0 and rows_w[:, 0].sum() > 0   # the sparse cases do exercise the unit rows
