@@ -45,8 +45,7 @@ static int check_state(const espm_mu_state* st) {
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
   ESPM_REQUIRE(st->n_cm == roundup(st->n, ESPM_NCM), "n_cm must be roundup(n, %d)", ESPM_NCM);
-  ESPM_REQUIRE(st->h_variant == 0 || (st->gw_a && st->gw_p && st->tile_px == 128 && st->x_dtype != ESPM_X_F32),
-               "h_variant 1 needs gw_a, gw_p, tile_px = 128 and a 1- or 2-byte X store");
+  ESPM_REQUIRE(st->h_variant == 0, "h_variant %d is not built (the matrix-core H-step was retired, DESIGN.md)", st->h_variant);
   ESPM_REQUIRE(st->x_tile >= 64 && ESPM_PPAD % st->x_tile == 0 && st->x_tile % st->tile_px == 0,
                "x_tile=%d must divide %d and be a multiple of tile_px=%d", st->x_tile, ESPM_PPAD, st->tile_px);
   ESPM_REQUIRE(st->m >= 0, "m must be >= 0");
@@ -180,8 +179,8 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.scratch = st->w_scratch;
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
-  a.gw_a = st->h_variant ? st->gw_a : nullptr;  // only the matrix-core H-step consumes these
-  a.gw_p = st->h_variant ? st->gw_p : nullptr;
+  a.gw_a = nullptr;  // reserved (matrix-core H-step, retired)
+  a.gw_p = nullptr;
   a.n_cm = st->n_cm;
   a.hist_slot = (slot >= 0 && st->hist) ? st->hist + (size_t)slot * ESPM_HI_STRIDE : nullptr;
   a.n = st->n;
@@ -208,7 +207,7 @@ int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t 
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
   if (st->x_dtype == ESPM_X_ELL) return launch_h_ell(make_h_args(st, src, write_h), nblk_h(st), static_cast<hipStream_t>(stream));
-  return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->h_variant ? -128 : st->tile_px, nblk_h(st),
+  return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->tile_px, nblk_h(st),
                          static_cast<hipStream_t>(stream));
 }
 

@@ -22,7 +22,8 @@ template <int K>
 static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
   constexpr int UNR = ESPM_ELL_UNR_H;
   const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
-  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float);  // [nsplit][K][tile_px]: K * 512 floats whatever the split
+  // [nsplit][K][tile_px]: K * 512 floats whatever the split; two such sets when the groups of a 512-pixel window are walked in pairs
+  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
   if (red > part) part = red;
   const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
   if (args.compute_loss) {

@@ -33,6 +33,10 @@
 #pragma once
 #include "mu_h_kernel.hpp"
 
+#ifndef ESPM_ELL_AHEAD
+#define ESPM_ELL_AHEAD 1  // batches of list rows requested ahead of their use
+#endif
+
 namespace espm {
 
 // LDS table of rows of K floats: components 0..3 as float4 (ds_read_b128 at a 16-byte stride: the 16 lanes of
@@ -83,17 +87,17 @@ struct EllTab {
   // unit entry: off = 16 * row.  The table sits at LDS address 0 (ell_table_at_lds_zero), lds_q = LDS address of its
   // float4 part: the address of the second array is a shift of the entry, with no base to add.
   static __device__ __forceinline__ void get_unit(uint32_t lds_q, uint32_t off, float (&g)[K]) {
-    const lds_v4f lo = *(ESPM_LDS(lds_v4f))(lds_q + off);
+    const lds_v4f lo = *(ESPM_LDS(lds_v4f))(uintptr_t)(lds_q + off);
 #pragma unroll
     for (int i = 0; i < (K < 4 ? K : 4); ++i) g[i] = lo[i];
-    if constexpr (WB == 1) g[4] = *(ESPM_LDS(float))(off >> 2);
+    if constexpr (WB == 1) g[4] = *(ESPM_LDS(float))(uintptr_t)(off >> 2);
     if constexpr (WB == 2) {
-      const lds_v2f v = *(ESPM_LDS(lds_v2f))(off >> 1);
+      const lds_v2f v = *(ESPM_LDS(lds_v2f))(uintptr_t)(off >> 1);
       g[4] = v[0];
       g[5] = v[1];
     }
     if constexpr (WB == 4) {
-      const lds_v4f v = *(ESPM_LDS(lds_v4f))(off);
+      const lds_v4f v = *(ESPM_LDS(lds_v4f))(uintptr_t)(off);
 #pragma unroll
       for (int i = 4; i < K; ++i) g[i] = v[i - 4];
     }
@@ -144,6 +148,26 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
   };
   int j = 0;
   if (len >= UNR) {
+#if ESPM_ELL_AHEAD == 2
+    // two batches in flight per wave: the list stream is bound by the bytes in flight (latency), not by issue
+    uint32_t e[UNR], en[UNR], en2[UNR];
+    const int j1 = min(UNR, len - UNR);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) en[u] = row[(size_t)(j1 + u) * 64];
+    for (; j + UNR <= len; j += UNR) {
+      const int jn = min(j + 2 * UNR, len - UNR);  // the last batches re-request the final one (no branch, no overrun)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) en2[u] = row[(size_t)(jn + u) * 64];
+      batch(e);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        e[u] = en[u];
+        en[u] = en2[u];
+      }
+    }
+#else
     uint32_t e[UNR], en[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
@@ -155,6 +179,7 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
 #pragma unroll
       for (int u = 0; u < UNR; ++u) e[u] = en[u];
     }
+#endif
   }
   for (; j < len; ++j) {
     const uint32_t v = row[(size_t)j * 64];
@@ -189,67 +214,99 @@ struct EllGetUnit {
 };
 
 // ---- H-step --------------------------------------------------------------------------------------
-// One workgroup = 8 waves = TP = 512 / nsplit pixels: every 64-pixel list group is walked by `nsplit` waves,
-// each taking a contiguous slice of its rows (nsplit = 1 at the headline size; small images use 2, 4 or 8 so
-// that the grid still covers the chip).  updates.py:127-132 restricted to the non-zero entries of X; the
-// per-pixel epilogue (regularisers, simplex, clamp, statistics) is h_epilogue, which sums the nsplit partial
-// numerators.
+// One workgroup = 8 waves = TP = 512 / nsplit pixels.  updates.py:127-132 restricted to the non-zero entries of X;
+// the per-pixel epilogue (regularisers, simplex, clamp, statistics) is h_epilogue, which sums the partial
+// numerators of a pixel.
+//   TP = 512 (the headline size), k <= 6: the 8 list groups of the window are in order of decreasing length, so
+//     group w is paired with group 7 - w: wave w walks the first half of the pair's rows (all in group w), wave
+//     7 - w walks group 7 - w and then the rest of group w.  Every wave carries half a pair - without this the
+//     workgroup waits for the wave with the longest lists (+11 % at the headline size) - and a pixel has at
+//     most two partial numerators.
+//   otherwise every 64-pixel list group is walked by `nsplit` waves, each taking a contiguous slice of its rows
+//     (small images use nsplit = 2, 4 or 8 so that the grid still covers the chip).
 template <int K, bool LOSS, int UNR>
-__global__ __launch_bounds__(ESPM_ELL_TILE) void h_step_ell_kernel(const HStepArgs a) {
+__global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HStepArgs a) {
   constexpr int NT = ESPM_ELL_TILE;
+  constexpr bool PAIRS_OK = K <= ESPM_ELL_PAIR_MAX_K;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;                                          // [n_pad] rows of GW
   ell_table_at_lds_zero(tab);
-  float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [nsplit][K][TP] numerators, then reduction scratch
+  float* part = smem + (size_t)a.n_pad * EllTab<K>::FLOATS;   // [parts][K][TP] numerators, then reduction scratch
+  const int TP = a.ell_tp;             // pixels of this workgroup: 64 * (8 / nsplit)
+  const int gpw = TP >> 6;             // list groups per workgroup
+  const bool pairs = PAIRS_OK && gpw == NT / 64;
   for (int r = threadIdx.x; r < a.n_pad; r += NT) {
     const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
     EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
   }
+  if (pairs) {  // second partial numerator: only the pixels of the longer group of a pair receive one
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) part[((size_t)K + kk) * TP + threadIdx.x] = 0.f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int TP = a.ell_tp;             // pixels of this workgroup: 64 * (8 / nsplit)
-  const int gpw = TP >> 6;             // list groups per workgroup
-  const int nsplit = (NT / 64) / gpw;
-  const int gi = wave % gpw, si = wave / gpw;
   const int tile0 = blockIdx.x * TP;
-  const int grp = tile0 / 64 + gi;
-  // the lists of a window are ordered by length: slot -> pixel of the window (pad pixels have empty lists)
-  const int lp = a.ell_pix[tile0 + gi * 64 + lane];
-  const int px = tile0 + lp;  // < p_pad (a multiple of 512)
-
-  float hk[K], acc[K];
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) {
-    hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
-    acc[kk] = 0.f;
-  }
   float kl = 0.f;
-  // rows [beg, mid): unit entries, [mid, end): general entries; this wave takes rows [r0, r1) of the group
-  const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg, len = a.ell_off[2 * grp + 2] - beg;
-  const int r0 = (int)((long)len * si / nsplit), r1 = (int)((long)len * (si + 1) / nsplit);
-  const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-  if (r0 < mid) {
-    ell_walk<K, UNR>(lrow + (size_t)r0 * 64, min(r1, mid) - r0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
-      const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
-      ell_axpy<K>(acc, g, r);
-      if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
-    });
-  }
-  if (r1 > mid) {
-    const int g0 = max(r0, mid);
-    ell_walk<K, UNR>(lrow + (size_t)g0 * 64, r1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
-      const float y = ell_dot<K>(g, hk);
-      // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
-      const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-      ell_axpy<K>(acc, g, r);
-      if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-    });
-  }
+
+  // rows [x0, x1) of list group gi of the window -> partial numerator `slot` of its pixels
+  auto walk_rows = [&](int gi, int x0, int x1, int slot) {
+    const int grp = tile0 / 64 + gi;
+    // the lists of a window are ordered by length: slot -> pixel of the window (pad pixels have empty lists)
+    const int lp = a.ell_pix[tile0 + gi * 64 + lane];
+    const int px = tile0 + lp;  // < p_pad (a multiple of 512)
+    float hk[K], acc[K];
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) part[((size_t)si * K + kk) * TP + lp] = acc[kk];
-  if (LOSS && si == 0) kl += a.ell_klc[px];
-  h_epilogue<K>(a, part, nsplit, TP, tile0, LOSS ? kl : 0.f);
+    for (int kk = 0; kk < K; ++kk) {
+      hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
+      acc[kk] = 0.f;
+    }
+    // rows [0, mid) of the group: unit entries, [mid, len): general entries
+    const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg;
+    const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
+    if (x0 < mid) {
+      ell_walk<K, UNR>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
+        const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+        ell_axpy<K>(acc, g, r);
+        if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
+      });
+    }
+    if (x1 > mid) {
+      const int g0 = max(x0, mid);
+      ell_walk<K, UNR>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
+        const float y = ell_dot<K>(g, hk);
+        // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+        const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+        ell_axpy<K>(acc, g, r);
+        if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+      });
+    }
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) part[((size_t)slot * K + kk) * TP + lp] = acc[kk];
+    if (LOSS && slot == 0) kl += a.ell_klc[px];
+  };
+  auto group_rows = [&](int gi) { return a.ell_off[2 * (tile0 / 64 + gi) + 2] - a.ell_off[2 * (tile0 / 64 + gi)]; };
+
+  int nparts;
+  if (pairs) {
+    const int gl = wave < 4 ? wave : 7 - wave;           // the longer group of this wave's pair
+    const int len_l = group_rows(gl), len_s = group_rows(7 - gl);
+    const int half = min(len_l, (len_l + len_s + 1) / 2);   // rows of the longer group its own wave takes
+    if (wave < 4) {
+      walk_rows(gl, 0, half, 0);
+    } else {
+      walk_rows(wave, 0, len_s, 0);
+      if (half < len_l) walk_rows(gl, half, len_l, 1);
+    }
+    nparts = 2;
+  } else {
+    const int nsplit = (NT / 64) / gpw;
+    const int gi = wave % gpw, si = wave / gpw;
+    const int len = group_rows(gi);
+    walk_rows(gi, (int)((long)len * si / nsplit), (int)((long)len * (si + 1) / nsplit), si);
+    nparts = nsplit;
+  }
+  h_epilogue<K>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------

@@ -5,11 +5,54 @@
 
 namespace espm {
 
+// What the epilogue needs of one pixel besides its numerators: requested in one go (no branch between the
+// loads, so they are all in flight together) BEFORE the barrier that ends the accumulation phase - a wave that
+// finishes its part early has them by the time the slowest wave arrives.
+template <int K>
+struct HEpiIn {
+  float hin[K], hprev[K];
+  float l[K], r[K], u[K], d[K];   // the four neighbours (raw: combined after the barrier, so that nothing waits for them before it)
+  float wl, wr, wu, wd;           // 1 where the neighbour exists, else 0
+};
+template <int K>
+__device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool stencil, HEpiIn<K>& v) {
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) {
+    v.hin[kk] = a.h_in[(size_t)kk * a.p_pad + q];
+    v.hprev[kk] = a.have_prev ? a.h_out[(size_t)kk * a.p_pad + q] : 0.f;
+    v.l[kk] = v.r[kk] = v.u[kk] = v.d[kk] = 0.f;
+  }
+  v.wl = v.wr = v.wu = v.wd = 0.f;
+  if (stencil) {
+    // 5-point Laplacian (utils.py:39-76): the four neighbours through clamped addresses and 0/1 weights; rows
+    // above / below the local block come from the halo rows when present (sharded image)
+    const int i = q / a.ny, j = q - i * a.ny;
+    v.wl = j > 0 ? 1.f : 0.f;
+    v.wr = j < a.ny - 1 ? 1.f : 0.f;
+    const bool up_in = i > 0, dn_in = i < a.nx - 1;
+    v.wu = (up_in || a.halo_top) ? 1.f : 0.f;
+    v.wd = (dn_in || a.halo_bot) ? 1.f : 0.f;
+    const int ql = j > 0 ? q - 1 : q, qr = j < a.ny - 1 ? q + 1 : q;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+      const float* hrow = a.h_in + (size_t)kk * a.p_pad;
+      const float* pu = up_in ? hrow + (q - a.ny) : (a.halo_top ? a.halo_top + (size_t)kk * a.ny + j : hrow + q);
+      const float* pd = dn_in ? hrow + (q + a.ny) : (a.halo_bot ? a.halo_bot + (size_t)kk * a.ny + j : hrow + q);
+      v.l[kk] = hrow[ql];
+      v.r[kk] = hrow[qr];
+      v.u[kk] = *pu;
+      v.d[kk] = *pd;
+    }
+  }
+}
+
 // Epilogue shared by the H-step kernels: `smem` holds `nparts` partial numerators [part][K][TP] (written by
 // the caller, not yet synchronised); one thread per pixel adds the regularisation terms, solves the simplex
 // multiplier, clamps, writes H', H'^T and the per-workgroup record.  kl_lane = this lane's part of
 // sum X log2(X / Y).
-template <int K>
+// EARLY = false requests the pixel's inputs after the barrier (the matrix-core variant keeps its registers for
+// the accumulation phase).
+template <int K, bool EARLY = true>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
@@ -18,6 +61,13 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
   constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
   red[ESPM_HP_KL] = (double)kl_lane;
+  const bool stencil = a.lambda_l != 0.f && a.grid_mode;
+  HEpiIn<K> in;
+  bool loaded = false;
+  if (EARLY && K <= 6 && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {   // (k = 7, 8: too many registers to hold across the barrier)
+    h_epilogue_load<K>(a, tile0 + (int)threadIdx.x, stencil, in);
+    loaded = true;
+  }
   __syncthreads();
 
   // ---- epilogue: one thread per pixel -------------------------------------------------------
@@ -32,12 +82,14 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   for (int jj = threadIdx.x; jj < TP; jj += (int)blockDim.x) {
     const int q = tile0 + jj;
     if (q >= a.p) continue;
+    if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
+    loaded = false;
     float hin[K], nv[K], dv[K];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
       float s = 0.f;
       for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * K + kk) * TP + jj];
-      hin[kk] = a.h_in[(size_t)kk * a.p_pad + q];
+      hin[kk] = in.hin[kk];
       nv[kk] = s * a.xscale;
       dv[kk] = (float)a.colsum_gw[kk];
     }
@@ -46,10 +98,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       // (each thread reads its own entries before overwriting them below), base.py:324
       float worst = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        const float hp = a.h_out[(size_t)kk * a.p_pad + q];
-        worst = fmaxf(worst, fabsf(hin[kk] - hp) / (hin[kk] + rel_shift));
-      }
+      for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) / (hin[kk] + rel_shift));
       red[R_RELH] = fmax(red[R_RELH], (double)worst);
     }
     if (a.mu) {
@@ -63,12 +112,10 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     if (a.lambda_l != 0.f) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
-        const float hl = a.grid_mode
-                             ? stencil_hl(a.h_in + (size_t)kk * a.p_pad,
-                                          a.halo_top ? a.halo_top + (size_t)kk * a.ny : nullptr,
-                                          a.halo_bot ? a.halo_bot + (size_t)kk * a.ny : nullptr, q, a.nx, a.ny,
-                                          hin[kk])
-                             : hin[kk];
+        // (H L)[q] = deg(q) H[q] - sum of the existing neighbours, utils.py:39-76
+        const float hl = a.grid_mode ? ((in.wl + in.wr) + (in.wu + in.wd)) * hin[kk] -
+                                           (((in.wl * in.l[kk] + in.wr * in.r[kk]) + in.wu * in.u[kk]) + in.wd * in.d[kk])
+                                     : hin[kk];
         const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
         nv[kk] += ls * mh;                                      // updates.py:140
         dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141

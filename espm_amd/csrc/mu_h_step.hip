@@ -11,8 +11,7 @@
 //   - KL data term of the INPUT state: sum X log2(X / Y)   (measures.py:493-504, base.py:200-203)
 //   - log regulariser and Laplacian quadratic form of the input state (measures.py:543-548, :574-577)
 //   - row sums / row maxima of H' (updates.py:60, :139 of the NEXT half steps)
-
-#include "mu_h_mfma_kernel.hpp"
+#include "mu_h_kernel.hpp"
 
 namespace espm {
 
@@ -35,28 +34,8 @@ static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
   return check_hip(hipGetLastError(), "h_step launch");
 }
 
-template <int K, typename XT, int NW>
-static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
-  constexpr int NMF = MfmaCount<K>::value;
-  const size_t img = (size_t)128 * (32 * NMF + 8) * sizeof(uint16_t);
-  const size_t part = (size_t)NW * 4 * K * 128 * sizeof(float);
-  const size_t red = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
-  size_t bytes = img > part ? img : part;
-  if (red > bytes) bytes = red;
-  if (args.compute_loss)
-    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, NW, true>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
-  else
-    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, NW, false>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
-  return check_hip(hipGetLastError(), "h_step (mfma) launch");
-}
-
 template <int K>
 static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
-  if (tile_px == -128) {  // matrix-core variant
-    if (x_dtype == ESPM_X_U8) return launch_h_mfma<K, uint8_t, 4>(args, nblk, stream);
-    if (x_dtype == ESPM_X_BF16) return launch_h_mfma<K, bf16_t, 4>(args, nblk, stream);
-    return set_error(ESPM_EINVAL, "h_step: the matrix-core variant needs a u8 or bf16 X store");
-  }
   if (x_dtype == ESPM_X_U8) {
     if (tile_px == 256) return launch_h<K, uint8_t, 4, 4, 8, 0>(args, nblk, stream);
     if (tile_px == 128) return launch_h<K, uint8_t, 2, 8, 8, 2>(args, nblk, stream);

@@ -215,6 +215,8 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
 
 
 def lds_bytes_h(n_pad, k):
-    """LDS the sparse H-step needs: the GW table plus the numerators of a 512-pixel tile."""
+    """LDS the sparse H-step needs: the GW table plus the partial numerators of a 512-pixel tile (two sets for k <= 6,
+    where the list groups of a window are walked in pairs)."""
     wb = 0 if k <= 4 else (1 if k == 5 else (2 if k == 6 else 4))
-    return n_pad * (4 + wb) * 4 + max(k * _lib.ELL_TILE * 4, 9 * (5 + 2 * k) * 8)
+    sets = 2 if k <= _lib.ELL_PAIR_MAX_K else 1
+    return n_pad * (4 + wb) * 4 + max(sets * k * _lib.ELL_TILE * 4, 9 * (5 + 2 * k) * 8)

@@ -109,8 +109,9 @@ class MUEngine:
         if group is not None:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
-        if h_variant is None:
-            h_variant = int(os.environ.get("ESPM_H_VARIANT", "0"))
+        if h_variant:
+            raise NotImplementedError("h_variant=1 (Y = GW H on the matrix cores) was retired: slower than the vector kernels "
+                                      "at k <= 8 and sensitive to a transcendental-operand hazard (DESIGN.md)")
         if x_store in ("auto", "ell"):
             # u8 / ell: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
             # which is not an integer: such data keep the bf16 store and the reference's exact semantics.
@@ -124,7 +125,7 @@ class MUEngine:
                 n_pad8 = (self.n + 7) // 8 * 8
                 fits = self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
                 sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
-                if fits and (x_store == "ell" or (sparse and not h_variant)):
+                if fits and (x_store == "ell" or sparse):
                     code = 3
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
             if group is not None:
@@ -166,9 +167,6 @@ class MUEngine:
             self.x_bytes = 4 * (self.ell["ell_h"].numel() + self.ell["ell_w"].numel())
         else:
             xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
-            if h_variant and x_store in ("u8", "bf16"):  # Y = GW H on the matrix cores: 128-pixel tiles
-                st.h_variant = 1
-                tile_px = 128
             if tile_px is not None:  # override the H-step tile chosen by espm_mu_query (tests, tuning)
                 st.tile_px = int(tile_px)
                 st.x_tile = int(tile_px)
@@ -222,9 +220,6 @@ class MUEngine:
         self.h_t = torch.zeros((self.p, _lib.KP), **f32)
         self.gw_s = torch.zeros((st.n_pad, _lib.KP), **f32)
         self.colsum_gw = torch.zeros(_lib.KP, **f64)
-        nmf = (6 * k + 31) // 32
-        self.gw_a = torch.zeros((st.n_cm // 16, nmf, 64, 8), dtype=torch.bfloat16, device=dev)
-        self.gw_p = torch.zeros((st.n_cm // 2, k, 2), **f32)
         nblk_h = (self.p + st.tile_px - 1) // st.tile_px
         self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
         self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
@@ -258,7 +253,7 @@ class MUEngine:
         st.w[0], st.w[1] = self.w[0].data_ptr(), self.w[1].data_ptr()
         st.h[0], st.h[1] = self.h[0].data_ptr(), self.h[1].data_ptr()
         st.gw_s, st.colsum_gw, st.h_t = self.gw_s.data_ptr(), self.colsum_gw.data_ptr(), self.h_t.data_ptr()
-        st.gw_a, st.gw_p = self.gw_a.data_ptr(), self.gw_p.data_ptr()
+        st.gw_a, st.gw_p = None, None
         st.mu = self.mu.data_ptr() if self.mu is not None else None
         st.fixed_h = self.fixed_h.data_ptr() if self.fixed_h is not None else None
         st.fixed_w = self.fixed_w.data_ptr() if self.fixed_w is not None else None

@@ -69,6 +69,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
 #define ESPM_ELL_UNIT_ROWS 4 /* sparse store: the unit rows of a list group are a multiple of this             */
 #define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
+#define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
@@ -115,7 +116,7 @@ typedef struct espm_mu_state {
   int32_t nblk_w;   /* pixel blocks of the W accumulation (rows of a_slab)              */
   int32_t x_tile;   /* pixel-block width of the tile-major x_cm (multiple of tile_px)   */
   int32_t n_cm;     /* roundup(n, ESPM_NCM): channel rows per pixel block of x_cm       */
-  int32_t h_variant; /* 0: fp32 VALU H-step, 1: Y = GW H on the matrix cores (tile_px = 128) */
+  int32_t h_variant; /* must be 0 (1 was the retired matrix-core H-step) */
   int64_t p_total;  /* pixels of the whole image over all ranks (= p on one GPU)        */
   /* flags */
   int32_t simplex_h, simplex_w;

@@ -242,30 +242,6 @@ def test_ragged_shapes_match_oracle(SmoothNMF, n, nx, ny, k, m):
     np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
 
 
-@pytest.mark.parametrize("n,nx,ny,k,m", [(64, 12, 10, 5, None), (333, 7, 19, 8, 17), (1980, 16, 16, 4, None), (50, 5, 6, 1, None)])
-def test_matrix_core_variant_matches_oracle(n, nx, ny, k, m):
-    """The MFMA H-step (engine h_variant=1; k <= 5 one MFMA per tile, k <= 8 two; channel padding to 16)."""
-    import torch
-    from espm_amd import synth
-    from espm_amd.engine import MUEngine
-    prob = synth.make_problem(n, nx, ny, k, N=90.0, seed=n, m=m)
-    X = synth.sample_numpy(prob, seed=n)
-    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=n, scale=0.2)
-    kw = dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False, tol=0)
-    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
-                 max_iter=6, **kw)
-    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=6, h_variant=1, **kw)
-    assert eng.st.h_variant == 1
-    eng.load_state(W0, H0)
-    eng.iterate(6, final_loss=True)
-    torch.cuda.synchronize()
-    h = eng.history()
-    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
-    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
-    assert h["bad"].sum() == 0
-
-
 @pytest.mark.parametrize("store", ["ell", "u8"])
 @pytest.mark.parametrize("n,nx,ny,k,m,counts,hot,kw", [
     (64, 12, 10, 5, None, 90.0, 0, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),

@@ -117,23 +117,3 @@ def test_w_step_is_linear_in_the_pixel_blocks(big):
     np.testing.assert_allclose(slabs.cpu().numpy(), half.cpu().numpy(), rtol=1e-12)
 
 
-def test_matrix_core_h_step_variant(big):
-    """h_variant = 1 forms Y = GW H with v_mfma_f32_16x16x32_bf16 on 3-way bf16 splits of GW and H (six product
-    groups in the 32 k-slots): it must reproduce the fp32 VALU kernel to fp32 rounding at the headline size."""
-    from espm_amd.engine import MUEngine
-    ref = big["engs"][256]
-    ref.load_state(big["W0"], big["H0"])
-    ref.iterate(4, final_loss=True)
-    eng = MUEngine(ref.x_pm[:, :N], K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=8, h_variant=1, x_store="u8")
-    assert eng.st.h_variant == 1 and eng.st.tile_px == 128
-    eng.load_state(big["W0"], big["H0"])
-    eng.iterate(4, final_loss=True)
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(eng.get_H(), ref.get_H(), rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(eng.get_W(), ref.get_W(), rtol=2e-5, atol=1e-8)
-    np.testing.assert_allclose(eng.history()["loss"], ref.history()["loss"], rtol=1e-6)
-    H4 = eng.get_H()
-    eng.load_state(big["W0"], big["H0"])
-    eng.iterate(4, final_loss=True)
-    assert np.array_equal(H4, eng.get_H())                                # and bitwise reproducible (see the rcp note)

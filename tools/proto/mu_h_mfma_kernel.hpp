@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_mfma_kernel(const HStepArgs a)
       dst[2 * u + 1] = acc[kk][u].y;
     }
   }
-  h_epilogue<K>(a, smem, NW * 4, TP, tile0, LOSS ? kl.x + kl.y : 0.f);
+  h_epilogue<K, false>(a, smem, NW * 4, TP, tile0, LOSS ? kl.x + kl.y : 0.f);
 }
 
 }  // namespace espm
