@@ -277,6 +277,39 @@ int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_
   return launch_w_finish(finish_args(st, src, hsrc, slot, 1), static_cast<hipStream_t>(stream));
 }
 
+// W' needs nothing global but the row sums of the new H: the reduction workgroups finish W themselves
+static bool w_update_is_local(const espm_mu_state* st) {
+  return st->m == 0 && !st->simplex_w && st->n >= 64 && st->w_scratch != nullptr;
+}
+
+int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with_finalize, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const HFinalizeArgs fin = finalize_args(st, src, slot, true);
+  if (w_update_is_local(st)) {
+    return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
+                                  st->nblk_w, st->a, st->hpart, nblk_h(st), 0, nullptr, with_finalize ? &fin : nullptr, s);
+  }
+  if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, with_finalize ? &fin : nullptr, s)) return rc;
+  return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
+}
+
+int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, int world, int src, int slot,
+                                 espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(records && world >= 1 && (src == 0 || src == 1), "shard_combine_finish: bad arguments");
+  ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
+  if (w_update_is_local(st)) {
+    return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), records, espm_mu_shard_record_bytes(st), world, st->a,
+                                  nullptr, 0, (size_t)st->k * st->n_pad * sizeof(float), st->hstat[1 - src], nullptr,
+                                  static_cast<hipStream_t>(stream));
+  }
+  if (int rc = espm_mu_shard_combine(st, records, world, 1 - src, stream)) return rc;
+  return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
+}
+
 int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
@@ -286,12 +319,8 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
     int rc;
     if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
     if ((rc = espm_mu_w_accum(st, stream))) return rc;
-    {  // slab reduction with the H-step's finalize riding in the same launch
-      const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
-      if ((rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, &fin, static_cast<hipStream_t>(stream))))
-        return rc;
-    }
-    if ((rc = espm_mu_w_finish(st, cur, 1 - cur, slot + 1, stream))) return rc;
+    // slab reduction with the H-step's finalize riding in the same launch, then (or, when W' is local, in it) the W update
+    if ((rc = espm_mu_w_reduce_finish(st, cur, slot, 1, stream))) return rc;
     st->cur = 1 - cur;
     st->it = slot + 1;
   }

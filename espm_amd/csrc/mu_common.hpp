@@ -533,6 +533,9 @@ int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipSt
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
                     hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
+int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
+                           const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,
+                           const HFinalizeArgs* fused_finalize, hipStream_t stream);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                   int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream);
 int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream);

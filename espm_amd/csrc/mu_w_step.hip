@@ -55,8 +55,182 @@ __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
   }
 }
 
-// ---- W finish: one workgroup of 1024 threads --------------------------------------------------
 constexpr int WF_THREADS = 1024;
+
+// ---- Slab (or rank-record) reduction with the W update folded in: G = identity, no simplex_W -------------------
+// When W' needs nothing global beyond the row sums of the new H (updates.py:58-60, :70-76 with G = I and no
+// simplex over W), the update of an entry of W only needs the matching entry of A = sum of the sources: the
+// workgroups that reduce the sources finish "their" entries of W right away - W' = max(W A / rowsum(H'), eps),
+// fixed_W, the row of G W' for the next half step - instead of one workgroup doing all of W afterwards.  What IS
+// global (column sums of G W', mean of W' for rel_W) leaves as per-workgroup partials for w_update_tail_kernel.
+//   sources: `nsrc` arrays of (k, n_pad) floats, `src_stride` bytes apart: the slabs of the W accumulation, or
+//            the A blocks of the ranks' records (sharded image), always summed in the same fixed order.
+//   row sums of the new H: from the H-step's per-workgroup records (same order of operations as h_finalize_body,
+//            so the value equals hstat's), or the sum over the ranks' records (which this kernel also turns into
+//            the global hstat, like shard_combine).
+// Workgroup (kk, j) owns channels [32 j, 32 j + 32) of component kk; one extra workgroup runs h_finalize_body.
+struct WUpdateArgs {
+  const unsigned char* src;
+  size_t src_stride;
+  int nsrc, n, n_pad, k, nbk;
+  float* a_out;
+  const double* hpart;          // slab mode: H-step records (field-major), nblk_h of them
+  int nblk_h;
+  size_t rec_hstat_off;         // records mode (hpart == null): byte offset of the 16 statistics inside a record
+  double* hstat_out;            // records mode: global row sums / maxima of the new H
+  const float* w_old;
+  float* w_new;
+  const float* fixed_w;
+  float* gw_s;
+  double* parts;                // [2][k * nbk]: partial column sum of G W' (component of the workgroup), partial sum of W'
+  float log_shift, gw_floor, xscale;
+  int fuse_finalize;
+  HFinalizeArgs fin;
+};
+
+__global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs a) {
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ float s_part[8][32];
+  __shared__ double s_rs;
+  const int nwg = a.k * a.nbk;
+  if ((int)blockIdx.x >= nwg) {  // the extra workgroup
+    h_finalize_body(a.fin, fscratch);
+    return;
+  }
+  const int kk = blockIdx.x / a.nbk, j = blockIdx.x - kk * a.nbk;
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = 32 * j + col;
+  const int e = kk * a.n_pad + c;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
+  if (c < a.n_pad) {
+    int b = grp;
+    for (; b + 56 < a.nsrc; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src(b + 8 * u);
+    }
+    for (int u = 0; b < a.nsrc; b += 8, ++u) acc[u & 7] += src(b);
+  }
+  s_part[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  // row sum of component kk of the new H
+  double rs = 0.0;
+  if (a.hpart) {
+    double v[1] = {0.0};
+    const size_t nb = a.nblk_h;
+    for (int b = threadIdx.x; b < a.nblk_h; b += 256) v[0] += a.hpart[(ESPM_HP_ROWSUM + kk) * nb + b];
+    block_reduce<1, 1>(v, fscratch);   // (its barriers also order s_part)
+    if (threadIdx.x == 0) s_rs = v[0];
+    __syncthreads();
+    rs = s_rs;
+  } else {
+    for (int r = 0; r < a.nsrc; ++r)
+      rs += reinterpret_cast<const double*>(a.src + (size_t)r * a.src_stride + a.rec_hstat_off)[ESPM_HS_ROWSUM + kk];
+    if (blockIdx.x == 0 && threadIdx.x < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
+      double t = 0.0;
+      for (int r = 0; r < a.nsrc; ++r) {
+        const double v = reinterpret_cast<const double*>(a.src + (size_t)r * a.src_stride + a.rec_hstat_off)[threadIdx.x];
+        t = (int)threadIdx.x < ESPM_HS_MAX ? t + v : fmax(t, v);
+      }
+      a.hstat_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) {  // wave 0; its first 32 lanes own the 32 entries
+    double cs = 0.0, sw = 0.0;
+    if (grp == 0 && c < a.n_pad) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += s_part[g][col];
+      a.a_out[e] = t;
+      if (c < a.n) {
+        const float wo = a.w_old[(size_t)c * a.k + kk];
+        float v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
+        if (a.fixed_w) {
+          const float fx = a.fixed_w[(size_t)c * a.k + kk];
+          if (fx >= 0.f) v = fx;                              // updates.py:75-76
+        }
+        a.w_new[(size_t)c * a.k + kk] = v;
+        const float gv = fmaxf(v, a.gw_floor);
+        a.gw_s[(size_t)c * KP + kk] = gv * (1.f / a.xscale);
+        cs = (double)gv;
+        sw = (double)v;
+      } else {
+        a.gw_s[(size_t)c * KP + kk] = 1.f;  // padding channels: X = 0 there
+      }
+    }
+    cs = wave_sum(cs);
+    sw = wave_sum(sw);
+    if (threadIdx.x == 0) {
+      a.parts[blockIdx.x] = cs;
+      a.parts[nwg + blockIdx.x] = sw;
+    }
+  }
+}
+
+// Column sums of G W' and rel_W (base.py:323) from the partials and W', W: one workgroup.
+struct WTailArgs {
+  const double* parts;
+  const float* w_old;
+  const float* w_new;
+  double* colsum_gw;
+  double* hist_slot;
+  int n, k, nbk;
+  float rel_tol;
+};
+// 256 threads: the cross-wave stage of a block reduction costs per wave, and everything here is latency - the
+// entries of W are requested up front, before the partials are reduced, so that only one memory round trip and
+// two short reductions separate the launch from the result.
+constexpr int WT_THREADS = 256;
+constexpr int WT_HELD = 40;  // entries of W per thread held in registers (10240 = the headline size); more take the loop
+__global__ __launch_bounds__(WT_THREADS) void w_update_tail_kernel(const WTailArgs a) {
+  __shared__ double scratch[(WT_THREADS / 64 + 1) * (KP + 1)];
+  __shared__ double s_mean;
+  const int tid = threadIdx.x, nwg = a.k * a.nbk, mk = a.n * a.k;
+  float wn[WT_HELD], wo[WT_HELD];
+  if (a.hist_slot) {
+#pragma unroll
+    for (int u = 0; u < WT_HELD; ++u) {
+      const int i = tid + u * WT_THREADS;
+      wn[u] = i < mk ? a.w_new[i] : 1.f;
+      wo[u] = i < mk ? a.w_old[i] : 1.f;
+    }
+  }
+  double v[KP + 1];
+#pragma unroll
+  for (int i = 0; i <= KP; ++i) v[i] = 0.0;
+  for (int j = tid; j < a.nbk; j += WT_THREADS) {
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+      if (kk < a.k) {
+        v[kk] += a.parts[kk * a.nbk + j];
+        v[KP] += a.parts[nwg + kk * a.nbk + j];
+      }
+  }
+  block_reduce<KP + 1, KP + 1>(v, scratch);
+  if (tid == 0) {
+    for (int kk = 0; kk < KP; ++kk) a.colsum_gw[kk] = kk < a.k ? v[kk] : 0.0;
+    s_mean = v[KP] / (double)mk;
+  }
+  __syncthreads();
+  if (!a.hist_slot) return;
+  const float shift = (float)((double)a.rel_tol * s_mean);
+  float rel = 0.f;   // fp32 like the register-resident W finish compares doubles of fp32 values: the quotient of two
+                     // fp32 numbers rounded once is within 1 ulp of that; rel_W is a stop-rule statistic (base.py:323)
+#pragma unroll
+  for (int u = 0; u < WT_HELD; ++u)
+    if (tid + u * WT_THREADS < mk) rel = fmaxf(rel, fabsf(wn[u] - wo[u]) / (wn[u] + shift));
+  for (int i = tid + WT_HELD * WT_THREADS; i < mk; i += WT_THREADS) {
+    const float x = a.w_new[i], y = a.w_old[i];
+    rel = fmaxf(rel, fabsf(x - y) / (x + shift));
+  }
+  double r1[1] = {(double)rel};
+  block_reduce<1, 0>(r1, scratch);
+  if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = r1[0];
+}
+
+// ---- W finish: one workgroup of 1024 threads --------------------------------------------------
 
 __device__ __forceinline__ double block_sum1(double v, double* scratch) {
   double a[1] = {v};
@@ -596,6 +770,47 @@ int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HF
   if (fused_finalize) a.fin = *fused_finalize;
   hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce launch");
+}
+
+int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
+                           const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,
+                           const HFinalizeArgs* fused_finalize, hipStream_t stream) {
+  WUpdateArgs a;
+  a.src = static_cast<const unsigned char*>(src);
+  a.src_stride = src_stride;
+  a.nsrc = nsrc;
+  a.n = f.n;
+  a.n_pad = f.n_pad;
+  a.k = f.k;
+  a.nbk = (f.n_pad + 31) / 32;
+  a.a_out = a_out;
+  a.hpart = hpart;
+  a.nblk_h = nblk_h;
+  a.rec_hstat_off = rec_hstat_off;
+  a.hstat_out = hstat_out;
+  a.w_old = f.w_old;
+  a.w_new = f.w_new;
+  a.fixed_w = f.fixed_w;
+  a.gw_s = f.gw_s;
+  a.parts = reinterpret_cast<double*>(f.scratch);
+  a.log_shift = f.log_shift;
+  a.gw_floor = f.gw_floor;
+  a.xscale = f.xscale;
+  a.fuse_finalize = fused_finalize != nullptr;
+  if (fused_finalize) a.fin = *fused_finalize;
+  hipLaunchKernelGGL(w_reduce_update_kernel, dim3(a.k * a.nbk + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
+  WTailArgs t;
+  t.parts = a.parts;
+  t.w_old = f.w_old;
+  t.w_new = f.w_new;
+  t.colsum_gw = f.colsum_gw;
+  t.hist_slot = f.hist_slot;
+  t.n = f.n;
+  t.k = f.k;
+  t.nbk = a.nbk;
+  t.rel_tol = f.rel_tol;
+  hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
+  return check_hip(hipGetLastError(), "w_reduce_update launch");
 }
 
 template <int KK>

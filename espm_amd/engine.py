@@ -395,18 +395,23 @@ class MUEngine:
             raise ValueError("history buffer exhausted: raise max_iter")
         s = _stream()
         check(lib.espm_mu_w_accum(C.byref(st), s))
-        if getattr(self, "_pending_finalize", None) == (cur, slot):
+        ride = getattr(self, "_pending_finalize", None) == (cur, slot)   # the H-step's record reduction rides along
+        if ride:
             self._pending_finalize = None
-            check(lib.espm_mu_w_reduce_finalize(C.byref(st), cur, slot, s))
         else:
             self._flush_finalize()
-            check(lib.espm_mu_w_reduce(C.byref(st), s))
         if self.world > 1:
+            if ride:
+                check(lib.espm_mu_w_reduce_finalize(C.byref(st), cur, slot, s))
+            else:
+                check(lib.espm_mu_w_reduce(C.byref(st), s))
             check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
             self.exchange.gather()
-            check(lib.espm_mu_shard_combine(C.byref(st), _ptr(self.exchange.recv), self.world, 1 - cur, s))
+            # sum over the ranks + W update (one launch when W' needs nothing global, include/espm_mu.h)
+            check(lib.espm_mu_shard_combine_finish(C.byref(st), _ptr(self.exchange.recv), self.world, cur, slot, s))
             self._set_halo_from_records()
-        check(lib.espm_mu_w_finish(C.byref(st), cur, 1 - cur, slot + 1, s))
+        else:
+            check(lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
         st.cur, st.it = 1 - cur, slot + 1
 
     def iterate(self, n_iter, final_loss=True):

@@ -249,6 +249,13 @@ int espm_mu_w_reduce_finalize(const espm_mu_state* st, int src, int slot, espm_s
  * row sums of the new H): reads w[src], writes w[1-src], gw_s, colsum_gw and rel_W into history slot `slot`. */
 int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_stream_t stream);
 
+/* The rest of the W-step after espm_mu_w_accum in one call: slab reduction (with espm_mu_h_finalize(st, src, slot)
+ * riding in its launch when with_finalize != 0) and the W update w[src] -> w[1-src] with the row sums of the new H
+ * h[1-src]; rel_W goes to history slot + 1.  When W' needs nothing global (G = identity, no simplex_W, n >= 64) the
+ * reduction workgroups finish their own entries of W and a one-workgroup tail forms colsum(GW') and rel_W (w_scratch
+ * holds the partials); otherwise this is espm_mu_w_reduce[_finalize] + espm_mu_w_finish. */
+int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with_finalize, espm_stream_t stream);
+
 /* n_iter full iterations on one GPU, no host synchronisation; updates st->cur / st->it.
  * History slot t holds the loss pieces of state t (slot 0 = initial state) and the relative
  * changes of the update that produced it.  A final loss-only H-step fills the last slot when
@@ -264,6 +271,10 @@ size_t espm_mu_shard_record_bytes(const espm_mu_state* st);
 int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_stream_t stream);
 int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int world, int hnew,
                           espm_stream_t stream);
+/* espm_mu_shard_combine(.., hnew = 1 - src) + espm_mu_w_finish(st, src, 1 - src, slot + 1) in one call; the sum over
+ * the ranks and the W update share a launch when W' needs nothing global (see espm_mu_w_reduce_finish). */
+int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, int world, int src, int slot,
+                                 espm_stream_t stream);
 
 /* nu (p) with sum_i max(num_ij / (nu_j + den_ij), log_shift) = 1.  num (k, p), den (k, den_cols)
  * with den_cols in {1, p}, fp64 device arrays.  status_out (device int32): number of columns
