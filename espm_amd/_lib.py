@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("ESPM_MU_LIB", os.path.join(_HERE, "lib", "libespm_mu.
 OK, EINVAL, ENOSOLUTION, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4
 X_F32, X_BF16, X_U8, X_ELL = 0, 1, 2, 3
 ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = 512, 1024, 10, 144 * 1024
-ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = 4, 4096, 6
+ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = 8, 4096, 6
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8

@@ -7,8 +7,9 @@
 //   espm_mu_ell_plan  : list orders (channels per pixel block, pixels per window: decreasing length), row offsets
 //                       (two per group: first unit row, first general row), row totals
 //   espm_mu_ell_fill  : the entries.  Unit rows of a group: ESPM_ELL_UNIT_ROWS * floor(min over its 64 lists of the
-//                       unit elements / (2 ESPM_ELL_UNIT_ROWS)); a list's first 2 * (unit rows) elements with
-//                       count 1 go there as index << 4, everything else to the general rows.
+//                       unit elements / (2 ESPM_ELL_UNIT_ROWS)); 2 * (unit rows) of a list's elements with count 1
+//                       go there as index << 4, placed so that the gathers of a wave spread over the LDS banks
+//                       (EllBuckets), everything else to the general rows.
 #include "mu_common.hpp"
 
 namespace espm {
@@ -163,6 +164,50 @@ __global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __rest
   });
 }
 
+// Placement of a list's ones in its unit rows so that the table gathers of a wave spread over the LDS banks.
+// The kernels gather 16-byte table rows with ds_read_b128, which the hardware serves in groups of 16 lanes with
+// distinct lane numbers mod 16; two lanes of a group collide when their rows differ but share index mod 16 (the
+// bank quad).  Lane l therefore puts a one of bucket q = index mod 16 at a position p with (p + l) mod 16 = q: the
+// r-th one of the bucket (ascending index) goes to p = ((q - l) mod 16) + 16 r while that is inside the unit
+// entries (`slots` = unit entries / 16 positions per bucket).  Positions a short bucket leaves empty ("holes") are
+// filled, in order of (bucket, position), by the ones that did not fit their bucket, in order of index; the rest
+// joins the general rows.  Every lane decides alone, from the bucket counts of its own list.
+struct EllBuckets {
+  uint16_t* cnt;    // [16][nthreads]: ones per bucket (pass 1)
+  uint16_t* seen;   // [16][nthreads]: ones of the bucket met so far (pass 2)
+  uint16_t* hole0;  // [17][nthreads]: holes before bucket q
+  int nt, t;
+  __device__ __forceinline__ uint16_t& c(int q) { return cnt[q * nt + t]; }
+  __device__ __forceinline__ uint16_t& s(int q) { return seen[q * nt + t]; }
+  __device__ __forceinline__ uint16_t& h(int q) { return hole0[q * nt + t]; }
+  __device__ __forceinline__ void clear() {
+    for (int q = 0; q < 16; ++q) { c(q) = 0; s(q) = 0; }
+  }
+  __device__ __forceinline__ void count(int idx) { c(idx & 15) += 1; }
+  // after pass 1: holes per bucket; returns their total
+  __device__ __forceinline__ int plan(int slots) {
+    int run = 0;
+    for (int q = 0; q < 16; ++q) {
+      h(q) = (uint16_t)run;
+      run += max(0, slots - (int)c(q));
+    }
+    h(16) = (uint16_t)run;
+    return run;
+  }
+  // pass 2: unit position of this one, or -1 when it belongs to the general rows
+  __device__ __forceinline__ int place(int idx, int lane, int slots, int holes, int& overflow) {
+    const int q = idx & 15;
+    const int r = s(q);
+    s(q) = (uint16_t)(r + 1);
+    if (r < slots) return ((q - lane) & 15) + 16 * r;
+    const int k = overflow++;
+    if (k >= holes) return -1;
+    int qh = 0;
+    while (h(qh + 1) <= k) ++qh;   // the bucket of hole k (h is non-decreasing, h(16) = holes > k)
+    return ((qh - lane) & 15) + 16 * ((int)c(qh) + k - (int)h(qh));
+  }
+};
+
 __device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, int lane, uint32_t entry) {
   base16[((row0 + (size_t)(j >> 1)) * 64 + lane) * 2 + (j & 1)] = (uint16_t)entry;
 }
@@ -171,6 +216,7 @@ __device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, in
 __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
                                                          int cbits, int win, const int32_t* __restrict__ pix_perm,
                                                          const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
+  __shared__ uint16_t s_b[(16 + 16 + 17) * 256];
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= p_pad) return;
   const int q = slot / win * win + pix_perm[slot];
@@ -178,15 +224,26 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
   const int xmax = (1 << (16 - cbits)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_h);
   const size_t row0 = (size_t)h_off[2 * (slot >> 6)], row1 = (size_t)h_off[2 * (slot >> 6) + 1];
-  const int units = 2 * (int)(row1 - row0);
+  const int units = 2 * (int)(row1 - row0), slots = units / 16;
   const int lane = slot & 63;
   const uint8_t* row = x_pm + (size_t)q * n_pad;
-  int j = 0, ju = 0;
+  EllBuckets b{s_b, s_b + 16 * 256, s_b + 32 * 256, 256, (int)threadIdx.x};
+  int holes = 0;
+  if (units) {
+    b.clear();
+    for (int c = 0; c < n; ++c)
+      if (row[c] == 1) b.count(c);
+    holes = b.plan(slots);
+  }
+  int j = 0, overflow = 0;
   for (int c = 0; c < n; ++c) {
     int x = row[c];
-    if (x == 1 && ju < units) {
-      ell_put(base16, row0, ju++, lane, (uint32_t)c << 4);
-      continue;
+    if (x == 1 && units) {
+      const int pos = b.place(c, lane, slots, holes, overflow);
+      if (pos >= 0) {
+        ell_put(base16, row0, pos, lane, (uint32_t)c << 4);
+        continue;
+      }
     }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;
@@ -200,20 +257,32 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg,
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
                                                         uint32_t* __restrict__ ell_w) {
+  __shared__ uint16_t s_b[(16 + 16 + 17) * 64];
   const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
   const int c = chan_perm[((size_t)b * n_cg + cg) * 64 + lane];
   if (c < 0) return;
   constexpr int xmax = (1 << (16 - ESPM_ELL_PBITS)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_w);
   const size_t row0 = (size_t)w_off[2 * ((size_t)b * n_cg + cg)], row1 = (size_t)w_off[2 * ((size_t)b * n_cg + cg) + 1];
-  const int units = 2 * (int)(row1 - row0);
+  const int units = 2 * (int)(row1 - row0), slots = units / 16;
   const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
-  int j = 0, ju = 0;
+  EllBuckets bk{s_b, s_b + 16 * 64, s_b + 32 * 64, 64, lane};
+  int holes = 0;
+  if (units) {
+    bk.clear();
+    for (int q = q0; q < q1; ++q)
+      if (x_pm[(size_t)q * n_pad + c] == 1) bk.count(q - q0);
+    holes = bk.plan(slots);
+  }
+  int j = 0, overflow = 0;
   for (int q = q0; q < q1; ++q) {
     int x = x_pm[(size_t)q * n_pad + c];
-    if (x == 1 && ju < units) {
-      ell_put(base16, row0, ju++, lane, (uint32_t)(q - q0) << 4);
-      continue;
+    if (x == 1 && units) {
+      const int pos = bk.place(q - q0, lane, slots, holes, overflow);
+      if (pos >= 0) {
+        ell_put(base16, row0, pos, lane, (uint32_t)(q - q0) << 4);
+        continue;
+      }
     }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;

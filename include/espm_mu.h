@@ -67,7 +67,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
 #define ESPM_ELL_PB 1024   /* sparse store: pixels per block of the W accumulation                          */
 #define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
-#define ESPM_ELL_UNIT_ROWS 4 /* sparse store: the unit rows of a list group are a multiple of this             */
+#define ESPM_ELL_UNIT_ROWS 8 /* sparse store: the unit rows of a list group are a multiple of this (16 entries: one per bank quad) */
 #define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
@@ -172,9 +172,11 @@ typedef struct espm_mu_state {
    *           a group hold only entries with count 1, in EVERY lane and position (no padding), stored without a
    *           count as index << 4 (the byte offset of a 16-byte table row): u = min over the 64 lists of their
    *           elements equal to 1, unit rows = ESPM_ELL_UNIT_ROWS * floor(u / (2 ESPM_ELL_UNIT_ROWS)); a list's
-   *           first 2 * (unit rows) ones (ascending index) go there, all its other elements to the general rows
-   *           [off[2 i + 1], off[2 i + 2]) in the count << bits | index form.  H-step lists have unit rows only
-   *           when n <= ESPM_ELL_UNIT_MAX_N. */
+   *           2 * (unit rows) of a list's ones go there - which ones and in which order is the builder's choice
+   *           (espm_mu_ell_fill places the ones of lane l with index = q mod 16 at positions = q - l mod 16, so
+   *           that the 16 lanes of a ds_read_b128 group address 16 different bank quads of the table) - all its
+   *           other elements go to the general rows [off[2 i + 1], off[2 i + 2]) in the count << bits | index
+   *           form.  H-step lists have unit rows only when n <= ESPM_ELL_UNIT_MAX_N. */
   const uint32_t* ell_h;    /* (rows_h, 64) */
   const int32_t* ell_h_off; /* (2 p_pad / 64 + 1) */
   const float* ell_klc;     /* (p_pad): loss correction of split counts per pixel: sum over the elements of

@@ -9,50 +9,7 @@ import torch
 from espm_amd import _lib, ell
 
 
-def _decode_group(X_rows, words, off, i, bits, row_of_lane):
-    """Adds the entries of list group i (unit rows, then general rows) to X_rows[row_of_lane(lane)][index].
-    Returns the group's (unit rows, general rows)."""
-    unit = words[off[2 * i] * 64:off[2 * i + 1] * 64].reshape(-1, 64)
-    gen = words[off[2 * i + 1] * 64:off[2 * i + 2] * 64].reshape(-1, 64)
-    for half in (0, 1):
-        u = (unit >> (16 * half)) & 0xFFFF
-        assert not (u & 15).any()                      # index << 4, count 1 implied
-        ent = (gen >> (16 * half)) & 0xFFFF
-        cnt, idx = ent >> bits, ent & ((1 << bits) - 1)
-        for lane in range(64):
-            tgt = row_of_lane(lane)
-            if tgt is None:
-                assert not cnt[:, lane].any() and unit.shape[0] == 0
-                continue
-            np.add.at(tgt, u[:, lane] >> 4, 1)
-            np.add.at(tgt, idx[:, lane], cnt[:, lane])
-    return unit.shape[0], gen.shape[0]
-
-
-def decode(store, p, n, p_pad, cbits, tile_px):
-    PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
-    eh = store["ell_h"].numpy().astype(np.int64) & 0xFFFFFFFF
-    off = store["ell_h_off"].numpy()
-    assert off.shape == (2 * (p_pad // 64) + 1,)
-    Xh = np.zeros((p_pad, n), dtype=np.int64)
-    pix = store["pix_perm"].numpy()
-    rows_h = []
-    for g in range(p_pad // 64):
-        rows_h.append(_decode_group(None, eh, off, g, cbits,
-                                    lambda lane: Xh[(g * 64 + lane) // tile_px * tile_px + pix[g * 64 + lane]]))
-    ew = store["ell_w"].numpy().astype(np.int64) & 0xFFFFFFFF
-    woff = store["ell_w_off"].numpy()
-    perm = store["chan_perm"].numpy()
-    n_cg = store["n_cg"]
-    assert perm.shape == (store["nblk_w"], n_cg * 64) and woff.shape == (2 * store["nblk_w"] * n_cg + 1,)
-    XwT = np.zeros((store["nblk_w"], n, PB), dtype=np.int64)   # [block][channel][pixel of the block]
-    rows_w = []
-    for b in range(store["nblk_w"]):
-        for cg in range(n_cg):
-            rows_w.append(_decode_group(None, ew, woff, b * n_cg + cg, PBITS,
-                                        lambda lane: XwT[b, perm[b, cg * 64 + lane]] if perm[b, cg * 64 + lane] >= 0 else None))
-    Xw = XwT.transpose(0, 2, 1).reshape(store["nblk_w"] * PB, n)
-    return Xh, Xw, np.array(rows_h), np.array(rows_w)
+from ell_decode import decode
 
 
 @pytest.mark.parametrize("n,p,rate,big,tile_px", [(100, 400, 0.3, False, 64), (1980, 1300, 0.2, True, 512), (70, 2049, 1.5, True, 128)])

@@ -219,7 +219,8 @@ def test_initialize_algorithms_golden(api, golden):
 @pytest.mark.parametrize("n,nx,ny,layout", [(100, 20, 20, "cm"), (1980, 33, 31, "pm"), (2050, 40, 30, "cm"), (70, 64, 33, "pm")])
 def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
     """The C-ABI builder of the sparse count store (espm_mu_ell_count / _plan / _fill) and the tensor-op builder
-    espm_amd.ell.build (decoded back to X on the CPU by tests/test_ell_cpu.py) produce identical lists."""
+    espm_amd.ell.build agree on the plan (orders, offsets) and both decode to X; the C builder spreads the unit entries
+    over the LDS banks."""
     import torch
     from espm_amd import synth
     from espm_amd.engine import MUEngine
@@ -236,8 +237,25 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
         eng = MUEngine(Xin, 3, layout=layout, shape_2d=(nx, ny), x_store="ell")
         stores[builder] = eng.ell
     a, b = stores["hip"], stores["torch"]
-    for key in ("ell_h_off", "ell_w_off", "chan_perm", "pix_perm", "ell_h", "ell_w"):
+    for key in ("ell_h_off", "ell_w_off", "chan_perm", "pix_perm"):
         assert torch.equal(a[key].cpu(), b[key].cpu()), key
-    for key in ("nnz", "entries_h", "entries_w", "rows_h", "rows_w", "n_cg", "nblk_w"):
+    for key in ("nnz", "entries_h", "entries_w", "rows_h", "rows_w", "unit_rows_h", "unit_rows_w", "n_cg", "nblk_w"):
         assert a[key] == b[key], key
     np.testing.assert_allclose(a["klc"].cpu().numpy(), b["klc"].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    # which ones of a list sit in its unit rows, and in which order, is the builder's choice (the C builder spreads
+    # them over the LDS banks): both sets of lists must decode to X
+    from ell_decode import decode, unit_bank_spread
+    p, cbits = nx * ny, eng.st.ell_cbits
+    Xi = np.ascontiguousarray(X.T).astype(np.int64)
+    spread = {}
+    for name, st in stores.items():
+        host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+        Xh, Xw, _, _ = decode(host, p, n, eng.st.p_pad, cbits, eng.st.tile_px)
+        assert np.array_equal(Xh[:p], Xi) and not Xh[p:].any(), name
+        assert np.array_equal(Xw[:p], Xi) and not Xw[p:].any(), name
+        spread[name] = (unit_bank_spread(host["ell_h"].numpy(), host["ell_h_off"].numpy()),
+                        unit_bank_spread(host["ell_w"].numpy(), host["ell_w_off"].numpy()))
+    for which in (0, 1):
+        (s_hip, rows), (s_torch, _) = spread["hip"][which], spread["torch"][which]
+        if rows >= 64:  # conflict-free gathers: most read groups of the C builder's unit rows, few of an index-ordered list
+            assert s_hip > 0.6 and s_hip > 3 * s_torch, (which, s_hip, s_torch)
