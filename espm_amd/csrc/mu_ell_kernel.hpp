@@ -33,9 +33,6 @@
 #pragma once
 #include "mu_h_kernel.hpp"
 
-#ifndef ESPM_ELL_AHEAD
-#define ESPM_ELL_AHEAD 1  // batches of list rows requested ahead of their use
-#endif
 
 namespace espm {
 
@@ -148,26 +145,6 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
   };
   int j = 0;
   if (len >= UNR) {
-#if ESPM_ELL_AHEAD == 2
-    // two batches in flight per wave: the list stream is bound by the bytes in flight (latency), not by issue
-    uint32_t e[UNR], en[UNR], en2[UNR];
-    const int j1 = min(UNR, len - UNR);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) en[u] = row[(size_t)(j1 + u) * 64];
-    for (; j + UNR <= len; j += UNR) {
-      const int jn = min(j + 2 * UNR, len - UNR);  // the last batches re-request the final one (no branch, no overrun)
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) en2[u] = row[(size_t)(jn + u) * 64];
-      batch(e);
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        e[u] = en[u];
-        en[u] = en2[u];
-      }
-    }
-#else
     uint32_t e[UNR], en[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
@@ -179,7 +156,6 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
 #pragma unroll
       for (int u = 0; u < UNR; ++u) e[u] = en[u];
     }
-#endif
   }
   for (; j < len; ++j) {
     const uint32_t v = row[(size_t)j * 64];
