@@ -259,3 +259,43 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
         (s_hip, rows), (s_torch, _) = spread["hip"][which], spread["torch"][which]
         if rows >= 64:  # conflict-free gathers: most read groups of the C builder's unit rows, few of an index-ordered list
             assert s_hip > 0.6 and s_hip > 3 * s_torch, (which, s_hip, s_torch)
+
+
+@pytest.mark.parametrize("n,nx,ny,k,fix", [(70, 9, 13, 6, True), (2048, 16, 32, 5, False), (333, 7, 19, 3, True)])
+def test_local_w_update_equals_the_one_workgroup_finish(n, nx, ny, k, fix):
+    """G = identity, no simplex_W: the slab-reduction workgroups update their own entries of W (w_reduce_update_kernel +
+    tail).  Same W, H, losses and rel_W as the reduction followed by w_finish (forced by withholding the workspace the
+    local update needs), including fixed_W, a channel count that leaves the last channel block ragged, and k = 6."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(n, nx, ny, k, N=120.0, seed=n)
+    X = synth.sample_numpy(prob, seed=n)
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=n, scale=0.2)
+    fixed_W = None
+    if fix:
+        fixed_W = -np.ones((n, k))
+        fixed_W[::7, 0] = 0.05
+        fixed_W[3, :] = 0.0
+    out = {}
+    for name in ("local", "finish"):
+        eng = MUEngine(X, k, shape_2d=(nx, ny), lambda_L=0.5, simplex_H=True, simplex_W=False, fixed_W=fixed_W, tol=0.0,
+                       max_iter=12)
+        if name == "finish":
+            eng.st.w_scratch = None
+        eng.load_state(W0, H0)
+        eng.iterate(6, final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        out[name] = (eng.get_W(), eng.get_H(), h["loss"], h["rel_W"], h["rel_H"], h["bad"].sum())
+    a, b = out["local"], out["finish"]
+    assert a[5] == 0 and b[5] == 0
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-7)
+    np.testing.assert_allclose(a[3][1:], b[3][1:], rtol=1e-5)
+    np.testing.assert_allclose(a[4][1:-1], b[4][1:-1], rtol=1e-4, atol=1e-9)
+    assert (a[3][1:] > 0).all()
+    if fix:
+        m = fixed_W >= 0
+        assert np.array_equal(a[0][m], fixed_W[m].astype(np.float32))
