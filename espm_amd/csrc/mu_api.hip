@@ -358,6 +358,17 @@ int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_str
                            with_halo, record, static_cast<hipStream_t>(stream));
 }
 
+int espm_mu_w_reduce_pack(const espm_mu_state* st, int src, int slot, void* record, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(record && (src == 0 || src == 1), "w_reduce_pack: bad arguments");
+  ESPM_REQUIRE(slot >= 0 && slot < st->hist_len, "history slot %d outside [0, %d)", slot, st->hist_len);
+  HFinalizeArgs fin = finalize_args(st, src, slot, true);
+  fin.hstat_out = reinterpret_cast<double*>(static_cast<unsigned char*>(record) + (size_t)st->k * st->n_pad * 4);
+  const int with_halo = st->grid_mode && st->lambda_l != 0.f;
+  return launch_w_reduce_pack(st->a_slab, st->nblk_w, st->k, st->n_pad, fin, st->h[1 - src], st->nx, st->ny, st->p_pad, with_halo,
+                              record, static_cast<hipStream_t>(stream));
+}
+
 int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int world, int hnew, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(records && world >= 1 && (hnew == 0 || hnew == 1), "shard_combine: bad arguments");

@@ -532,6 +532,8 @@ int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
                     hipStream_t stream);
+int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HFinalizeArgs& fin_to_record,
+                         const float* h_new, int nx, int ny, int p_pad, int with_halo, void* rec, hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
                            const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,

@@ -23,12 +23,25 @@ struct WReduceArgs {
   float* out;
   int nblk, total, nred_blocks, fuse_finalize;
   HFinalizeArgs fin;
+  // sharded image: `out` is the A block of this rank's record and the extra workgroup also copies the first and
+  // the last owned image row of the new H behind the statistics (shard_pack_kernel's job, without its launch)
+  const float* halo_h;
+  float* halo_top;
+  float* halo_bot;
+  int halo_k, halo_nx, halo_ny, halo_ppad;
 };
 
 __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
   __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
   __shared__ float s_part[8][32];
   if ((int)blockIdx.x >= a.nred_blocks) {  // the extra workgroup
+    if (a.halo_top) {
+      for (int e = threadIdx.x; e < a.halo_k * a.halo_ny; e += 256) {
+        const int kk = e / a.halo_ny, j = e - kk * a.halo_ny;
+        a.halo_top[e] = a.halo_h[(size_t)kk * a.halo_ppad + j];
+        a.halo_bot[e] = a.halo_h[(size_t)kk * a.halo_ppad + (size_t)(a.halo_nx - 1) * a.halo_ny + j];
+      }
+    }
     h_finalize_body(a.fin, fscratch);
     return;
   }
@@ -768,8 +781,36 @@ int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HF
   a.nred_blocks = (total + 31) / 32;
   a.fuse_finalize = fused_finalize != nullptr;
   if (fused_finalize) a.fin = *fused_finalize;
+  a.halo_h = nullptr;
+  a.halo_top = a.halo_bot = nullptr;
+  a.halo_k = a.halo_nx = a.halo_ny = a.halo_ppad = 0;
   hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce launch");
+}
+
+// Slab reduction straight into a rank's record: A block, statistics of the new H (the finalize workgroup writes them
+// there), boundary rows of the new H.
+int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HFinalizeArgs& fin_to_record,
+                         const float* h_new, int nx, int ny, int p_pad, int with_halo, void* rec, hipStream_t stream) {
+  WReduceArgs a;
+  unsigned char* r = static_cast<unsigned char*>(rec);
+  const int na = k * n_pad;
+  a.slab = slab;
+  a.out = reinterpret_cast<float*>(r);
+  a.nblk = nblk;
+  a.total = na;
+  a.nred_blocks = (na + 31) / 32;
+  a.fuse_finalize = 1;
+  a.fin = fin_to_record;
+  a.halo_h = h_new;
+  a.halo_top = with_halo ? reinterpret_cast<float*>(r + (size_t)na * 4 + ESPM_HS_STRIDE * 8) : nullptr;
+  a.halo_bot = with_halo ? a.halo_top + (size_t)k * ny : nullptr;
+  a.halo_k = k;
+  a.halo_nx = nx;
+  a.halo_ny = ny;
+  a.halo_ppad = p_pad;
+  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + 1), dim3(256), 0, stream, a);
+  return check_hip(hipGetLastError(), "w_reduce_pack launch");
 }
 
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,

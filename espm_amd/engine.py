@@ -401,11 +401,11 @@ class MUEngine:
         else:
             self._flush_finalize()
         if self.world > 1:
-            if ride:
-                check(lib.espm_mu_w_reduce_finalize(C.byref(st), cur, slot, s))
+            if ride:   # slab reduction + record reduction + this rank's record, one launch
+                check(lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, _ptr(self.exchange.send), s))
             else:
                 check(lib.espm_mu_w_reduce(C.byref(st), s))
-            check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
+                check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
             self.exchange.gather()
             # sum over the ranks + W update (one launch when W' needs nothing global, include/espm_mu.h)
             check(lib.espm_mu_shard_combine_finish(C.byref(st), _ptr(self.exchange.recv), self.world, cur, slot, s))

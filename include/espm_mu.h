@@ -271,6 +271,10 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
  * from the neighbours' records: offsets k*n_pad*4 + ESPM_HS_STRIDE*8 (+ k*ny*4 for the last row). */
 size_t espm_mu_shard_record_bytes(const espm_mu_state* st);
 int espm_mu_shard_pack(const espm_mu_state* st, int hnew, void* record, espm_stream_t stream);
+/* espm_mu_w_reduce_finalize(st, src, slot) + espm_mu_shard_pack(st, 1 - src, record) in ONE launch: the slab reduction
+ * writes A straight into the record, the finalize workgroup puts the statistics of the new H h[1-src] there (the
+ * LOCAL ones; st->a and st->hstat[1-src] are not written) and copies its boundary rows. */
+int espm_mu_w_reduce_pack(const espm_mu_state* st, int src, int slot, void* record, espm_stream_t stream);
 int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int world, int hnew,
                           espm_stream_t stream);
 /* espm_mu_shard_combine(.., hnew = 1 - src) + espm_mu_w_finish(st, src, 1 - src, slot + 1) in one call; the sum over
