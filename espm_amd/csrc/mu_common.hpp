@@ -167,11 +167,12 @@ __device__ __forceinline__ T wave_max(T v) {
 // Block-wide reduction of NV doubles (sum for the first NSUM, max for the rest).  `scratch` holds at
 // least (blockDim.x / 64 + 1) * NV doubles.  Result valid in thread 0.  Stage 1: shuffles inside each
 // wave; stage 2: thread i < NV combines value i over the waves (in wave order - deterministic).
-template <int NV, int NSUM>
+// FMAX: the maxima are fp32 values held in doubles - their wave stage moves one dword per step instead of two.
+template <int NV, int NSUM, bool FMAX = false>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
+  for (int i = 0; i < NV; ++i) v[i] = (i < NSUM) ? wave_sum(v[i]) : (FMAX ? (double)wave_max((float)v[i]) : wave_max(v[i]));
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = v[i];
@@ -302,7 +303,7 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     if (fabs(f) <= tol) break;
     if (f > 0) lo = x; else hi = x;
     // Newton step, replaced by bisection when it leaves the bracket or stops halving the step
-    T dx = fp < 0 ? -f / fp : (T)0;
+    T dx = fp < 0 ? -f * fast_rcp<T>(fp) : (T)0;   // (a Newton step tolerates a 1 ulp reciprocal)
     T xn = x + dx;
     if (!(fp < 0) || !(xn > lo && xn < hi) || fabs(dx) > (T)0.5 * fabs(dxold)) {
       dx = (hi - lo) / 2;

@@ -98,14 +98,14 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       // (each thread reads its own entries before overwriting them below), base.py:324
       float worst = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) / (hin[kk] + rel_shift));
+      for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) * __builtin_amdgcn_rcpf(hin[kk] + rel_shift));   // (a stop-rule statistic: 1 ulp reciprocal)
       red[R_RELH] = fmax(red[R_RELH], (double)worst);
     }
     if (a.mu) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         const float m = a.mu[kk];
-        dv[kk] += m / (hin[kk] + a.eps_reg);                          // updates.py:134-137
+        dv[kk] += m * __builtin_amdgcn_rcpf(hin[kk] + a.eps_reg);     // updates.py:134-137
         red[ESPM_HP_REG] += (double)(m * logf(hin[kk] + a.eps_reg));  // measures.py:543-548
       }
     }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
-      float hn = fmaxf(nv[kk] / dv[kk], a.log_shift);          // updates.py:152
+      float hn = fmaxf(nv[kk] * __builtin_amdgcn_rcpf(dv[kk]), a.log_shift);   // updates.py:152 (v_rcp_f32: 1 ulp)
       if (a.fixed_h) {
         const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
         if (f >= 0.f) hn = f;                                   // updates.py:154-155
@@ -153,7 +153,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
 
   __syncthreads();  // smem is reused as reduction scratch
-  block_reduce<NRED, R_RELH>(red, reinterpret_cast<double*>(smem));
+  block_reduce<NRED, R_RELH, true>(red, reinterpret_cast<double*>(smem));   // rel_H and the row maxima are fp32 values
   if (threadIdx.x == 0) {
     // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
     double* out = a.hpart + blockIdx.x;
