@@ -349,3 +349,52 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=2, algo="l2_surrogate", verbose=0).fit, X)
+
+
+@pytest.mark.parametrize("case", ["all_ones", "no_ones", "wide", "ones_and_bright"])
+def test_sparse_store_unit_rows_edge_cases(case):
+    """The two segments of the sparse store's lists at their extremes, against the fp64 oracle: an image of ones (unit
+    rows only), an image without a single one (general rows only), more than 4096 channels (no unit rows in the H
+    lists, unit rows in the W lists), and ones next to counts that need several general entries."""
+    import torch
+    from espm_amd.engine import MUEngine
+    rng = np.random.default_rng(11)
+    if case == "all_ones":
+        n, nx, ny, k = 128, 24, 24, 3
+        X = np.ones((n, nx * ny))
+    elif case == "no_ones":
+        n, nx, ny, k = 96, 20, 27, 4
+        X = 2.0 * rng.poisson(0.3, size=(n, nx * ny))
+    elif case == "wide":
+        n, nx, ny, k = 4100, 30, 30, 2
+        X = rng.poisson(0.4, size=(n, nx * ny)).astype(np.float64)
+    else:
+        n, nx, ny, k = 200, 33, 32, 5
+        X = rng.poisson(0.5, size=(n, nx * ny)).astype(np.float64)
+        X[rng.integers(0, n, 300), rng.integers(0, nx * ny, 300)] = rng.integers(100, 256, 300)
+    X[X.sum(axis=1) == 0, 0] = 2.0
+    X[0, X.sum(axis=0) == 0] = 2.0
+    W0 = rng.uniform(0.05, 1.0, size=(n, k))
+    H0 = rng.uniform(0.05, 1.0, size=(k, nx * ny))
+    H0 /= H0.sum(axis=0, keepdims=True)
+    kw = dict(lambda_L=0.4, simplex_H=True, simplex_W=False)
+    ref = oc.fit(X, k, G=None, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                 max_iter=5, tol=0, **kw)
+    eng = MUEngine(X, k, shape_2d=(nx, ny), max_iter=5, tol=0, x_store="ell", **kw)
+    e = eng.ell
+    if case == "all_ones":
+        assert e["unit_rows_h"] * 128 == e["entries_h"] and e["unit_rows_w"] > 0
+    if case == "no_ones":
+        assert e["unit_rows_h"] == 0 and e["unit_rows_w"] == 0
+    if case == "wide":
+        assert e["unit_rows_h"] == 0 and e["unit_rows_w"] > 0
+    if case == "ones_and_bright":
+        assert 0 < e["unit_rows_h"] < e["rows_h"] and 0 < e["unit_rows_w"] < e["rows_w"]
+    eng.load_state(W0, H0)
+    eng.iterate(5, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
