@@ -33,7 +33,7 @@ BF16_PEAK = 2.5e15      # dense bf16 MFMA FLOP/s (spec)
 VALU_F32_PEAK = 157.3e12
 
 
-def cpu_baseline(prob, rows=64, iters=4):
+def cpu_baseline(prob, rows=64, iters=8):
     """Oracle (numpy fp64, reference op sequence incl. the dense identity G) on the first `rows`
     image rows; time scales linearly with pixels, so it/s(full) = it/s(crop) * crop / full."""
     from oracle import mu_oracle as oc
