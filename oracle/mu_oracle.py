@@ -359,13 +359,66 @@ def rescaled_DH(D, H):
     return D @ np.diag(1 / s), np.diag(s) @ H
 
 
+# ---- linesearch on the Laplacian surrogate -------------------------------------------
+def smooth_dgkl_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
+    """espm/estimators/surrogates.py:65-114: lambda/2 (2 tr(Ht L H^T) - tr(Ht L Ht^T) + sigma sum_k max_j H_kj sum_j dgkl(Ht_kj, H_kj))."""
+    HtL = Ht @ L
+    t1 = np.sum(HtL * Ht)
+    t2 = np.sum(HtL * H)
+    t3 = np.sum(np.max(H, axis=1) * np.sum(Ht * np.log(Ht / H) - Ht + H, axis=1))
+    return lambda_L / 2 * (2 * t2 - t1 + sigmaL * t3)
+
+
+def diff_surrogate(Ht, H, L, sigmaL=SIGMA_L, lambda_L=1):
+    """espm/estimators/surrogates.py:116-149 (algo "log_surrogate"): surrogate minus the Laplacian term at H."""
+    return smooth_dgkl_surrogate(Ht, L, H, sigmaL, lambda_L) - trace_xtLx(L, H.T) * lambda_L / 2
+
+
+def linesearch_gamma(gamma, Hold, H, L):
+    """espm/estimators/smooth_nmf.py:376-381: the caller passes neither lambda_L nor its own value - diff_surrogate runs
+    with its default lambda_L = 1 whatever the estimator's lambda_L is."""
+    return gamma / 1.05 if diff_surrogate(Hold, H, L, sigmaL=gamma) > 0 else gamma * 1.5
+
+
+# ---- truth tracking (true_D / true_H; base.py:301-347, measures.py) ---------------------------------------
+def spectral_angle(v1, v2):
+    """espm/measures.py:13-47 (2-D branch): angles in degrees between the rows of v1 and the rows of v2."""
+    a = v1 / np.sqrt(np.sum(v1 ** 2, axis=1, keepdims=True))
+    b = v2 / np.sqrt(np.sum(v2 ** 2, axis=1, keepdims=True))
+    return np.arccos(np.clip(a @ b.T, -1.0, 1.0)) * 180 / np.pi
+
+
+def squared_distance(x, y):
+    """espm/measures.py:579-626: mean squared distance between the rows of x and the rows of y."""
+    xx = (x * x).sum(axis=1)
+    yy = (y * y).sum(axis=1)
+    return np.abs(xx[:, None] + yy[None, :] - 2 * (x @ y.T)) / x.shape[1]
+
+
+def unique_min(matrix):
+    """espm/measures.py:172-207: the assignment (one row per column) with the smallest sum, by brute force over the
+    permutations in itertools order (the first minimum wins); returns its entries in column order."""
+    from itertools import permutations
+    k = matrix.shape[0]
+    perms = list(permutations(range(k), k))
+    sums = [sum(matrix[perm[i], i] for i in range(k)) for perm in perms]   # same order of additions as the reference
+    best = perms[sums.index(min(sums))]
+    return [matrix[best[i], i] for i in range(k)], best
+
+
+def truth_metrics(true_D, true_H, GW, H):
+    """base.py:342-343: find_min_angle(true_D.T, GW.T, unique=True), find_min_MSE(true_H, H, unique=True)."""
+    return unique_min(spectral_angle(true_D.T, GW.T))[0], unique_min(squared_distance(true_H, H))[0]
+
+
 def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_reg=1,
         simplex_H=False, simplex_W=True, shape_2d=None, tol=1e-4, max_iter=200, init=None,
         random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
         gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
-        record_at=(), time_iterations=False, exact_root=False):
+        record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
-    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", no linesearch).
+    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate"; linesearch: smooth_nmf.py:376-381;
+    true_D / true_H tracking: base.py:301-347).
 
     Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
     """
@@ -382,8 +435,13 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     gamma_ = SIGMA_L if gamma is None else gamma  # smooth_nmf.py:290-306
     c_kl = const_KL(X_, log_shift)
 
-    def loss(Wc, Hc):
-        return smooth_nmf_loss(X_, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl, gamma_)
+    def loss(Wc, Hc, Xc=None):
+        # base.py:196-203: with another X (the noiseless truth) the constant cached for the DATA is still the one added
+        return smooth_nmf_loss(X_ if Xc is None else Xc, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl, gamma_)
+
+    track = true_D is not None and true_H is not None and true_D.shape[1] == n_components and true_H.shape[0] == n_components
+    true_DH = true_D @ true_H if track else None
+    angles, mses, true_losses = [], [], []
 
     eval_before = np.inf
     # the reference evaluates the initial loss before gamma_ is set (it is None then); only the
@@ -398,10 +456,18 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
                                    epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
                                    lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
                                    exact_root=exact_root)
+        if linesearch:
+            gamma_ = linesearch_gamma(gamma_, old_H, H_, L_)
         W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
                                    simplex_W=simplex_W, fixed_W=fixed_W)
         eval_after, det = loss(W_, H_)
         n_iter += 1
+        if track:  # base.py:335-347
+            Wt, Ht = (W_, H_) if (simplex_H or simplex_W) else rescaled_DH(W_, H_)
+            a_, m_ = truth_metrics(true_D, true_H, G_ @ Wt, Ht)
+            angles.append(a_)
+            mses.append(m_)
+            true_losses.append(loss(W_, Ht, true_DH)[0])
         rel_W = np.max(np.abs(W_ - old_W) / (W_ + tol * np.mean(W_)))  # base.py:323-324
         rel_H = np.max(np.abs(H_ - old_H) / (H_ + tol * np.mean(H_)))
         losses.append(eval_after)
@@ -435,6 +501,8 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     out = dict(W=W_, H=H_, G=G_, GW=G_ @ W_, losses=np.array(losses), detailed_losses=np.array(detailed, dtype=float),
                rel=np.array(rel), n_iter=n_iter, exit=reason, reconstruction_err=recon, snapshots=snaps,
                eval_init=eval_init, const_KL=c_kl, norm_factor=norm)
+    if track:
+        out.update(angles=np.array(angles, dtype=float), mse=np.array(mses, dtype=float), true_losses=np.array(true_losses, dtype=float))
     if time_iterations:
         out["seconds"] = elapsed
     return out

@@ -9,7 +9,8 @@ path, so an empty stand-in package is put on sys.path from a temp dir (outside t
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
 
 Only DATA is stored: inputs and the reference's outputs.  Each archive also records the
-library versions used.  Fixture families follow SURVEY.md section 8(c): F1..F8.
+library versions used.  Fixture families follow SURVEY.md section 8(c): F1..F8; F9 covers the options of section 8(f) rank 4 that
+are built (linesearch, true_D / true_H tracking).
 """
 import contextlib
 import io
@@ -350,6 +351,59 @@ def f8():
     save("f8_api", **out)
 
 
+# ------------------------------------------------------------------ F9: linesearch and truth tracking
+LS = {
+    # lambda_L != 1 on purpose: diff_surrogate is called with its default lambda_L = 1 (smooth_nmf.py:377)
+    "ls3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=40, kw=dict(simplex_H=True, simplex_W=False, lambda_L=2.0, mu=0)),
+    "ls5": dict(n=60, nx=10, ny=12, k=4, m=9, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0.05)),
+    "lsw": dict(n=32, nx=6, ny=6, k=3, m=None, iters=30, kw=dict(simplex_H=False, simplex_W=True, lambda_L=0.5, mu=0, gamma=3.0)),
+}
+TM = {
+    "tm_h": dict(n=48, nx=8, ny=8, k=3, m=None, iters=12, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.5, mu=0)),
+    "tm_0": dict(n=40, nx=6, ny=7, k=3, m=7, iters=10, kw=dict(simplex_H=False, simplex_W=False, lambda_L=0.0, mu=0.02)),
+}
+
+
+def f9():
+    rng = np.random.default_rng(909)
+    out = {}
+    for name, c in {**LS, **TM}.items():
+        X, G, W, H = synth(rng, c["n"], c["nx"], c["ny"], c["k"], c["m"])
+        p = c["nx"] * c["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c["nx"], c["ny"]])
+        extra = dict(tol=0, no_stop_criterion=True, max_iter=c["iters"])
+        if name in LS:
+            est = SmoothNMF(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, linesearch=True, **c["kw"], **extra)
+        else:
+            true_D = W if G is None else G @ W
+            out[f"{name}_true_D"], out[f"{name}_true_H"] = true_D, H
+            est = SmoothNMF(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, true_D=true_D, true_H=H,
+                            **c["kw"], **extra)
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+        if name in TM:
+            out[f"{name}_angles"] = np.array(est.angles_, dtype=float)
+            out[f"{name}_mse"] = np.array(est.mse_, dtype=float)
+            out[f"{name}_true_losses"] = np.array(est.true_losses_, dtype=float)
+            gl = est.get_losses()
+            out[f"{name}_loss_names"] = np.array(json.dumps(list(gl.dtype.names)))
+            out[f"{name}_get_losses"] = np.array(gl.tolist())
+    out["names_ls"] = np.array(list(LS))
+    out["names_tm"] = np.array(list(TM))
+    out["configs"] = np.array(json.dumps({**LS, **TM}))
+    save("f9_linesearch_truth", **out)
+
+
 if __name__ == "__main__":
-    for fn in (f1, f2, f3, f4, f5, f6, f7, f8):
-        fn()
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9)}
+    for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
+        todo[name]()

@@ -177,3 +177,33 @@ def test_f8_fit_outputs(golden):
     np.testing.assert_allclose(r["GW"], g["nosimplex_GW"], rtol=1e-8)
     np.testing.assert_allclose(r["H"], g["nosimplex_H"], rtol=1e-8)
     np.testing.assert_allclose(r["reconstruction_err"], g["nosimplex_recon"], rtol=1e-9)
+
+
+def test_f9_linesearch_and_truth_tracking(golden):
+    """The options of SURVEY 8(f) rank 4 that are built: linesearch on the Laplacian surrogate (gamma adapts every
+    iteration, smooth_nmf.py:376-381) and true_D / true_H tracking (base.py:301-347)."""
+    g = golden("f9_linesearch_truth")
+    cfgs = json.loads(str(g["configs"]))
+    for name in list(g["names_ls"]) + list(g["names_tm"]):
+        c = cfgs[name]
+        G = g.get(f"{name}_G")
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        extra = dict(tol=0, no_stop_criterion=True, max_iter=c["iters"])
+        if name in g["names_ls"]:
+            extra["linesearch"] = True
+        else:
+            extra.update(true_D=g[f"{name}_true_D"], true_H=g[f"{name}_true_H"])
+        r = oc.fit(g[f"{name}_X"], c["k"], G=G, W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy(), shape_2d=shape,
+                   **c["kw"], **extra)
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-9, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["rel"], g[f"{name}_rel"], rtol=1e-7, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-8, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-8, atol=1e-14, err_msg=name)
+        if name in g["names_ls"]:
+            gam = g[f"{name}_detailed"][:, 3]
+            assert len(set(np.round(gam, 9))) > 5, "the fixture must exercise the adaptation"
+        else:
+            np.testing.assert_allclose(r["angles"], g[f"{name}_angles"], rtol=1e-7, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(r["mse"], g[f"{name}_mse"], rtol=1e-8, atol=1e-16, err_msg=name)
+            np.testing.assert_allclose(r["true_losses"], g[f"{name}_true_losses"], rtol=1e-9, err_msg=name)
