@@ -344,6 +344,16 @@ int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* 
 }
 
 
+int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(out && (hold == 0 || hold == 1) && hnew == 1 - hold, "linesearch_terms: bad arguments");
+  ESPM_REQUIRE(!st->halo_top && !st->halo_bot && (st->p_total == 0 || st->p_total == st->p), "linesearch_terms: not built for a sharded image");
+  // the H-step's record buffer is free between espm_mu_h_finalize and the next espm_mu_step_h: ESPM_HP_STRIDE rows of
+  // ceil(p / tile_px) >= ceil(p / 512) doubles hold the 3 + KP rows of partials
+  return launch_linesearch_terms(st->h[hold], st->h[hnew], st->k, st->p, st->p_pad, st->nx, st->ny, st->grid_mode, st->hpart, out,
+                                 static_cast<hipStream_t>(stream));
+}
+
 size_t espm_mu_shard_record_bytes(const espm_mu_state* st) {
   if (!st) return 0;
   size_t b = (size_t)st->k * st->n_pad * 4 + ESPM_HS_STRIDE * 8 + 2 * (size_t)st->k * (st->ny > 0 ? st->ny : 0) * 4;

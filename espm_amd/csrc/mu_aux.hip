@@ -183,6 +183,58 @@ int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* o
 }
 
 
+// ---- linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381) -------
+// d = g(H, Ht) - lambda/2 tr(H L H^T) needs, over all pixels, with Ht = the H before the update and H = the new one:
+//   t1 = sum Ht (Ht L), t2 = sum (Ht L) H, b = sum H (H L), and per component dg_k = sum_j Ht log(Ht / H) - Ht + H
+// (the caller weights dg_k with max_j H_kj, which the H-step already leaves in hstat).  One thread per pixel, stencil
+// as in the H-step; workgroup partials (field-major, LS_FIELDS rows) then a one-workgroup sum in fixed order.
+constexpr int LS_FIELDS = 3 + KP;
+__global__ __launch_bounds__(256) void linesearch_terms_kernel(const float* __restrict__ h_old, const float* __restrict__ h_new,
+                                                               int k, int p, int p_pad, int nx, int ny, int grid_mode,
+                                                               double* __restrict__ part) {
+  __shared__ double scratch[5 * LS_FIELDS];
+  double v[LS_FIELDS];
+#pragma unroll
+  for (int i = 0; i < LS_FIELDS; ++i) v[i] = 0.0;
+  for (int q = blockIdx.x * 512 + threadIdx.x; q < min(p, (int)(blockIdx.x + 1) * 512); q += 256) {
+    for (int kk = 0; kk < k; ++kk) {
+      const float* ro = h_old + (size_t)kk * p_pad;
+      const float* rn = h_new + (size_t)kk * p_pad;
+      const float ho = ro[q], hn = rn[q];
+      const float lo = grid_mode ? stencil_hl(ro, nullptr, nullptr, q, nx, ny, ho) : ho;   // L = identity without a grid (base.py:289-291)
+      const float ln = grid_mode ? stencil_hl(rn, nullptr, nullptr, q, nx, ny, hn) : hn;
+      v[0] += (double)ho * (double)lo;
+      v[1] += (double)lo * (double)hn;
+      v[2] += (double)hn * (double)ln;
+      v[3 + kk] += (double)ho * log((double)ho / (double)hn) - (double)ho + (double)hn;
+    }
+  }
+  block_reduce<LS_FIELDS, LS_FIELDS>(v, scratch);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < LS_FIELDS; ++i) part[(size_t)i * gridDim.x + blockIdx.x] = v[i];
+}
+__global__ __launch_bounds__(256) void linesearch_sum_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+  __shared__ double scratch[5 * LS_FIELDS];
+  double v[LS_FIELDS];
+#pragma unroll
+  for (int i = 0; i < LS_FIELDS; ++i) {
+    v[i] = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) v[i] += part[(size_t)i * nblk + b];
+  }
+  block_reduce<LS_FIELDS, LS_FIELDS>(v, scratch);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < LS_FIELDS; ++i) out[i] = v[i];
+}
+
+int launch_linesearch_terms(const float* h_old, const float* h_new, int k, int p, int p_pad, int nx, int ny, int grid_mode,
+                            double* part, double* out, hipStream_t stream) {
+  const int nblk = (p + 511) / 512;
+  hipLaunchKernelGGL(linesearch_terms_kernel, dim3(nblk), dim3(256), 0, stream, h_old, h_new, k, p, p_pad, nx, ny, grid_mode, part);
+  hipLaunchKernelGGL(linesearch_sum_kernel, dim3(1), dim3(256), 0, stream, part, nblk, out);
+  return check_hip(hipGetLastError(), "linesearch_terms launch");
+}
+
+
 // ---- sharded image: per-rank exchange record ------------------------------------------------------
 // One record per rank and iteration:  [ A (k*n_pad f32) | hstat of the new H
 // (ESPM_HS_STRIDE f64) | first owned image row of the new H (k*ny f32) | last owned row (k*ny f32) ].

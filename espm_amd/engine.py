@@ -414,6 +414,28 @@ class MUEngine:
             check(lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
         st.cur, st.it = 1 - cur, slot + 1
 
+    def linesearch_step(self, gamma):
+        """Adapts sigma_L after an iteration (espm/estimators/smooth_nmf.py:376-381, surrogates.py:116-149): with Ht the
+        H before the last update and H the current one, d = g(H, Ht) - 1/2 tr(H L H^T) (lambda_L = 1, as the reference
+        calls it); gamma / 1.05 when d > 0, else gamma * 1.5.  Call after ``finish_iteration``; returns the new gamma
+        (already in effect for the next H-step).  One host synchronisation."""
+        if self.world > 1:
+            raise NotImplementedError("linesearch is not built for a sharded image")
+        st = self.st
+        if st.it < 1:
+            raise ValueError("linesearch needs a completed iteration")
+        self._flush_finalize()
+        if getattr(self, "_ls_out", None) is None:
+            self._ls_out = torch.zeros(3 + _lib.KP, dtype=torch.float64, device=self.device)
+        check(lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
+        t = self._ls_out.cpu().numpy()
+        maxh = self.hstat[st.cur][_lib.HS_MAX:_lib.HS_MAX + self.k].cpu().numpy()   # max_j H[k, j] of the new H (global)
+        t3 = float((maxh * t[3:3 + self.k]).sum())
+        d = 0.5 * (2.0 * t[1] - t[0] + float(gamma) * t3) - 0.5 * t[2]
+        gamma = float(gamma) / 1.05 if d > 0 else float(gamma) * 1.5
+        st.sigma_l = gamma
+        return gamma
+
     def iterate(self, n_iter, final_loss=True):
         """``n_iter`` iterations without host synchronisation (no stop criterion)."""
         st = self.st

@@ -161,8 +161,6 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 pass
         if self.l2:
             raise NotImplementedError("the Frobenius loss (l2=True) is not built for the GPU path")
-        if self.true_D is not None or self.true_H is not None:
-            raise NotImplementedError("ground-truth tracking (true_D / true_H) is outside the accelerated path")
 
         # Large X: ONE upload; the passes the reference makes over X on the host before the loop (sign check, zero
         # lines base.py:519-528, mean for normalize, const_KL_ base.py:200-201, the NNDSVD's products) run on that
@@ -235,7 +233,13 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self.n_iter_ = 0
         self._begin_fit()
         self.losses_, self.rel_, self.detailed_losses_ = [], [], []
-        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None
+        # ground-truth tracking (base.py:301-311): every iteration compares G W with true_D, H with true_H and
+        # evaluates the loss against the noiseless true_D @ true_H (a second, loss-only engine holds that X)
+        track = self._begin_truth_tracking()
+        adapt = bool(getattr(self, "linesearch", False))
+        if (track or adapt) and getattr(eng, "world", 1) > 1:
+            raise NotImplementedError("linesearch / ground-truth tracking are not built for a sharded image")
+        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt
         eval_before = np.inf
         eval_init = None
         stop = False
@@ -251,6 +255,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                         chunk = min(chunk, self.eval_print - self.n_iter_ % self.eval_print)
                     chunk = max(chunk, 1)
                 eng.finish_iteration()
+                if adapt:  # smooth_nmf.py:376-381: gamma_ follows the Laplacian surrogate; in effect from the next H-step
+                    self.gamma_ = eng.linesearch_step(self._gamma_value())
                 if chunk > 1:
                     eng.iterate(chunk - 1, final_loss=False)
                     eng.eval_current(advance_h=(self.n_iter_ + chunk) < self.max_iter)
@@ -268,6 +274,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     self.detailed_losses_.append(self._detailed(float(h["kl"][t]), float(h["reg"][t]),
                                                                 float(h["lap"][t])))
                     self.rel_.append([float(h["rel_W"][t]), float(h["rel_H"][t])])
+                if track:
+                    self._track_truth(eng)
                 eval_after = self.losses_[-1]
                 rel_W, rel_H = self.rel_[-1]
 
@@ -340,12 +348,53 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return self.G_ @ W @ self.H_
 
     def get_losses(self):
-        """Structured array of the loss history (espm/estimators/base.py:479-517)."""
+        """Structured array of the loss history (espm/estimators/base.py:479-517); with true_D / true_H given also the
+        spectral angles, the map errors and the loss against the noiseless truth of every iteration."""
         names = ["full_loss"] + self.loss_names_ + ["rel_W", "rel_H"]
+        tracked = self.true_D is not None and self.true_H is not None
+        if tracked:  # base.py:483-499 (the reference fails here when the truth was ignored for its shape; so does this)
+            names += [f"ang_p{i}" for i in range(self.n_components)] + [f"mse_p{i}" for i in range(self.n_components)]
+            names += ["true_KL_loss"]
         dt = np.dtype([(elt, "float64") for elt in names])
-        rows = [(self.losses_[i],) + tuple(self.detailed_losses_[i]) + tuple(self.rel_[i])
-                for i in range(len(self.losses_))]
+        rows = []
+        for i in range(len(self.losses_)):
+            row = (self.losses_[i],) + tuple(self.detailed_losses_[i]) + tuple(self.rel_[i])
+            if tracked:
+                row += tuple(self.angles_[i]) + tuple(self.mse_[i]) + (self.true_losses_[i],)
+            rows.append(row)
         return np.array(rows, dtype=dt)
+
+    # ---- ground-truth tracking (espm/estimators/base.py:301-311, :335-347) ------------------------------------------
+    def _begin_truth_tracking(self):
+        self._truth_engine = None
+        if self.true_D is None or self.true_H is None:
+            return False
+        true_D, true_H = np.asarray(self.true_D), np.asarray(self.true_H)
+        if true_D.shape[1] != self.n_components or true_H.shape[0] != self.n_components:
+            print("The chosen number of components does not match the number of components of the provided truth. "
+                  "The ground truth will be ignored.")
+            return False
+        self.angles_, self.mse_, self.true_losses_ = [], [], []
+        true_DH = (true_D @ true_H).astype(np.float64)
+        # loss(W, H, X = true_DH) adds the constant cached for the DATA, not the one of true_DH (base.py:196-203)
+        self._truth_const = float(np.sum(true_DH * np.log(np.maximum(true_DH, self.log_shift))) - np.sum(true_DH))
+        self._truth_engine = self._make_engine(true_DH, 1.0, self._engine_G())
+        return True
+
+    def _track_truth(self, eng):
+        from espm_amd.measures import find_min_angle, find_min_MSE
+        W, H = eng.get_W().astype(np.float64), eng.get_H().astype(np.float64)
+        Wc, Hc = (W, H) if (self.simplex_H or self.simplex_W) else rescaled_DH(W, H)
+        GW = self.G_ @ Wc
+        self.angles_.append(find_min_angle(np.asarray(self.true_D).T, GW.T, unique=True))
+        self.mse_.append(find_min_MSE(np.asarray(self.true_H), Hc, unique=True))
+        te = self._truth_engine
+        te.load_state(W, Hc)                      # base.py:344: loss(self.W_, H, X = true_DH) - W as fitted, H rescaled
+        te.eval_current(advance_h=False)
+        h = te.history(upto=0, average=False)
+        numel = float(self.G_.shape[0] * Hc.shape[1])
+        lkl = float(h["kl"][0]) - self._truth_const + self.const_KL_
+        self.true_losses_.append((lkl + float(h["reg"][0]) + float(h["lap"][0])) / numel)
 
     def remove_zeros_lines(self, X, epsilon):
         """All-zero rows / columns of X become epsilon (espm/estimators/base.py:519-528)."""

@@ -15,8 +15,9 @@ class SmoothNMF(NMFEstimator):
 
     .. math:: \min_{W, H \ge \epsilon} D_{GKL}(X \| GWH) + \lambda_L tr(H \Delta H^T) + \mu \sum \log(H + \epsilon_{reg})
 
-    Parameters as in espm/estimators/smooth_nmf.py:46-79.  Only the default solver
-    ``algo="log_surrogate"`` without line search is accelerated; the alternates raise
+    Parameters as in espm/estimators/smooth_nmf.py:46-79.  The default solver ``algo="log_surrogate"`` is
+    accelerated, with or without ``linesearch`` (gamma_ adapts to the Laplacian surrogate every iteration,
+    smooth_nmf.py:376-381) and with ``true_D`` / ``true_H`` tracking; the other solvers raise
     ``NotImplementedError`` at fit time.
     """
 
@@ -133,9 +134,8 @@ class SmoothNMF(NMFEstimator):
 
     def fit_transform(self, X, y=None, W=None, H=None):
         """Fit the model to X (n, p) and return G W (espm/estimators/smooth_nmf.py:239-282)."""
-        if self.algo != "log_surrogate" or self.linesearch:
-            raise NotImplementedError("the GPU path implements algo='log_surrogate' without linesearch "
-                                      f"(got algo={self.algo!r}, linesearch={self.linesearch})")
+        if self.algo != "log_surrogate":
+            raise NotImplementedError(f"the GPU path implements algo='log_surrogate' (got algo={self.algo!r})")
         self.gamma_ = None
         return super().fit_transform(X, y=y, W=W, H=H)
 
@@ -145,7 +145,10 @@ class SmoothNMF(NMFEstimator):
             self.gamma_ = sigmaL if self.gamma is None else deepcopy(self.gamma)
         eng = self._get_engine()
         eng.load_state(W, H)
+        eng.st.sigma_l = float(self._gamma_value())
         eng.iterate(1, final_loss=False)
+        if self.linesearch:  # smooth_nmf.py:376-381
+            self.gamma_ = eng.linesearch_step(self._gamma_value())
         return eng.get_W().astype(W.dtype), eng.get_H().astype(H.dtype)
 
     def loss(self, W, H, average=True, X=None):

@@ -1,4 +1,5 @@
-"""Objective pieces of the path (espm/measures.py:456-504, :524-548, :560-577) on the GPU."""
+"""Objective pieces of the path (espm/measures.py:456-504, :524-548, :560-577) on the GPU, and the ground-truth
+comparison of a fit (espm/measures.py:13-47, :125-285, :579-626; k x k problems, host numpy)."""
 import ctypes as C
 
 import numpy as np
@@ -66,3 +67,62 @@ def trace_xtLx(L, x, average=False):
         _lib.check(_lib.lib.espm_mu_laplacian(_ptr(h), k, shape[0], shape[1], p, _ptr(hl), _stream()))
     t = (h.double() * hl.double())
     return float(t.mean() if average else t.sum())
+
+
+# ---- ground-truth comparison (true_D / true_H tracking, espm/estimators/base.py:335-347) --------------------------
+def spectral_angle(v1, v2):
+    """Angle in degrees between two spectra, or between the rows of two (phases, channels) arrays (espm/measures.py:13-47)."""
+    v1, v2 = np.asarray(v1, dtype=np.float64), np.asarray(v2, dtype=np.float64)
+    if v1.ndim == 1:
+        if v1.shape != v2.shape:
+            raise ValueError("v1 and v2 should have the same shape.")
+        return np.arccos(np.clip(np.dot(v1 / np.linalg.norm(v1), v2 / np.linalg.norm(v2)), -1.0, 1.0)) * 180 / np.pi
+    if v1.shape[1] != v2.shape[1]:
+        raise ValueError("The second dimensions of v1 and v2 should be the same.")
+    a = v1 / np.sqrt(np.sum(v1 ** 2, axis=1, keepdims=True))
+    b = v2 / np.sqrt(np.sum(v2 ** 2, axis=1, keepdims=True))
+    return np.arccos(np.clip(a @ b.T, -1.0, 1.0)) * 180 / np.pi
+
+
+def squared_distance(x, y=None):
+    """Mean squared distance between the rows of x and the rows of y (espm/measures.py:579-626)."""
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    y = x if y is None else np.atleast_2d(np.asarray(y, dtype=np.float64))
+    if x.shape[1] != y.shape[1]:
+        raise ValueError("The sizes of x and y do not fit")
+    xx, yy = (x * x).sum(axis=1), (y * y).sum(axis=1)
+    return np.abs(xx[:, None] + yy[None, :] - 2 * np.dot(x, y.T)) / x.shape[1]
+
+
+def global_min(matr):
+    """Row-wise minima and their columns (espm/measures.py:157-170)."""
+    import warnings
+    res = [float(np.min(row)) for row in matr]
+    ind = [int(np.argmin(row)) for row in matr]
+    if any(ind.count(x) > 1 for x in ind):
+        warnings.warn("Several results share the same truth")
+    return res, ind
+
+
+def unique_min(matrix):
+    """The one-row-per-column assignment of a square matrix with the smallest sum, by brute force over the permutations
+    (espm/measures.py:172-207; not meant for more than ~10 phases): its entries in column order and the permutation."""
+    from itertools import permutations
+    matrix = np.asarray(matrix)
+    k = matrix.shape[0]
+    perms = list(permutations(range(k), k))
+    sums = [sum(matrix[perm[i], i] for i in range(k)) for perm in perms]
+    best = perms[sums.index(min(sums))]
+    return [matrix[best[i], i] for i in range(k)], best
+
+
+def find_min_angle(true_vectors, algo_vectors, get_ind=False, unique=False):
+    """Best match of NMF spectra to true spectra by spectral angle (espm/measures.py:125-155)."""
+    out = (unique_min if unique else global_min)(spectral_angle(true_vectors, algo_vectors))
+    return out if get_ind else out[0]
+
+
+def find_min_MSE(true_maps, algo_maps, get_ind=False, unique=False):
+    """Best match of NMF maps to true maps by mean squared error (espm/measures.py:244-270)."""
+    out = (unique_min if unique else global_min)(squared_distance(true_maps, algo_maps))
+    return out if get_ind else out[0]

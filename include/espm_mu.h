@@ -289,6 +289,14 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                            double log_shift, double tol, int maxit, double* nu_out,
                            int32_t* status_out, espm_stream_t stream);
 
+/* Terms of the linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381)
+ * between two H buffers, Ht = h[hold] (before the update) and H = h[hnew]: out (3 + ESPM_KP device doubles) =
+ * [sum Ht (Ht L), sum (Ht L) H, sum H (H L), dg_0 .. dg_7] with dg_k = sum_j Ht log(Ht / H) - Ht + H.  The caller
+ * forms d = 1/2 (2 out[1] - out[0] + gamma sum_k max_j H_kj dg_k) - 1/2 out[2] (lambda_L = 1 as the reference calls
+ * it) and lowers gamma by 1.05 when d > 0, else raises it by 1.5.  Uses st->hpart as scratch: call it between
+ * espm_mu_h_finalize and the next espm_mu_step_h.  One GPU only. */
+int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream);
+
 /* out = H @ L for the 5-point Laplacian on an (nx, ny) grid (k, nx*ny) with leading dim ld. */
 int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out,
                       espm_stream_t stream);

@@ -398,3 +398,34 @@ def test_sparse_store_unit_rows_edge_cases(case):
     np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
     assert h["bad"].sum() == 0
+
+
+def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden):
+    """linesearch=True (gamma_ adapts every iteration) and true_D / true_H tracking against the reference's own
+    trajectories (fixture F9)."""
+    g = golden("f9_linesearch_truth")
+    cfgs = json.loads(str(g["configs"]))
+    for name in list(g["names_ls"]) + list(g["names_tm"]):
+        c = cfgs[name]
+        G = g.get(f"{name}_G")
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        kw = dict(c["kw"], tol=0, no_stop_criterion=True, max_iter=c["iters"])
+        if name in g["names_ls"]:
+            kw["linesearch"] = True
+        else:
+            kw.update(true_D=g[f"{name}_true_D"], true_H=g[f"{name}_true_H"])
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=shape, verbose=0, **kw)
+        GW = est.fit_transform(g[f"{name}_X"], W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy())
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")   # same decisions
+        np.testing.assert_allclose(det[:, :3], g[f"{name}_detailed"][:, :3], rtol=2e-5, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=5e-4, atol=5e-5, err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=5e-4, atol=5e-4 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+        if name in g["names_tm"]:
+            np.testing.assert_allclose(est.angles_, g[f"{name}_angles"], rtol=1e-3, atol=1e-3, err_msg=name)
+            np.testing.assert_allclose(est.mse_, g[f"{name}_mse"], rtol=1e-3, atol=1e-9, err_msg=name)
+            np.testing.assert_allclose(est.true_losses_, g[f"{name}_true_losses"], rtol=LOSS_RTOL, err_msg=name)
+            gl = est.get_losses()
+            assert list(gl.dtype.names) == json.loads(str(g[f"{name}_loss_names"]))
+            np.testing.assert_allclose(np.array(gl.tolist()), g[f"{name}_get_losses"], rtol=2e-3, atol=1e-6)
