@@ -344,6 +344,44 @@ int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* 
 }
 
 
+// ---- Frobenius ("l2") branch of the step functions (mu_l2.hip) ----------------------------------------------------
+static int check_l2(const espm_mu_state* st, const float* work, const double* scratch, int scratch_doubles) {
+  ESPM_REQUIRE(work && scratch && scratch_doubles >= ESPM_KP * ESPM_KP, "l2 step: work (2, KP, KP) and a scratch of >= %d doubles are needed", ESPM_KP * ESPM_KP);
+  ESPM_REQUIRE(st->x_dtype == ESPM_X_F32, "l2 step: the f32 store is required");
+  ESPM_REQUIRE(st->xscale == 1.f && st->lambda_l == 0.f && st->mu == nullptr, "l2 step: xscale = 1, lambda_L = 0 and mu = 0 are required (updates.py:110-114)");
+  return ESPM_OK;
+}
+
+int espm_mu_l2_step_h(const espm_mu_state* st, int src, float* work, double* scratch, int scratch_doubles, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  if (int rc = check_l2(st, work, scratch, scratch_doubles)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = launch_gram(st->gw_s, st->n, st->k, scratch, scratch_doubles, work, s)) return rc;   // GW^T GW
+  HStepArgs a = make_h_args(st, src, 1);
+  a.compute_loss = 0;
+  a.l2_m = work;
+  return dispatch_h_step(a, st->x_dtype, st->tile_px, nblk_h(st), s);
+}
+
+int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float* work, double* scratch, int scratch_doubles,
+                      espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  if (int rc = check_l2(st, work, scratch, scratch_doubles)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  ESPM_REQUIRE(st->m == 0 || gtg, "l2 W step: G^T G (m, m) is needed when G is given");
+  ESPM_REQUIRE(!st->simplex_w, "l2 W step: no simplex over W in the Frobenius branch (updates.py:31-36)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* hh = work + ESPM_KP * ESPM_KP;
+  if (int rc = launch_gram(st->h_t, st->p, st->k, scratch, scratch_doubles, hh, s)) return rc;      // H H^T
+  WAccumArgs wa = make_w_args(st);
+  wa.l2 = 1;
+  if (int rc = dispatch_w_accum(wa, st->k, st->x_dtype, st->nblk_w, s)) return rc;                 // slabs of X H^T
+  if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, s)) return rc;
+  return launch_w_finish_l2(st->a, st->n, st->n_pad, st->m, st->k, st->m > 0 ? st->g : nullptr, gtg, hh, st->w[src], st->w[1 - src],
+                            st->fixed_w, st->log_shift, s);
+}
+
 int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(out && (hold == 0 || hold == 1) && hnew == 1 - hold, "linesearch_terms: bad arguments");

@@ -365,6 +365,7 @@ struct HStepArgs {
   const int32_t* ell_pix;
   int ell_bits, n_pad;
   int ell_tp;        // pixels per workgroup of the sparse H-step (= tile_px: 64, 128, 256 or 512)
+  const float* l2_m; // Frobenius branch: (KP, KP) GW^T GW, else null
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -386,6 +387,7 @@ struct WAccumArgs {
   const int32_t* ell_off;
   const int32_t* chan_perm;
   int n_cg;
+  int l2;            // Frobenius branch: A = X H^T
 };
 struct WFinishArgs {
   const float* g;
@@ -499,6 +501,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.ell_pix = st->pix_perm;
   a.ell_bits = st->ell_cbits;
   a.ell_tp = st->tile_px;
+  a.l2_m = nullptr;
   a.n_pad = st->n_pad;
   return a;
 }
@@ -516,6 +519,7 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
   a.ell_off = st->ell_w_off;
   a.chan_perm = st->chan_perm;
   a.n_cg = st->n_cg;
+  a.l2 = 0;
   return a;
 }
 
@@ -536,6 +540,9 @@ int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HF
 int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HFinalizeArgs& fin_to_record,
                          const float* h_new, int nx, int ny, int p_pad, int with_halo, void* rec, hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);
+int launch_gram(const float* m, int rows, int k, double* part, int part_cap, float* out, hipStream_t stream);
+int launch_w_finish_l2(const float* a, int n, int n_pad, int m, int k, const float* g, const float* gtg, const float* hh, const float* w_old,
+                       float* w_new, const float* fixed_w, float log_shift, hipStream_t stream);
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
                            const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream);

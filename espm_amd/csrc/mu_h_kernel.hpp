@@ -93,6 +93,15 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       nv[kk] = s * a.xscale;
       dv[kk] = (float)a.colsum_gw[kk];
     }
+    if (a.l2_m) {  // Frobenius branch: denum = (GW^T GW) H, updates.py:115-118
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float d = 0.f;
+#pragma unroll
+        for (int l = 0; l < K; ++l) d = fmaf(a.l2_m[kk * KP + l], hin[l], d);
+        dv[kk] = d;
+      }
+    }
     if (a.have_prev) {
       // rel_H of the update that produced h_in: the other buffer still holds the previous H
       // (each thread reads its own entries before overwriting them below), base.py:324
@@ -174,7 +183,9 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 // K components, XT storage type of X, PX pixels per lane (tile = 64 * PX pixels), NW waves per
 // workgroup (they split the channel range), LOSS: accumulate the KL term, U channels per load group,
 // NBUF: depth of the register ring of X load groups kept in flight (0 / 1: no explicit prefetch).
-template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF>
+// L2: the Frobenius branch (updates.py:109-118): num = GW^T X, no ratio, no loss; the epilogue takes the denominator
+// (GW^T GW) H from a.l2_m.
+template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false>
 __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   constexpr int TP = 64 * PX;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
       const f2 inv = f2{__builtin_amdgcn_rcpf(y.x), __builtin_amdgcn_rcpf(y.y)};
       // R = X / Y; with the loss the tiny offset keeps log2(R) finite where X = 0 (0 * finite = 0) at
       // no extra cost (it rides in the fma) and is far below fp32 resolution of any non-zero R
-      const f2 r = LOSS ? x[i] * inv + f2{1e-37f, 1e-37f} : x[i] * inv;
+      const f2 r = L2 ? x[i] : (LOSS ? x[i] * inv + f2{1e-37f, 1e-37f} : x[i] * inv);
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) num[kk][i] = gk[kk] * r + num[kk][i];
       if constexpr (LOSS) kl[i] = x[i] * f2{__builtin_amdgcn_logf(r.x), __builtin_amdgcn_logf(r.y)} + kl[i];

@@ -7,7 +7,8 @@ namespace espm {
 // K components, XT storage type, CH channels per lane (one 16-byte load), UP pixels per load group,
 // NBUF: depth of the register ring of X load groups kept in flight.  A workgroup = 4 waves = 256 * CH channels,
 // blockIdx.y walks further channel chunks, blockIdx.x the pixel blocks.
-template <int K, typename XT, int CH, int UP, int NBUF>
+// L2: the Frobenius branch (updates.py:31-36): A = X H^T, no ratio.
+template <int K, typename XT, int CH, int UP, int NBUF, bool L2 = false>
 __global__ __launch_bounds__(256) void w_accum_kernel(const WAccumArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void w_accum_kernel(const WAccumArgs a) {
       f2 y = hk[0] * gw[i][0];
 #pragma unroll
       for (int kk = 1; kk < K; ++kk) y = hk[kk] * gw[i][kk] + y;
-      const f2 r = x[i] * f2{__builtin_amdgcn_rcpf(y.x), __builtin_amdgcn_rcpf(y.y)};
+      const f2 r = L2 ? x[i] : x[i] * f2{__builtin_amdgcn_rcpf(y.x), __builtin_amdgcn_rcpf(y.y)};
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) acc[i][kk] = hk[kk] * r + acc[i][kk];
     }

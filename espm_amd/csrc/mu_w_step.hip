@@ -744,6 +744,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
 // ---- dispatch -----------------------------------------------------------------------------------
 template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
+  if (args.l2 && x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "the l2 W accumulation needs the f32 store");
   if (x_dtype == ESPM_X_U8) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
     hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, 8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
@@ -752,7 +753,10 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
     hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
   } else {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 4 - 1) / (4 * 64 * 4));
-    hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, 0>), grid, dim3(256), 0, stream, args);
+    if (args.l2)
+      hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, 0, true>), grid, dim3(256), 0, stream, args);
+    else
+      hipLaunchKernelGGL((w_accum_kernel<K, float, 4, 4, 0>), grid, dim3(256), 0, stream, args);
   }
   return check_hip(hipGetLastError(), "w_accum launch");
 }

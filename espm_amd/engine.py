@@ -452,14 +452,25 @@ class MUEngine:
                 self.eval_current(False)
 
     # ---- single half steps for the module-level functions ----------------------------------------------
-    def step_h_only(self):
+    def _l2_buffers(self):
+        if getattr(self, "_l2_work", None) is None:
+            self._l2_work = torch.zeros((2, _lib.KP, _lib.KP), dtype=torch.float32, device=self.device)
+            self._l2_scratch = torch.zeros(64 * _lib.KP * _lib.KP, dtype=torch.float64, device=self.device)
+        return self._l2_work, self._l2_scratch
+
+    def step_h_only(self, l2=False):
         st = self.st
         self._flush_finalize()
+        if l2:  # Frobenius branch, updates.py:109-118
+            work, scratch = self._l2_buffers()
+            check(lib.espm_mu_l2_step_h(C.byref(st), st.cur, _ptr(work), _ptr(scratch), scratch.numel(), _stream()))
+            check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+            return self._h_numpy(1 - st.cur)
         check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
         check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
         return self._h_numpy(1 - st.cur)
 
-    def step_w_only(self):
+    def step_w_only(self, l2=False):
         """W update using the CURRENT H (its transposed copy is refreshed first)."""
         st = self.st
         cur = st.cur
@@ -467,6 +478,14 @@ class MUEngine:
         self.h_t.zero_()
         self.h_t[:, :self.k].copy_(self.h[cur][:, :self.p].t())
         s = _stream()
+        if l2:  # Frobenius branch, updates.py:31-36
+            work, scratch = self._l2_buffers()
+            gtg = None
+            if self.m > 0:
+                gtg = (self.g.double().t() @ self.g.double()).float().contiguous()   # G^T G (m, m): a constant of the fit
+            check(lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(gtg) if gtg is not None else None, _ptr(work), _ptr(scratch),
+                                        scratch.numel(), s))
+            return self.w[1 - cur].cpu().numpy()
         check(lib.espm_mu_w_accum(C.byref(st), s))
         check(lib.espm_mu_w_reduce(C.byref(st), s))
         check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))

@@ -33,12 +33,16 @@ def _engine(X, G, W, H, **kw):
 
 def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe=True, l2=False, fixed_W=None,
                           physics_model=None, use_bregman=False):
-    """Multiplicative step in W (espm/estimators/updates.py:6-78, KL branch)."""
-    if l2 or use_bregman:
-        raise NotImplementedError("only the KL multiplicative update (algo='log_surrogate') is built for the GPU")
+    """Multiplicative step in W (espm/estimators/updates.py:6-78: KL branch, and the Frobenius branch l2=True :31-36)."""
+    if use_bregman:
+        raise NotImplementedError("the Bregman variant (use_bregman=True) is not built for the GPU")
     W = np.asarray(W)
     H = np.asarray(H)
     W, H = _safe_inputs(G, W, H, log_shift, safe)
+    if l2:  # new_W = W / (G^T G W H H^T) * (G^T X H^T): no simplex in this branch
+        eng = _engine(X, G, W, H, simplex_H=False, simplex_W=False, log_shift=log_shift, fixed_W=fixed_W, x_store="f32")
+        out = eng.step_w_only(l2=True)
+        return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
     rows = physics_model.NMF_simplex() if (simplex_W and physics_model is not None) else None
     eng = _engine(X, G, W, H, simplex_H=False, simplex_W=simplex_W, log_shift=log_shift, fixed_W=fixed_W,
                   simplex_rows=rows)
@@ -49,7 +53,7 @@ def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe
 def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
                           dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, sigmaL=sigmaL, fixed_H=None,
                           use_bregman=False):
-    """Multiplicative step in H (espm/estimators/updates.py:83-156, KL branch)."""
+    """Multiplicative step in H (espm/estimators/updates.py:83-156: KL branch, and the Frobenius branch l2=True :109-118)."""
     shape_2d = None
     W = np.asarray(W)
     H = np.asarray(H)
@@ -57,9 +61,18 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
         if L is None:
             raise ValueError("Please provide the laplacian")  # updates.py:94-95
         kind, shape_2d = classify_laplacian(L, H.shape[1])
-    if l2 or use_bregman:
-        raise NotImplementedError("only the KL multiplicative update (algo='log_surrogate') is built for the GPU")
+    if use_bregman:
+        raise NotImplementedError("the Bregman variant (use_bregman=True) is not built for the GPU")
     W, H = _safe_inputs(G, W, H, log_shift, safe)
+    if l2:  # updates.py:109-118
+        assert lambda_L == 0
+        assert np.all(np.asarray(mu) == 0)
+        eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, log_shift=log_shift, dicotomy_tol=dicotomy_tol,
+                      fixed_H=fixed_H, compute_loss=False, x_store="f32")
+        out = eng.step_h_only(l2=True)
+        if eng.bad_count() > 0 and safe:
+            raise AssertionError("multiplicative_step_h: non-finite update or simplex preconditions violated")
+        return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
     eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, mu=mu, log_shift=log_shift,
                   epsilon_reg=epsilon_reg, dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, shape_2d=shape_2d,
                   sigmaL=sigmaL, fixed_H=fixed_H, compute_loss=False)

@@ -289,6 +289,17 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                            double log_shift, double tol, int maxit, double* nu_out,
                            int32_t* status_out, espm_stream_t stream);
 
+/* Frobenius ("l2") branch of the step functions, espm/estimators/updates.py:109-118 (H) and :31-36 (W); in the reference
+ * reachable only by calling multiplicative_step_h / _w with l2=True (espm/tests/test_updates.py:457-568).  f32 store,
+ * xscale = 1, lambda_L = 0, mu = NULL.  work: (2, KP, KP) device floats (GW^T GW, then H H^T); scratch: device doubles
+ * for the partial Gram sums (>= KP * KP, more = more workgroups).
+ *   l2_step_h: H' = max(H * (GW^T X) / ((GW^T GW) H + nu), eps), simplex_h / fixed_h as in espm_mu_step_h; h[src] -> h[1-src].
+ *   l2_step_w: W' = max(W / (G^T G W H H^T) * (G^T (X H^T)), eps), fixed_w; H = h_t (the caller keeps it current);
+ *              gtg = G^T G (m, m) when G is given (a property of G alone: formed once by the caller); w[src] -> w[1-src]. */
+int espm_mu_l2_step_h(const espm_mu_state* st, int src, float* work, double* scratch, int scratch_doubles, espm_stream_t stream);
+int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float* work, double* scratch, int scratch_doubles,
+                      espm_stream_t stream);
+
 /* Terms of the linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381)
  * between two H buffers, Ht = h[hold] (before the update) and H = h[hnew]: out (3 + ESPM_KP device doubles) =
  * [sum Ht (Ht L), sum (Ht L) H, sum H (H L), dg_0 .. dg_7] with dg_k = sum_j Ht log(Ht / H) - Ht + H.  The caller

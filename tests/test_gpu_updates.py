@@ -116,7 +116,43 @@ def test_step_h_golden_special(api, golden):
     with pytest.raises(ValueError):
         api["step_h"](X, G, W, H, lambda_L=1.0, L=None)
     with pytest.raises(NotImplementedError):
-        api["step_h"](X, G, W, H, l2=True)
+        api["step_h"](X, G, W, H, use_bregman=True)
+
+
+def test_frobenius_branch_golden_and_properties(api, golden):
+    """l2=True: the Frobenius branch of both step functions (updates.py:31-36, :109-118) against the reference's outputs
+    (fixtures F2 / F3) and its own property tests (espm/tests/test_updates.py:457-475, :508-513, :562-577): an exact
+    factorisation is a fixed point, the update stays positive and does not increase the Frobenius loss."""
+    gh, gw = golden("f2_step_h"), golden("f3_step_w")
+    for t in (0, 1):
+        X, G, W, H = (gh[f"in{t}_{s}"] for s in ("X", "G", "W", "H"))
+        np.testing.assert_allclose(api["step_h"](X, G, W, H.copy(), simplex_H=True, l2=True), gh[f"l2_{t}_H"], rtol=3e-5, atol=3e-6)
+        X, G, W, H = (gw[f"in{t}_{s}"] for s in ("X", "G", "W", "H"))
+        np.testing.assert_allclose(api["step_w"](X, G, W.copy(), H, l2=True), gw[f"l2_{t}_W"], rtol=3e-5, atol=1e-7)
+    rng = np.random.default_rng(5)
+    n, m, k, p = 70, 9, 3, 150
+    G = rng.random((n, m))
+    W = rng.random((m, k)) + 0.05
+    H = rng.random((k, p)) + 0.05
+    H /= H.sum(axis=0, keepdims=True)
+    X = G @ W @ H                                                    # exact: (W, H) is a fixed point
+    np.testing.assert_allclose(api["step_w"](X, G, W.copy(), H, l2=True, simplex_W=False), W, rtol=2e-5)
+    np.testing.assert_allclose(api["step_h"](X, G, W, H.copy(), simplex_H=False, l2=True), H, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(api["step_h"](X, G, W, H.copy(), simplex_H=True, l2=True), H, atol=1e-5)
+    frob = lambda Wc, Hc: float(np.sum((X - G @ Wc @ Hc) ** 2))
+    for _ in range(3):
+        W2 = rng.random((m, k)) + 0.01
+        Wn = api["step_w"](X, G, W2.copy(), H, l2=True, simplex_W=False)
+        assert (Wn > 0).all() and frob(Wn, H) <= frob(W2, H) * (1 + 1e-6)
+        H2 = rng.random((k, p)) + 0.01
+        Hn = api["step_h"](X, G, W, H2.copy(), simplex_H=False, l2=True)
+        assert (Hn > 0).all() and frob(W, Hn) <= frob(W, H2) * (1 + 1e-6)
+    Xi = rng.random((40, 60))                                        # G = identity
+    Wi, Hi = rng.random((40, 2)) + 0.1, rng.random((2, 60)) + 0.1
+    Wn = api["step_w"](Xi, np.eye(40), Wi.copy(), Hi, l2=True)
+    np.testing.assert_allclose(Wn, Wi / (Wi @ (Hi @ Hi.T)) * (Xi @ Hi.T), rtol=3e-5)
+    Hn = api["step_h"](Xi, np.eye(40), Wi, Hi.copy(), l2=True)
+    np.testing.assert_allclose(Hn, Hi * (Wi.T @ Xi) / ((Wi.T @ Wi) @ Hi), rtol=3e-5)
 
 
 def test_step_h_reference_properties(api):
