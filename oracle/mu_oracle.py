@@ -167,8 +167,9 @@ def identity_L(p):
 # --------------------------------------------------------------------------------------
 def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT, epsilon_reg=1,
                           safe=True, dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, l2=False,
-                          sigmaL=SIGMA_L, fixed_H=None, exact_root=False):
-    """One multiplicative H update, updates.py:83-156 (KL branch :127-132, l2 branch :109-118).
+                          sigmaL=SIGMA_L, fixed_H=None, exact_root=False, use_bregman=False):
+    """One multiplicative H update, updates.py:83-156 (KL branch :127-132, l2 branch :109-118, Bregman variant
+    :120-125).
 
     ``exact_root`` swaps the reference's bisection for ``dichotomy_simplex_exact`` (test yardstick)."""
     if lambda_L != 0:
@@ -185,11 +186,16 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT
         num = GW.T @ X
         den = (GW.T @ GW) @ H
     else:
-        Y = GW @ H
-        num = GW.T @ (X / Y)
-        if np.isnan(num).any():  # updates.py:129-131
-            num = GW.T @ (X / np.maximum(Y, log_shift))
-        den = GW.sum(axis=0)[:, None]
+        if use_bregman:  # updates.py:120-125
+            sigmaR = X.sum(axis=0, keepdims=True)
+            num = sigmaR / H
+            den = -GW.T @ (X / (GW @ H)) + GW.sum(axis=0)[:, None] + sigmaR / H
+        else:
+            Y = GW @ H
+            num = GW.T @ (X / Y)
+            if np.isnan(num).any():  # updates.py:129-131
+                num = GW.T @ (X / np.maximum(Y, log_shift))
+            den = GW.sum(axis=0)[:, None]
         if not (np.isscalar(mu) and mu == 0):
             mu_col = np.asarray(mu, dtype=float)
             if mu_col.ndim == 1:
@@ -216,8 +222,8 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=LOG_SHIFT
 
 
 def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=LOG_SHIFT, safe=True, l2=False,
-                          fixed_W=None, simplex_rows=None):
-    """One multiplicative W update, updates.py:6-78.
+                          fixed_W=None, simplex_rows=None, use_bregman=False):
+    """One multiplicative W update, updates.py:6-78 (Bregman variant :40-48: no simplex over W there).
 
     ``simplex_rows`` stands for ``physics_model.NMF_simplex()`` (updates.py:62-65).
     """
@@ -227,6 +233,11 @@ def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=LOG_SHIFT, safe
         W = np.maximum(W, log_shift)
     if l2:
         new_W = W / ((G.T @ G) @ W @ (H @ H.T)) * (G.T @ (X @ H.T))  # updates.py:30-36
+    elif use_bregman:
+        # updates.py:41-48 (np.allclose(G, np.eye(n)) needs a square G: the reference fails for a dictionary)
+        sigmaR = X.sum(axis=1, keepdims=True) if np.allclose(G, np.eye(G.shape[0])) else np.sum(X)
+        gradg = -G.T @ (X / ((G @ W) @ H)) @ H.T + G.sum(axis=0)[:, None] @ H.sum(axis=1)[None, :]
+        new_W = (sigmaR * W) / (gradg * W + sigmaR)
     else:
         Y = (G @ W) @ H
         R = X / Y
@@ -415,9 +426,10 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         simplex_H=False, simplex_W=True, shape_2d=None, tol=1e-4, max_iter=200, init=None,
         random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
         gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
-        record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None):
+        record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None,
+        algo="log_surrogate"):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
-    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate"; linesearch: smooth_nmf.py:376-381;
+    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate" or "bmd"; linesearch: smooth_nmf.py:376-381;
     true_D / true_H tracking: base.py:301-347).
 
     Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
@@ -433,6 +445,9 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     p = X_.shape[1]
     L_ = laplacian_matrix(*shape_2d) if shape_2d is not None else identity_L(p)
     gamma_ = SIGMA_L if gamma is None else gamma  # smooth_nmf.py:290-306
+    if algo not in ("log_surrogate", "bmd"):
+        raise NotImplementedError(algo)
+    breg = algo == "bmd"  # smooth_nmf.py:358-372, :416-426: both steps with use_bregman=True
     c_kl = const_KL(X_, log_shift)
 
     def loss(Wc, Hc, Xc=None):
@@ -455,11 +470,11 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         H_ = multiplicative_step_h(X_, G_, W_, H_, simplex_H=simplex_H, mu=mu, log_shift=log_shift,
                                    epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
                                    lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
-                                   exact_root=exact_root)
+                                   exact_root=exact_root, use_bregman=breg)
         if linesearch:
             gamma_ = linesearch_gamma(gamma_, old_H, H_, L_)
         W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
-                                   simplex_W=simplex_W, fixed_W=fixed_W)
+                                   simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
         eval_after, det = loss(W_, H_)
         n_iter += 1
         if track:  # base.py:335-347

@@ -403,7 +403,49 @@ def f9():
     save("f9_linesearch_truth", **out)
 
 
+# ------------------------------------------------------------------ F10: the Bregman variant (algo="bmd", use_bregman=True)
+BMD = {
+    "b3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0)),
+    # (a non-square G makes the reference's own W step fail: np.allclose(G, np.eye(n)) at updates.py:43 cannot broadcast)
+    "bm": dict(n=60, nx=10, ny=12, k=4, m=None, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0.05)),
+    "b0": dict(n=32, nx=6, ny=6, k=3, m=None, iters=20, kw=dict(simplex_H=False, simplex_W=False, lambda_L=0.0, mu=0)),
+    "bl": dict(n=48, nx=8, ny=8, k=3, m=None, iters=25, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.7, mu=0, linesearch=True)),
+}
+
+
+def f10():
+    rng = np.random.default_rng(1010)
+    out = {}
+    for name, c in BMD.items():
+        X, G, W, H = synth(rng, c["n"], c["nx"], c["ny"], c["k"], c["m"])
+        p = c["nx"] * c["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        Gd = np.eye(c["n"]) if G is None else G
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c["nx"], c["ny"]])
+        L = create_laplacian_matrix(c["nx"], c["ny"])
+        # single steps (direct calls)
+        mu = c["kw"]["mu"]
+        out[f"{name}_step_H"] = multiplicative_step_h(X, Gd, W0, H0.copy(), simplex_H=c["kw"]["simplex_H"], mu=mu,
+                                                      lambda_L=c["kw"]["lambda_L"], L=L, sigmaL=8, use_bregman=True)
+        out[f"{name}_step_W"] = multiplicative_step_w(X, Gd, W0.copy(), H0, simplex_W=False, use_bregman=True)
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, algo="bmd", tol=0,
+                        no_stop_criterion=True, max_iter=c["iters"], **c["kw"])
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+    out["names"] = np.array(list(BMD))
+    out["configs"] = np.array(json.dumps(BMD))
+    save("f10_bregman", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

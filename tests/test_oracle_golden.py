@@ -207,3 +207,28 @@ def test_f9_linesearch_and_truth_tracking(golden):
             np.testing.assert_allclose(r["angles"], g[f"{name}_angles"], rtol=1e-7, atol=1e-9, err_msg=name)
             np.testing.assert_allclose(r["mse"], g[f"{name}_mse"], rtol=1e-8, atol=1e-16, err_msg=name)
             np.testing.assert_allclose(r["true_losses"], g[f"{name}_true_losses"], rtol=1e-9, err_msg=name)
+
+
+def test_f10_bregman_variant(golden):
+    """use_bregman=True in both step functions and algo="bmd" trajectories (updates.py:40-48, :120-125)."""
+    g = golden("f10_bregman")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = np.eye(c["n"])
+        L = oc.laplacian_matrix(*shape)
+        kw = dict(c["kw"])
+        ls = kw.pop("linesearch", False)
+        Hs = oc.multiplicative_step_h(X, G, W0, H0.copy(), simplex_H=kw["simplex_H"], mu=kw["mu"], lambda_L=kw["lambda_L"], L=L,
+                                      sigmaL=8, use_bregman=True)
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=1e-9, atol=1e-14, err_msg=name)
+        Ws = oc.multiplicative_step_w(X, G, W0.copy(), H0, use_bregman=True)
+        np.testing.assert_allclose(Ws, g[f"{name}_step_W"], rtol=1e-10, err_msg=name)
+        r = oc.fit(X, c["k"], W=W0.copy(), H=H0.copy(), shape_2d=shape, algo="bmd", linesearch=ls, tol=0, no_stop_criterion=True,
+                   max_iter=c["iters"], **kw)
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-9, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-8, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-8, atol=1e-14, err_msg=name)
