@@ -45,6 +45,9 @@ static int check_state(const espm_mu_state* st) {
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
   ESPM_REQUIRE(st->n_cm == roundup(st->n, ESPM_NCM), "n_cm must be roundup(n, %d)", ESPM_NCM);
+  ESPM_REQUIRE((st->breg_sr_px == nullptr) == (st->breg_sr_ch == nullptr), "breg_sr_px and breg_sr_ch come together");
+  ESPM_REQUIRE(!st->breg_sr_px || (st->m == 0 && !st->simplex_w && st->n <= 4096),
+               "the Bregman variant is built for G = identity without simplex_W (and n <= 4096)");
   ESPM_REQUIRE(st->h_variant == 0, "h_variant %d is not built (the matrix-core H-step was retired, DESIGN.md)", st->h_variant);
   ESPM_REQUIRE(st->x_tile >= 64 && ESPM_PPAD % st->x_tile == 0 && st->x_tile % st->tile_px == 0,
                "x_tile=%d must divide %d and be a multiple of tile_px=%d", st->x_tile, ESPM_PPAD, st->tile_px);
@@ -177,6 +180,7 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.fixed_w = st->fixed_w;
   a.simplex_rows = st->simplex_rows;
   a.scratch = st->w_scratch;
+  a.breg_sr = st->breg_sr_ch;
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
   a.gw_a = nullptr;  // reserved (matrix-core H-step, retired)

@@ -366,6 +366,7 @@ struct HStepArgs {
   int ell_bits, n_pad;
   int ell_tp;        // pixels per workgroup of the sparse H-step (= tile_px: 64, 128, 256 or 512)
   const float* l2_m; // Frobenius branch: (KP, KP) GW^T GW, else null
+  const float* breg_sr; // Bregman variant: per-pixel sums of the stored X (p_pad), else null
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -400,6 +401,7 @@ struct WFinishArgs {
   const float* fixed_w;
   const int32_t* simplex_rows;
   float* scratch;
+  const float* breg_sr; // Bregman variant: per-channel sums of the stored X (n), else null
   float* gw_s;
   double* colsum_gw;
   void* gw_a;    // MFMA A fragments of the bf16 splits of gw_s (may be null)
@@ -502,6 +504,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.ell_bits = st->ell_cbits;
   a.ell_tp = st->tile_px;
   a.l2_m = nullptr;
+  a.breg_sr = st->breg_sr_px;
   a.n_pad = st->n_pad;
   return a;
 }

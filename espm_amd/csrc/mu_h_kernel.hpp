@@ -93,6 +93,15 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       nv[kk] = s * a.xscale;
       dv[kk] = (float)a.colsum_gw[kk];
     }
+    if (a.breg_sr) {  // Bregman variant, updates.py:120-125: num = sR / H, denum = colsum(GW) - GW^T (X / GWH) + sR / H
+      const float sr = a.xscale * a.breg_sr[q];
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        const float t = sr * __builtin_amdgcn_rcpf(hin[kk]);
+        dv[kk] = (dv[kk] - nv[kk]) + t;
+        nv[kk] = t;
+      }
+    }
     if (a.l2_m) {  // Frobenius branch: denum = (GW^T GW) H, updates.py:115-118
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {

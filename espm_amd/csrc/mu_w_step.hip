@@ -94,6 +94,7 @@ struct WUpdateArgs {
   const float* w_old;
   float* w_new;
   const float* fixed_w;
+  const float* breg_sr;         // Bregman variant (updates.py:40-48): per-channel sums of the stored X, else null
   float* gw_s;
   double* parts;                // [2][k * nbk]: partial column sum of G W' (component of the workgroup), partial sum of W'
   float log_shift, gw_floor, xscale;
@@ -159,7 +160,13 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
       a.a_out[e] = t;
       if (c < a.n) {
         const float wo = a.w_old[(size_t)c * a.k + kk];
-        float v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
+        float v;
+        if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
+          const float sr = a.xscale * a.breg_sr[c];
+          v = fmaxf((sr * wo) / (((float)rs - t) * wo + sr), a.log_shift);
+        } else {
+          v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
+        }
         if (a.fixed_w) {
           const float fx = a.fixed_w[(size_t)c * a.k + kk];
           if (fx >= 0.f) v = fx;                              // updates.py:75-76
@@ -394,6 +401,11 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
             wo[r][kk] = a.w_old[mm * k + kk];
             nv[r][kk] = wo[r][kk] * gta;        // updates.py:59
             dv[r][kk] = cg * rs[kk];            // updates.py:60
+            if (a.breg_sr) {                    // Bregman variant (G = identity), updates.py:41-48
+              const float sr = a.xscale * a.breg_sr[mm];
+              dv[r][kk] = (dv[r][kk] - gta) * wo[r][kk] + sr;
+              nv[r][kk] = sr * wo[r][kk];
+            }
           }
         }
       }
@@ -836,6 +848,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.w_old = f.w_old;
   a.w_new = f.w_new;
   a.fixed_w = f.fixed_w;
+  a.breg_sr = f.breg_sr;
   a.gw_s = f.gw_s;
   a.parts = reinterpret_cast<double*>(f.scratch);
   a.log_shift = f.log_shift;

@@ -62,7 +62,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -109,6 +109,18 @@ class MUEngine:
         if group is not None:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
+        self.bregman = bool(bregman)
+        if self.bregman:
+            # Bregman variant (updates.py:40-48, :120-125): sums of X over the channels (per pixel) and over the pixels
+            # (per channel, global); built for G = identity only - the reference's own W step needs a square G
+            if G is not None:
+                raise NotImplementedError("the Bregman variant (algo='bmd' / use_bregman) is built for G = identity only: "
+                                          "the reference's W step fails for a non-square G (updates.py:43)")
+            sr_ch = Xd.sum(dim=px_axis, dtype=torch.float64)
+            if group is not None:
+                torch.distributed.all_reduce(sr_ch, group=group)
+            self._breg_ch = sr_ch.to(torch.float32).contiguous()
+            self._breg_px_local = Xd.sum(dim=ch_axis, dtype=torch.float64).to(torch.float32)
         if h_variant:
             raise NotImplementedError("h_variant=1 (Y = GW H on the matrix cores) was retired: slower than the vector kernels "
                                       "at k <= 8 and sensitive to a transcendental-operand hazard (DESIGN.md)")
@@ -259,6 +271,13 @@ class MUEngine:
         st.fixed_w = self.fixed_w.data_ptr() if self.fixed_w is not None else None
         st.simplex_rows = self.simplex_rows.data_ptr() if self.simplex_rows is not None else None
         st.halo_top = st.halo_bot = None
+        if self.bregman:
+            self.breg_px = torch.zeros(st.p_pad, **f32)
+            self.breg_px[:self.p] = self._breg_px_local
+            del self._breg_px_local
+            st.breg_sr_px, st.breg_sr_ch = self.breg_px.data_ptr(), self._breg_ch.data_ptr()
+        else:
+            st.breg_sr_px = st.breg_sr_ch = None
         st.hpart = self.hpart.data_ptr()
         st.hstat[0], st.hstat[1] = self.hstat[0].data_ptr(), self.hstat[1].data_ptr()
         st.a_slab, st.a, st.w_scratch = self.a_slab.data_ptr(), self.a.data_ptr(), self.w_scratch.data_ptr()

@@ -100,8 +100,10 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         rows = None
         if self.physics_model_ is not None and self.simplex_W:
             rows = self.physics_model_.NMF_simplex()
+        # (the Bregman W update has no simplex branch, updates.py:40-48: algo="bmd" ignores simplex_W there, like the reference)
+        simplex_W = self.simplex_W and getattr(self, "algo", None) != "bmd"
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
-                        simplex_W=self.simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
+                        simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
                         fixed_W=self.fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
                         fix_zero_lines=False, **self._engine_kwargs())
 

@@ -34,11 +34,13 @@ def _engine(X, G, W, H, **kw):
 def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe=True, l2=False, fixed_W=None,
                           physics_model=None, use_bregman=False):
     """Multiplicative step in W (espm/estimators/updates.py:6-78: KL branch, and the Frobenius branch l2=True :31-36)."""
-    if use_bregman:
-        raise NotImplementedError("the Bregman variant (use_bregman=True) is not built for the GPU")
     W = np.asarray(W)
     H = np.asarray(H)
     W, H = _safe_inputs(G, W, H, log_shift, safe)
+    if use_bregman and not l2:  # updates.py:40-48: no simplex in this branch either; G = identity only (engine)
+        eng = _engine(X, G, W, H, simplex_H=False, simplex_W=False, log_shift=log_shift, fixed_W=fixed_W, bregman=True)
+        out = eng.step_w_only()
+        return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
     if l2:  # new_W = W / (G^T G W H H^T) * (G^T X H^T): no simplex in this branch
         eng = _engine(X, G, W, H, simplex_H=False, simplex_W=False, log_shift=log_shift, fixed_W=fixed_W, x_store="f32")
         out = eng.step_w_only(l2=True)
@@ -61,8 +63,6 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
         if L is None:
             raise ValueError("Please provide the laplacian")  # updates.py:94-95
         kind, shape_2d = classify_laplacian(L, H.shape[1])
-    if use_bregman:
-        raise NotImplementedError("the Bregman variant (use_bregman=True) is not built for the GPU")
     W, H = _safe_inputs(G, W, H, log_shift, safe)
     if l2:  # updates.py:109-118
         assert lambda_L == 0
@@ -75,7 +75,7 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
         return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
     eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, mu=mu, log_shift=log_shift,
                   epsilon_reg=epsilon_reg, dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, shape_2d=shape_2d,
-                  sigmaL=sigmaL, fixed_H=fixed_H, compute_loss=False)
+                  sigmaL=sigmaL, fixed_H=fixed_H, compute_loss=False, bregman=bool(use_bregman))   # (updates.py:120-125)
     out = eng.step_h_only()
     if eng.bad_count() > 0 and safe:
         raise AssertionError("multiplicative_step_h: non-finite update or simplex preconditions violated")

@@ -189,6 +189,12 @@ typedef struct espm_mu_state {
   const int32_t* pix_perm;  /* (p_pad): slot -> pixel offset inside its tile_px window (H-step lists) */
   const float* g_t;         /* optional (m, n_pad): G transposed, zero padded; the W finish then reads G with
                                coalesced loads (NULL: it reads g with a stride of m) */
+  /* Bregman variant of both updates (updates.py:40-48, :120-125; algo = "bmd"), G = identity only (the reference's own W
+   * step needs a square G).  Sums of the STORED X, both or neither:
+   *   H: num = sR / H, denum = colsum(GW) - GW^T (X / GWH) + sR / H      with sR_j = xscale * breg_sr_px[j] = sum_c X_cj
+   *   W: W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), no simplex    with sR_c = xscale * breg_sr_ch[c] = sum_j X_cj */
+  const float* breg_sr_px;  /* (p_pad) or NULL */
+  const float* breg_sr_ch;  /* (n) or NULL */
 } espm_mu_state;
 
 const char* espm_mu_version(void);

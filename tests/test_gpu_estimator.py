@@ -429,3 +429,31 @@ def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden):
             gl = est.get_losses()
             assert list(gl.dtype.names) == json.loads(str(g[f"{name}_loss_names"]))
             np.testing.assert_allclose(np.array(gl.tolist()), g[f"{name}_get_losses"], rtol=2e-3, atol=1e-6)
+
+
+def test_bregman_variant_golden(SmoothNMF, golden):
+    """use_bregman=True in both step functions and algo="bmd" fits (with mu, lambda, linesearch) against the reference's
+    outputs (fixture F10)."""
+    from espm_amd.estimators.updates import multiplicative_step_h, multiplicative_step_w
+    from espm_amd.utils import create_laplacian_matrix
+    g = golden("f10_bregman")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        kw = dict(c["kw"])
+        G = np.eye(c["n"])
+        Hs = multiplicative_step_h(X, G, W0, H0.copy(), simplex_H=kw["simplex_H"], mu=kw["mu"], lambda_L=kw["lambda_L"],
+                                   L=create_laplacian_matrix(*shape), sigmaL=8, use_bregman=True)
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=5e-5, atol=5e-6, err_msg=name)
+        Ws = multiplicative_step_w(X, G, W0.copy(), H0, use_bregman=True)
+        np.testing.assert_allclose(Ws, g[f"{name}_step_W"], rtol=3e-5, atol=1e-7, err_msg=name)
+        est = SmoothNMF(n_components=c["k"], shape_2d=shape, verbose=0, algo="bmd", tol=0, no_stop_criterion=True,
+                        max_iter=c["iters"], **kw)
+        GW = est.fit_transform(X, W=W0.copy(), H=H0.copy())
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=5e-4, atol=5e-5, err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=5e-4, atol=5e-4 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)

@@ -116,7 +116,7 @@ def test_step_h_golden_special(api, golden):
     with pytest.raises(ValueError):
         api["step_h"](X, G, W, H, lambda_L=1.0, L=None)
     with pytest.raises(NotImplementedError):
-        api["step_h"](X, G, W, H, use_bregman=True)
+        api["step_h"](X, G, W, H, use_bregman=True)   # G is a dictionary here: the Bregman variant needs G = identity
 
 
 def test_frobenius_branch_golden_and_properties(api, golden):
