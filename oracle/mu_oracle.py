@@ -370,6 +370,56 @@ def rescaled_DH(D, H):
     return D @ np.diag(1 / s), np.diag(s) @ H
 
 
+# ---- quadratic ("l2") surrogate of the Laplacian term: algo = "l2_surrogate"  -------------------
+def dichotomy_simplex_acc(a, b, minus_c, log_shift=LOG_SHIFT, tol=DICOTOMY_TOL, maxit=MAXIT_DICHOTOMY):
+    """nu (p,) with sum_k max(sqrt((b_kj + nu_j)^2 + 4 a c_kj) - nu_j - b_kj, 2 a eps) = 2 a, dicotomy.py:57-82."""
+    assert a >= 0 and (minus_c >= 0).all()
+    if log_shift > 0 and b.shape[0] * log_shift >= 1:
+        raise ValueError("No solution exists!")
+    n_p = len(b)
+    nu_max = n_p * np.max(b ** 2 / a + 2 * a + 2 * (b + minus_c), axis=0) * 1.5 + 1e-3
+    nu_min = -(2 * a + np.sum(b, axis=0)) / n_p * 1.1 - 1e-3
+
+    def func(x):
+        return 2 * a - np.sum(np.maximum(np.sqrt((b + x) ** 2 + 4 * a * minus_c) - x - b, log_shift * 2 * a), axis=0)
+
+    return bisect(nu_max, nu_min, func, maxit, tol)[0]
+
+
+def multiplicative_step_hq(X, G, W, H, simplex_H=True, log_shift=LOG_SHIFT, safe=True, dicotomy_tol=DICOTOMY_TOL,
+                           lambda_L=0, L=None, sigmaL=SIGMA_L, fixed_H=None):
+    """updates.py:263-315: H update from the quadratic surrogate of the Laplacian term - the positive root of
+    a H'^2 + b H' - c = 0 with a = lambda sigma, b = colsum(GW) + lambda (H L) - lambda sigma H (+ nu), c = H GW^T (X / GWH)."""
+    if lambda_L != 0 and L is None:
+        raise ValueError("Please provide the laplacian")
+    if safe:
+        assert (H >= -log_shift / 2).all() and (W >= -log_shift / 2).all() and (G >= -log_shift / 2).all()
+    GW = G @ W
+    minus_c = H * (GW.T @ (X / (GW @ H + log_shift)))
+    b = GW.sum(axis=0)[:, None]
+    if lambda_L != 0:
+        b = b + lambda_L * (H @ L) - lambda_L * sigmaL * H
+        a = lambda_L * sigmaL
+        if simplex_H:
+            b = b + dichotomy_simplex_acc(a, b, minus_c, log_shift=log_shift, tol=dicotomy_tol)
+        new_H = (-b + np.sqrt(b ** 2 + 4 * a * minus_c)) / (2 * a)
+    else:  # the classic case
+        if simplex_H:
+            b = b + dichotomy_simplex(minus_c, b, log_shift=log_shift, tol=dicotomy_tol)
+        new_H = minus_c / b
+    new_H = np.maximum(new_H, log_shift)
+    if fixed_H is not None:
+        keep = fixed_H >= 0
+        new_H[keep] = fixed_H[keep]
+    return new_H
+
+
+def smooth_l2_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
+    """espm/estimators/surrogates.py:6-58: lambda/2 (2 tr(Ht L H^T) - tr(Ht L Ht^T) + sigma ||Ht - H||^2)."""
+    HtL = Ht @ L
+    return lambda_L / 2 * (2 * np.sum(HtL * H) - np.sum(HtL * Ht) + sigmaL * np.sum((Ht - H) ** 2))
+
+
 # ---- linesearch on the Laplacian surrogate (SURVEY 8f rank 4) -------------------------------------------
 def smooth_dgkl_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
     """espm/estimators/surrogates.py:65-114: lambda/2 (2 tr(Ht L H^T) - tr(Ht L Ht^T) + sigma sum_k max_j H_kj sum_j dgkl(Ht_kj, H_kj))."""
@@ -380,15 +430,17 @@ def smooth_dgkl_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
     return lambda_L / 2 * (2 * t2 - t1 + sigmaL * t3)
 
 
-def diff_surrogate(Ht, H, L, sigmaL=SIGMA_L, lambda_L=1):
-    """espm/estimators/surrogates.py:116-149 (algo "log_surrogate"): surrogate minus the Laplacian term at H."""
-    return smooth_dgkl_surrogate(Ht, L, H, sigmaL, lambda_L) - trace_xtLx(L, H.T) * lambda_L / 2
+def diff_surrogate(Ht, H, L, sigmaL=SIGMA_L, lambda_L=1, algo="log_surrogate"):
+    """espm/estimators/surrogates.py:116-149: surrogate ("log_surrogate" / "bmd": dgkl; "l2_surrogate": quadratic)
+    minus the Laplacian term at H."""
+    surr = smooth_l2_surrogate if algo == "l2_surrogate" else smooth_dgkl_surrogate
+    return surr(Ht, L, H, sigmaL, lambda_L) - trace_xtLx(L, H.T) * lambda_L / 2
 
 
-def linesearch_gamma(gamma, Hold, H, L):
+def linesearch_gamma(gamma, Hold, H, L, algo="log_surrogate"):
     """espm/estimators/smooth_nmf.py:376-381: the caller passes neither lambda_L nor its own value - diff_surrogate runs
     with its default lambda_L = 1 whatever the estimator's lambda_L is."""
-    return gamma / 1.05 if diff_surrogate(Hold, H, L, sigmaL=gamma) > 0 else gamma * 1.5
+    return gamma / 1.05 if diff_surrogate(Hold, H, L, sigmaL=gamma, algo=algo) > 0 else gamma * 1.5
 
 
 # ---- truth tracking (true_D / true_H; base.py:301-347, measures.py) ---------------------------------------
@@ -429,7 +481,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None,
         algo="log_surrogate"):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
-    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate" or "bmd"; linesearch: smooth_nmf.py:376-381;
+    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", "bmd" or "l2_surrogate"; linesearch: smooth_nmf.py:376-381;
     true_D / true_H tracking: base.py:301-347).
 
     Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
@@ -445,7 +497,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     p = X_.shape[1]
     L_ = laplacian_matrix(*shape_2d) if shape_2d is not None else identity_L(p)
     gamma_ = SIGMA_L if gamma is None else gamma  # smooth_nmf.py:290-306
-    if algo not in ("log_surrogate", "bmd"):
+    if algo not in ("log_surrogate", "bmd", "l2_surrogate"):
         raise NotImplementedError(algo)
     breg = algo == "bmd"  # smooth_nmf.py:358-372, :416-426: both steps with use_bregman=True
     c_kl = const_KL(X_, log_shift)
@@ -467,12 +519,16 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     t0 = time.perf_counter()
     while True:
         old_W, old_H = W_.copy(), H_.copy()
-        H_ = multiplicative_step_h(X_, G_, W_, H_, simplex_H=simplex_H, mu=mu, log_shift=log_shift,
-                                   epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
-                                   lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
-                                   exact_root=exact_root, use_bregman=breg)
+        if algo == "l2_surrogate":  # smooth_nmf.py:311-323 (mu does not enter this update)
+            H_ = multiplicative_step_hq(X_, G_, W_, H_, simplex_H=simplex_H, log_shift=log_shift, safe=safe,
+                                        dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, L=L_, sigmaL=gamma_, fixed_H=fixed_H)
+        else:
+            H_ = multiplicative_step_h(X_, G_, W_, H_, simplex_H=simplex_H, mu=mu, log_shift=log_shift,
+                                       epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
+                                       lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
+                                       exact_root=exact_root, use_bregman=breg)
         if linesearch:
-            gamma_ = linesearch_gamma(gamma_, old_H, H_, L_)
+            gamma_ = linesearch_gamma(gamma_, old_H, H_, L_, algo)
         W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
                                    simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
         eval_after, det = loss(W_, H_)

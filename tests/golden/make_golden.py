@@ -445,7 +445,54 @@ def f10():
     save("f10_bregman", **out)
 
 
+# ------------------------------------------------------------------ F11: the quadratic ("l2") surrogate of the Laplacian term
+HQ = {
+    "q3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0)),
+    "q5": dict(n=60, nx=10, ny=12, k=4, m=9, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.6)),
+    "qw": dict(n=32, nx=6, ny=6, k=3, m=None, iters=20, kw=dict(simplex_H=False, simplex_W=True, lambda_L=0.5)),
+    "q0": dict(n=40, nx=6, ny=7, k=3, m=None, iters=15, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.0)),
+    "ql": dict(n=48, nx=8, ny=8, k=3, m=None, iters=25, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.7, linesearch=True)),
+}
+
+
+def f11():
+    from espm.estimators.updates import multiplicative_step_hq
+    from espm.estimators.dicotomy import dichotomy_simplex_acc
+    rng = np.random.default_rng(1111)
+    out = {}
+    # root finder known answers: sum_k (sqrt((b + nu)^2 + 4 a c) - nu - b) / (2 a) = 1
+    a = 3.7
+    b = rng.standard_normal((5, 40)) * 2.0 + 1.0
+    c = rng.random((5, 40)) * 3.0
+    out["acc_a"], out["acc_b"], out["acc_c"] = np.array(a), b, c
+    out["acc_nu"] = dichotomy_simplex_acc(a, b.copy(), c.copy(), log_shift=0.0, tol=1e-12, maxit=200)
+    for name, c_ in HQ.items():
+        X, G, W, H = synth(rng, c_["n"], c_["nx"], c_["ny"], c_["k"], c_["m"])
+        p = c_["nx"] * c_["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c_["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        Gd = np.eye(c_["n"]) if G is None else G
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c_["nx"], c_["ny"]])
+        L = create_laplacian_matrix(c_["nx"], c_["ny"])
+        out[f"{name}_step_H"] = multiplicative_step_hq(X, Gd, W0, H0.copy(), simplex_H=c_["kw"]["simplex_H"],
+                                                       lambda_L=c_["kw"]["lambda_L"], L=L, sigmaL=8)
+        est = SmoothNMF(n_components=c_["k"], G=G, shape_2d=(c_["nx"], c_["ny"]), verbose=0, algo="l2_surrogate", tol=0,
+                        no_stop_criterion=True, max_iter=c_["iters"], **c_["kw"])
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+    out["names"] = np.array(list(HQ))
+    out["configs"] = np.array(json.dumps(HQ))
+    save("f11_quadratic_surrogate", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

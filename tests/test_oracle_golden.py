@@ -232,3 +232,32 @@ def test_f10_bregman_variant(golden):
         np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-9, atol=1e-18, err_msg=name)
         np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-8, atol=1e-14, err_msg=name)
         np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-8, atol=1e-14, err_msg=name)
+
+
+def test_f11_quadratic_surrogate(golden):
+    """algo="l2_surrogate": multiplicative_step_hq, its root finder dichotomy_simplex_acc and whole fits
+    (updates.py:263-315, dicotomy.py:57-82, surrogates.py:6-58)."""
+    g = golden("f11_quadratic_surrogate")
+    nu = oc.dichotomy_simplex_acc(float(g["acc_a"]), g["acc_b"].copy(), g["acc_c"].copy(), log_shift=0.0, tol=1e-12, maxit=200)
+    np.testing.assert_allclose(nu, g["acc_nu"], rtol=1e-9, atol=1e-10)
+    a, b, c = float(g["acc_a"]), g["acc_b"], g["acc_c"]
+    np.testing.assert_allclose(((np.sqrt((b + nu) ** 2 + 4 * a * c) - nu - b) / (2 * a)).sum(axis=0), 1.0, atol=1e-9)
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = g.get(f"{name}_G")
+        Gd = np.eye(c["n"]) if G is None else G
+        kw = dict(c["kw"])
+        ls = kw.pop("linesearch", False)
+        Hs = oc.multiplicative_step_hq(X, Gd, W0, H0.copy(), simplex_H=kw["simplex_H"], lambda_L=kw["lambda_L"],
+                                       L=oc.laplacian_matrix(*shape), sigmaL=8)
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=1e-9, atol=1e-14, err_msg=name)
+        r = oc.fit(X, c["k"], G=G, W=W0.copy(), H=H0.copy(), shape_2d=shape, algo="l2_surrogate", linesearch=ls, tol=0,
+                   no_stop_criterion=True, max_iter=c["iters"], **kw)
+        # (single steps agree to 1e-9; over a fit the 1e-5 stop rule of the bisection amplifies rounding to ~1e-9 .. 1e-8)
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-7, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-7, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-6, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-6, atol=1e-12, err_msg=name)
