@@ -185,10 +185,11 @@ int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* o
 
 // ---- linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381) -------
 // d = g(H, Ht) - lambda/2 tr(H L H^T) needs, over all pixels, with Ht = the H before the update and H = the new one:
-//   t1 = sum Ht (Ht L), t2 = sum (Ht L) H, b = sum H (H L), and per component dg_k = sum_j Ht log(Ht / H) - Ht + H
-// (the caller weights dg_k with max_j H_kj, which the H-step already leaves in hstat).  One thread per pixel, stencil
+//   t1 = sum Ht (Ht L), t2 = sum (Ht L) H, b = sum H (H L), sq = sum (Ht - H)^2 (the quadratic surrogate's term) and per
+// component dg_k = sum_j Ht log(Ht / H) - Ht + H (the caller weights dg_k with max_j H_kj, which the H-step already
+// leaves in hstat).  One thread per pixel, stencil
 // as in the H-step; workgroup partials (field-major, LS_FIELDS rows) then a one-workgroup sum in fixed order.
-constexpr int LS_FIELDS = 3 + KP;
+constexpr int LS_FIELDS = 4 + KP;
 __global__ __launch_bounds__(256) void linesearch_terms_kernel(const float* __restrict__ h_old, const float* __restrict__ h_new,
                                                                int k, int p, int p_pad, int nx, int ny, int grid_mode,
                                                                double* __restrict__ part) {
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(256) void linesearch_terms_kernel(const float* __re
       v[0] += (double)ho * (double)lo;
       v[1] += (double)lo * (double)hn;
       v[2] += (double)hn * (double)ln;
-      v[3 + kk] += (double)ho * log((double)ho / (double)hn) - (double)ho + (double)hn;
+      v[3] += ((double)ho - (double)hn) * ((double)ho - (double)hn);
+      v[4 + kk] += (double)ho * log((double)ho / (double)hn) - (double)ho + (double)hn;
     }
   }
   block_reduce<LS_FIELDS, LS_FIELDS>(v, scratch);

@@ -317,6 +317,62 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
   return true;
 }
 
+// ---- quadratic surrogate of the Laplacian term (algo = "l2_surrogate") ----------------------------------------
+// H' is the positive root of a H'^2 + (b + nu) H' - c = 0 (updates.py:285-300): g(s, q) = sqrt(s^2 + q) - s with
+// s = b + nu and q = 4 a c, formed without cancellation, gives H' = g / (2 a).
+// (v_sqrt_f32 / v_rcp_f32: 1 ulp each, and far fewer registers than the correctly rounded expansions)
+__device__ __forceinline__ float hq_root(float s, float q) {
+  const float r = __builtin_amdgcn_sqrtf(fmaf(s, s, q));
+  return s >= 0.f ? q * __builtin_amdgcn_rcpf(r + s) : r - s;
+}
+// nu with sum_k max(g(b_k + nu, 4 a c_k), 2 a eps) = 2 a (dicotomy.py:57-82: same bracket), by a Newton iteration kept
+// inside the running bracket; the sum decreases with nu.  Returns false when the preconditions (a > 0, c >= 0) fail.
+template <int K>
+__device__ __forceinline__ bool simplex_root_hq(float a, const float (&b)[K], const float (&c)[K], float eps, int maxit, float& nu) {
+  bool ok = a > 0.f;
+  float bmax = -INFINITY, bsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    ok = ok && c[i] >= 0.f && b[i] == b[i];
+    bmax = fmaxf(bmax, b[i] * b[i] * __builtin_amdgcn_rcpf(a) + 2.f * a + 2.f * (b[i] + c[i]));
+    bsum += b[i];
+  }
+  nu = 0.f;
+  if (!ok) return false;
+  float hi = (float)K * bmax * 1.5f + 1e-3f;              // sum < 2 a there
+  float lo = -(2.f * a + bsum) * (1.1f / (float)K) - 1e-3f;  // sum > 2 a there
+  const float target = 2.f * a, floor_g = 2.f * a * eps;
+  float x = fminf(fmaxf(0.f, lo), hi), dxold = hi - lo;
+  for (int it = 0; it < maxit; ++it) {
+    float f = -target, fp = 0.f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float s = b[i] + x, q = 4.f * a * c[i];
+      const float r = __builtin_amdgcn_sqrtf(fmaf(s, s, q));
+      const float g = s >= 0.f ? q * __builtin_amdgcn_rcpf(r + s) : r - s;
+      if (g > floor_g) {
+        f += g;
+        fp -= g * __builtin_amdgcn_rcpf(r);   // d g / d nu = s / r - 1 = -g / r
+      } else {
+        f += floor_g;
+      }
+    }
+    if (fabsf(f) <= 4e-7f * target) break;
+    if (f > 0.f) lo = x; else hi = x;
+    float dx = fp < 0.f ? -f * __builtin_amdgcn_rcpf(fp) : 0.f;
+    float xn = x + dx;
+    if (!(fp < 0.f) || !(xn > lo && xn < hi) || fabsf(dx) > 0.5f * fabsf(dxold)) {
+      dx = (hi - lo) * 0.5f;
+      xn = lo + dx;
+    }
+    dxold = dx;
+    if (xn == x) break;
+    x = xn;
+  }
+  nu = x;
+  return true;
+}
+
 // ---- 5-point graph Laplacian (espm/utils.py:39-76) as a stencil on the local row block ------
 // (H L)[q] = deg(q) H[q] - sum of the existing 4-neighbours; rows above/below the local block
 // come from halo_top / halo_bot when present (sharded image), otherwise the block edge is the
@@ -367,6 +423,7 @@ struct HStepArgs {
   int ell_tp;        // pixels per workgroup of the sparse H-step (= tile_px: 64, 128, 256 or 512)
   const float* l2_m; // Frobenius branch: (KP, KP) GW^T GW, else null
   const float* breg_sr; // Bregman variant: per-pixel sums of the stored X (p_pad), else null
+  int h_rule;        // 0: log surrogate (multiplicative_step_h), 1: quadratic surrogate (multiplicative_step_hq)
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -505,6 +562,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.ell_tp = st->tile_px;
   a.l2_m = nullptr;
   a.breg_sr = st->breg_sr_px;
+  a.h_rule = st->h_rule;
   a.n_pad = st->n_pad;
   return a;
 }

@@ -26,7 +26,15 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
   size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
   if (red > part) part = red;
   const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
-  if (args.compute_loss) {
+  if (args.h_rule == 1) {  // quadratic surrogate of the Laplacian term
+    if (args.compute_loss) {
+      if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR, true>, bytes, "h_step (ell)")) return rc;
+      hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR, true>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+    } else {
+      if (int rc = allow_lds(h_step_ell_kernel<K, false, UNR, true>, bytes, "h_step (ell)")) return rc;
+      hipLaunchKernelGGL((h_step_ell_kernel<K, false, UNR, true>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+    }
+  } else if (args.compute_loss) {
     if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR>, bytes, "h_step (ell)")) return rc;
     hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
   } else {

@@ -52,7 +52,9 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // sum X log2(X / Y).
 // EARLY = false requests the pixel's inputs after the barrier (the matrix-core variant keeps its registers for
 // the accumulation phase).
-template <int K, bool EARLY = true>
+// QUAD: the H rule of the quadratic surrogate (a.h_rule == 1) - a compile-time switch so that the default rule does not
+// carry its registers.
+template <int K, bool EARLY = true, bool QUAD = false>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
@@ -119,14 +121,18 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) * __builtin_amdgcn_rcpf(hin[kk] + rel_shift));   // (a stop-rule statistic: 1 ulp reciprocal)
       red[R_RELH] = fmax(red[R_RELH], (double)worst);
     }
+    constexpr bool quad = QUAD;   // quadratic surrogate of the Laplacian term (multiplicative_step_hq, updates.py:263-315)
     if (a.mu) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         const float m = a.mu[kk];
-        dv[kk] += m * __builtin_amdgcn_rcpf(hin[kk] + a.eps_reg);     // updates.py:134-137
+        if (!quad) dv[kk] += m * __builtin_amdgcn_rcpf(hin[kk] + a.eps_reg);   // updates.py:134-137 (mu is not in the hq update)
         red[ESPM_HP_REG] += (double)(m * logf(hin[kk] + a.eps_reg));  // measures.py:543-548
       }
     }
+    float hlv[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) hlv[kk] = 0.f;
     if (a.lambda_l != 0.f) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
@@ -134,13 +140,48 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         const float hl = a.grid_mode ? ((in.wl + in.wr) + (in.wu + in.wd)) * hin[kk] -
                                            (((in.wl * in.l[kk] + in.wr * in.r[kk]) + in.wu * in.u[kk]) + in.wd * in.d[kk])
                                      : hin[kk];
-        const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
-        nv[kk] += ls * mh;                                      // updates.py:140
-        dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
+        hlv[kk] = hl;
         red[ESPM_HP_LAP] += (double)(hin[kk] * hl);             // measures.py:574-577
+        if (!quad) {
+          const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
+          nv[kk] += ls * mh;                                      // updates.py:140
+          dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
+        }
       }
     }
     if (!a.write_h) continue;
+    if constexpr (QUAD) if (a.lambda_l != 0.f) {
+      // a H'^2 + b H' - c = 0 with a = lambda sigma, b = colsum(GW) + lambda (H L) - lambda sigma H (+ nu), c = H GW^T (X / GWH)
+      float bq[K], cq[K];
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        cq[kk] = hin[kk] * nv[kk];
+        bq[kk] = dv[kk] + a.lambda_l * hlv[kk] - ls * hin[kk];
+      }
+      const float inv2a = __builtin_amdgcn_rcpf(2.f * ls);
+      float nu = 0.f;
+      if (a.simplex_h && !simplex_root_hq<K>(ls, bq, cq, a.log_shift, 100, nu)) red[ESPM_HP_BAD] += 1.0;
+      float ht[KP];
+#pragma unroll
+      for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float hn = fmaxf(hq_root(bq[kk] + nu, 4.f * ls * cq[kk]) * inv2a, a.log_shift);   // updates.py:300, :307
+        if (a.fixed_h) {
+          const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
+          if (f >= 0.f) hn = f;
+        }
+        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;
+        a.h_out[(size_t)kk * a.p_pad + q] = hn;
+        ht[kk] = hn;
+        red[R_ROWSUM + kk] += (double)hn;
+        red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+      }
+      float4* dstq = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
+      dstq[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
+      dstq[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
     if (a.simplex_h) {
@@ -194,7 +235,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 // NBUF: depth of the register ring of X load groups kept in flight (0 / 1: no explicit prefetch).
 // L2: the Frobenius branch (updates.py:109-118): num = GW^T X, no ratio, no loss; the epilogue takes the denominator
 // (GW^T GW) H from a.l2_m.
-template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false>
+template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false, bool QUAD = false>
 __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   constexpr int TP = 64 * PX;
@@ -348,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
 #pragma unroll
     for (int i = 0; i < P2; ++i) kl_lane += kl[i].x + kl[i].y;
   }
-  h_epilogue<K>(a, smem, NW, TP, tile0, kl_lane);
+  h_epilogue<K, true, QUAD>(a, smem, NW, TP, tile0, kl_lane);
 }
 
 }  // namespace espm

@@ -62,7 +62,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -145,6 +145,8 @@ class MUEngine:
             if x_store == "ell" and int(flag.item()) != 3:
                 raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS")
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
+        if int(h_rule) == 1 and x_store in ("u8", "bf16"):
+            x_store = "f32"   # the quadratic-surrogate H rule is built for the sparse and the fp32 store
         if x_store not in ("u8", "bf16", "f32", "ell"):
             raise ValueError("x_store must be 'auto', 'ell', 'u8', 'bf16' or 'f32'")
         self.x_store = x_store
@@ -214,6 +216,7 @@ class MUEngine:
         st.simplex_h, st.simplex_w = int(bool(simplex_H)), int(bool(simplex_W))
         st.compute_loss = int(bool(compute_loss))
         st.lambda_l, st.sigma_l = float(lambda_L), float(sigmaL)
+        st.h_rule = int(h_rule)   # 1: quadratic surrogate of the Laplacian term (multiplicative_step_hq)
         st.eps_reg, st.log_shift = float(epsilon_reg), float(log_shift)
         st.dicotomy_tol, st.rel_tol = float(dicotomy_tol), float(tol)
         st.xscale, st.gw_floor = float(xscale), float(gw_floor)
@@ -445,11 +448,14 @@ class MUEngine:
             raise ValueError("linesearch needs a completed iteration")
         self._flush_finalize()
         if getattr(self, "_ls_out", None) is None:
-            self._ls_out = torch.zeros(3 + _lib.KP, dtype=torch.float64, device=self.device)
+            self._ls_out = torch.zeros(4 + _lib.KP, dtype=torch.float64, device=self.device)
         check(lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
         t = self._ls_out.cpu().numpy()
-        maxh = self.hstat[st.cur][_lib.HS_MAX:_lib.HS_MAX + self.k].cpu().numpy()   # max_j H[k, j] of the new H (global)
-        t3 = float((maxh * t[3:3 + self.k]).sum())
+        if st.h_rule == 1:     # quadratic surrogate: sigma ||Ht - H||^2 (surrogates.py:6-58)
+            t3 = float(t[3])
+        else:                  # sigma sum_k max_j H_kj sum_j dgkl(Ht, H) (surrogates.py:65-114)
+            maxh = self.hstat[st.cur][_lib.HS_MAX:_lib.HS_MAX + self.k].cpu().numpy()   # max_j H[k, j] of the new H (global)
+            t3 = float((maxh * t[4:4 + self.k]).sum())
         d = 0.5 * (2.0 * t[1] - t[0] + float(gamma) * t3) - 0.5 * t[2]
         gamma = float(gamma) / 1.05 if d > 0 else float(gamma) * 1.5
         st.sigma_l = gamma

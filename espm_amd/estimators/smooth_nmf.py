@@ -18,7 +18,9 @@ class SmoothNMF(NMFEstimator):
     Parameters as in espm/estimators/smooth_nmf.py:46-79.  The default solver ``algo="log_surrogate"`` is
     accelerated, with or without ``linesearch`` (gamma_ adapts to the Laplacian surrogate every iteration,
     smooth_nmf.py:376-381) and with ``true_D`` / ``true_H`` tracking; so is ``algo="bmd"`` (both updates in their Bregman
-    variant, smooth_nmf.py:358-372, :416-426) for G = None; the other solvers raise ``NotImplementedError`` at fit time.
+    variant, smooth_nmf.py:358-372, :416-426) for G = None and ``algo="l2_surrogate"`` (H from the quadratic surrogate
+    of the Laplacian term, smooth_nmf.py:311-323) with ``l2=False``; ``projected_gradient`` raises
+    ``NotImplementedError`` at fit time.
     """
 
     loss_names_ = NMFEstimator.loss_names_ + ["log_reg_loss"] + ["Lapl_reg_loss"] + ["gamma"]
@@ -123,7 +125,8 @@ class SmoothNMF(NMFEstimator):
 
     def _engine_kwargs(self):
         return dict(lambda_L=self.lambda_L, mu=self.mu, epsilon_reg=self.epsilon_reg,
-                    dicotomy_tol=self.dicotomy_tol, sigmaL=float(self._gamma_value()), bregman=self.algo == "bmd")
+                    dicotomy_tol=self.dicotomy_tol, sigmaL=float(self._gamma_value()), bregman=self.algo == "bmd",
+                    h_rule=1 if self.algo == "l2_surrogate" else 0)
 
     def _detailed(self, lkl, reg, lap):
         return [lkl, reg, lap, self._gamma_value()]
@@ -134,8 +137,11 @@ class SmoothNMF(NMFEstimator):
 
     def fit_transform(self, X, y=None, W=None, H=None):
         """Fit the model to X (n, p) and return G W (espm/estimators/smooth_nmf.py:239-282)."""
-        if self.algo not in ("log_surrogate", "bmd"):
-            raise NotImplementedError(f"the GPU path implements algo='log_surrogate' and 'bmd' (got algo={self.algo!r})")
+        if self.algo not in ("log_surrogate", "bmd", "l2_surrogate"):
+            raise NotImplementedError("the GPU path implements algo='log_surrogate', 'bmd' and 'l2_surrogate' "
+                                      f"(got algo={self.algo!r})")
+        if self.l2:  # only reachable with algo="l2_surrogate" (smooth_nmf.py:233-237)
+            raise NotImplementedError("the Frobenius loss (l2=True) inside a fit is not built for the GPU path")
         self.gamma_ = None
         return super().fit_transform(X, y=y, W=W, H=H)
 

@@ -82,6 +82,28 @@ def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift
     return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
 
 
+def multiplicative_step_hq(X, G, W, H, simplex_H=True, log_shift=log_shift, safe=True, dicotomy_tol=dicotomy_tol, lambda_L=0,
+                           L=None, sigmaL=sigmaL, fixed_H=None):
+    """Multiplicative step in H from the quadratic surrogate of the Laplacian term (espm/estimators/updates.py:263-315)."""
+    shape_2d = None
+    W = np.asarray(W)
+    H = np.asarray(H)
+    if not (lambda_L == 0):
+        if L is None:
+            raise ValueError("Please provide the laplacian")
+        kind, shape_2d = classify_laplacian(L, H.shape[1])
+    if safe:  # updates.py:279-283 (asserts only: no clamping in this function)
+        assert np.sum(H < -log_shift / 2) == 0
+        assert np.sum(W < -log_shift / 2) == 0
+        assert np.sum(np.asarray(G) < -log_shift / 2) == 0
+    eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, log_shift=log_shift, dicotomy_tol=dicotomy_tol,
+                  lambda_L=lambda_L, shape_2d=shape_2d, sigmaL=sigmaL, fixed_H=fixed_H, compute_loss=False, h_rule=1)
+    out = eng.step_h_only()
+    if eng.bad_count() > 0 and safe:
+        raise AssertionError("multiplicative_step_hq: non-finite update or preconditions violated")
+    return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
+
+
 def _initial_factors(X, n_components, init, random_state, sklearn_init, X_device=None):
     from espm_amd import init_device
 

@@ -195,6 +195,9 @@ typedef struct espm_mu_state {
    *   W: W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), no simplex    with sR_c = xscale * breg_sr_ch[c] = sum_j X_cj */
   const float* breg_sr_px;  /* (p_pad) or NULL */
   const float* breg_sr_ch;  /* (n) or NULL */
+  int32_t h_rule;           /* H update: 0 = log surrogate (multiplicative_step_h, updates.py:83-156), 1 = quadratic surrogate
+                               of the Laplacian term (multiplicative_step_hq, updates.py:263-315: positive root of
+                               a H'^2 + b H' - c = 0, its own simplex multiplier dicotomy.py:57-82; mu only enters the loss) */
 } espm_mu_state;
 
 const char* espm_mu_version(void);
@@ -307,10 +310,11 @@ int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float*
                       espm_stream_t stream);
 
 /* Terms of the linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381)
- * between two H buffers, Ht = h[hold] (before the update) and H = h[hnew]: out (3 + ESPM_KP device doubles) =
- * [sum Ht (Ht L), sum (Ht L) H, sum H (H L), dg_0 .. dg_7] with dg_k = sum_j Ht log(Ht / H) - Ht + H.  The caller
- * forms d = 1/2 (2 out[1] - out[0] + gamma sum_k max_j H_kj dg_k) - 1/2 out[2] (lambda_L = 1 as the reference calls
- * it) and lowers gamma by 1.05 when d > 0, else raises it by 1.5.  Uses st->hpart as scratch: call it between
+ * between two H buffers, Ht = h[hold] (before the update) and H = h[hnew]: out (4 + ESPM_KP device doubles) =
+ * [sum Ht (Ht L), sum (Ht L) H, sum H (H L), sum (Ht - H)^2, dg_0 .. dg_7] with dg_k = sum_j Ht log(Ht / H) - Ht + H.
+ * The caller forms d = 1/2 (2 out[1] - out[0] + gamma t3) - 1/2 out[2] with t3 = sum_k max_j H_kj dg_k (log surrogate,
+ * Bregman) or t3 = out[3] (quadratic surrogate) - lambda_L = 1 as the reference calls it - and lowers gamma by 1.05
+ * when d > 0, else raises it by 1.5.  Uses st->hpart as scratch: call it between
  * espm_mu_h_finalize and the next espm_mu_step_h.  One GPU only. */
 int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream);
 

@@ -348,7 +348,9 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
     with pytest.raises(NotImplementedError):
-        quiet(SmoothNMF(n_components=2, algo="l2_surrogate", verbose=0).fit, X)
+        quiet(SmoothNMF(n_components=2, algo="projected_gradient", verbose=0).fit, X)
+    with pytest.raises(NotImplementedError):   # the Frobenius loss inside a fit
+        quiet(SmoothNMF(n_components=2, algo="l2_surrogate", l2=True, verbose=0).fit, X)
 
 
 @pytest.mark.parametrize("case", ["all_ones", "no_ones", "wide", "ones_and_bright"])
@@ -457,3 +459,33 @@ def test_bregman_variant_golden(SmoothNMF, golden):
         np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
         np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=5e-4, atol=5e-5, err_msg=name)
         np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=5e-4, atol=5e-4 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+
+
+def test_quadratic_surrogate_golden(SmoothNMF, golden):
+    """algo="l2_surrogate": multiplicative_step_hq (positive root of the quadratic surrogate, its own simplex multiplier)
+    as a direct call and inside fits (G given, simplex_W, lambda = 0, linesearch) against the reference (fixture F11)."""
+    from espm_amd.estimators.updates import multiplicative_step_hq
+    from espm_amd.utils import create_laplacian_matrix
+    g = golden("f11_quadratic_surrogate")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = g.get(f"{name}_G")
+        Gd = np.eye(c["n"]) if G is None else G
+        kw = dict(c["kw"])
+        Hs = multiplicative_step_hq(X, Gd, W0, H0.copy(), simplex_H=kw["simplex_H"], lambda_L=kw["lambda_L"],
+                                    L=create_laplacian_matrix(*shape), sigmaL=8)
+        # the reference's multiplier is converged to dicotomy_tol = 1e-5 only (global stop rule)
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=5e-5, atol=5e-6, err_msg=name)
+        if kw["simplex_H"]:
+            np.testing.assert_allclose(Hs.sum(axis=0), 1.0, atol=5e-6)
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=shape, verbose=0, algo="l2_surrogate", tol=0, no_stop_criterion=True,
+                        max_iter=c["iters"], **kw)
+        GW = est.fit_transform(X, W=W0.copy(), H=H0.copy())
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=3 * LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)

