@@ -23,6 +23,13 @@
  *   espm_dichotomy_simplex<- espm/estimators/dicotomy.py:4-55 (module-level function)
  *   espm_mu_pack_x        <- base.py:243-247 (validate_data / hspy_comp transpose) as a layout step
  *   espm_mu_laplacian     <- espm/utils.py:39-76 applied to H (H @ L), measures.py:560-577
+ *   espm_mu_w_reduce_finish, espm_mu_shard_combine_finish, espm_mu_w_reduce_pack
+ *                         <- (new) the W-step after the accumulation in one call / launch (updates.py:58-76 folded into
+ *                            the slab or rank-record reduction when W' needs nothing global)
+ *   espm_mu_linesearch_terms <- espm/estimators/surrogates.py:6-149 + smooth_nmf.py:376-381 (linesearch=True)
+ *   espm_mu_l2_step_h / _w <- espm/estimators/updates.py:109-118, :31-36 (Frobenius branch, l2=True, direct calls)
+ *   state fields breg_sr_* <- updates.py:40-48, :120-125 (Bregman variant, algo = "bmd")
+ *   state field h_rule = 1 <- updates.py:263-315 + dicotomy.py:57-82 (multiplicative_step_hq, algo = "l2_surrogate")
  *
  * Conventions
  *   - extern "C", plain pointers and sizes.  All array pointers are DEVICE pointers owned by the
