@@ -420,6 +420,72 @@ def smooth_l2_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
     return lambda_L / 2 * (2 * np.sum(HtL * H) - np.sum(HtL * Ht) + sigmaL * np.sum((Ht - H) ** 2))
 
 
+# ---- projected gradient (algo = "projected_gradient"; without its linesearch) ------------------------
+def gradW(X, G, W, H, log_shift=LOG_SHIFT, safe=False):
+    """updates.py:317-328 (KL branch): G^T (-(X / GWH) H^T + rowsum(H)^T)."""
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    return G.T @ (-(X / ((G @ W) @ H)) @ H.T + np.sum(H, axis=1, keepdims=True).T)
+
+
+def gradH(X, G, W, H, mu=0, lambda_L=0, L=None, epsilon_reg=1, log_shift=LOG_SHIFT, safe=False):
+    """updates.py:330-351 (KL branch): -GW^T (X / GWH) + colsum(GW) + mu / (H + eps) + lambda (L H^T)^T."""
+    if lambda_L != 0 and L is None:
+        raise ValueError("Please provide the laplacian")
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    D = G @ W
+    grad = -D.T @ (X / (D @ H)) + np.sum(D, axis=0, keepdims=True).T
+    if not (np.isscalar(mu) and mu == 0):
+        mu_col = np.asarray(mu, dtype=float)
+        if mu_col.ndim == 1:
+            mu_col = mu_col[:, None]
+        grad = grad + mu_col / (H + epsilon_reg)
+    if lambda_L != 0:
+        grad = grad + (lambda_L * (L @ H.T)).T
+    return grad
+
+
+def dichotomy_simplex_projected_gradient(a, log_shift=LOG_SHIFT, tol=DICOTOMY_TOL, maxit=MAXIT_DICHOTOMY):
+    """nu (p,) with sum_k max(a_kj + nu_j, eps) = 1, dicotomy.py:84-108."""
+    if log_shift > 0 and a.shape[0] * log_shift >= 1:
+        raise ValueError("No solution exists!")
+    nu_min = -np.max(a, axis=0)
+    nu_max = 1 / a.shape[0] - np.min(a, axis=0)
+    return bisect(nu_max, nu_min, lambda x: np.sum(np.maximum(a + x, log_shift), axis=0) - 1, maxit, tol)[0]
+
+
+def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=LOG_SHIFT, safe=True, fixed_W=None):
+    """updates.py:353-370: W - grad / gamma, clamped; no simplex over W with this method."""
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    new_W = np.maximum(W - 1 / gamma * gradW(X, G, W, H, log_shift=log_shift, safe=safe), log_shift)
+    if fixed_W is not None:
+        keep = fixed_W >= 0
+        new_W[keep] = fixed_W[keep]
+    if simplex_W:
+        raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
+    return new_W
+
+
+def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=LOG_SHIFT, epsilon_reg=1, safe=True,
+                     dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, fixed_H=None):
+    """updates.py:372-395: H - grad / gamma, projected on the simplex (or just clamped)."""
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    new_H = H - 1 / gamma * gradH(X, G, W, H, log_shift=log_shift, safe=safe, mu=mu, epsilon_reg=epsilon_reg, lambda_L=lambda_L, L=L)
+    nu = dichotomy_simplex_projected_gradient(new_H, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
+    new_H = np.maximum(new_H + nu, log_shift)
+    if fixed_H is not None:
+        keep = fixed_H >= 0
+        new_H[keep] = fixed_H[keep]
+    return new_H
+
+
 # ---- linesearch on the Laplacian surrogate (SURVEY 8f rank 4) -------------------------------------------
 def smooth_dgkl_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
     """espm/estimators/surrogates.py:65-114: lambda/2 (2 tr(Ht L H^T) - tr(Ht L Ht^T) + sigma sum_k max_j H_kj sum_j dgkl(Ht_kj, H_kj))."""
@@ -481,7 +547,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None,
         algo="log_surrogate"):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
-    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", "bmd" or "l2_surrogate"; linesearch: smooth_nmf.py:376-381;
+    SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", "bmd", "l2_surrogate" or "projected_gradient" with a given gamma; linesearch: smooth_nmf.py:376-381;
     true_D / true_H tracking: base.py:301-347).
 
     Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
@@ -497,14 +563,19 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     p = X_.shape[1]
     L_ = laplacian_matrix(*shape_2d) if shape_2d is not None else identity_L(p)
     gamma_ = SIGMA_L if gamma is None else gamma  # smooth_nmf.py:290-306
-    if algo not in ("log_surrogate", "bmd", "l2_surrogate"):
+    if algo not in ("log_surrogate", "bmd", "l2_surrogate", "projected_gradient"):
         raise NotImplementedError(algo)
+    if algo == "projected_gradient":  # smooth_nmf.py:297-306: a list [gamma_H, gamma_W] (the Lipschitz default is not restated)
+        if gamma is None or linesearch:
+            raise NotImplementedError("projected_gradient: pass gamma=[gamma_H, gamma_W]; its linesearch is not restated")
+        gamma_ = list(gamma)
     breg = algo == "bmd"  # smooth_nmf.py:358-372, :416-426: both steps with use_bregman=True
     c_kl = const_KL(X_, log_shift)
 
     def loss(Wc, Hc, Xc=None):
         # base.py:196-203: with another X (the noiseless truth) the constant cached for the DATA is still the one added
-        return smooth_nmf_loss(X_ if Xc is None else Xc, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl, gamma_)
+        return smooth_nmf_loss(X_ if Xc is None else Xc, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl,
+                               gamma_[0] if isinstance(gamma_, list) else gamma_)   # smooth_nmf.py:470-473
 
     track = true_D is not None and true_H is not None and true_D.shape[1] == n_components and true_H.shape[0] == n_components
     true_DH = true_D @ true_H if track else None
@@ -519,7 +590,11 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     t0 = time.perf_counter()
     while True:
         old_W, old_H = W_.copy(), H_.copy()
-        if algo == "l2_surrogate":  # smooth_nmf.py:311-323 (mu does not enter this update)
+        if algo == "projected_gradient":  # smooth_nmf.py:340-353
+            H_ = proj_grad_step_h(X_, G_, W_, H_, gamma_[0], simplex_H=simplex_H, mu=mu, log_shift=log_shift,
+                                  epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, L=L_,
+                                  fixed_H=fixed_H)
+        elif algo == "l2_surrogate":  # smooth_nmf.py:311-323 (mu does not enter this update)
             H_ = multiplicative_step_hq(X_, G_, W_, H_, simplex_H=simplex_H, log_shift=log_shift, safe=safe,
                                         dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, L=L_, sigmaL=gamma_, fixed_H=fixed_H)
         else:
@@ -529,8 +604,11 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
                                        exact_root=exact_root, use_bregman=breg)
         if linesearch:
             gamma_ = linesearch_gamma(gamma_, old_H, H_, L_, algo)
-        W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
-                                   simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
+        if algo == "projected_gradient":  # smooth_nmf.py:427-437 (fixed_W is not passed there)
+            W_ = proj_grad_step_w(X_, G_, W_, H_, gamma_[1], simplex_W=simplex_W, log_shift=log_shift, safe=safe)
+        else:
+            W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
+                                       simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
         eval_after, det = loss(W_, H_)
         n_iter += 1
         if track:  # base.py:335-347

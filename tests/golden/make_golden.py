@@ -492,7 +492,48 @@ def f11():
     save("f11_quadratic_surrogate", **out)
 
 
+# ------------------------------------------------------------------ F12: projected gradient (no linesearch)
+PG = {
+    # gamma = [gamma_H, gamma_W]: the default (Lipschitz bounds at log_shift) is ~1e28 and freezes the iterates
+    "p3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0, gamma=[400.0, 4000.0])),
+    "p5": dict(n=60, nx=10, ny=12, k=4, m=9, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.6, mu=0.05, gamma=[2000.0, 20000.0])),
+    "p0": dict(n=32, nx=6, ny=6, k=3, m=None, iters=20, kw=dict(simplex_H=False, simplex_W=False, lambda_L=0.0, mu=0, gamma=[300.0, 1500.0])),
+}
+
+
+def f12():
+    from espm.estimators.updates import proj_grad_step_h, proj_grad_step_w
+    rng = np.random.default_rng(1212)
+    out = {}
+    for name, c in PG.items():
+        X, G, W, H = synth(rng, c["n"], c["nx"], c["ny"], c["k"], c["m"])
+        p = c["nx"] * c["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        Gd = np.eye(c["n"]) if G is None else G
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c["nx"], c["ny"]])
+        L = create_laplacian_matrix(c["nx"], c["ny"])
+        gh, gw = c["kw"]["gamma"]
+        out[f"{name}_step_H"] = proj_grad_step_h(X, Gd, W0, H0.copy(), gh, simplex_H=c["kw"]["simplex_H"], mu=c["kw"]["mu"],
+                                                 lambda_L=c["kw"]["lambda_L"], L=L)
+        out[f"{name}_step_W"] = proj_grad_step_w(X, Gd, W0.copy(), H0, gw, simplex_W=False)
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, algo="projected_gradient", tol=0,
+                        no_stop_criterion=True, max_iter=c["iters"], **c["kw"])
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+    out["names"] = np.array(list(PG))
+    out["configs"] = np.array(json.dumps(PG))
+    save("f12_projected_gradient", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -262,3 +262,28 @@ def test_f11_quadratic_surrogate(golden):
         np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-6, atol=1e-18, err_msg=name)
         np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=2e-5, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
+
+
+def test_f12_projected_gradient(golden):
+    """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W] (updates.py:317-395, dicotomy.py:84-108)."""
+    g = golden("f12_projected_gradient")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = g.get(f"{name}_G")
+        Gd = np.eye(c["n"]) if G is None else G
+        kw = dict(c["kw"])
+        gh, gw = kw["gamma"]
+        Hs = oc.proj_grad_step_h(X, Gd, W0, H0.copy(), gh, simplex_H=kw["simplex_H"], mu=kw["mu"], lambda_L=kw["lambda_L"],
+                                 L=oc.laplacian_matrix(*shape))
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=1e-9, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(oc.proj_grad_step_w(X, Gd, W0.copy(), H0, gw, simplex_W=False), g[f"{name}_step_W"], rtol=1e-10,
+                                   atol=1e-16, err_msg=name)
+        r = oc.fit(X, c["k"], G=G, W=W0.copy(), H=H0.copy(), shape_2d=shape, algo="projected_gradient", tol=0,
+                   no_stop_criterion=True, max_iter=c["iters"], **kw)
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-7, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-6, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=2e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
