@@ -48,7 +48,9 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE((st->breg_sr_px == nullptr) == (st->breg_sr_ch == nullptr), "breg_sr_px and breg_sr_ch come together");
   ESPM_REQUIRE(!st->breg_sr_px || (st->m == 0 && !st->simplex_w && st->n <= 4096),
                "the Bregman variant is built for G = identity without simplex_W (and n <= 4096)");
-  ESPM_REQUIRE(st->h_rule == 0 || (st->h_rule == 1 && !st->breg_sr_px), "h_rule must be 0 or 1 (and not with the Bregman variant)");
+  ESPM_REQUIRE(st->h_rule == 0 || ((st->h_rule == 1 || st->h_rule == 2) && !st->breg_sr_px), "h_rule must be 0, 1 or 2 (1, 2 not with the Bregman variant)");
+  ESPM_REQUIRE(!(st->pg_gamma_w > 0.f) || (!st->simplex_w && !st->breg_sr_px && (st->m == 0 || (long)st->m * st->k <= 8192)),
+               "the projected-gradient W step has no simplex over W (updates.py:368-369), no Bregman variant, and needs M k <= 8192 with a dictionary");
   ESPM_REQUIRE(st->h_variant == 0, "h_variant %d is not built (the matrix-core H-step was retired, DESIGN.md)", st->h_variant);
   ESPM_REQUIRE(st->x_tile >= 64 && ESPM_PPAD % st->x_tile == 0 && st->x_tile % st->tile_px == 0,
                "x_tile=%d must divide %d and be a multiple of tile_px=%d", st->x_tile, ESPM_PPAD, st->tile_px);
@@ -182,6 +184,7 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.simplex_rows = st->simplex_rows;
   a.scratch = st->w_scratch;
   a.breg_sr = st->breg_sr_ch;
+  a.pg_gamma_w = st->pg_gamma_w;
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
   a.gw_a = nullptr;  // reserved (matrix-core H-step, retired)

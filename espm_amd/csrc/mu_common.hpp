@@ -459,6 +459,7 @@ struct WFinishArgs {
   const int32_t* simplex_rows;
   float* scratch;
   const float* breg_sr; // Bregman variant: per-channel sums of the stored X (n), else null
+  float pg_gamma_w;     // > 0: projected-gradient step W - grad / gamma (updates.py:353-370)
   float* gw_s;
   double* colsum_gw;
   void* gw_a;    // MFMA A fragments of the bf16 splits of gw_s (may be null)

@@ -26,14 +26,16 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
   size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
   if (red > part) part = red;
   const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
-  if (args.h_rule == 1) {  // quadratic surrogate of the Laplacian term
-    if (args.compute_loss) {
-      if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR, true>, bytes, "h_step (ell)")) return rc;
-      hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR, true>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
-    } else {
-      if (int rc = allow_lds(h_step_ell_kernel<K, false, UNR, true>, bytes, "h_step (ell)")) return rc;
-      hipLaunchKernelGGL((h_step_ell_kernel<K, false, UNR, true>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
-    }
+  if (args.h_rule == 1 || args.h_rule == 2) {  // quadratic surrogate of the Laplacian term / projected gradient
+    auto go = [&](auto kern) -> int {
+      if (int rc = allow_lds(kern, bytes, "h_step (ell)")) return rc;
+      hipLaunchKernelGGL(kern, dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+      return ESPM_OK;
+    };
+    int rc;
+    if (args.h_rule == 1) rc = args.compute_loss ? go(h_step_ell_kernel<K, true, UNR, 1>) : go(h_step_ell_kernel<K, false, UNR, 1>);
+    else rc = args.compute_loss ? go(h_step_ell_kernel<K, true, UNR, 2>) : go(h_step_ell_kernel<K, false, UNR, 2>);
+    if (rc) return rc;
   } else if (args.compute_loss) {
     if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR>, bytes, "h_step (ell)")) return rc;
     hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);

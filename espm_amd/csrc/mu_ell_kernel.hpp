@@ -200,7 +200,7 @@ struct EllGetUnit {
 //     most two partial numerators.
 //   otherwise every 64-pixel list group is walked by `nsplit` waves, each taking a contiguous slice of its rows
 //     (small images use nsplit = 2, 4 or 8 so that the grid still covers the chip).
-template <int K, bool LOSS, int UNR, bool QUAD = false>
+template <int K, bool LOSS, int UNR, int RULE = 0>
 __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HStepArgs a) {
   constexpr int NT = ESPM_ELL_TILE;
   constexpr bool PAIRS_OK = K <= ESPM_ELL_PAIR_MAX_K;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HSte
     walk_rows(gi, (int)((long)len * si / nsplit), (int)((long)len * (si + 1) / nsplit), si);
     nparts = nsplit;
   }
-  h_epilogue<K, true, QUAD>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f);
+  h_epilogue<K, true, RULE>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------

@@ -52,9 +52,9 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // sum X log2(X / Y).
 // EARLY = false requests the pixel's inputs after the barrier (the matrix-core variant keeps its registers for
 // the accumulation phase).
-// QUAD: the H rule of the quadratic surrogate (a.h_rule == 1) - a compile-time switch so that the default rule does not
-// carry its registers.
-template <int K, bool EARLY = true, bool QUAD = false>
+// RULE: the H rule (a.h_rule) - 0 log surrogate, 1 quadratic surrogate, 2 projected gradient - as a compile-time switch,
+// so that the default rule does not carry the registers of the others.
+template <int K, bool EARLY = true, int RULE = 0>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
@@ -121,7 +121,8 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) * __builtin_amdgcn_rcpf(hin[kk] + rel_shift));   // (a stop-rule statistic: 1 ulp reciprocal)
       red[R_RELH] = fmax(red[R_RELH], (double)worst);
     }
-    constexpr bool quad = QUAD;   // quadratic surrogate of the Laplacian term (multiplicative_step_hq, updates.py:263-315)
+    constexpr bool quad = RULE == 1;   // quadratic surrogate of the Laplacian term (multiplicative_step_hq, updates.py:263-315)
+    constexpr bool pgrad = RULE == 2;  // projected gradient (proj_grad_step_h, updates.py:372-395)
     if (a.mu) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
@@ -142,15 +143,63 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
                                      : hin[kk];
         hlv[kk] = hl;
         red[ESPM_HP_LAP] += (double)(hin[kk] * hl);             // measures.py:574-577
-        if (!quad) {
+        if constexpr (RULE == 0) {
           const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
           nv[kk] += ls * mh;                                      // updates.py:140
           dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
         }
+        if constexpr (pgrad) dv[kk] += a.lambda_l * hl;           // gradient of the Laplacian term, updates.py:349-350
       }
     }
     if (!a.write_h) continue;
-    if constexpr (QUAD) if (a.lambda_l != 0.f) {
+    if constexpr (pgrad) {
+      // H - grad / gamma with grad = -GW^T (X / GWH) + colsum(GW) + mu / (H + eps) + lambda (H L) = dv - nv, then the
+      // projection on the simplex: nu with sum_k max(h_k + nu, eps) = 1 (dicotomy.py:84-108).  The sum is convex, piecewise
+      // linear and increasing: Newton from the right end of the reference's bracket reaches the root in at most K steps.
+      const float inv_gamma = __builtin_amdgcn_rcpf(a.sigma_l);   // gamma_H travels in sigma_l
+      float hg[K];
+      float hmin = INFINITY;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        hg[kk] = hin[kk] - (dv[kk] - nv[kk]) * inv_gamma;
+        hmin = fminf(hmin, hg[kk]);
+      }
+      float nu = 0.f;
+      if (a.simplex_h) {
+        nu = 1.f / (float)K - hmin;
+        for (int it = 0; it < K + 2; ++it) {
+          float f = -1.f, cnt = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < K; ++kk) {
+            const float t = hg[kk] + nu;
+            if (t > a.log_shift) { f += t; cnt += 1.f; } else { f += a.log_shift; }
+          }
+          if (!(cnt > 0.f) || fabsf(f) <= 2e-7f) break;
+          nu -= f / cnt;
+        }
+      }
+      float ht[KP];
+#pragma unroll
+      for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float hn = fmaxf(hg[kk] + nu, a.log_shift);
+        if (a.fixed_h) {
+          const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
+          if (f >= 0.f) hn = f;
+        }
+        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;
+        a.h_out[(size_t)kk * a.p_pad + q] = hn;
+        ht[kk] = hn;
+        red[R_ROWSUM + kk] += (double)hn;
+        red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+      }
+      float4* dstp = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
+      dstp[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
+      dstp[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+      continue;
+    }
+    if constexpr (quad) if (a.lambda_l != 0.f) {
       // a H'^2 + b H' - c = 0 with a = lambda sigma, b = colsum(GW) + lambda (H L) - lambda sigma H (+ nu), c = H GW^T (X / GWH)
       float bq[K], cq[K];
 #pragma unroll
@@ -235,7 +284,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 // NBUF: depth of the register ring of X load groups kept in flight (0 / 1: no explicit prefetch).
 // L2: the Frobenius branch (updates.py:109-118): num = GW^T X, no ratio, no loss; the epilogue takes the denominator
 // (GW^T GW) H from a.l2_m.
-template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false, bool QUAD = false>
+template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false, int RULE = 0>
 __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   constexpr int TP = 64 * PX;
@@ -389,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
 #pragma unroll
     for (int i = 0; i < P2; ++i) kl_lane += kl[i].x + kl[i].y;
   }
-  h_epilogue<K, true, QUAD>(a, smem, NW, TP, tile0, kl_lane);
+  h_epilogue<K, true, RULE>(a, smem, NW, TP, tile0, kl_lane);
 }
 
 }  // namespace espm

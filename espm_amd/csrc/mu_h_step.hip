@@ -43,25 +43,27 @@ static int launch_h_l2(const HStepArgs& args, int nblk, hipStream_t stream) {
   return check_hip(hipGetLastError(), "h_step (l2) launch");
 }
 
-template <int K, int PX, int NW, int U, int NBUF>
-static int launch_h_quad(const HStepArgs& args, int nblk, hipStream_t stream) {
+template <int K, int PX, int NW, int U, int NBUF, int RULE>
+static int launch_h_rule(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
   if (args.compute_loss)
-    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, true, U, NBUF, false, true>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   else
-    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, false, true>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
-  return check_hip(hipGetLastError(), "h_step (quadratic surrogate) launch");
+    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+  return check_hip(hipGetLastError(), "h_step (alternate rule) launch");
 }
 
 template <int K>
 static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
-  if (args.h_rule == 1) {  // quadratic surrogate of the Laplacian term: dense stores through the fp32 one
-    if (x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "h_rule 1 is built for the sparse and the f32 store");
-    if (tile_px == 256) return launch_h_quad<K, 4, 4, 8, 0>(args, nblk, stream);
-    if (tile_px == 128) return launch_h_quad<K, 2, 8, 8, 2>(args, nblk, stream);
-    return set_error(ESPM_EINVAL, "h_step (quadratic surrogate): tile_px %d not available", tile_px);
+  if (args.h_rule != 0) {  // quadratic surrogate / projected gradient: dense stores through the fp32 one
+    if (x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "h_rule %d is built for the sparse and the f32 store", args.h_rule);
+    if (args.h_rule == 1 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 1>(args, nblk, stream);
+    if (args.h_rule == 1 && tile_px == 128) return launch_h_rule<K, 2, 8, 8, 2, 1>(args, nblk, stream);
+    if (args.h_rule == 2 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 2>(args, nblk, stream);
+    if (args.h_rule == 2 && tile_px == 128) return launch_h_rule<K, 2, 8, 8, 2, 2>(args, nblk, stream);
+    return set_error(ESPM_EINVAL, "h_step (rule %d): tile_px %d not available", args.h_rule, tile_px);
   }
   if (args.l2_m) {  // Frobenius branch: fp32 store only
     if (x_dtype != ESPM_X_F32 || args.compute_loss) return set_error(ESPM_EUNSUPPORTED, "the l2 H-step needs the f32 store and no loss");

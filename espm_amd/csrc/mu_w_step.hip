@@ -95,6 +95,7 @@ struct WUpdateArgs {
   float* w_new;
   const float* fixed_w;
   const float* breg_sr;         // Bregman variant (updates.py:40-48): per-channel sums of the stored X, else null
+  float pg_gamma_w;             // > 0: projected-gradient step (updates.py:353-370)
   float* gw_s;
   double* parts;                // [2][k * nbk]: partial column sum of G W' (component of the workgroup), partial sum of W'
   float log_shift, gw_floor, xscale;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
       if (c < a.n) {
         const float wo = a.w_old[(size_t)c * a.k + kk];
         float v;
-        if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
+        if (a.pg_gamma_w > 0.f) {  // W - grad / gamma with grad = rowsum(H) - (X / GWH) H^T (G = I), updates.py:353-362
+          v = fmaxf(wo - ((float)rs - t) / a.pg_gamma_w, a.log_shift);
+        } else if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
           const float sr = a.xscale * a.breg_sr[c];
           v = fmaxf((sr * wo) / (((float)rs - t) * wo + sr), a.log_shift);
         } else {
@@ -401,7 +404,10 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
             wo[r][kk] = a.w_old[mm * k + kk];
             nv[r][kk] = wo[r][kk] * gta;        // updates.py:59
             dv[r][kk] = cg * rs[kk];            // updates.py:60
-            if (a.breg_sr) {                    // Bregman variant (G = identity), updates.py:41-48
+            if (a.pg_gamma_w > 0.f) {           // projected gradient: W - (colsum(G) rowsum(H) - G^T A) / gamma, updates.py:353-362
+              nv[r][kk] = wo[r][kk] - (dv[r][kk] - gta) / a.pg_gamma_w;
+              dv[r][kk] = 1.f;
+            } else if (a.breg_sr) {             // Bregman variant (G = identity), updates.py:41-48
               const float sr = a.xscale * a.breg_sr[mm];
               dv[r][kk] = (dv[r][kk] - gta) * wo[r][kk] + sr;
               nv[r][kk] = sr * wo[r][kk];
@@ -849,6 +855,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.w_new = f.w_new;
   a.fixed_w = f.fixed_w;
   a.breg_sr = f.breg_sr;
+  a.pg_gamma_w = f.pg_gamma_w;
   a.gw_s = f.gw_s;
   a.parts = reinterpret_cast<double*>(f.scratch);
   a.log_shift = f.log_shift;

@@ -62,7 +62,7 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -145,8 +145,8 @@ class MUEngine:
             if x_store == "ell" and int(flag.item()) != 3:
                 raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS")
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
-        if int(h_rule) == 1 and x_store in ("u8", "bf16"):
-            x_store = "f32"   # the quadratic-surrogate H rule is built for the sparse and the fp32 store
+        if int(h_rule) != 0 and x_store in ("u8", "bf16"):
+            x_store = "f32"   # the alternate H rules are built for the sparse and the fp32 store
         if x_store not in ("u8", "bf16", "f32", "ell"):
             raise ValueError("x_store must be 'auto', 'ell', 'u8', 'bf16' or 'f32'")
         self.x_store = x_store
@@ -216,7 +216,8 @@ class MUEngine:
         st.simplex_h, st.simplex_w = int(bool(simplex_H)), int(bool(simplex_W))
         st.compute_loss = int(bool(compute_loss))
         st.lambda_l, st.sigma_l = float(lambda_L), float(sigmaL)
-        st.h_rule = int(h_rule)   # 1: quadratic surrogate of the Laplacian term (multiplicative_step_hq)
+        st.h_rule = int(h_rule)   # 1: quadratic surrogate of the Laplacian term (multiplicative_step_hq), 2: projected gradient
+        st.pg_gamma_w = float(pg_gamma_w)
         st.eps_reg, st.log_shift = float(epsilon_reg), float(log_shift)
         st.dicotomy_tol, st.rel_tol = float(dicotomy_tol), float(tol)
         st.xscale, st.gw_floor = float(xscale), float(gw_floor)

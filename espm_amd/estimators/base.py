@@ -102,9 +102,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             rows = self.physics_model_.NMF_simplex()
         # (the Bregman W update has no simplex branch, updates.py:40-48: algo="bmd" ignores simplex_W there, like the reference)
         simplex_W = self.simplex_W and getattr(self, "algo", None) != "bmd"
+        # (and the projected-gradient W step of a fit is called without fixed_W, smooth_nmf.py:430-437)
+        fixed_W = None if getattr(self, "algo", None) == "projected_gradient" else self.fixed_W
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
-                        fixed_W=self.fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
+                        fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
                         fix_zero_lines=False, **self._engine_kwargs())
 
     def _engine_G(self):

@@ -19,8 +19,8 @@ class SmoothNMF(NMFEstimator):
     accelerated, with or without ``linesearch`` (gamma_ adapts to the Laplacian surrogate every iteration,
     smooth_nmf.py:376-381) and with ``true_D`` / ``true_H`` tracking; so is ``algo="bmd"`` (both updates in their Bregman
     variant, smooth_nmf.py:358-372, :416-426) for G = None and ``algo="l2_surrogate"`` (H from the quadratic surrogate
-    of the Laplacian term, smooth_nmf.py:311-323) with ``l2=False``; ``projected_gradient`` raises
-    ``NotImplementedError`` at fit time.
+    of the Laplacian term, smooth_nmf.py:311-323) with ``l2=False`` and ``algo="projected_gradient"`` with a given
+    ``gamma=[gamma_H, gamma_W]`` and without its linesearch; what is not built raises ``NotImplementedError`` at fit time.
     """
 
     loss_names_ = NMFEstimator.loss_names_ + ["log_reg_loss"] + ["Lapl_reg_loss"] + ["gamma"]
@@ -126,7 +126,8 @@ class SmoothNMF(NMFEstimator):
     def _engine_kwargs(self):
         return dict(lambda_L=self.lambda_L, mu=self.mu, epsilon_reg=self.epsilon_reg,
                     dicotomy_tol=self.dicotomy_tol, sigmaL=float(self._gamma_value()), bregman=self.algo == "bmd",
-                    h_rule=1 if self.algo == "l2_surrogate" else 0)
+                    h_rule={"l2_surrogate": 1, "projected_gradient": 2}.get(self.algo, 0),
+                    pg_gamma_w=float(self.gamma[1]) if self.algo == "projected_gradient" else 0.0)
 
     def _detailed(self, lkl, reg, lap):
         return [lkl, reg, lap, self._gamma_value()]
@@ -137,9 +138,13 @@ class SmoothNMF(NMFEstimator):
 
     def fit_transform(self, X, y=None, W=None, H=None):
         """Fit the model to X (n, p) and return G W (espm/estimators/smooth_nmf.py:239-282)."""
-        if self.algo not in ("log_surrogate", "bmd", "l2_surrogate"):
-            raise NotImplementedError("the GPU path implements algo='log_surrogate', 'bmd' and 'l2_surrogate' "
-                                      f"(got algo={self.algo!r})")
+        if self.algo == "projected_gradient":
+            # smooth_nmf.py:297-306, :340-353, :427-437.  The default gamma (Lipschitz bounds at log_shift, ~1e28) freezes the
+            # iterates and is not restated; its linesearch (two more loss evaluations and a gradient per half step) is not built
+            if not isinstance(self.gamma, list) or len(self.gamma) != 2 or self.linesearch:
+                raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] and linesearch=False on the GPU path")
+            if self.simplex_W:
+                raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
         if self.l2:  # only reachable with algo="l2_surrogate" (smooth_nmf.py:233-237)
             raise NotImplementedError("the Frobenius loss (l2=True) inside a fit is not built for the GPU path")
         self.gamma_ = None

@@ -104,6 +104,44 @@ def multiplicative_step_hq(X, G, W, H, simplex_H=True, log_shift=log_shift, safe
     return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
 
 
+def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
+                     dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, fixed_H=None):
+    """Projected-gradient step in H (espm/estimators/updates.py:372-395, KL branch)."""
+    if l2:
+        raise NotImplementedError("the Frobenius gradient (l2=True) is not built for the GPU")
+    shape_2d = None
+    W = np.asarray(W)
+    H = np.asarray(H)
+    if not (lambda_L == 0):
+        if L is None:
+            raise ValueError("Please provide the laplacian")
+        kind, shape_2d = classify_laplacian(L, H.shape[1])
+    if safe:  # updates.py:376-378
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    eng = _engine(X, G, W, H, simplex_H=simplex_H, simplex_W=False, mu=mu, log_shift=log_shift, epsilon_reg=epsilon_reg,
+                  dicotomy_tol=dicotomy_tol, lambda_L=lambda_L, shape_2d=shape_2d, sigmaL=float(gamma), fixed_H=fixed_H,
+                  compute_loss=False, h_rule=2)
+    out = eng.step_h_only()
+    return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
+
+
+def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=log_shift, safe=True, l2=False, fixed_W=None):
+    """Projected-gradient step in W (espm/estimators/updates.py:353-370, KL branch)."""
+    if l2:
+        raise NotImplementedError("the Frobenius gradient (l2=True) is not built for the GPU")
+    if simplex_W:  # updates.py:368-369 (the reference raises after the step; here before)
+        raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
+    W = np.asarray(W)
+    H = np.asarray(H)
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    eng = _engine(X, G, W, H, simplex_H=False, simplex_W=False, log_shift=log_shift, fixed_W=fixed_W, pg_gamma_w=float(gamma))
+    out = eng.step_w_only()
+    return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
+
+
 def _initial_factors(X, n_components, init, random_state, sklearn_init, X_device=None):
     from espm_amd import init_device
 

@@ -30,6 +30,7 @@
  *   espm_mu_l2_step_h / _w <- espm/estimators/updates.py:109-118, :31-36 (Frobenius branch, l2=True, direct calls)
  *   state fields breg_sr_* <- updates.py:40-48, :120-125 (Bregman variant, algo = "bmd")
  *   state field h_rule = 1 <- updates.py:263-315 + dicotomy.py:57-82 (multiplicative_step_hq, algo = "l2_surrogate")
+ *   h_rule = 2, pg_gamma_w <- updates.py:317-395 + dicotomy.py:84-108 (proj_grad_step_h / _w, algo = "projected_gradient")
  *
  * Conventions
  *   - extern "C", plain pointers and sizes.  All array pointers are DEVICE pointers owned by the
@@ -204,7 +205,11 @@ typedef struct espm_mu_state {
   const float* breg_sr_ch;  /* (n) or NULL */
   int32_t h_rule;           /* H update: 0 = log surrogate (multiplicative_step_h, updates.py:83-156), 1 = quadratic surrogate
                                of the Laplacian term (multiplicative_step_hq, updates.py:263-315: positive root of
-                               a H'^2 + b H' - c = 0, its own simplex multiplier dicotomy.py:57-82; mu only enters the loss) */
+                               a H'^2 + b H' - c = 0, its own simplex multiplier dicotomy.py:57-82; mu only enters the loss),
+                               2 = projected gradient (proj_grad_step_h, updates.py:372-395: H - grad / gamma_H with
+                               gamma_H in sigma_l, projection on the simplex dicotomy.py:84-108) */
+  float pg_gamma_w;         /* > 0: the W update is the projected-gradient step W - grad / pg_gamma_w, clamped
+                               (proj_grad_step_w, updates.py:353-370; no simplex over W); 0: multiplicative update */
 } espm_mu_state;
 
 const char* espm_mu_version(void);

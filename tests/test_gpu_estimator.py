@@ -347,8 +347,11 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
     X = np.random.default_rng(0).random((20, 30))
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
+    with pytest.raises(NotImplementedError):   # the default gamma of the projected gradient, its linesearch
+        quiet(SmoothNMF(n_components=2, algo="projected_gradient", simplex_W=False, verbose=0).fit, X)
     with pytest.raises(NotImplementedError):
-        quiet(SmoothNMF(n_components=2, algo="projected_gradient", verbose=0).fit, X)
+        quiet(SmoothNMF(n_components=2, algo="projected_gradient", simplex_W=False, gamma=[10.0, 10.0], linesearch=True,
+                        lambda_L=1.0, shape_2d=(5, 6), verbose=0).fit, X)
     with pytest.raises(NotImplementedError):   # the Frobenius loss inside a fit
         quiet(SmoothNMF(n_components=2, algo="l2_surrogate", l2=True, verbose=0).fit, X)
 
@@ -489,3 +492,35 @@ def test_quadratic_surrogate_golden(SmoothNMF, golden):
         np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
         np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
         np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+
+
+def test_projected_gradient_golden(SmoothNMF, golden):
+    """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W]: both steps as direct calls and whole fits (G
+    given, mu, lambda, entries at the clamp) against the reference (fixture F12)."""
+    from espm_amd.estimators.updates import proj_grad_step_h, proj_grad_step_w
+    from espm_amd.utils import create_laplacian_matrix
+    g = golden("f12_projected_gradient")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = g.get(f"{name}_G")
+        Gd = np.eye(c["n"]) if G is None else G
+        kw = dict(c["kw"])
+        gh, gw = kw["gamma"]
+        Hs = proj_grad_step_h(X, Gd, W0, H0.copy(), gh, simplex_H=kw["simplex_H"], mu=kw["mu"], lambda_L=kw["lambda_L"],
+                              L=create_laplacian_matrix(*shape))
+        np.testing.assert_allclose(Hs, g[f"{name}_step_H"], rtol=5e-5, atol=5e-6, err_msg=name)
+        Ws = proj_grad_step_w(X, Gd, W0.copy(), H0, gw, simplex_W=False)
+        np.testing.assert_allclose(Ws, g[f"{name}_step_W"], rtol=5e-5, atol=1e-6 * np.abs(W0).mean(), err_msg=name)
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=shape, verbose=0, algo="projected_gradient", tol=0,
+                        no_stop_criterion=True, max_iter=c["iters"], **kw)
+        GW = est.fit_transform(X, W=W0.copy(), H=H0.copy())
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=3 * LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+    with pytest.raises(NotImplementedError):
+        quiet(SmoothNMF(n_components=2, algo="projected_gradient", verbose=0).fit, g["p0_X"])   # default gamma / simplex_W
