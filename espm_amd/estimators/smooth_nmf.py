@@ -120,6 +120,8 @@ class SmoothNMF(NMFEstimator):
 
     # ---- hooks of the base fit loop ---------------------------------------------------------------------
     def _gamma_value(self):
+        if self.algo == "projected_gradient" and self.gamma is None:
+            return self._pg_gamma()[0]
         g = self.gamma_ if getattr(self, "gamma_", None) is not None else (sigmaL if self.gamma is None else self.gamma)
         return g[0] if isinstance(g, list) else g
 
@@ -127,7 +129,20 @@ class SmoothNMF(NMFEstimator):
         return dict(lambda_L=self.lambda_L, mu=self.mu, epsilon_reg=self.epsilon_reg,
                     dicotomy_tol=self.dicotomy_tol, sigmaL=float(self._gamma_value()), bregman=self.algo == "bmd",
                     h_rule={"l2_surrogate": 1, "projected_gradient": 2}.get(self.algo, 0),
-                    pg_gamma_w=float(self.gamma[1]) if self.algo == "projected_gradient" else 0.0)
+                    pg_gamma_w=float(self._pg_gamma()[1]) if self.algo == "projected_gradient" else 0.0)
+
+    def _pg_gamma(self):
+        """[gamma_H, gamma_W] of the projected gradient: the user's list, or the Lipschitz bounds at W = H = log_shift
+        (smooth_nmf.py:297-306) - astronomically large, so that the iterates do not move, exactly like the reference."""
+        if self.gamma is not None:
+            return self.gamma
+        if getattr(self, "_pg_gamma_cache", None) is None:
+            from espm_amd.estimators.updates import estimate_Lipschitz_bound_h, estimate_Lipschitz_bound_w
+            G = None if self._identity_G else self.G_
+            self._pg_gamma_cache = [float(estimate_Lipschitz_bound_h(self.log_shift, self.X_, G, self.n_components,
+                                                                      lambda_L=self.lambda_L, mu=self.mu, epsilon_reg=self.epsilon_reg)),
+                                    float(estimate_Lipschitz_bound_w(self.log_shift, self.X_, G, self.n_components))]
+        return self._pg_gamma_cache
 
     def _detailed(self, lkl, reg, lap):
         return [lkl, reg, lap, self._gamma_value()]
@@ -135,19 +150,23 @@ class SmoothNMF(NMFEstimator):
     def _begin_fit(self):
         # smooth_nmf.py:290-306: gamma_ is fixed on the first iteration
         self.gamma_ = sigmaL if self.gamma is None else deepcopy(self.gamma)
+        if self.algo == "projected_gradient" and self.gamma is None:
+            self.gamma_ = list(self._pg_gamma())
 
     def fit_transform(self, X, y=None, W=None, H=None):
         """Fit the model to X (n, p) and return G W (espm/estimators/smooth_nmf.py:239-282)."""
         if self.algo == "projected_gradient":
-            # smooth_nmf.py:297-306, :340-353, :427-437.  The default gamma (Lipschitz bounds at log_shift, ~1e28) freezes the
-            # iterates and is not restated; its linesearch (two more loss evaluations and a gradient per half step) is not built
-            if not isinstance(self.gamma, list) or len(self.gamma) != 2 or self.linesearch:
-                raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] and linesearch=False on the GPU path")
+            # smooth_nmf.py:297-306, :340-353, :427-437.  Its linesearch (two more loss evaluations and a gradient per half
+            # step) is not built; the default gamma (Lipschitz bounds at log_shift) is formed in _pg_gamma
+            if self.linesearch or not (self.gamma is None or (isinstance(self.gamma, list) and len(self.gamma) == 2)):
+                raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] (or None) and linesearch=False "
+                                          "on the GPU path")
             if self.simplex_W:
                 raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
         if self.l2:  # only reachable with algo="l2_surrogate" (smooth_nmf.py:233-237)
             raise NotImplementedError("the Frobenius loss (l2=True) inside a fit is not built for the GPU path")
         self.gamma_ = None
+        self._pg_gamma_cache = None
         return super().fit_transform(X, y=y, W=W, H=H)
 
     def _iteration(self, W, H):

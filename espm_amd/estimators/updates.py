@@ -104,6 +104,29 @@ def multiplicative_step_hq(X, G, W, H, simplex_H=True, log_shift=log_shift, safe
     return out.astype(np.float32 if H.dtype == np.float32 else np.float64)
 
 
+def estimate_Lipschitz_bound_w(log_shift, X, G, k):
+    """Lipschitz bound of the KL gradient in W at the corner W = H = log_shift (espm/estimators/updates.py:397-407): the
+    default gamma_W of the projected gradient (of the order of X / log_shift^3: the iterates do not move with it).  One
+    elementwise pass over X on the host, once per fit."""
+    if G is None:
+        G = np.eye(X.shape[0])
+    Wlim = np.ones([G.shape[1], k]) * log_shift
+    Hlim = np.ones([k, X.shape[1]]) * log_shift
+    DH = (G @ Wlim) @ Hlim
+    return np.max((np.sum(Hlim, axis=0, keepdims=True) * X / (DH ** 2)) @ Hlim.T)
+
+
+def estimate_Lipschitz_bound_h(log_shift, X, G, k, lambda_L=0, mu=0, epsilon_reg=1):
+    """Lipschitz bound of the gradient in H at the corner W = H = log_shift (espm/estimators/updates.py:409-419)."""
+    if G is None:
+        G = np.eye(X.shape[0])
+    Wlim = np.ones([G.shape[1], k]) * log_shift
+    Hlim = np.ones([k, X.shape[1]]) * log_shift
+    D = G @ Wlim
+    DH = D @ Hlim
+    return np.max(D.T @ (np.sum(D, axis=1, keepdims=True) * X / (DH ** 2))) + 2 * lambda_L + mu * epsilon_reg
+
+
 def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
                      dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, fixed_H=None):
     """Projected-gradient step in H (espm/estimators/updates.py:372-395, KL branch)."""

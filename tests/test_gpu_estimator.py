@@ -347,9 +347,7 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
     X = np.random.default_rng(0).random((20, 30))
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
-    with pytest.raises(NotImplementedError):   # the default gamma of the projected gradient, its linesearch
-        quiet(SmoothNMF(n_components=2, algo="projected_gradient", simplex_W=False, verbose=0).fit, X)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):   # the linesearch of the projected gradient
         quiet(SmoothNMF(n_components=2, algo="projected_gradient", simplex_W=False, gamma=[10.0, 10.0], linesearch=True,
                         lambda_L=1.0, shape_2d=(5, 6), verbose=0).fit, X)
     with pytest.raises(NotImplementedError):   # the Frobenius loss inside a fit
@@ -523,4 +521,10 @@ def test_projected_gradient_golden(SmoothNMF, golden):
         np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
         np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
     with pytest.raises(NotImplementedError):
-        quiet(SmoothNMF(n_components=2, algo="projected_gradient", verbose=0).fit, g["p0_X"])   # default gamma / simplex_W
+        quiet(SmoothNMF(n_components=2, algo="projected_gradient", verbose=0).fit, g["p0_X"])   # simplex_W (the default) is refused
+    # default gamma: the Lipschitz bounds at log_shift (~X / log_shift^3) - the iterates do not move, like the reference's
+    est = SmoothNMF(n_components=3, algo="projected_gradient", simplex_W=False, simplex_H=False, max_iter=3, tol=0, verbose=0,
+                    no_stop_criterion=True)
+    quiet(est.fit, g["p0_X"], W=g["p0_W0"].copy(), H=g["p0_H0"].copy())
+    assert est.gamma_[0] > 1e25 and est.gamma_[1] > 1e25
+    assert np.allclose(est.losses_, est.losses_[0], rtol=1e-6)
