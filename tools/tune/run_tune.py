@@ -15,7 +15,7 @@ def build():
     csrc = os.path.join(ROOT, "espm_amd", "csrc")
     u8 = os.environ.get("TUNE_XT", "bf16") == "u8"
     out = os.path.join(HERE, "libespm_tune_u8.so" if u8 else "libespm_tune.so")
-    srcs = [os.path.join(csrc, f) for f in ("mu_api.hip", "mu_h_step.hip", "mu_w_step.hip", "mu_aux.hip")] + [os.path.join(HERE, "tune.hip")]
+    srcs = [os.path.join(csrc, f) for f in ("mu_api.hip", "mu_h_step.hip", "mu_w_step.hip", "mu_aux.hip", "mu_ell.hip", "mu_ell_build.hip", "mu_l2.hip")] + [os.path.join(HERE, "tune.hip")]
     newest = max(os.path.getmtime(f) for f in srcs + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".hpp")])
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
