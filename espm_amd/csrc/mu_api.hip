@@ -346,6 +346,21 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                           static_cast<hipStream_t>(stream));
 }
 
+int espm_dichotomy_simplex_acc(double a, const double* b, const double* minus_c, int k, int p, int b_cols, double log_shift,
+                               double tol, int maxit, double* nu_out, int32_t* status_out, espm_stream_t stream) {
+  ESPM_REQUIRE(b && minus_c && nu_out && status_out, "dichotomy_acc: NULL pointer");
+  ESPM_REQUIRE(k >= 1 && p >= 1 && (b_cols == 1 || b_cols == p) && a >= 0, "dichotomy_acc: bad arguments k=%d p=%d b_cols=%d", k, p, b_cols);
+  if (log_shift > 0 && (double)k * log_shift >= 1.0) return set_error(ESPM_ENOSOLUTION, "No solution exists!");
+  return launch_dichotomy_acc(a, b, minus_c, k, p, b_cols, log_shift, tol, maxit, nu_out, status_out, static_cast<hipStream_t>(stream));
+}
+
+int espm_dichotomy_simplex_pg(const double* a, int k, int p, double log_shift, double tol, int maxit, double* nu_out,
+                              espm_stream_t stream) {
+  ESPM_REQUIRE(a && nu_out && k >= 1 && p >= 1, "dichotomy_pg: bad arguments");
+  if (log_shift > 0 && (double)k * log_shift >= 1.0) return set_error(ESPM_ENOSOLUTION, "No solution exists!");
+  return launch_dichotomy_pg(a, k, p, log_shift, tol, maxit, nu_out, static_cast<hipStream_t>(stream));
+}
+
 int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, espm_stream_t stream) {
   ESPM_REQUIRE(h && out && k >= 1 && nx >= 1 && ny >= 1 && ld >= (int64_t)nx * ny, "laplacian: bad arguments");
   return launch_laplacian(h, k, nx, ny, ld, out, static_cast<hipStream_t>(stream));

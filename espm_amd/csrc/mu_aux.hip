@@ -166,6 +166,90 @@ int launch_dichotomy(const double* num, const double* den, int k, int p, int den
   return check_hip(hipGetLastError(), "dichotomy launch");
 }
 
+// ---- the other two multipliers of espm/estimators/dicotomy.py as module-level functions (fp64, one thread per column) ----
+// acc (dicotomy.py:57-82):  sum_k max(sqrt((b_kj + nu)^2 + 4 a c_kj) - nu - b_kj, 2 a eps) = 2 a
+// pg  (dicotomy.py:84-108): sum_k max(a_kj + nu, eps) = 1
+// Both sums are monotone in nu; the reference's bracket, a Newton iteration kept inside it, per-column convergence.
+__global__ __launch_bounds__(256) void dichotomy_acc_kernel(double a, const double* __restrict__ b, const double* __restrict__ c,
+                                                            int k, int p, int b_cols, double eps, double tol, int maxit,
+                                                            double* __restrict__ nu_out, int32_t* __restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p) return;
+  auto bb = [&](int i) { return b[(size_t)i * b_cols + (b_cols > 1 ? j : 0)]; };
+  double bmax = -INFINITY, bsum = 0.0;
+  bool ok = a > 0;
+  for (int i = 0; i < k; ++i) {
+    const double cc = c[(size_t)i * p + j];
+    ok = ok && cc >= 0;
+    bmax = fmax(bmax, bb(i) * bb(i) / a + 2 * a + 2 * (bb(i) + cc));
+    bsum += bb(i);
+  }
+  if (!ok) {
+    atomicAdd(status, 1);
+    nu_out[j] = NAN;
+    return;
+  }
+  double hi = k * bmax * 1.5 + 1e-3, lo = -(2 * a + bsum) / k * 1.1 - 1e-3;
+  const double floor_g = 2 * a * eps;
+  double x = fmin(fmax(0.0, lo), hi), dxold = hi - lo;
+  for (int it = 0; it < maxit; ++it) {
+    double f = -2 * a, fp = 0.0;
+    for (int i = 0; i < k; ++i) {
+      const double s = bb(i) + x, q = 4 * a * c[(size_t)i * p + j];
+      const double r = sqrt(s * s + q);
+      const double g = s >= 0 ? q / (r + s) : r - s;
+      if (g > floor_g) {
+        f += g;
+        fp -= g / r;
+      } else {
+        f += floor_g;
+      }
+    }
+    if (fabs(f) <= tol) break;
+    if (f > 0) lo = x; else hi = x;
+    double dx = fp < 0 ? -f / fp : 0.0;
+    double xn = x + dx;
+    if (!(fp < 0) || !(xn > lo && xn < hi) || fabs(dx) > 0.5 * fabs(dxold)) {
+      dx = (hi - lo) / 2;
+      xn = lo + dx;
+    }
+    dxold = dx;
+    if (xn == x) break;
+    x = xn;
+  }
+  nu_out[j] = x;
+}
+
+__global__ __launch_bounds__(256) void dichotomy_pg_kernel(const double* __restrict__ a, int k, int p, double eps, double tol,
+                                                           int maxit, double* __restrict__ nu_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p) return;
+  double amin = INFINITY;
+  for (int i = 0; i < k; ++i) amin = fmin(amin, a[(size_t)i * p + j]);
+  double x = 1.0 / k - amin;   // right end of the bracket: every term is active there and the sum is >= 1
+  for (int it = 0; it < maxit; ++it) {
+    double f = -1.0, cnt = 0.0;
+    for (int i = 0; i < k; ++i) {
+      const double t = a[(size_t)i * p + j] + x;
+      if (t > eps) { f += t; cnt += 1.0; } else { f += eps; }
+    }
+    if (fabs(f) <= tol || !(cnt > 0)) break;
+    x -= f / cnt;   // convex, piecewise linear, increasing: Newton from the right is monotone and finite
+  }
+  nu_out[j] = x;
+}
+
+int launch_dichotomy_acc(double a, const double* b, const double* c, int k, int p, int b_cols, double eps, double tol, int maxit,
+                         double* nu_out, int32_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(dichotomy_acc_kernel, dim3((p + 255) / 256), dim3(256), 0, stream, a, b, c, k, p, b_cols, eps, tol, maxit, nu_out,
+                     status);
+  return check_hip(hipGetLastError(), "dichotomy_acc launch");
+}
+int launch_dichotomy_pg(const double* a, int k, int p, double eps, double tol, int maxit, double* nu_out, hipStream_t stream) {
+  hipLaunchKernelGGL(dichotomy_pg_kernel, dim3((p + 255) / 256), dim3(256), 0, stream, a, k, p, eps, tol, maxit, nu_out);
+  return check_hip(hipGetLastError(), "dichotomy_pg launch");
+}
+
 // ---- stand-alone H @ L ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void laplacian_kernel(const float* __restrict__ h, int k, int nx, int ny, int64_t ld,
                                                         float* __restrict__ out) {

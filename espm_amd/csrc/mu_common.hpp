@@ -617,6 +617,9 @@ int launch_shard_pack(const float* a, const double* hstat, const float* h_new, i
                       int p_pad, int with_halo, void* rec, hipStream_t stream);
 int launch_shard_combine(const void* recs, int world, size_t stride, int na, float* a_out, double* hstat_out,
                          hipStream_t stream);
+int launch_dichotomy_acc(double a, const double* b, const double* c, int k, int p, int b_cols, double eps, double tol, int maxit,
+                         double* nu_out, int32_t* status, hipStream_t stream);
+int launch_dichotomy_pg(const double* a, int k, int p, double eps, double tol, int maxit, double* nu_out, hipStream_t stream);
 int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, hipStream_t stream);
 int launch_linesearch_terms(const float* h_old, const float* h_new, int k, int p, int p_pad, int nx, int ny, int grid_mode,
                             double* part, double* out, hipStream_t stream);

@@ -1,4 +1,4 @@
-"""Simplex Lagrange-multiplier root finder (espm/estimators/dicotomy.py:4-55) on the GPU."""
+"""Simplex Lagrange-multiplier root finders (espm/estimators/dicotomy.py:4-108) on the GPU."""
 import ctypes as C
 
 import numpy as np
@@ -39,3 +39,51 @@ def dichotomy_simplex(num, denum, log_shift=log_shift, tol=dicotomy_tol, maxit=m
     nu = d_nu.cpu().numpy()
     assert int(d_status.item()) == 0, "dichotomy_simplex preconditions violated on device"
     return nu
+
+
+def dichotomy_simplex_acc(a, b, minus_c, log_shift=log_shift, tol=dicotomy_tol, maxit=maxit_dichotomy):
+    """Multiplier of the quadratic-surrogate H update (dicotomy.py:57-82): for every column j the nu with
+    sum_k max(sqrt((b_kj + nu)^2 + 4 a c_kj) - nu - b_kj, 2 a log_shift) = 2 a.  Same arguments and checks as the
+    reference; per-column convergence to ``tol`` inside the reference's bracket."""
+    import torch
+
+    from espm_amd import _lib
+    from espm_amd.engine import _ptr, _stream, require_gpu
+
+    b = np.asarray(b, dtype=np.float64)
+    minus_c = np.asarray(minus_c, dtype=np.float64)
+    assert a >= 0                        # dicotomy.py:66-67
+    assert (minus_c >= 0).all()
+    if log_shift > 0 and b.shape[0] * log_shift >= 1:
+        raise ValueError("No solution exists!")
+    k, p = minus_c.shape
+    if b.ndim != 2 or b.shape[0] != k or b.shape[1] not in (1, p):
+        raise ValueError("b must be (k, p) or (k, 1)")
+    dev = require_gpu()
+    d_b = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+    d_c = torch.from_numpy(np.ascontiguousarray(minus_c)).to(dev)
+    d_nu = torch.empty(p, dtype=torch.float64, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.espm_dichotomy_simplex_acc(float(a), _ptr(d_b), _ptr(d_c), k, p, b.shape[1], float(log_shift), float(tol),
+                                                   int(maxit), _ptr(d_nu), _ptr(d_status), _stream()))
+    nu = d_nu.cpu().numpy()
+    assert int(d_status.item()) == 0, "dichotomy_simplex_acc preconditions violated on device"
+    return nu
+
+
+def dichotomy_simplex_projected_gradient(a, log_shift=log_shift, tol=dicotomy_tol, maxit=maxit_dichotomy):
+    """Projection multiplier of the projected-gradient H step (dicotomy.py:84-108): sum_k max(a_kj + nu_j, log_shift) = 1."""
+    import torch
+
+    from espm_amd import _lib
+    from espm_amd.engine import _ptr, _stream, require_gpu
+
+    a = np.asarray(a, dtype=np.float64)
+    if log_shift > 0 and a.shape[0] * log_shift >= 1:
+        raise ValueError("No solution exists!")
+    k, p = a.shape
+    dev = require_gpu()
+    d_a = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_nu = torch.empty(p, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib.espm_dichotomy_simplex_pg(_ptr(d_a), k, p, float(log_shift), float(tol), int(maxit), _ptr(d_nu), _stream()))
+    return d_nu.cpu().numpy()

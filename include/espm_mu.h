@@ -310,6 +310,14 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                            double log_shift, double tol, int maxit, double* nu_out,
                            int32_t* status_out, espm_stream_t stream);
 
+/* The other two multipliers of espm/estimators/dicotomy.py as module-level functions (fp64 device arrays, per-column
+ * convergence): acc (dicotomy.py:57-82): sum_k max(sqrt((b_kj + nu_j)^2 + 4 a c_kj) - nu_j - b_kj, 2 a eps) = 2 a with b
+ * (k, b_cols in {1, p}), minus_c (k, p) >= 0; pg (dicotomy.py:84-108): sum_k max(a_kj + nu_j, eps) = 1 with a (k, p). */
+int espm_dichotomy_simplex_acc(double a, const double* b, const double* minus_c, int k, int p, int b_cols, double log_shift,
+                               double tol, int maxit, double* nu_out, int32_t* status_out, espm_stream_t stream);
+int espm_dichotomy_simplex_pg(const double* a, int k, int p, double log_shift, double tol, int maxit, double* nu_out,
+                              espm_stream_t stream);
+
 /* Frobenius ("l2") branch of the step functions, espm/estimators/updates.py:109-118 (H) and :31-36 (W); in the reference
  * reachable only by calling multiplicative_step_h / _w with l2=True (espm/tests/test_updates.py:457-568).  f32 store,
  * xscale = 1, lambda_L = 0, mu = NULL.  work: (2, KP, KP) device floats (GW^T GW, then H H^T); scratch: device doubles

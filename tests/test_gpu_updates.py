@@ -335,3 +335,26 @@ def test_local_w_update_equals_the_one_workgroup_finish(n, nx, ny, k, fix):
     if fix:
         m = fixed_W >= 0
         assert np.array_equal(a[0][m], fixed_W[m].astype(np.float32))
+
+
+def test_other_multipliers_known_answers(golden):
+    """dichotomy_simplex_acc and dichotomy_simplex_projected_gradient as module-level functions: the reference's root of
+    fixture F11, the defining equations, and the reference's own checks (espm/tests/test_updates.py:251-437, :675-731)."""
+    from espm_amd.estimators.dicotomy import dichotomy_simplex_acc, dichotomy_simplex_projected_gradient
+    g = golden("f11_quadratic_surrogate")
+    a, b, c = float(g["acc_a"]), g["acc_b"], g["acc_c"]
+    nu = dichotomy_simplex_acc(a, b, c, log_shift=0.0, tol=1e-12, maxit=200)
+    np.testing.assert_allclose(nu, g["acc_nu"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(((np.sqrt((b + nu) ** 2 + 4 * a * c) - nu - b) / (2 * a)).sum(axis=0), 1.0, atol=1e-10)
+    nu1 = dichotomy_simplex_acc(a, b[:, :1], c, log_shift=0.02, tol=1e-10)       # broadcast b, active floor
+    h = np.maximum((np.sqrt((b[:, :1] + nu1) ** 2 + 4 * a * c) - nu1 - b[:, :1]) / (2 * a), 0.02)
+    np.testing.assert_allclose(h.sum(axis=0), 1.0, atol=1e-8)
+    with pytest.raises(ValueError):
+        dichotomy_simplex_acc(a, b, c, log_shift=0.25)
+    rng = np.random.default_rng(9)
+    v = rng.standard_normal((6, 300)) * 3
+    for eps in (0.0, 0.05):
+        nu2 = dichotomy_simplex_projected_gradient(v, log_shift=eps, tol=1e-12)
+        np.testing.assert_allclose(np.maximum(v + nu2, eps).sum(axis=0), 1.0, atol=1e-10)
+    with pytest.raises(ValueError):
+        dichotomy_simplex_projected_gradient(v, log_shift=0.2)
