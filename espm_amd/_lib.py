@@ -78,6 +78,7 @@ SYMBOLS = {
     "espm_mu_w_reduce_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_w_reduce_pack": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
     "espm_mu_linesearch_terms": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
+    "espm_surrogate_terms": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "espm_dichotomy_simplex_acc": (C.c_int, [C.c_double, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "espm_dichotomy_simplex_pg": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp]),
     "espm_mu_l2_step_h": (C.c_int, [_SP, C.c_int, _vp, _vp, C.c_int, _vp]),

@@ -346,6 +346,14 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                           static_cast<hipStream_t>(stream));
 }
 
+int espm_surrogate_terms(const float* h_old, const float* h_new, int k, int p, int64_t ld, int nx, int ny, int grid_mode, double* part,
+                         int part_doubles, double* out, espm_stream_t stream) {
+  ESPM_REQUIRE(h_old && h_new && part && out && k >= 1 && k <= ESPM_KP && p >= 1 && ld >= p, "surrogate_terms: bad arguments");
+  ESPM_REQUIRE(!grid_mode || (nx >= 1 && ny >= 1 && (int64_t)nx * ny == p), "surrogate_terms: grid %d x %d does not match p=%d", nx, ny, p);
+  ESPM_REQUIRE(part_doubles >= (4 + ESPM_KP) * ((p + 511) / 512), "surrogate_terms: scratch of %d doubles is too small", part_doubles);
+  return launch_linesearch_terms(h_old, h_new, k, p, (int)ld, nx, ny, grid_mode, part, out, static_cast<hipStream_t>(stream));
+}
+
 int espm_dichotomy_simplex_acc(double a, const double* b, const double* minus_c, int k, int p, int b_cols, double log_shift,
                                double tol, int maxit, double* nu_out, int32_t* status_out, espm_stream_t stream) {
   ESPM_REQUIRE(b && minus_c && nu_out && status_out, "dichotomy_acc: NULL pointer");

@@ -126,3 +126,56 @@ def find_min_MSE(true_maps, algo_maps, get_ind=False, unique=False):
     """Best match of NMF maps to true maps by mean squared error (espm/measures.py:244-270)."""
     out = (unique_min if unique else global_min)(squared_distance(true_maps, algo_maps))
     return out if get_ind else out[0]
+
+
+def mse(map1, map2):
+    """Mean squared error between two maps (espm/measures.py:51-72)."""
+    return np.mean((np.asarray(map1) - np.asarray(map2)) ** 2)
+
+
+def mae(map1, map2):
+    """Mean absolute error between two maps (espm/measures.py:75-96)."""
+    return np.mean(np.abs(np.asarray(map1) - np.asarray(map2)))
+
+
+def ordered_mse(true_maps, algo_maps, input_inds):
+    """MSE of every phase for a given correspondence (espm/measures.py:287-299)."""
+    return [float(mse(true_maps[j], algo_maps[i])) for i, j in enumerate(input_inds)]
+
+
+def ordered_mae(true_maps, algo_maps, input_inds):
+    """MAE of every phase for a given correspondence (espm/measures.py:301-313)."""
+    return [float(mae(true_maps[j], algo_maps[i])) for i, j in enumerate(input_inds)]
+
+
+def ordered_angles(true_spectra, algo_spectra, input_inds):
+    """Spectral angle of every phase for a given correspondence (espm/measures.py:330-339)."""
+    return [spectral_angle(true_spectra[j], algo_spectra[i]) for i, j in enumerate(input_inds)]
+
+
+def find_min_config(true_maps, true_spectra, algo_maps, algo_spectra, angles=True):
+    """Best match of NMF phases to the truth by angles (or by map errors) and whether the two criteria agree
+    (espm/measures.py:222-256)."""
+    min_MSE_config = find_min_MSE(true_maps, algo_maps, get_ind=True, unique=True)[1]
+    min_angle_config = find_min_angle(true_spectra, algo_spectra, get_ind=True, unique=True)[1]
+    warning = False
+    if min_MSE_config != min_angle_config:
+        print("WARNING : angles and mse disagree there's probably an issue")
+        warning = True
+    if angles:
+        return (find_min_angle(true_spectra, algo_spectra, unique=True), ordered_mse(true_maps, algo_maps, min_angle_config),
+                min_angle_config, warning)
+    return (ordered_angles(true_spectra, algo_spectra, min_MSE_config), find_min_MSE(true_maps, algo_maps, unique=True),
+            min_MSE_config, warning)
+
+
+def Frobenius_loss(X, W, H, average=False):
+    """||X - W H||_F^2 (espm/measures.py:350-384): one GEMM and an element-wise reduction with torch on the device."""
+    import torch
+
+    from espm_amd.engine import require_gpu
+    dev = require_gpu()
+    Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
+    r = Xd - torch.from_numpy(np.ascontiguousarray(W, dtype=np.float64)).to(dev) @ torch.from_numpy(np.ascontiguousarray(H, dtype=np.float64)).to(dev)
+    t = r * r
+    return float(t.mean() if average else t.sum())

@@ -31,6 +31,8 @@
  *   state fields breg_sr_* <- updates.py:40-48, :120-125 (Bregman variant, algo = "bmd")
  *   state field h_rule = 1 <- updates.py:263-315 + dicotomy.py:57-82 (multiplicative_step_hq, algo = "l2_surrogate")
  *   h_rule = 2, pg_gamma_w <- updates.py:317-395 + dicotomy.py:84-108 (proj_grad_step_h / _w, algo = "projected_gradient")
+ *   espm_dichotomy_simplex_acc / _pg <- dicotomy.py:57-108 (module-level functions)
+ *   espm_surrogate_terms  <- espm/estimators/surrogates.py:6-149 (module-level surrogates)
  *
  * Conventions
  *   - extern "C", plain pointers and sizes.  All array pointers are DEVICE pointers owned by the
@@ -337,6 +339,11 @@ int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float*
  * when d > 0, else raises it by 1.5.  Uses st->hpart as scratch: call it between
  * espm_mu_h_finalize and the next espm_mu_step_h.  One GPU only. */
 int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream);
+
+/* The same terms without a state (module-level surrogates, espm/estimators/surrogates.py): h_old, h_new (k, ld) fp32 with p
+ * used columns, grid (nx, ny) when grid_mode != 0 else L = identity; part: scratch of (4 + KP) * ceil(p / 512) doubles. */
+int espm_surrogate_terms(const float* h_old, const float* h_new, int k, int p, int64_t ld, int nx, int ny, int grid_mode, double* part,
+                         int part_doubles, double* out, espm_stream_t stream);
 
 /* out = H @ L for the 5-point Laplacian on an (nx, ny) grid (k, nx*ny) with leading dim ld. */
 int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out,

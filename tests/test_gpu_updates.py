@@ -358,3 +358,37 @@ def test_other_multipliers_known_answers(golden):
         np.testing.assert_allclose(np.maximum(v + nu2, eps).sum(axis=0), 1.0, atol=1e-10)
     with pytest.raises(ValueError):
         dichotomy_simplex_projected_gradient(v, log_shift=0.2)
+
+
+def test_surrogates_and_reporting_measures(golden):
+    """Module-level surrogates (surrogates.py) against the oracle's restatement, the reference's majorisation tests
+    (espm/tests/test_estimators.py:168-204: the surrogate is >= the Laplacian term, with equality at Ht), and the small
+    reporting measures."""
+    from espm_amd.estimators import surrogates as sg
+    from espm_amd import measures as ms
+    from espm_amd.utils import create_laplacian_matrix
+    rng = np.random.default_rng(21)
+    nx, ny, k = 9, 14, 4
+    L = create_laplacian_matrix(nx, ny)
+    Lo = oc.laplacian_matrix(nx, ny)
+    for _ in range(3):
+        A1 = rng.random((k, nx * ny)) + 0.01
+        A2 = rng.random((k, nx * ny)) + 0.01
+        for algo, ref in (("l2_surrogate", oc.smooth_l2_surrogate), ("log_surrogate", oc.smooth_dgkl_surrogate)):
+            fn = sg.smooth_l2_surrogate if algo == "l2_surrogate" else sg.smooth_dgkl_surrogate
+            np.testing.assert_allclose(fn(A1, L, A2, sigmaL=8, lambda_L=0.7), ref(A1, Lo, A2, 8, 0.7), rtol=2e-6)
+            d = sg.diff_surrogate(A1, A2, L=L, algo=algo)
+            np.testing.assert_allclose(d, oc.diff_surrogate(A1, A2, Lo, algo=algo), rtol=1e-4, atol=1e-4)
+            assert d >= 0
+            np.testing.assert_allclose(sg.diff_surrogate(A1, A1, L=L, algo=algo), 0.0, atol=1e-3)
+        np.testing.assert_allclose(sg.smooth_l2_surrogate(A1, L), 0.5 * np.sum(A1 * (A1 @ Lo)), rtol=2e-6)
+    x, xt, gr = rng.random((3, 5)), rng.random((3, 5)), rng.standard_normal((3, 5))
+    np.testing.assert_allclose(sg.quadratic_surrogate(x, xt, 1.5, gr, 2.0), 1.5 + np.sum((x - xt) * gr) + 2.0 * np.sum((x - xt) ** 2))
+    X, W, H = rng.random((12, 30)), rng.random((12, 3)), rng.random((3, 30))
+    np.testing.assert_allclose(ms.Frobenius_loss(X, W, H), np.sum((X - W @ H) ** 2), rtol=1e-12)
+    tm, ts = rng.random((3, 40)), rng.random((3, 25))
+    perm = [2, 0, 1]
+    am, as_ = tm[perm] + 0.01 * rng.random((3, 40)), ts[perm] * 1.3
+    ang, mse_, cfg, warn = ms.find_min_config(tm, ts, am, as_)
+    assert list(cfg) == perm and not warn and max(ang) < 1e-4 and max(mse_) < 1e-3   # algo phase i <-> true phase cfg[i]
+    assert ms.ordered_mae(tm, am, cfg)[0] < 0.01 and abs(ms.mse(tm[0], tm[0])) == 0
