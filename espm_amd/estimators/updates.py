@@ -52,6 +52,16 @@ def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe
     return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
 
 
+def multiplicative_step_wq(X, G, W, H, simplex_W=True, log_shift=log_shift, safe=True, physics_model=None):
+    """Multiplicative step in W "using the WQ technique" (espm/estimators/updates.py:232-261): by its own docstring exactly
+    multiplicative_step_w (it adds log_shift to GW and GWH instead of clamping them, a difference of that order)."""
+    if safe:  # asserts only, no clamping (updates.py:239-243)
+        assert np.sum(np.asarray(H) < -log_shift / 2) == 0
+        assert np.sum(np.asarray(W) < -log_shift / 2) == 0
+        assert np.sum(np.asarray(G) < -log_shift / 2) == 0
+    return multiplicative_step_w(X, G, W, H, simplex_W=simplex_W, log_shift=log_shift, safe=False, physics_model=physics_model)
+
+
 def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
                           dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, sigmaL=sigmaL, fixed_H=None,
                           use_bregman=False):
