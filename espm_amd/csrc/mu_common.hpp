@@ -195,44 +195,6 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
   __syncthreads();
 }
 
-// ---- 3-way bf16 splits for the matrix-core product Y = GW H (mu_h_mfma_kernel.hpp) ----------------------
-// which bf16 term of GW (A side) and of H (B side) product group q uses: 0 = hi, 1 = mid, 2 = lo
-__host__ __device__ constexpr int split_a(int q) { return q == 2 ? 1 : (q == 4 ? 2 : (q == 5 ? 1 : 0)); }
-__host__ __device__ constexpr int split_b(int q) { return q == 1 ? 1 : (q == 3 ? 2 : (q == 5 ? 1 : 0)); }
-
-__device__ __forceinline__ uint16_t bf16_rne(float v) {
-  uint32_t u = __float_as_uint(v);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf16_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
-// v = t[0] + t[1] + t[2] with bf16 terms (the residuals are exact in fp32)
-__device__ __forceinline__ void split3(float v, uint16_t (&t)[3]) {
-  t[0] = bf16_rne(v);
-  const float r1 = v - bf16_f32(t[0]);
-  t[1] = bf16_rne(r1);
-  t[2] = bf16_rne(r1 - bf16_f32(t[1]));
-}
-// the 32 * NMF k-slots of one row of GW (side = 0) or one column of H (side = 1); slot q * K + kk
-template <int K, int NMF>
-__device__ __forceinline__ void build_slots(const float (&v)[K], int side, uint16_t (&slots)[32 * NMF]) {
-  uint16_t parts[K][3];
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) split3(v[kk], parts[kk]);
-#pragma unroll
-  for (int s = 0; s < 32 * NMF; ++s) slots[s] = 0;
-#pragma unroll
-  for (int q = 0; q < 6; ++q)
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) slots[q * K + kk] = side == 0 ? parts[kk][split_a(q)] : parts[kk][split_b(q)];
-}
-
-template <int K>
-struct MfmaCount {
-  static constexpr int value = (6 * K + 31) / 32;
-};
-
-
 // ---- per-column simplex multiplier ----------------------------------------------------------
 // Root of f(nu) = sum_i max(num_i / (nu + den_i), eps) - 1 inside the reference's bracket
 // (espm/estimators/dicotomy.py:29-49).
@@ -408,8 +370,8 @@ struct HStepArgs {
   int n, k, p, nx, ny, p_pad;
   int x_tile;        // pixel-block width of the tile-major x_cm
   int n_cm;          // channel rows per pixel block of x_cm
-  const void* gw_a;  // MFMA A fragments of GW (bf16 splits)
-  const float* gw_p; // GW as channel pairs
+  const void* gw_a;  // reserved (null)
+  const float* gw_p; // reserved (null)
   int simplex_h, grid_mode, compute_loss, write_h;
   int have_prev;     // h_out still holds the H that preceded h_in: evaluate rel_H (base.py:324)
   float lambda_l, sigma_l, eps_reg, log_shift, tol, xscale, rel_tol;
@@ -462,8 +424,8 @@ struct WFinishArgs {
   float pg_gamma_w;     // > 0: projected-gradient step W - grad / gamma (updates.py:353-370)
   float* gw_s;
   double* colsum_gw;
-  void* gw_a;    // MFMA A fragments of the bf16 splits of gw_s (may be null)
-  float* gw_p;   // gw_s as channel pairs (may be null)
+  void* gw_a;    // reserved (null)
+  float* gw_p;   // reserved (null)
   double* hist_slot;
   int n, m, k, n_pad, n_cm, simplex_w, update_w;
   float log_shift, tol, rel_tol, xscale, gw_floor;

@@ -50,8 +50,7 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // the caller, not yet synchronised); one thread per pixel adds the regularisation terms, solves the simplex
 // multiplier, clamps, writes H', H'^T and the per-workgroup record.  kl_lane = this lane's part of
 // sum X log2(X / Y).
-// EARLY = false requests the pixel's inputs after the barrier (the matrix-core variant keeps its registers for
-// the accumulation phase).
+// EARLY = false requests the pixel's inputs after the barrier (for a kernel that cannot spare the registers across it).
 // RULE: the H rule (a.h_rule) - 0 log surrogate, 1 quadratic surrogate, 2 projected gradient - as a compile-time switch,
 // so that the default rule does not carry the registers of the others.
 template <int K, bool EARLY = true, int RULE = 0>

@@ -554,33 +554,8 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       dst[0] = make_float4(row[0], row[1], row[2], row[3]);
       dst[1] = make_float4(row[4], row[5], row[6], row[7]);
     }
-    if (a.gw_p) {  // operands of the matrix-core H-step: channel pairs and A fragments of the bf16 splits
-      float rv[KA];
-#pragma unroll
-      for (int kk = 0; kk < KA; ++kk) {
-        rv[kk] = row[kk];
-        a.gw_p[(size_t)(c >> 1) * 2 * KA + 2 * kk + (c & 1)] = row[kk];
-      }
-      constexpr int NMF = MfmaCount<KA>::value;
-      uint16_t slots[32 * NMF];
-      build_slots<KA, NMF>(rv, 0, slots);
-      uint4* ga = reinterpret_cast<uint4*>(a.gw_a);
-      const int blk = c >> 4, rr = c & 15;
-#pragma unroll
-      for (int m = 0; m < NMF; ++m)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int s0 = 32 * m + 8 * gq;
-          uint4 v;
-          v.x = slots[s0] | ((uint32_t)slots[s0 + 1] << 16);
-          v.y = slots[s0 + 2] | ((uint32_t)slots[s0 + 3] << 16);
-          v.z = slots[s0 + 4] | ((uint32_t)slots[s0 + 5] << 16);
-          v.w = slots[s0 + 6] | ((uint32_t)slots[s0 + 7] << 16);
-          ga[((size_t)blk * NMF + m) * 64 + gq * 16 + rr] = v;
-        }
-    }
   };
-  const int n_rows = a.gw_p ? a.n_cm : a.n_pad;
+  const int n_rows = a.n_pad;
   if (a.g) {
     for (int c = tid; c < n_rows; c += WF_THREADS) {
       float row[KA];
@@ -907,7 +882,6 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
       default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
     }
   } else {
-    if (args.gw_p) return set_error(ESPM_EUNSUPPORTED, "matrix-core H-step operands need M, n <= 4096 rows");
     hipLaunchKernelGGL(w_finish_kernel, dim3(1), dim3(WF_THREADS), 0, stream, args);
   }
   return check_hip(hipGetLastError(), "w_finish launch");

@@ -40,9 +40,10 @@
  *   - Every call only enqueues work on `stream` (a hipStream_t) and returns; no host sync.
  *   - Return value: 0 on success, negative espm_status otherwise; espm_mu_last_error() gives
  *     the message of the last failure on the calling thread.
- *   - X is kept twice in HBM: channel-major inside pixel blocks (p_pad / x_tile, n, x_tile) for the
- *     H-step and pixel-major (p, n_pad) for the W-step, as bf16 (lossless for count data) or fp32:
- *     both streaming kernels read one contiguous region per workgroup.
+ *   - X is kept twice in HBM, once in the order each half-step streams it.  Dense stores: channel-major inside
+ *     pixel blocks (p_pad / x_tile, n_cm, x_tile) for the H-step and pixel-major (p, n_pad) for the W-step, as u8
+ *     (integer counts <= 255), bf16 or fp32, whichever is lossless.  Sparse count store (ESPM_X_ELL): 16-bit lists
+ *     of the non-zero entries by pixel and by (pixel block, channel), described at the state fields below.
  *   - W, H, G, GW and every accumulator are fp32; loss sums are fp64.
  */
 #ifndef ESPM_MU_H
@@ -82,7 +83,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
-#define ESPM_NCM 16        /* channel rows of x_cm (and of gw_a / gw_p) are padded to a multiple of this */
+#define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
 
 /* per-workgroup partial record written by the H-step (doubles), stored field-major:
  * hpart[field * nblk + block] */
@@ -144,8 +145,8 @@ typedef struct espm_mu_state {
   float* w[2];              /* (m or n, k) row-major, ping-pong                          */
   float* gw_s;              /* (n_pad, KP): GW / xscale, pad rows = 1                    */
   double* colsum_gw;        /* (KP): column sums of GW over real rows                    */
-  void* gw_a;               /* (n_cm / 16, NMF, 64, 8) bf16: MFMA A fragments of the 3-way bf16 split of gw_s, NMF = ceil(6k/32) */
-  float* gw_p;              /* (n_cm / 2, k, 2): gw_s as channel pairs for v_pk_fma_f32   */
+  void* gw_a;               /* reserved (NULL): operands of the retired matrix-core H-step */
+  float* gw_p;              /* reserved (NULL) */
   float* h[2];              /* (k, p_pad), ping-pong, pad columns must be positive       */
   float* h_t;               /* (p, KP): transposed copy of the newest H                  */
   const float* mu;          /* (k) or NULL                                               */

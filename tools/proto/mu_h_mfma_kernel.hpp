@@ -18,6 +18,8 @@
 // Pairs for v_pk_fma_f32 are pixel pairs (2u, 2u+1) of one channel: adjacent elements of the X row; the two Y
 // entries come from two accumulator tiles (the accumulator reads place them in one register pair).
 #pragma once
+// (retired from the product in round 1; kept as a record - it needs the product headers of that
+//  time plus the helpers below, which moved here from mu_common.hpp when the variant was retired)
 #include <type_traits>
 
 #include "mu_h_kernel.hpp"
@@ -171,3 +173,46 @@ __global__ __launch_bounds__(NW * 64) void h_step_mfma_kernel(const HStepArgs a)
 }
 
 }  // namespace espm
+
+
+// ---- helpers that lived in mu_common.hpp while the variant was part of the library ----------------------------
+#if 0
+// ---- 3-way bf16 splits for the matrix-core product Y = GW H (mu_h_mfma_kernel.hpp) ----------------------
+// which bf16 term of GW (A side) and of H (B side) product group q uses: 0 = hi, 1 = mid, 2 = lo
+__host__ __device__ constexpr int split_a(int q) { return q == 2 ? 1 : (q == 4 ? 2 : (q == 5 ? 1 : 0)); }
+__host__ __device__ constexpr int split_b(int q) { return q == 1 ? 1 : (q == 3 ? 2 : (q == 5 ? 1 : 0)); }
+
+__device__ __forceinline__ uint16_t bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// v = t[0] + t[1] + t[2] with bf16 terms (the residuals are exact in fp32)
+__device__ __forceinline__ void split3(float v, uint16_t (&t)[3]) {
+  t[0] = bf16_rne(v);
+  const float r1 = v - bf16_f32(t[0]);
+  t[1] = bf16_rne(r1);
+  t[2] = bf16_rne(r1 - bf16_f32(t[1]));
+}
+// the 32 * NMF k-slots of one row of GW (side = 0) or one column of H (side = 1); slot q * K + kk
+template <int K, int NMF>
+__device__ __forceinline__ void build_slots(const float (&v)[K], int side, uint16_t (&slots)[32 * NMF]) {
+  uint16_t parts[K][3];
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) split3(v[kk], parts[kk]);
+#pragma unroll
+  for (int s = 0; s < 32 * NMF; ++s) slots[s] = 0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) slots[q * K + kk] = side == 0 ? parts[kk][split_a(q)] : parts[kk][split_b(q)];
+}
+
+template <int K>
+struct MfmaCount {
+  static constexpr int value = (6 * K + 31) / 32;
+};
+
+
+#endif
