@@ -1,0 +1,92 @@
+"""Randomised parity sweep: every solver / option combination the GPU path accepts, on small random problems, against the
+fp64 oracle (which is pinned to the reference by the golden fixtures).  Seeded - the same 36 cases every run
+(ESPM_FUZZ_CASES=240 for a longer sweep: 238 pass, 2 are draws the reference itself refuses)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import mu_oracle as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(20, 260))
+    nx, ny = int(rng.integers(3, 18)), int(rng.integers(3, 18))
+    k = int(rng.integers(1, 9))
+    p = nx * ny
+    algo = ["log_surrogate", "log_surrogate", "bmd", "l2_surrogate", "projected_gradient"][seed % 5]
+    use_G = algo != "bmd" and rng.random() < 0.45
+    m = int(rng.integers(k, k + 14)) if use_G else None
+    counts = rng.random() < 0.6            # integer counts (sparse / u8 store) or arbitrary non-negative data (fp32 store)
+    H = rng.random((k, p)) ** 2 + 0.03
+    H /= H.sum(axis=0, keepdims=True)
+    if use_G:
+        G = rng.random((n, m)) * (rng.random((n, m)) < 0.5) + 0.01
+        W = rng.random((m, k)) * 30.0 / n
+        D = G @ W
+    else:
+        G = None
+        W = rng.random((n, k)) ** 3 * 100.0 / n + 1e-3
+        D = W
+    Y = D @ H
+    X = rng.poisson(Y).astype(np.float64) if counts else Y * (0.5 + rng.random(Y.shape))
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+    H0 = rng.random((k, p)) + 0.05
+    H0 /= H0.sum(axis=0, keepdims=True)
+    kw = dict(simplex_H=bool(rng.random() < 0.6), simplex_W=False, lambda_L=float(rng.choice([0.0, 0.3, 1.0, 2.5])),
+              mu=0)
+    if algo in ("log_surrogate", "bmd", "projected_gradient") and rng.random() < 0.4:
+        kw["mu"] = rng.random(k) * 0.2
+    if algo == "log_surrogate" and not kw["simplex_H"] and rng.random() < 0.5:
+        kw["simplex_W"] = True
+    if algo == "l2_surrogate" and not kw["simplex_H"] and rng.random() < 0.3:
+        kw["simplex_W"] = True
+    extra = {}
+    if algo != "projected_gradient" and kw["lambda_L"] > 0 and rng.random() < 0.35 and not (k == 1 and kw["simplex_H"]):
+        # (k = 1 on the simplex pins H to 1: the surrogate gap is exactly 0 and the sign the linesearch tests is rounding noise)
+        extra["linesearch"] = True
+    if algo == "projected_gradient":
+        Gd = np.eye(n) if G is None else G
+        L = oc.laplacian_matrix(nx, ny)
+        gh = np.abs(oc.gradH(X, Gd, W0, H0, mu=kw["mu"], lambda_L=kw["lambda_L"], L=L)).max()
+        gw = np.abs(oc.gradW(X, Gd, W0, H0)).max()
+        extra["gamma"] = [float(gh / 0.05), float(gw / (0.2 * W0.mean()))]
+    if rng.random() < 0.25 and kw["simplex_H"] is False and k >= 2:
+        fH = -np.ones((k, p))
+        fH[0, ::4] = 0.2
+        extra["fixed_H"] = fH
+    return dict(X=X, G=G, W0=W0, H0=H0, k=k, shape=(nx, ny), algo=algo, kw=kw, extra=extra, counts=counts)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_CASES", "36"))))
+def test_random_configuration_matches_oracle(seed):
+    from espm_amd.estimators import SmoothNMF
+    c = _case(seed)
+    iters = 6
+    try:
+        ref = oc.fit(c["X"], c["k"], G=c["G"], W=c["W0"].copy(), H=c["H0"].copy(), shape_2d=c["shape"], algo=c["algo"], tol=0,
+                     no_stop_criterion=True, max_iter=iters, exact_root=(c["algo"] == "log_surrogate"), **c["kw"], **c["extra"])
+    except AssertionError:
+        # e.g. the projected gradient with k = 1 on the simplex: the reference's bracket has f = 0 at its end (dicotomy.py:141-144)
+        pytest.skip("the reference's own bisection refuses this draw")
+    if not np.isfinite(ref["losses"]).all():
+        pytest.skip("the oracle itself diverges on this draw")
+    est = SmoothNMF(n_components=c["k"], G=c["G"], shape_2d=c["shape"], algo=c["algo"], tol=0, no_stop_criterion=True, max_iter=iters,
+                    verbose=0, **c["kw"], **c["extra"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        GW = est.fit_transform(c["X"], W=c["W0"].copy(), H=c["H0"].copy())
+    tag = f"seed {seed}: {c['algo']} k={c['k']} G={'yes' if c['G'] is not None else 'no'} {c['kw']} {sorted(c['extra'])} store={est._engine.x_store}"
+    # the reference's bisections stop at 1e-5 (global rule); the oracle uses the exact root only for the default solver
+    loose = c["algo"] != "log_surrogate" and c["kw"]["simplex_H"]
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=1e-4 if loose else 2e-5, err_msg=tag)
+    det = np.array(est.detailed_losses_, dtype=float)
+    np.testing.assert_allclose(det[:, 3], ref["detailed_losses"][:, 3], rtol=1e-9, err_msg=tag + " (gamma)")
+    np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-3 if loose else 5e-4, atol=2e-4 if loose else 5e-5, err_msg=tag)
+    np.testing.assert_allclose(GW, ref["GW"], rtol=2e-3 if loose else 5e-4, atol=(2e-3 if loose else 5e-4) * np.abs(ref["GW"]).mean(),
+                               err_msg=tag)
