@@ -117,3 +117,33 @@ def test_w_step_is_linear_in_the_pixel_blocks(big):
     np.testing.assert_allclose(slabs.cpu().numpy(), half.cpu().numpy(), rtol=1e-12)
 
 
+
+
+@pytest.mark.parametrize("algo", ["bmd", "l2_surrogate", "projected_gradient"])
+def test_other_solvers_on_full_tiles(algo):
+    """The other H rules on an image large enough for 512-pixel tiles, paired list groups and unit rows (512 x 512 pixels, 256
+    channels), against the oracle."""
+    from espm_amd import synth
+    from espm_amd.estimators import SmoothNMF
+    n, nx, ny, k = 256, 512, 512, 5
+    prob = synth.make_problem(n, nx, ny, k, N=60.0, seed=4)
+    X = synth.sample_numpy(prob, seed=4)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=4, scale=60.0 / n)
+    kw = dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0)
+    extra = {}
+    if algo == "projected_gradient":
+        L = oc.laplacian_matrix(nx, ny)
+        extra["gamma"] = [float(np.abs(oc.gradH(X, np.eye(n), W0, H0, lambda_L=1.0, L=L)).max() / 0.05),
+                          float(np.abs(oc.gradW(X, np.eye(n), W0, H0)).max() / (0.2 * W0.mean()))]
+    ref = oc.fit(X, k, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), algo=algo, tol=0, no_stop_criterion=True, max_iter=3, **kw, **extra)
+    est = SmoothNMF(n_components=k, shape_2d=(nx, ny), algo=algo, tol=0, no_stop_criterion=True, max_iter=3, verbose=0, **kw, **extra)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit_transform(X, W=W0.copy(), H=H0.copy())
+    eng = est._engine
+    assert eng.x_store == "ell" and eng.st.tile_px == 512 and eng.ell["unit_rows_h"] > 0
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=1e-4)
+    np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-3, atol=2e-3 * np.abs(ref["W"]).mean())
