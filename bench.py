@@ -78,13 +78,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (rehearsal of the N > 1 path on a box with fewer GPUs than ranks: ESPM_BENCH_BACKEND=gloo puts the ranks on the
+    #  GPUs that exist and exchanges the records through gloo; the driver's runs use RCCL, one rank per GPU)
+    backend = os.environ.get("ESPM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from espm_amd import _lib, synth
