@@ -486,6 +486,11 @@ def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=LOG_SHIF
     return new_H
 
 
+def quadratic_surrogate(x, xt, f_xt, gradf_xt, sigma):
+    """espm/estimators/surrogates.py:153-170: f(xt) + <x - xt, grad f(xt)> + sigma ||x - xt||^2."""
+    return f_xt + np.sum((x - xt) * gradf_xt) + sigma * np.sum((x - xt) ** 2)
+
+
 # ---- linesearch on the Laplacian surrogate (SURVEY 8f rank 4) -------------------------------------------
 def smooth_dgkl_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
     """espm/estimators/surrogates.py:65-114: lambda/2 (2 tr(Ht L H^T) - tr(Ht L Ht^T) + sigma sum_k max_j H_kj sum_j dgkl(Ht_kj, H_kj))."""
@@ -566,8 +571,8 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     if algo not in ("log_surrogate", "bmd", "l2_surrogate", "projected_gradient"):
         raise NotImplementedError(algo)
     if algo == "projected_gradient":  # smooth_nmf.py:297-306: a list [gamma_H, gamma_W] (the Lipschitz default is not restated)
-        if gamma is None or linesearch:
-            raise NotImplementedError("projected_gradient: pass gamma=[gamma_H, gamma_W]; its linesearch is not restated")
+        if gamma is None:
+            raise NotImplementedError("projected_gradient: pass gamma=[gamma_H, gamma_W]")
         gamma_ = list(gamma)
     breg = algo == "bmd"  # smooth_nmf.py:358-372, :416-426: both steps with use_bregman=True
     c_kl = const_KL(X_, log_shift)
@@ -577,6 +582,10 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         return smooth_nmf_loss(X_ if Xc is None else Xc, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl,
                                gamma_[0] if isinstance(gamma_, list) else gamma_)   # smooth_nmf.py:470-473
 
+    def loss_sum(Wc, Hc):
+        return smooth_nmf_loss(X_, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, False, c_kl)[0]
+
+    gammas = []
     track = true_D is not None and true_H is not None and true_D.shape[1] == n_components and true_H.shape[0] == n_components
     true_DH = true_D @ true_H if track else None
     angles, mses, true_losses = [], [], []
@@ -602,15 +611,24 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
                                        epsilon_reg=epsilon_reg, safe=safe, dicotomy_tol=dicotomy_tol,
                                        lambda_L=lambda_L, L=L_, l2=False, fixed_H=fixed_H, sigmaL=gamma_,
                                        exact_root=exact_root, use_bregman=breg)
-        if linesearch:
+        if linesearch and algo == "projected_gradient":  # smooth_nmf.py:382-401 (losses not averaged)
+            grad = gradH(X_, G_, W_, old_H, mu=mu, lambda_L=lambda_L, L=L_, epsilon_reg=epsilon_reg, log_shift=log_shift, safe=safe)
+            f_xt, f_x = loss_sum(W_, old_H), loss_sum(W_, H_)
+            gamma_[0] = gamma_[0] / 1.05 if quadratic_surrogate(H_, old_H, f_xt, grad, gamma_[0]) - f_x > 0 else gamma_[0] * 1.5
+        elif linesearch:
             gamma_ = linesearch_gamma(gamma_, old_H, H_, L_, algo)
-        if algo == "projected_gradient":  # smooth_nmf.py:427-437 (fixed_W is not passed there)
+        if algo == "projected_gradient":  # smooth_nmf.py:427-447 (fixed_W is not passed there)
             W_ = proj_grad_step_w(X_, G_, W_, H_, gamma_[1], simplex_W=simplex_W, log_shift=log_shift, safe=safe)
+            if linesearch:
+                grad = gradW(X_, G_, old_W, H_, log_shift=log_shift, safe=safe)
+                f_xt, f_x = loss_sum(old_W, H_), loss_sum(W_, H_)
+                gamma_[1] = gamma_[1] / 1.05 if quadratic_surrogate(W_, old_W, f_xt, grad, gamma_[1]) - f_x > 0 else gamma_[1] * 1.5
         else:
             W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
                                        simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
         eval_after, det = loss(W_, H_)
         n_iter += 1
+        gammas.append(list(gamma_) if isinstance(gamma_, list) else gamma_)
         if track:  # base.py:335-347
             Wt, Ht = (W_, H_) if (simplex_H or simplex_W) else rescaled_DH(W_, H_)
             a_, m_ = truth_metrics(true_D, true_H, G_ @ Wt, Ht)
@@ -650,6 +668,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
     out = dict(W=W_, H=H_, G=G_, GW=G_ @ W_, losses=np.array(losses), detailed_losses=np.array(detailed, dtype=float),
                rel=np.array(rel), n_iter=n_iter, exit=reason, reconstruction_err=recon, snapshots=snaps,
                eval_init=eval_init, const_KL=c_kl, norm_factor=norm)
+    out["gammas"] = np.array(gammas, dtype=float)
     if track:
         out.update(angles=np.array(angles, dtype=float), mse=np.array(mses, dtype=float), true_losses=np.array(true_losses, dtype=float))
     if time_iterations:

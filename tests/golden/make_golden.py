@@ -533,7 +533,50 @@ def f12():
     save("f12_projected_gradient", **out)
 
 
+# ------------------------------------------------------------------ F13: projected gradient WITH its linesearch
+PGL = {
+    "l3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=40, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0, gamma=[400.0, 4000.0])),
+    "l5": dict(n=60, nx=10, ny=12, k=4, m=9, iters=40, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.6, mu=0.05, gamma=[2000.0, 20000.0])),
+    "l0": dict(n=32, nx=6, ny=6, k=3, m=None, iters=30, kw=dict(simplex_H=False, simplex_W=False, lambda_L=0.5, mu=0, gamma=[300.0, 1500.0])),
+    # small gammas: at iteration 11 an entry of GWH reaches the clamp, the loss jumps to ~5e9 and gamma goes UP (x 1.5)
+    "lx": dict(n=40, nx=7, ny=6, k=3, m=None, iters=12, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.4, mu=0, gamma=[25.0, 120.0])),
+}
+
+
+def f13():
+    rng = np.random.default_rng(1313)
+    out = {}
+    for name, c in PGL.items():
+        X, G, W, H = synth(rng, c["n"], c["nx"], c["ny"], c["k"], c["m"])
+        p = c["nx"] * c["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c["nx"], c["ny"]])
+        gam = []
+
+        class Rec(SmoothNMF):
+            def _iteration(self, W, H):
+                W, H = super()._iteration(W, H)
+                gam.append(list(self.gamma_))
+                return W, H
+
+        est = Rec(n_components=c["k"], G=G, shape_2d=(c["nx"], c["ny"]), verbose=0, algo="projected_gradient", linesearch=True, tol=0,
+                  no_stop_criterion=True, max_iter=c["iters"], **c["kw"])
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_gammas"] = np.array(gam, dtype=float)
+    out["names"] = np.array(list(PGL))
+    out["configs"] = np.array(json.dumps(PGL))
+    save("f13_projected_gradient_linesearch", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -287,3 +287,18 @@ def test_f12_projected_gradient(golden):
         np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-6, atol=1e-18, err_msg=name)
         np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=2e-5, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
+
+
+def test_f13_projected_gradient_linesearch(golden):
+    """The projected gradient's own linesearch (smooth_nmf.py:382-401, :438-447): gamma_H and gamma_W follow the quadratic bound."""
+    g = golden("f13_projected_gradient_linesearch")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        r = oc.fit(g[f"{name}_X"], c["k"], G=g.get(f"{name}_G"), W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy(), shape_2d=shape,
+                   algo="projected_gradient", linesearch=True, tol=0, no_stop_criterion=True, max_iter=c["iters"], **c["kw"])
+        np.testing.assert_allclose(r["gammas"], g[f"{name}_gammas"], rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-6, err_msg=name)
+        if name == "lx":
+            assert (np.diff(g[f"{name}_gammas"][:, 0]) > 0).any(), "the fixture must contain an increase of gamma"
