@@ -185,6 +185,7 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.scratch = st->w_scratch;
   a.breg_sr = st->breg_sr_ch;
   a.pg_gamma_w = st->pg_gamma_w;
+  a.pg_q = (st->pg_q && st->pg_gamma_w > 0.f && slot >= 0) ? st->pg_q + 2 * (size_t)slot + 1 : nullptr;
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
   a.gw_a = nullptr;  // reserved (matrix-core H-step, retired)
@@ -231,6 +232,7 @@ static HFinalizeArgs finalize_args(const espm_mu_state* st, int src, int slot, b
   a.compute_loss = st->compute_loss;
   a.have_prev = st->it > 0;
   a.xscale = st->xscale;
+  a.pg_q = (st->pg_q && st->h_rule == 2 && write_hstat) ? st->pg_q + 2 * (size_t)slot : nullptr;   // (not for loss-only evaluations)
   return a;
 }
 
@@ -298,7 +300,8 @@ int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with
   const HFinalizeArgs fin = finalize_args(st, src, slot, true);
   if (w_update_is_local(st)) {
     return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
-                                  st->nblk_w, st->a, st->hpart, nblk_h(st), 0, nullptr, with_finalize ? &fin : nullptr, s);
+                                  st->nblk_w, st->a, with_finalize ? st->hpart : nullptr, nblk_h(st), with_finalize ? nullptr : st->hstat[1 - src],
+                                  0, nullptr, with_finalize ? &fin : nullptr, s);   // (no riding finalize: hstat[1-src] is already reduced)
   }
   if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, with_finalize ? &fin : nullptr, s)) return rc;
   return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
@@ -311,7 +314,7 @@ int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, i
   ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
   if (w_update_is_local(st)) {
     return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), records, espm_mu_shard_record_bytes(st), world, st->a,
-                                  nullptr, 0, (size_t)st->k * st->n_pad * sizeof(float), st->hstat[1 - src], nullptr,
+                                  nullptr, 0, nullptr, (size_t)st->k * st->n_pad * sizeof(float), st->hstat[1 - src], nullptr,
                                   static_cast<hipStream_t>(stream));
   }
   if (int rc = espm_mu_shard_combine(st, records, world, 1 - src, stream)) return rc;

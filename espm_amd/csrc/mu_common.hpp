@@ -395,6 +395,7 @@ struct HFinalizeArgs {
   double* hist_slot;
   int nblk, k, compute_loss, have_prev;
   float xscale;
+  double* pg_q;  // projected-gradient rule: where the sum of the records' PGQ field goes, else null
 };
 struct WAccumArgs {
   const void* x_pm;
@@ -422,6 +423,7 @@ struct WFinishArgs {
   float* scratch;
   const float* breg_sr; // Bregman variant: per-channel sums of the stored X (n), else null
   float pg_gamma_w;     // > 0: projected-gradient step W - grad / gamma (updates.py:353-370)
+  double* pg_q;         // its linesearch term sum <W' - W, grad> + gamma ||W' - W||^2, else null
   float* gw_s;
   double* colsum_gw;
   void* gw_a;    // reserved (null)
@@ -460,6 +462,12 @@ __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* 
     }
   }
   block_reduce<NV, 4 + KP>(v, scratch);
+  if (a.pg_q) {  // (uniform) the quadratic bound of the projected gradient's linesearch
+    double q1[1] = {0.0};
+    for (int b = threadIdx.x; b < a.nblk; b += 256) q1[0] += a.hpart[(size_t)ESPM_HP_PGQ * nb + b];
+    block_reduce<1, 1>(q1, scratch);
+    if (threadIdx.x == 0) *a.pg_q = q1[0];
+  }
   if (threadIdx.x == 0) {
     double sumy = 0.0;
     for (int kk = 0; kk < a.k; ++kk) sumy += a.colsum_gw[kk] * a.hstat_in[ESPM_HS_ROWSUM + kk];
@@ -568,7 +576,7 @@ int launch_gram(const float* m, int rows, int k, double* part, int part_cap, flo
 int launch_w_finish_l2(const float* a, int n, int n_pad, int m, int k, const float* g, const float* gtg, const float* hh, const float* w_old,
                        float* w_new, const float* fixed_w, float log_shift, hipStream_t stream);
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
-                           const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,
+                           const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                   int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream);

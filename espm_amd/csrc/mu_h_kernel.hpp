@@ -62,6 +62,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
   constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
   red[ESPM_HP_KL] = (double)kl_lane;
+  double pg_q = 0.0;   // rule 2: <H' - H, grad> + gamma ||H' - H||^2 of this thread's pixels (the linesearch's quadratic bound)
   const bool stencil = a.lambda_l != 0.f && a.grid_mode;
   HEpiIn<K> in;
   bool loaded = false;
@@ -187,6 +188,10 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
           const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
           if (f >= 0.f) hn = f;
         }
+        {
+          const double dh = (double)hn - (double)hin[kk];
+          pg_q += dh * (double)(dv[kk] - nv[kk]) + (double)a.sigma_l * dh * dh;
+        }
         if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;
         a.h_out[(size_t)kk * a.p_pad + q] = hn;
         ht[kk] = hn;
@@ -261,6 +266,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 
   __syncthreads();  // smem is reused as reduction scratch
   block_reduce<NRED, R_RELH, true>(red, reinterpret_cast<double*>(smem));   // rel_H and the row maxima are fp32 values
+  if constexpr (RULE == 2) {
+    double one[1] = {pg_q};
+    block_reduce<1, 1>(one, reinterpret_cast<double*>(smem));
+    if (threadIdx.x == 0) a.hpart[(size_t)ESPM_HP_PGQ * gridDim.x + blockIdx.x] = one[0];
+  }
   if (threadIdx.x == 0) {
     // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
     double* out = a.hpart + blockIdx.x;

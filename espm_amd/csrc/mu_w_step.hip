@@ -88,6 +88,7 @@ struct WUpdateArgs {
   int nsrc, n, n_pad, k, nbk;
   float* a_out;
   const double* hpart;          // slab mode: H-step records (field-major), nblk_h of them
+  const double* hstat_rs;       // slab mode without a riding finalize: the statistics of the new H are already reduced
   int nblk_h;
   size_t rec_hstat_off;         // records mode (hpart == null): byte offset of the 16 statistics inside a record
   double* hstat_out;            // records mode: global row sums / maxima of the new H
@@ -96,6 +97,7 @@ struct WUpdateArgs {
   const float* fixed_w;
   const float* breg_sr;         // Bregman variant (updates.py:40-48): per-channel sums of the stored X, else null
   float pg_gamma_w;             // > 0: projected-gradient step (updates.py:353-370)
+  int pg_track;                 // its linesearch term goes to parts[2 nwg + workgroup]
   float* gw_s;
   double* parts;                // [2][k * nbk]: partial column sum of G W' (component of the workgroup), partial sum of W'
   float log_shift, gw_floor, xscale;
@@ -139,6 +141,9 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     if (threadIdx.x == 0) s_rs = v[0];
     __syncthreads();
     rs = s_rs;
+  } else if (a.hstat_rs) {
+    rs = a.hstat_rs[ESPM_HS_ROWSUM + kk];
+    __syncthreads();
   } else {
     for (int r = 0; r < a.nsrc; ++r)
       rs += reinterpret_cast<const double*>(a.src + (size_t)r * a.src_stride + a.rec_hstat_off)[ESPM_HS_ROWSUM + kk];
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     __syncthreads();
   }
   if (threadIdx.x < 64) {  // wave 0; its first 32 lanes own the 32 entries
-    double cs = 0.0, sw = 0.0;
+    double cs = 0.0, sw = 0.0, qw = 0.0;
     if (grp == 0 && c < a.n_pad) {
       float t = 0.f;
 #pragma unroll
@@ -164,6 +169,8 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
         float v;
         if (a.pg_gamma_w > 0.f) {  // W - grad / gamma with grad = rowsum(H) - (X / GWH) H^T (G = I), updates.py:353-362
           v = fmaxf(wo - ((float)rs - t) / a.pg_gamma_w, a.log_shift);
+          const double dw = (double)v - (double)wo;   // (fixed_W is not part of a projected-gradient fit, smooth_nmf.py:430-437)
+          qw = dw * (double)((float)rs - t) + (double)a.pg_gamma_w * dw * dw;
         } else if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
           const float sr = a.xscale * a.breg_sr[c];
           v = fmaxf((sr * wo) / (((float)rs - t) * wo + sr), a.log_shift);
@@ -185,9 +192,11 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     }
     cs = wave_sum(cs);
     sw = wave_sum(sw);
+    if (a.pg_track) qw = wave_sum(qw);
     if (threadIdx.x == 0) {
       a.parts[blockIdx.x] = cs;
       a.parts[nwg + blockIdx.x] = sw;
+      if (a.pg_track) a.parts[2 * nwg + blockIdx.x] = qw;
     }
   }
 }
@@ -199,6 +208,7 @@ struct WTailArgs {
   const float* w_new;
   double* colsum_gw;
   double* hist_slot;
+  double* pg_q;   // projected gradient: sum of the third row of partials goes here, else null
   int n, k, nbk;
   float rel_tol;
 };
@@ -237,6 +247,12 @@ __global__ __launch_bounds__(WT_THREADS) void w_update_tail_kernel(const WTailAr
     s_mean = v[KP] / (double)mk;
   }
   __syncthreads();
+  if (a.pg_q) {
+    double q1[1] = {0.0};
+    for (int j = tid; j < nwg; j += WT_THREADS) q1[0] += a.parts[2 * nwg + j];
+    block_reduce<1, 1>(q1, scratch);
+    if (tid == 0) *a.pg_q = q1[0];
+  }
   if (!a.hist_slot) return;
   const float shift = (float)((double)a.rel_tol * s_mean);
   float rel = 0.f;   // fp32 like the register-resident W finish compares doubles of fp32 values: the quotient of two
@@ -386,14 +402,14 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     float rs[KA];
 #pragma unroll
     for (int kk = 0; kk < KA; ++kk) rs[kk] = kk < k ? (float)a.hstat[ESPM_HS_ROWSUM + kk] : 0.f;
-    float wo[WF_ROWS][KA], nv[WF_ROWS][KA], dv[WF_ROWS][KA];
+    float wo[WF_ROWS][KA], nv[WF_ROWS][KA], dv[WF_ROWS][KA], pgrad[WF_ROWS][KA];
     bool in_set[WF_ROWS];
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
       const int mm = tid + r * WF_THREADS;
       in_set[r] = false;
 #pragma unroll
-      for (int kk = 0; kk < KA; ++kk) { wo[r][kk] = 0.f; nv[r][kk] = 0.f; dv[r][kk] = 1.f; }
+      for (int kk = 0; kk < KA; ++kk) { wo[r][kk] = 0.f; nv[r][kk] = 0.f; dv[r][kk] = 1.f; pgrad[r][kk] = 0.f; }
       if (mm < M) {
         in_set[r] = !a.simplex_rows || a.simplex_rows[mm];
         const float cg = a.g ? a.colsum_g[mm] : 1.f;
@@ -405,7 +421,8 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
             nv[r][kk] = wo[r][kk] * gta;        // updates.py:59
             dv[r][kk] = cg * rs[kk];            // updates.py:60
             if (a.pg_gamma_w > 0.f) {           // projected gradient: W - (colsum(G) rowsum(H) - G^T A) / gamma, updates.py:353-362
-              nv[r][kk] = wo[r][kk] - (dv[r][kk] - gta) / a.pg_gamma_w;
+              pgrad[r][kk] = dv[r][kk] - gta;
+              nv[r][kk] = wo[r][kk] - pgrad[r][kk] / a.pg_gamma_w;
               dv[r][kk] = 1.f;
             } else if (a.breg_sr) {             // Bregman variant (G = identity), updates.py:41-48
               const float sr = a.xscale * a.breg_sr[mm];
@@ -512,6 +529,22 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     }
     const double rel_w = block_max1(rel_l, scratch);
     if (tid == 0 && a.hist_slot) a.hist_slot[ESPM_HI_REL_W] = rel_w;
+    if (a.pg_q) {  // (uniform) the projected gradient's linesearch term sum <W' - W, grad> + gamma ||W' - W||^2
+      double q_l = 0.0;
+#pragma unroll
+      for (int r = 0; r < WF_ROWS; ++r) {
+        if (tid + r * WF_THREADS < M) {
+#pragma unroll
+          for (int kk = 0; kk < KA; ++kk)
+            if (kk < k) {
+              const double dw = (double)wn[r][kk] - (double)wo[r][kk];
+              q_l += dw * (double)pgrad[r][kk] + (double)a.pg_gamma_w * dw * dw;
+            }
+        }
+      }
+      const double q_w = block_sum1(q_l, scratch);
+      if (tid == 0) *a.pg_q = q_w;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
@@ -811,7 +844,7 @@ int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HF
 }
 
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
-                           const double* hpart, int nblk_h, size_t rec_hstat_off, double* hstat_out,
+                           const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream) {
   WUpdateArgs a;
   a.src = static_cast<const unsigned char*>(src);
@@ -823,6 +856,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.nbk = (f.n_pad + 31) / 32;
   a.a_out = a_out;
   a.hpart = hpart;
+  a.hstat_rs = hstat_rs;
   a.nblk_h = nblk_h;
   a.rec_hstat_off = rec_hstat_off;
   a.hstat_out = hstat_out;
@@ -831,6 +865,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.fixed_w = f.fixed_w;
   a.breg_sr = f.breg_sr;
   a.pg_gamma_w = f.pg_gamma_w;
+  a.pg_track = f.pg_q != nullptr;
   a.gw_s = f.gw_s;
   a.parts = reinterpret_cast<double*>(f.scratch);
   a.log_shift = f.log_shift;
@@ -845,6 +880,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   t.w_new = f.w_new;
   t.colsum_gw = f.colsum_gw;
   t.hist_slot = f.hist_slot;
+  t.pg_q = f.pg_q;
   t.n = f.n;
   t.k = f.k;
   t.nbk = a.nbk;

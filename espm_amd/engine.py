@@ -242,7 +242,7 @@ class MUEngine:
         self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
         self.a = torch.zeros((k, st.n_pad), **f32)
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
-        self.hist_len = int(max_iter) + 2
+        self.hist_len = int(max_iter) + 3   # states 0..max_iter, a spare, and a scratch slot (the last) for loss-only evaluations
         self.hist = torch.zeros((self.hist_len, _lib.HI_STRIDE), **f64)
         self.fixed_h = self._pad_h(fixed_H) if fixed_H is not None else None
         self.fixed_w = (torch.from_numpy(np.ascontiguousarray(np.asarray(fixed_W, dtype=np.float32))).to(dev)
@@ -286,6 +286,8 @@ class MUEngine:
         st.hstat[0], st.hstat[1] = self.hstat[0].data_ptr(), self.hstat[1].data_ptr()
         st.a_slab, st.a, st.w_scratch = self.a_slab.data_ptr(), self.a.data_ptr(), self.w_scratch.data_ptr()
         st.hist, st.hist_len = self.hist.data_ptr(), self.hist_len
+        self.pg_q = torch.zeros((self.hist_len, 2), **f64) if float(pg_gamma_w) > 0 or int(h_rule) == 2 else None
+        st.pg_q = self.pg_q.data_ptr() if self.pg_q is not None else None
         st.cur, st.it = 0, 0
 
         # ---- sharding -----------------------------------------------------------------------------------
@@ -461,6 +463,40 @@ class MUEngine:
         gamma = float(gamma) / 1.05 if d > 0 else float(gamma) * 1.5
         st.sigma_l = gamma
         return gamma
+
+    # ---- linesearch of the projected gradient (espm/estimators/smooth_nmf.py:382-401, :438-447) -------------------------
+    def _loss_sum_of_slot(self, slot):
+        row = self.hist[slot].cpu().numpy()
+        return float(row[_lib.HI_KLX] + row[_lib.HI_SUMY] - self.xscale * self.sum_x + row[_lib.HI_REG]
+                     + 0.5 * self.lambda_L * row[_lib.HI_LAP])
+
+    def pg_linesearch_h(self, gamma_h):
+        """After the H-step from state t (``eval_current(True)``), before the W-step: d = f(W, Ht) + <H - Ht, grad> +
+        gamma ||H - Ht||^2 - f(W, H) with the losses not averaged; gamma_H / 1.05 when d > 0, else gamma_H * 1.5 (in effect
+        from the next H-step).  Costs one loss-only pass over X (the loss of (W_t, H_{t+1})) and two host synchronisations."""
+        if self.world > 1 or self.pg_q is None:
+            raise NotImplementedError("the projected gradient's linesearch needs one GPU and an engine built with h_rule=2")
+        st = self.st
+        t = st.it
+        f_xt = float(self.history(upto=t, average=False)["loss"][t])   # (also reduces the H-step's records: pg_q[t][0])
+        scratch = self.hist_len - 1
+        check(lib.espm_mu_loss_only(C.byref(st), 1 - st.cur, scratch, _stream()))   # state (W_t, H_{t+1})
+        self._pg_f_mid = self._loss_sum_of_slot(scratch)
+        d = f_xt + float(self.pg_q[t, 0]) - self._pg_f_mid
+        gamma_h = float(gamma_h) / 1.05 if d > 0 else float(gamma_h) * 1.5
+        st.sigma_l = gamma_h
+        return gamma_h
+
+    def pg_linesearch_w(self, gamma_w):
+        """After the state the W-step produced has been evaluated: the same test with f(Wt, H), the W-step's quadratic term
+        and f(W, H); the new gamma_W is in effect from the next W-step."""
+        st = self.st
+        t = st.it
+        f_x = float(self.history(upto=t, average=False)["loss"][t])
+        d = self._pg_f_mid + float(self.pg_q[t, 1]) - f_x
+        gamma_w = float(gamma_w) / 1.05 if d > 0 else float(gamma_w) * 1.5
+        st.pg_gamma_w = gamma_w
+        return gamma_w
 
     def iterate(self, n_iter, final_loss=True):
         """``n_iter`` iterations without host synchronisation (no stop criterion)."""

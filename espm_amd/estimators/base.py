@@ -258,10 +258,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         # ground-truth tracking (base.py:301-311): every iteration compares G W with true_D, H with true_H and
         # evaluates the loss against the noiseless true_D @ true_H (a second, loss-only engine holds that X)
         track = self._begin_truth_tracking()
-        adapt = bool(getattr(self, "linesearch", False))
-        if (track or adapt) and getattr(eng, "world", 1) > 1:
+        pg_ls = bool(getattr(self, "linesearch", False)) and getattr(self, "algo", None) == "projected_gradient"
+        adapt = bool(getattr(self, "linesearch", False)) and not pg_ls
+        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt or pg_ls
+        if (track or adapt or pg_ls) and getattr(eng, "world", 1) > 1:
             raise NotImplementedError("linesearch / ground-truth tracking are not built for a sharded image")
-        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt
         eval_before = np.inf
         eval_init = None
         stop = False
@@ -276,6 +277,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     if self.verbose > 0:
                         chunk = min(chunk, self.eval_print - self.n_iter_ % self.eval_print)
                     chunk = max(chunk, 1)
+                if pg_ls:  # smooth_nmf.py:382-401: gamma_H from the quadratic bound, before the W-step
+                    self.gamma_[0] = eng.pg_linesearch_h(self.gamma_[0])
                 eng.finish_iteration()
                 if adapt:  # smooth_nmf.py:376-381: gamma_ follows the Laplacian surrogate; in effect from the next H-step
                     self.gamma_ = eng.linesearch_step(self._gamma_value())
@@ -286,6 +289,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     last = self.n_iter_ + 1 >= self.max_iter
                     refresh_G = self.physics_model_ is not None and (self.n_iter_ + 1) % 3 == 0
                     eng.eval_current(advance_h=not (last or refresh_G))
+                if pg_ls:  # smooth_nmf.py:438-447: gamma_W, once the new state has been evaluated
+                    self.gamma_[1] = eng.pg_linesearch_w(self.gamma_[1])
                 first = self.n_iter_ + 1
                 self.n_iter_ += chunk
                 h = eng.history(upto=self.n_iter_)

@@ -156,11 +156,10 @@ class SmoothNMF(NMFEstimator):
     def fit_transform(self, X, y=None, W=None, H=None):
         """Fit the model to X (n, p) and return G W (espm/estimators/smooth_nmf.py:239-282)."""
         if self.algo == "projected_gradient":
-            # smooth_nmf.py:297-306, :340-353, :427-437.  Its linesearch (two more loss evaluations and a gradient per half
-            # step) is not built; the default gamma (Lipschitz bounds at log_shift) is formed in _pg_gamma
-            if self.linesearch or not (self.gamma is None or (isinstance(self.gamma, list) and len(self.gamma) == 2)):
-                raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] (or None) and linesearch=False "
-                                          "on the GPU path")
+            # smooth_nmf.py:297-306, :340-353, :427-447; the default gamma (Lipschitz bounds at log_shift) is formed in _pg_gamma,
+            # the linesearch runs in the fit loop (base.py here: pg_linesearch_h / _w of the engine)
+            if not (self.gamma is None or (isinstance(self.gamma, list) and len(self.gamma) == 2)):
+                raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] (or None) on the GPU path")
             if self.simplex_W:
                 raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
         if self.l2:  # only reachable with algo="l2_surrogate" (smooth_nmf.py:233-237)

@@ -30,7 +30,8 @@
  *   espm_mu_l2_step_h / _w <- espm/estimators/updates.py:109-118, :31-36 (Frobenius branch, l2=True, direct calls)
  *   state fields breg_sr_* <- updates.py:40-48, :120-125 (Bregman variant, algo = "bmd")
  *   state field h_rule = 1 <- updates.py:263-315 + dicotomy.py:57-82 (multiplicative_step_hq, algo = "l2_surrogate")
- *   h_rule = 2, pg_gamma_w <- updates.py:317-395 + dicotomy.py:84-108 (proj_grad_step_h / _w, algo = "projected_gradient")
+ *   h_rule = 2, pg_gamma_w, pg_q <- updates.py:317-395 + dicotomy.py:84-108 (proj_grad_step_h / _w, algo = "projected_gradient")
+ *                            + smooth_nmf.py:382-401, :438-447 (its linesearch)
  *   espm_dichotomy_simplex_acc / _pg <- dicotomy.py:57-108 (module-level functions)
  *   espm_surrogate_terms  <- espm/estimators/surrogates.py:6-149 (module-level surrogates)
  *
@@ -94,6 +95,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_HP_ROWSUM 4   /* [4, 4+KP): sum_j H_out[k, j]                             */
 #define ESPM_HP_MAX 12     /* [12, 12+KP): max_j H_out[k, j]                           */
 #define ESPM_HP_RELH 20    /* max |H_in - H_prev| / (H_in + tol mean H_in) over the block (base.py:324) */
+#define ESPM_HP_PGQ 21     /* projected-gradient rule only: sum <H' - H, grad> + gamma_H ||H' - H||^2 over the block   */
 #define ESPM_HP_NSCALAR 5  /* KL, REG, LAP, BAD, RELH                                  */
 #define ESPM_HP_STRIDE 24
 
@@ -213,6 +215,10 @@ typedef struct espm_mu_state {
                                gamma_H in sigma_l, projection on the simplex dicotomy.py:84-108) */
   float pg_gamma_w;         /* > 0: the W update is the projected-gradient step W - grad / pg_gamma_w, clamped
                                (proj_grad_step_w, updates.py:353-370; no simplex over W); 0: multiplicative update */
+  double* pg_q;             /* optional (hist_len, 2): terms of the projected gradient's linesearch (smooth_nmf.py:382-401,
+                               :438-447; surrogates.py:153-170).  [t][0] = sum <H' - H, grad_H> + gamma_H ||H' - H||^2 of
+                               the H update that STARTS from state t (written by espm_mu_h_finalize(.., slot = t));
+                               [t][1] = the same for the W update that PRODUCED state t.  The caller adds the losses. */
 } espm_mu_state;
 
 const char* espm_mu_version(void);

@@ -347,9 +347,6 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
     X = np.random.default_rng(0).random((20, 30))
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
-    with pytest.raises(NotImplementedError):   # the linesearch of the projected gradient
-        quiet(SmoothNMF(n_components=2, algo="projected_gradient", simplex_W=False, gamma=[10.0, 10.0], linesearch=True,
-                        lambda_L=1.0, shape_2d=(5, 6), verbose=0).fit, X)
     with pytest.raises(NotImplementedError):   # the Frobenius loss inside a fit
         quiet(SmoothNMF(n_components=2, algo="l2_surrogate", l2=True, verbose=0).fit, X)
 
@@ -528,3 +525,33 @@ def test_projected_gradient_golden(SmoothNMF, golden):
     quiet(est.fit, g["p0_X"], W=g["p0_W0"].copy(), H=g["p0_H0"].copy())
     assert est.gamma_[0] > 1e25 and est.gamma_[1] > 1e25
     assert np.allclose(est.losses_, est.losses_[0], rtol=1e-6)
+
+
+def test_projected_gradient_linesearch_golden(SmoothNMF, golden):
+    """The projected gradient WITH its linesearch (smooth_nmf.py:382-401, :438-447): the sequences of gamma_H / gamma_W the
+    quadratic bound produces, and the losses, against the reference (fixture F13; in 'lx' an entry of GWH reaches the clamp
+    at iteration 11, the loss jumps by ten orders of magnitude and gamma goes up)."""
+    g = golden("f13_projected_gradient_linesearch")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        gam = []
+
+        class Rec(SmoothNMF):
+            def _detailed(self, lkl, reg, lap):
+                gam.append(list(self.gamma_))
+                return super()._detailed(lkl, reg, lap)
+
+        est = Rec(n_components=c["k"], G=g.get(f"{name}_G"), shape_2d=shape, verbose=0, algo="projected_gradient", linesearch=True,
+                  tol=0, no_stop_criterion=True, max_iter=c["iters"], **c["kw"])
+        quiet(est.fit_transform, g[f"{name}_X"], W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy())
+        ref_g, ref_l = g[f"{name}_gammas"], g[f"{name}_losses"]
+        gam = np.array(gam)[:len(ref_g)]   # (one more _detailed call comes from the final loss() of a fit without any simplex)
+        # up to the first blow-up of the loss every decision is the reference's; at and after it (an entry of GWH at the clamp:
+        # the loss depends on the last bits of that entry) only the direction is required: gamma goes up
+        n_ok = int(np.argmax(ref_l >= 10.0)) if (ref_l >= 10.0).any() else len(ref_l)
+        np.testing.assert_allclose(gam[:n_ok], ref_g[:n_ok], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(np.array(est.losses_)[:n_ok], ref_l[:n_ok], rtol=3 * LOSS_RTOL, err_msg=name)
+        if n_ok < len(ref_l):
+            assert est.losses_[n_ok] > 1e3 and (np.diff(gam[n_ok - 1:, 0]) > 0).any() and np.isfinite(est.losses_).all()
