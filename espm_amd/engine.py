@@ -62,7 +62,8 @@ class MUEngine:
                  epsilon_reg=1.0, simplex_H=False, simplex_W=True, log_shift=1e-14, dicotomy_tol=1e-5,
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
-                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0):
+                 fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
+                 filled_channels=None):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -90,6 +91,12 @@ class MUEngine:
         self.out_dtype = np.float64 if Xd.dtype == torch.float64 else np.float32
         if bool((Xd < 0).any()):
             raise ValueError("Negative values in data")  # espm/estimators/base.py:528
+        # channels that hold nothing but the log_shift fill (all ranks see the same mask): the sparse store may leave them empty
+        empty_ch = None
+        if filled_channels is not None:
+            empty_ch = torch.as_tensor(filled_channels, dtype=torch.bool).to(dev)
+            if empty_ch.shape != (self.n,):
+                raise ValueError("filled_channels must be a boolean mask over the n channels")
         if fix_zero_lines:
             # all-zero channels / pixels become log_shift, base.py:519-528 (channel sums are global)
             ch_sum = Xd.sum(dim=px_axis, dtype=torch.float64)
@@ -99,6 +106,7 @@ class MUEngine:
             zc, zp = ch_sum == 0, px_sum == 0
             if bool(zc.any()) or bool(zp.any()):
                 Xd = Xd.clone()
+                empty_ch = zc
                 if layout == "cm":
                     Xd[:, zp] = log_shift
                     Xd[zc, :] = log_shift
@@ -124,11 +132,25 @@ class MUEngine:
         if h_variant:
             raise NotImplementedError("h_variant=1 (Y = GW H on the matrix cores) was retired: slower than the vector kernels "
                                       "at k <= 8 and sensitive to a transcendental-operand hazard (DESIGN.md)")
+        refill = False
+
+        def set_empty(v):
+            if layout == "cm":
+                Xd[empty_ch, :] = v
+            else:
+                Xd[:, empty_ch] = v
         if x_store in ("auto", "ell"):
             # u8 / ell: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
             # which is not an integer: such data keep the bf16 store and the reference's exact semantics.
             # ell (non-zero entries only) when at most ELL_MAX_DENSITY of the entries are non-zero and the GW table
             # fits in LDS; the decision is taken jointly by all ranks.
+            # Channels that are empty in the whole image (common in measured spectra: the bins below the detector's
+            # threshold and above the beam energy) do not cost the sparse store: their fill of log_shift = 1e-14 counts
+            # per bin moves W, H and the loss by O(1e-14) and is left out of the lists; without
+            # the sparse store the fill stays, as in the reference.
+            unfilled = empty_ch is not None and not self.bregman and bool(empty_ch.any())
+            if unfilled:
+                set_empty(0)
             is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
             exact = (Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16
             code = 2 if bool(is_count) else (1 if bool(exact) else 0)
@@ -142,8 +164,12 @@ class MUEngine:
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
             if group is not None:
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+            if unfilled and int(flag.item()) != 3:
+                set_empty(log_shift)
+                flag.fill_(0)      # (the fill is neither an integer nor a bf16 value)
             if x_store == "ell" and int(flag.item()) != 3:
                 raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS")
+            refill = unfilled and int(flag.item()) == 3 and filled_channels is not None  # (the caller's tensor: put the fill back)
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
         if int(h_rule) != 0 and x_store in ("u8", "bf16"):
             x_store = "f32"   # the alternate H rules are built for the sparse and the fp32 store
@@ -193,6 +219,8 @@ class MUEngine:
                                      _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
                                      _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, st.n_cm, _stream()))
             self.x_bytes = self.x_cm.numel() * self.x_cm.element_size() + self.x_pm.numel() * self.x_pm.element_size()
+        if refill:
+            set_empty(log_shift)
         torch.cuda.current_stream().synchronize()
         del Xd
 

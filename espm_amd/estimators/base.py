@@ -94,7 +94,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None):
         from espm_amd.engine import MUEngine
 
         rows = None
@@ -107,7 +107,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
-                        fix_zero_lines=False, **self._engine_kwargs())
+                        fix_zero_lines=False, filled_channels=filled_channels, **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -194,13 +194,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             assert_all_finite(Xv, input_name="X")
         self.const_KL_ = None
         xscale = 1.0
+        # (channels without a single count in the image: the engine's sparse store may leave their fill out)
         if Xd is None:
             X_fixed = self.remove_zeros_lines(Xv, self.log_shift)
             mean_x = None
+            empty_ch = Xv.sum(axis=1) == 0
         else:
             if bool((Xd < 0).any()):
                 raise ValueError("Negative values in data")
             zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
+            empty_ch = zc
             if bool(zp.any()) or bool(zc.any()):
                 X_fixed = Xv.copy()
                 X_fixed[:, zp.cpu().numpy()] = self.log_shift
@@ -242,7 +245,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._L_pixels = int(self.X_.shape[1])
 
         out_dtype = self.X_.dtype
-        self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd, xscale, None if self._identity_G else self.G_)
+        self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd, xscale, None if self._identity_G else self.G_,
+                                                filled_channels=empty_ch if bool(empty_ch.any()) else None)
         del X_fixed, Xd
         eng.load_state(self.W_, self.H_)
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]

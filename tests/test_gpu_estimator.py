@@ -284,6 +284,52 @@ def test_count_stores_match_oracle(store, n, nx, ny, k, m, counts, hot, kw):
     assert h["bad"].sum() == 0
 
 
+@pytest.mark.parametrize("kw", [dict(simplex_H=True, simplex_W=False, mu=0.3, lambda_L=2.0), dict(simplex_H=False, simplex_W=True)])
+@pytest.mark.parametrize("m", [None, 5])
+def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m):
+    """Measured spectra have channels without a single count in the whole image.  The reference fills them with
+    log_shift (base.py:519-528); the sparse store leaves that fill out of its lists (an O(1e-14) change) instead of
+    falling back to a dense fp32 X.  Engine and estimator against the fp64 oracle, which fills like the reference."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    n, nx, ny, k = 160, 16, 20, 3
+    prob = synth.make_problem(n, nx, ny, k, N=25.0, seed=3, m=m)
+    X = synth.sample_numpy(prob, seed=3)
+    X[0, X.sum(axis=0) == 0] = 1.0
+    X[:7] = 0
+    X[60:64] = 0
+    X[-9:] = 0
+    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=3, scale=0.2)
+    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                 max_iter=8, tol=0, **kw)
+    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=8, tol=0, **kw)
+    assert eng.x_store == "ell"
+    eng.load_state(W0, H0)
+    eng.iterate(8, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
+    est = SmoothNMF(n_components=k, G=prob["G"], shape_2d=(nx, ny), max_iter=8, tol=0, no_stop_criterion=True, verbose=0,
+                    normalize=True, **kw)
+    Xin = X.copy()
+    quiet(est.fit, Xin, W=W0.copy(), H=H0.copy())
+    assert est._engine.x_store == "ell" and (Xin == X).all()
+    refn = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                  max_iter=8, tol=0, normalize=True, **kw)
+    np.testing.assert_allclose(est.losses_, refn["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(est.H_, refn["H"], rtol=2e-4, atol=2e-5)
+    # an empty pixel (or the Bregman variant's channel sums) keeps the reference's fill and a dense store
+    Xp = X.copy()
+    Xp[:, 5] = 0
+    assert MUEngine(Xp, k, G=prob["G"], shape_2d=(nx, ny), **kw).x_store == "f32"
+    with pytest.raises(ValueError):
+        MUEngine(Xp, k, G=prob["G"], shape_2d=(nx, ny), x_store="ell", **kw)
+
+
 def test_sparse_store_is_chosen_for_sparse_counts_only():
     from espm_amd import synth
     from espm_amd.engine import MUEngine
