@@ -382,7 +382,7 @@ int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* 
 static int check_l2(const espm_mu_state* st, const float* work, const double* scratch, int scratch_doubles) {
   ESPM_REQUIRE(work && scratch && scratch_doubles >= ESPM_KP * ESPM_KP, "l2 step: work (2, KP, KP) and a scratch of >= %d doubles are needed", ESPM_KP * ESPM_KP);
   ESPM_REQUIRE(st->x_dtype == ESPM_X_F32, "l2 step: the f32 store is required");
-  ESPM_REQUIRE(st->xscale == 1.f && st->lambda_l == 0.f && st->mu == nullptr, "l2 step: xscale = 1, lambda_L = 0 and mu = 0 are required (updates.py:110-114)");
+  ESPM_REQUIRE(st->xscale == 1.f, "l2 step: xscale = 1 is required");
   return ESPM_OK;
 }
 
@@ -390,6 +390,7 @@ int espm_mu_l2_step_h(const espm_mu_state* st, int src, float* work, double* scr
   if (int rc = check_state(st)) return rc;
   if (int rc = check_l2(st, work, scratch, scratch_doubles)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  ESPM_REQUIRE(st->lambda_l == 0.f && st->mu == nullptr, "l2 H step: lambda_L = 0 and mu = 0 are required (updates.py:110-114)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (int rc = launch_gram(st->gw_s, st->n, st->k, scratch, scratch_doubles, work, s)) return rc;   // GW^T GW
   HStepArgs a = make_h_args(st, src, 1);

@@ -63,7 +63,7 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None):
+                 filled_channels=None, frobenius=False):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -129,6 +129,14 @@ class MUEngine:
                 torch.distributed.all_reduce(sr_ch, group=group)
             self._breg_ch = sr_ch.to(torch.float32).contiguous()
             self._breg_px_local = Xd.sum(dim=ch_axis, dtype=torch.float64).to(torch.float32)
+        # A fit with the Frobenius data term (l2=True with algo="l2_surrogate", smooth_nmf.py:223-237, :404-413, base.py:197-198):
+        # quadratic-surrogate H step, Frobenius W step and loss; on the dense fp32 store
+        self.frobenius = bool(frobenius)
+        if self.frobenius:
+            if group is not None or float(xscale) != 1.0 or int(h_rule) != 1 or simplex_W:
+                raise NotImplementedError("the Frobenius fit is built for one GPU, xscale = 1 (hand over the scaled X), "
+                                          "h_rule = 1 and no simplex over W (updates.py:31-36 has none)")
+            x_store = "f32"
         if h_variant:
             raise NotImplementedError("h_variant=1 (Y = GW H on the matrix cores) was retired: slower than the vector kernels "
                                       "at k <= 8 and sensitive to a transcendental-operand hazard (DESIGN.md)")
@@ -248,6 +256,7 @@ class MUEngine:
         st.pg_gamma_w = float(pg_gamma_w)
         st.eps_reg, st.log_shift = float(epsilon_reg), float(log_shift)
         st.dicotomy_tol, st.rel_tol = float(dicotomy_tol), float(tol)
+        self.rel_tol = float(tol)
         st.xscale, st.gw_floor = float(xscale), float(gw_floor)
         self.lambda_L, self.xscale = float(lambda_L), float(xscale)
         mu_arr = np.asarray(mu, dtype=np.float64)
@@ -272,6 +281,7 @@ class MUEngine:
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
         self.hist_len = int(max_iter) + 3   # states 0..max_iter, a spare, and a scratch slot (the last) for loss-only evaluations
         self.hist = torch.zeros((self.hist_len, _lib.HI_STRIDE), **f64)
+        self.frob = torch.zeros(self.hist_len, **f64) if self.frobenius else None
         self.fixed_h = self._pad_h(fixed_H) if fixed_H is not None else None
         self.fixed_w = (torch.from_numpy(np.ascontiguousarray(np.asarray(fixed_W, dtype=np.float32))).to(dev)
                         if fixed_W is not None else None)
@@ -428,11 +438,41 @@ class MUEngine:
         slab-reduction launch; any other consumer (``history``, ``step_*_only``, ...) flushes it first."""
         st = self.st
         self._flush_finalize()
+        if self.frobenius:
+            self._frobenius_of_current()
         if advance_h:
             check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
             self._pending_finalize = (st.cur, st.it)
         else:
             check(lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+
+    def _frobenius_of_current(self, rows=32768):
+        """||X - G W H||_F^2 of the current state (espm/measures.py:350-384) into its history slot: residual in fp32 over
+        blocks of pixels of the pixel-major X, sums in fp64."""
+        cur = self.st.cur
+        gw = self.w[cur] if self.m == 0 else self.g @ self.w[cur]          # (n, k)
+        ht = self.h[cur][:, :self.p].t()                                      # (p, k)
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        for lo in range(0, self.p, rows):
+            r = self.x_pm[lo:lo + rows, :self.n] - ht[lo:lo + rows] @ gw.t()
+            total += (r * r).sum(dtype=torch.float64)
+        self.frob[self.st.it] = total
+
+    def _finish_iteration_frobenius(self):
+        """Frobenius W step (updates.py:31-36) with the H of ``eval_current``; flips the buffers."""
+        st = self.st
+        cur, slot = st.cur, st.it
+        self._flush_finalize()
+        work, scratch = self._l2_buffers()
+        if self.m > 0 and getattr(self, "_gtg", None) is None:
+            self._gtg = (self.g.double().t() @ self.g.double()).float().contiguous()
+        s = _stream()
+        check(lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(self._gtg) if self.m > 0 else None, _ptr(work), _ptr(scratch),
+                                    scratch.numel(), s))
+        check(lib.espm_mu_build_gw(C.byref(st), 1 - cur, s))
+        wn, wo = self.w[1 - cur].double(), self.w[cur].double()
+        self.hist[slot + 1, _lib.HI_REL_W] = ((wn - wo).abs() / (wn + self.rel_tol * wn.mean())).max()   # base.py:323
+        st.cur, st.it = 1 - cur, slot + 1
 
     def _flush_finalize(self):
         pend = getattr(self, "_pending_finalize", None)
@@ -446,6 +486,8 @@ class MUEngine:
         cur, slot = st.cur, st.it
         if slot + 1 >= self.hist_len:
             raise ValueError("history buffer exhausted: raise max_iter")
+        if self.frobenius:
+            return self._finish_iteration_frobenius()
         s = _stream()
         check(lib.espm_mu_w_accum(C.byref(st), s))
         ride = getattr(self, "_pending_finalize", None) == (cur, slot)   # the H-step's record reduction rides along
@@ -532,7 +574,7 @@ class MUEngine:
         if st.it + n_iter + 1 > self.hist_len:
             raise ValueError("history buffer exhausted: raise max_iter")
         self._flush_finalize()
-        if self.world == 1:
+        if self.world == 1 and not self.frobenius:
             check(lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
         else:
             for _ in range(int(n_iter)):
@@ -612,6 +654,8 @@ class MUEngine:
         h = hist.cpu().numpy()
         numel = float(self.n) * float(self.p_total) if average else 1.0
         kl = (h[:, _lib.HI_KLX] + h[:, _lib.HI_SUMY] - self.xscale * self.sum_x) / numel
+        if self.frobenius:  # base.py:197-198
+            kl = 0.5 * self.frob[:upto + 1].cpu().numpy() / numel
         reg = h[:, _lib.HI_REG] / numel
         lap = 0.5 * self.lambda_L * h[:, _lib.HI_LAP] / numel
         return dict(loss=kl + reg + lap, kl=kl, reg=reg, lap=lap, rel_W=h[:, _lib.HI_REL_W],

@@ -102,6 +102,12 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             rows = self.physics_model_.NMF_simplex()
         # (the Bregman W update has no simplex branch, updates.py:40-48: algo="bmd" ignores simplex_W there, like the reference)
         simplex_W = self.simplex_W and getattr(self, "algo", None) != "bmd"
+        if self.l2:
+            # Frobenius data term (only kept by SmoothNMF with algo="l2_surrogate", smooth_nmf.py:223-237): the W step has no
+            # simplex there (updates.py:31-36); the engine's Frobenius mode takes the scaled X itself
+            simplex_W = False
+            if xscale != 1.0:
+                X_fixed, xscale = X_fixed * xscale, 1.0
         # (and the projected-gradient W step of a fit is called without fixed_W, smooth_nmf.py:430-437)
         fixed_W = None if getattr(self, "algo", None) == "projected_gradient" else self.fixed_W
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
@@ -119,8 +125,6 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         """Loss of (W, H) (espm/estimators/base.py:167-207): generalised KL divergence of X from
         G W H (plus the regularisers of the subclass), evaluated on the device."""
         self.GWH_numel_ = self.G_.shape[0] * H.shape[1]
-        if self.l2:
-            raise NotImplementedError("the Frobenius loss (l2=True) is not built for the GPU path")
         if X is None:
             eng = self._get_engine()
         else:
@@ -176,8 +180,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                           "If this argument is not set correctly, the function will not work properly!!!")
             except Exception:
                 pass
-        if self.l2:
-            raise NotImplementedError("the Frobenius loss (l2=True) is not built for the GPU path")
+        if self.l2 and getattr(self, "algo", None) != "l2_surrogate":
+            raise NotImplementedError("the Frobenius loss (l2=True) is built for SmoothNMF(algo='l2_surrogate'), the one "
+                                      "combination in which the reference keeps it (smooth_nmf.py:223-237)")
 
         # Large X: ONE upload; the passes the reference makes over X on the host before the loop (sign check, zero
         # lines base.py:519-528, mean for normalize, const_KL_ base.py:200-201, the NNDSVD's products) run on that
@@ -264,7 +269,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         track = self._begin_truth_tracking()
         pg_ls = bool(getattr(self, "linesearch", False)) and getattr(self, "algo", None) == "projected_gradient"
         adapt = bool(getattr(self, "linesearch", False)) and not pg_ls
-        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt or pg_ls
+        sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt or pg_ls or bool(self.l2)
         if (track or adapt or pg_ls) and getattr(eng, "world", 1) > 1:
             raise NotImplementedError("linesearch / ground-truth tracking are not built for a sharded image")
         eval_before = np.inf
@@ -439,7 +444,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         te.eval_current(advance_h=False)
         h = te.history(upto=0, average=False)
         numel = float(self.G_.shape[0] * Hc.shape[1])
-        lkl = float(h["kl"][0]) - self._truth_const + self.const_KL_
+        lkl = float(h["kl"][0]) if self.l2 else float(h["kl"][0]) - self._truth_const + self.const_KL_
         self.true_losses_.append((lkl + float(h["reg"][0]) + float(h["lap"][0])) / numel)
 
     def remove_zeros_lines(self, X, epsilon):

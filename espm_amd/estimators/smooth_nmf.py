@@ -17,10 +17,11 @@ class SmoothNMF(NMFEstimator):
 
     Parameters as in espm/estimators/smooth_nmf.py:46-79.  The default solver ``algo="log_surrogate"`` is
     accelerated, with or without ``linesearch`` (gamma_ adapts to the Laplacian surrogate every iteration,
-    smooth_nmf.py:376-381) and with ``true_D`` / ``true_H`` tracking; so is ``algo="bmd"`` (both updates in their Bregman
-    variant, smooth_nmf.py:358-372, :416-426) for G = None and ``algo="l2_surrogate"`` (H from the quadratic surrogate
-    of the Laplacian term, smooth_nmf.py:311-323) with ``l2=False`` and ``algo="projected_gradient"`` with a given
-    ``gamma=[gamma_H, gamma_W]`` and without its linesearch; what is not built raises ``NotImplementedError`` at fit time.
+    smooth_nmf.py:376-381) and with ``true_D`` / ``true_H`` tracking; so are ``algo="bmd"`` (both updates in their Bregman
+    variant, smooth_nmf.py:358-372, :416-426) for G = None, ``algo="l2_surrogate"`` (H from the quadratic surrogate
+    of the Laplacian term, smooth_nmf.py:311-323; with ``l2=True`` the Frobenius W step and data term, :404-413,
+    base.py:197-198) and ``algo="projected_gradient"`` (gamma given or the Lipschitz default, with or without its
+    linesearch); what is not built raises ``NotImplementedError`` at fit time.
     """
 
     loss_names_ = NMFEstimator.loss_names_ + ["log_reg_loss"] + ["Lapl_reg_loss"] + ["gamma"]
@@ -129,7 +130,8 @@ class SmoothNMF(NMFEstimator):
         return dict(lambda_L=self.lambda_L, mu=self.mu, epsilon_reg=self.epsilon_reg,
                     dicotomy_tol=self.dicotomy_tol, sigmaL=float(self._gamma_value()), bregman=self.algo == "bmd",
                     h_rule={"l2_surrogate": 1, "projected_gradient": 2}.get(self.algo, 0),
-                    pg_gamma_w=float(self._pg_gamma()[1]) if self.algo == "projected_gradient" else 0.0)
+                    pg_gamma_w=float(self._pg_gamma()[1]) if self.algo == "projected_gradient" else 0.0,
+                    frobenius=bool(self.l2))   # (l2 survives _validate only with algo="l2_surrogate", smooth_nmf.py:223-237)
 
     def _pg_gamma(self):
         """[gamma_H, gamma_W] of the projected gradient: the user's list, or the Lipschitz bounds at W = H = log_shift
@@ -162,8 +164,6 @@ class SmoothNMF(NMFEstimator):
                 raise NotImplementedError("algo='projected_gradient' needs gamma=[gamma_H, gamma_W] (or None) on the GPU path")
             if self.simplex_W:
                 raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
-        if self.l2:  # only reachable with algo="l2_surrogate" (smooth_nmf.py:233-237)
-            raise NotImplementedError("the Frobenius loss (l2=True) inside a fit is not built for the GPU path")
         self.gamma_ = None
         self._pg_gamma_cache = None
         return super().fit_transform(X, y=y, W=W, H=H)

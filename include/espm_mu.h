@@ -328,9 +328,10 @@ int espm_dichotomy_simplex_pg(const double* a, int k, int p, double log_shift, d
                               espm_stream_t stream);
 
 /* Frobenius ("l2") branch of the step functions, espm/estimators/updates.py:109-118 (H) and :31-36 (W); in the reference
- * reachable only by calling multiplicative_step_h / _w with l2=True (espm/tests/test_updates.py:457-568).  f32 store,
- * xscale = 1, lambda_L = 0, mu = NULL.  work: (2, KP, KP) device floats (GW^T GW, then H H^T); scratch: device doubles
- * for the partial Gram sums (>= KP * KP, more = more workgroups).
+ * reachable by calling multiplicative_step_h / _w with l2=True (espm/tests/test_updates.py:457-568) and, for the W step,
+ * from a fit with algo="l2_surrogate", l2=True (smooth_nmf.py:404-413).  f32 store, xscale = 1; the H step also needs
+ * lambda_L = 0, mu = NULL (the W step does not look at them).  work: (2, KP, KP) device floats (GW^T GW, then H H^T);
+ * scratch: device doubles for the partial Gram sums (>= KP * KP, more = more workgroups).
  *   l2_step_h: H' = max(H * (GW^T X) / ((GW^T GW) H + nu), eps), simplex_h / fixed_h as in espm_mu_step_h; h[src] -> h[1-src].
  *   l2_step_w: W' = max(W / (G^T G W H H^T) * (G^T (X H^T)), eps), fixed_w; H = h_t (the caller keeps it current);
  *              gtg = G^T G (m, m) when G is given (a property of G alone: formed once by the caller); w[src] -> w[1-src]. */

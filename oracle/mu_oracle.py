@@ -296,12 +296,16 @@ def Frobenius_loss(X, D, H, average=False):
 
 
 def smooth_nmf_loss(X, G, W, H, L, mu=0, epsilon_reg=1, lambda_L=0.0, log_shift=LOG_SHIFT,
-                    average=True, c_kl=None, gamma=SIGMA_L):
-    """SmoothNMF.loss: returns (total, [lkl, reg, lap, gamma]), smooth_nmf.py:457-475."""
+                    average=True, c_kl=None, gamma=SIGMA_L, l2=False):
+    """SmoothNMF.loss: returns (total, [lkl, reg, lap, gamma]), smooth_nmf.py:457-475; data term base.py:197-203
+    (l2: half the squared Frobenius distance instead of the KL divergence)."""
     numel = G.shape[0] * H.shape[1]
-    if c_kl is None:
-        c_kl = const_KL(X, log_shift)
-    lkl = KLdiv_loss(X, G @ W, H, log_shift) + c_kl
+    if l2:
+        lkl = 0.5 * Frobenius_loss(X, G @ W, H, average=False)
+    else:
+        if c_kl is None:
+            c_kl = const_KL(X, log_shift)
+        lkl = KLdiv_loss(X, G @ W, H, log_shift) + c_kl
     reg = log_reg(H, mu, epsilon_reg)
     lap = 0.5 * lambda_L * trace_xtLx(L, H.T)
     if average:
@@ -550,7 +554,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
         gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
         record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None,
-        algo="log_surrogate"):
+        algo="log_surrogate", l2=False):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
     SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", "bmd", "l2_surrogate" or "projected_gradient" with a given gamma; linesearch: smooth_nmf.py:376-381;
     true_D / true_H tracking: base.py:301-347).
@@ -574,13 +578,16 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         if gamma is None:
             raise NotImplementedError("projected_gradient: pass gamma=[gamma_H, gamma_W]")
         gamma_ = list(gamma)
+    l2 = bool(l2) and algo == "l2_surrogate" and not linesearch  # smooth_nmf.py:223-237: elsewhere the flag is switched off
+    # (with it, the W step takes its Frobenius branch - no simplex, updates.py:31-36 - and the loss its Frobenius data
+    # term, base.py:197-198; the H step of "l2_surrogate" has no such branch, smooth_nmf.py:311-323)
     breg = algo == "bmd"  # smooth_nmf.py:358-372, :416-426: both steps with use_bregman=True
     c_kl = const_KL(X_, log_shift)
 
     def loss(Wc, Hc, Xc=None):
         # base.py:196-203: with another X (the noiseless truth) the constant cached for the DATA is still the one added
         return smooth_nmf_loss(X_ if Xc is None else Xc, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, True, c_kl,
-                               gamma_[0] if isinstance(gamma_, list) else gamma_)   # smooth_nmf.py:470-473
+                               gamma_[0] if isinstance(gamma_, list) else gamma_, l2=l2)   # smooth_nmf.py:470-473
 
     def loss_sum(Wc, Hc):
         return smooth_nmf_loss(X_, G_, Wc, Hc, L_, mu, epsilon_reg, lambda_L, log_shift, False, c_kl)[0]
@@ -624,7 +631,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
                 f_xt, f_x = loss_sum(old_W, H_), loss_sum(W_, H_)
                 gamma_[1] = gamma_[1] / 1.05 if quadratic_surrogate(W_, old_W, f_xt, grad, gamma_[1]) - f_x > 0 else gamma_[1] * 1.5
         else:
-            W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=False,
+            W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=l2,
                                        simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
         eval_after, det = loss(W_, H_)
         n_iter += 1

@@ -576,7 +576,49 @@ def f13():
     save("f13_projected_gradient_linesearch", **out)
 
 
+# ------------------------------------------------------------------ F14: Frobenius data term inside a fit (l2=True)
+L2FIT = {
+    # l2 survives only with algo="l2_surrogate" and no linesearch (smooth_nmf.py:223-237): quadratic-surrogate H step,
+    # Frobenius W step (no simplex over W there), loss = half the squared Frobenius distance + the regularisations
+    "l3": dict(n=64, nx=12, ny=10, k=5, m=None, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0)),
+    "l5": dict(n=60, nx=10, ny=12, k=4, m=9, iters=30, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.6)),
+    "lw": dict(n=32, nx=6, ny=6, k=3, m=None, iters=20, kw=dict(simplex_H=False, simplex_W=True, lambda_L=0.5)),
+    "ln": dict(n=40, nx=6, ny=7, k=3, m=None, iters=15, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.3, normalize=True)),
+    "ls": dict(n=48, nx=8, ny=8, k=3, m=None, iters=40, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.7, tol=1e-3), stop=True),
+}
+
+
+def f14():
+    rng = np.random.default_rng(1414)
+    out = {}
+    for name, c_ in L2FIT.items():
+        X, G, W, H = synth(rng, c_["n"], c_["nx"], c_["ny"], c_["k"], c_["m"])
+        p = c_["nx"] * c_["ny"]
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((c_["k"], p)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        out[f"{name}_X"], out[f"{name}_W0"], out[f"{name}_H0"] = X, W0, H0
+        if G is not None:
+            out[f"{name}_G"] = G
+        out[f"{name}_shape"] = np.array([c_["nx"], c_["ny"]])
+        kw = dict(c_["kw"])
+        if not c_.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        est = SmoothNMF(n_components=c_["k"], G=G, shape_2d=(c_["nx"], c_["ny"]), verbose=0, algo="l2_surrogate", l2=True,
+                        max_iter=c_["iters"], **kw)
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        assert est.l2 is True
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"] = GW, est.W_, est.H_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+        out[f"{name}_n_iter"] = np.array(est.n_iter_)
+    out["names"] = np.array(list(L2FIT))
+    out["configs"] = np.array(json.dumps(L2FIT))
+    save("f14_frobenius_fit", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

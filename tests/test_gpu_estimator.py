@@ -393,8 +393,6 @@ def test_k_above_build_limit_is_refused(SmoothNMF):
     X = np.random.default_rng(0).random((20, 30))
     with pytest.raises(NotImplementedError):
         quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
-    with pytest.raises(NotImplementedError):   # the Frobenius loss inside a fit
-        quiet(SmoothNMF(n_components=2, algo="l2_surrogate", l2=True, verbose=0).fit, X)
 
 
 @pytest.mark.parametrize("case", ["all_ones", "no_ones", "wide", "ones_and_bright"])
@@ -533,6 +531,34 @@ def test_quadratic_surrogate_golden(SmoothNMF, golden):
         np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")
         np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
         np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+
+
+def test_frobenius_fit_golden(SmoothNMF, golden):
+    """l2=True inside a fit (the reference keeps it only with algo="l2_surrogate", smooth_nmf.py:223-237): quadratic-surrogate
+    H step, Frobenius W step (updates.py:31-36) and loss (base.py:197-198); G given, simplex_W asked for (ignored by that W
+    step), normalize, and a run that ends on the stop criterion - against the reference (fixture F14) and the oracle."""
+    g = golden("f14_frobenius_fit")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        G = g.get(f"{name}_G")
+        kw = dict(c["kw"])
+        if not c.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        est = SmoothNMF(n_components=c["k"], G=G, shape_2d=shape, verbose=0, algo="l2_surrogate", l2=True, max_iter=c["iters"], **kw)
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        assert est.l2 is True and est._engine.frobenius and est.n_iter_ == int(g[f"{name}_n_iter"]), name
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=3 * LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, :3], g[f"{name}_detailed"][:, :3], rtol=1e-3, atol=1e-7, err_msg=name)
+        np.testing.assert_allclose(np.array(est.rel_), g[f"{name}_rel"], rtol=2e-2, atol=1e-4, err_msg=name)
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4, err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+        # loss() of the fitted estimator is the Frobenius one too (base.py:197-198)
+        np.testing.assert_allclose(est.loss(est.W_ * (est.norm_factor_ if kw.get("normalize") else 1.0), est.H_), est.losses_[-1],
+                                   rtol=1e-5, err_msg=name)
 
 
 def test_projected_gradient_golden(SmoothNMF, golden):

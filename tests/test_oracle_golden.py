@@ -264,6 +264,27 @@ def test_f11_quadratic_surrogate(golden):
         np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
 
 
+def test_f14_frobenius_fit(golden):
+    """l2=True inside a fit (kept only with algo="l2_surrogate", smooth_nmf.py:223-237): Frobenius W step
+    (updates.py:30-36), Frobenius data term of the loss (base.py:197-198), with and without the stop criterion."""
+    g = golden("f14_frobenius_fit")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        X, W0, H0 = g[f"{name}_X"], g[f"{name}_W0"], g[f"{name}_H0"]
+        kw = dict(c["kw"])
+        if not c.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        r = oc.fit(X, c["k"], G=g.get(f"{name}_G"), W=W0.copy(), H=H0.copy(), shape_2d=shape, algo="l2_surrogate", l2=True,
+                   max_iter=c["iters"], **kw)
+        assert r["n_iter"] == int(g[f"{name}_n_iter"]), name
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-7, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-6, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=2e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
+
+
 def test_f12_projected_gradient(golden):
     """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W] (updates.py:317-395, dicotomy.py:84-108)."""
     g = golden("f12_projected_gradient")
