@@ -137,6 +137,61 @@ def estimate_Lipschitz_bound_h(log_shift, X, G, k, lambda_L=0, mu=0, epsilon_reg
     return np.max(D.T @ (np.sum(D, axis=1, keepdims=True) * X / (DH ** 2))) + 2 * lambda_L + mu * epsilon_reg
 
 
+def _dev64(*arrays):
+    import torch
+
+    from espm_amd.engine import require_gpu
+    dev = require_gpu()
+    return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev) for a in arrays]
+
+
+def update_q(D, H, log_shift=log_shift):
+    """The "Q step" (espm/estimators/updates.py:225-230): Q[i, j, k] = H[k, j] D[i, k] / ((D H)[i, j] + log_shift), an
+    (n, p, k) array formed on the device."""
+    Dd, Hd = _dev64(D, H)
+    q = Hd.t().unsqueeze(0) * (Dd.unsqueeze(1) / ((Dd @ Hd).unsqueeze(2) + log_shift))
+    return q.cpu().numpy()
+
+
+def gradW(X, G, W, H, log_shift=log_shift, safe=False, l2=False):
+    """Gradient of the data term in W (espm/estimators/updates.py:303-313): G^T (-(X / GWH) H^T + rowsum(H)^T), or
+    2 G^T (GWH - X) H^T with l2.  fp64 on the device."""
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    Xd, Gd, Wd, Hd = _dev64(X, G, W, H)
+    if l2:
+        grad = 2 * Gd.t() @ (((Gd @ Wd) @ Hd - Xd) @ Hd.t())
+    else:
+        grad = Gd.t() @ (-(Xd / ((Gd @ Wd) @ Hd)) @ Hd.t() + Hd.sum(dim=1, keepdim=True).t())
+    return grad.cpu().numpy()
+
+
+def gradH(X, G, W, H, mu=0, lambda_L=0, L=None, epsilon_reg=1, log_shift=log_shift, safe=False, l2=False):
+    """Gradient of the regularised loss in H (espm/estimators/updates.py:315-342): -(GW)^T (X / GWH) + colsum(GW)^T (or
+    (GW)^T (GWH - X) with l2) + mu / (H + epsilon_reg) + lambda_L (L H^T)^T.  fp64 on the device; L, whatever matrix the
+    caller hands over, is applied on the host."""
+    if not (lambda_L == 0) and L is None:
+        raise ValueError("Please provide the laplacian")
+    if safe:
+        H = np.maximum(H, log_shift)
+        W = np.maximum(W, log_shift)
+    Xd, Gd, Wd, Hd = _dev64(X, G, W, H)
+    D = Gd @ Wd
+    if l2:
+        grad = D.t() @ (D @ Hd - Xd)
+    else:
+        grad = -D.t() @ (Xd / (D @ Hd)) + D.sum(dim=0, keepdim=True).t()
+    grad = grad.cpu().numpy()
+    if not (np.isscalar(mu) and mu == 0):
+        if len(np.shape(mu)) == 1:
+            mu = np.expand_dims(mu, axis=1)
+        grad += mu / (np.asarray(H) + epsilon_reg)
+    if not (lambda_L == 0):
+        grad += (lambda_L * L @ np.asarray(H).T).T
+    return grad
+
+
 def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
                      dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, fixed_H=None):
     """Projected-gradient step in H (espm/estimators/updates.py:372-395, KL branch)."""

@@ -425,23 +425,30 @@ def smooth_l2_surrogate(Ht, L, H, sigmaL=SIGMA_L, lambda_L=1):
 
 
 # ---- projected gradient (algo = "projected_gradient"; without its linesearch) ------------------------
-def gradW(X, G, W, H, log_shift=LOG_SHIFT, safe=False):
-    """updates.py:317-328 (KL branch): G^T (-(X / GWH) H^T + rowsum(H)^T)."""
+def update_q(D, H, log_shift=LOG_SHIFT):
+    """updates.py:225-230: Q[i, j, k] = H[k, j] D[i, k] / ((D H)[i, j] + log_shift)."""
+    return H.T[None, :, :] * (D[:, None, :] / ((D @ H)[:, :, None] + log_shift))
+
+
+def gradW(X, G, W, H, log_shift=LOG_SHIFT, safe=False, l2=False):
+    """updates.py:303-313: G^T (-(X / GWH) H^T + rowsum(H)^T); l2: 2 G^T (GWH - X) H^T."""
     if safe:
         H = np.maximum(H, log_shift)
         W = np.maximum(W, log_shift)
+    if l2:
+        return 2 * G.T @ ((G @ W) @ H - X) @ H.T
     return G.T @ (-(X / ((G @ W) @ H)) @ H.T + np.sum(H, axis=1, keepdims=True).T)
 
 
-def gradH(X, G, W, H, mu=0, lambda_L=0, L=None, epsilon_reg=1, log_shift=LOG_SHIFT, safe=False):
-    """updates.py:330-351 (KL branch): -GW^T (X / GWH) + colsum(GW) + mu / (H + eps) + lambda (L H^T)^T."""
+def gradH(X, G, W, H, mu=0, lambda_L=0, L=None, epsilon_reg=1, log_shift=LOG_SHIFT, safe=False, l2=False):
+    """updates.py:315-342: -GW^T (X / GWH) + colsum(GW) (l2: GW^T (GWH - X)) + mu / (H + eps) + lambda (L H^T)^T."""
     if lambda_L != 0 and L is None:
         raise ValueError("Please provide the laplacian")
     if safe:
         H = np.maximum(H, log_shift)
         W = np.maximum(W, log_shift)
     D = G @ W
-    grad = -D.T @ (X / (D @ H)) + np.sum(D, axis=0, keepdims=True).T
+    grad = D.T @ (D @ H - X) if l2 else -D.T @ (X / (D @ H)) + np.sum(D, axis=0, keepdims=True).T
     if not (np.isscalar(mu) and mu == 0):
         mu_col = np.asarray(mu, dtype=float)
         if mu_col.ndim == 1:

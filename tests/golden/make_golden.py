@@ -618,7 +618,33 @@ def f14():
     save("f14_frobenius_fit", **out)
 
 
+# ------------------------------------------------------------------ F15: gradients and the Q step (module functions)
+def f15():
+    from espm.estimators.updates import gradH, gradW, update_q
+    rng = np.random.default_rng(1515)
+    out = {}
+    names = []
+    for name, (n, nx, ny, k, m) in {"i": (40, 6, 7, 3, None), "g": (36, 5, 8, 4, 7)}.items():
+        X, G, W, H = synth(rng, n, nx, ny, k, m)
+        Gd = np.eye(n) if G is None else G
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((k, nx * ny)) + 0.05
+        L = create_laplacian_matrix(nx, ny)
+        mu = rng.random(k) * 0.3
+        out[f"{name}_X"], out[f"{name}_G"], out[f"{name}_W0"], out[f"{name}_H0"], out[f"{name}_mu"] = X, Gd, W0, H0, mu
+        out[f"{name}_shape"] = np.array([nx, ny])
+        out[f"{name}_gradW"] = gradW(X, Gd, W0, H0)
+        out[f"{name}_gradW_l2"] = gradW(X, Gd, W0, H0, l2=True)
+        out[f"{name}_gradH"] = gradH(X, Gd, W0, H0, mu=mu, lambda_L=0.8, L=L, epsilon_reg=0.7)
+        out[f"{name}_gradH_plain"] = gradH(X, Gd, W0, H0)
+        out[f"{name}_gradH_l2"] = gradH(X, Gd, W0, H0, mu=0.2, lambda_L=0.5, L=L, l2=True)
+        out[f"{name}_Q"] = update_q(Gd @ W0, H0)
+        names.append(name)
+    out["names"] = np.array(names)
+    save("f15_gradients", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -337,6 +337,27 @@ def test_local_w_update_equals_the_one_workgroup_finish(n, nx, ny, k, fix):
         assert np.array_equal(a[0][m], fixed_W[m].astype(np.float32))
 
 
+def test_gradients_and_q_step_golden(golden):
+    """gradW / gradH (KL and l2 branches, vector mu, Laplacian) and update_q as module-level functions against the reference
+    (fixture F15; espm/estimators/updates.py:225-230, :303-342)."""
+    from espm_amd.estimators.updates import gradH, gradW, update_q
+    from espm_amd.utils import create_laplacian_matrix
+    g = golden("f15_gradients")
+    for name in g["names"]:
+        X, G, W0, H0, mu = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "mu"))
+        L = create_laplacian_matrix(*(int(v) for v in g[f"{name}_shape"]))
+        np.testing.assert_allclose(gradW(X, G, W0, H0), g[f"{name}_gradW"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(gradW(X, G, W0, H0, l2=True), g[f"{name}_gradW_l2"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(gradH(X, G, W0, H0, mu=mu, lambda_L=0.8, L=L, epsilon_reg=0.7), g[f"{name}_gradH"],
+                                   rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(gradH(X, G, W0, H0), g[f"{name}_gradH_plain"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(gradH(X, G, W0, H0, mu=0.2, lambda_L=0.5, L=L, l2=True), g[f"{name}_gradH_l2"],
+                                   rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(update_q(G @ W0, H0), g[f"{name}_Q"], rtol=1e-11, atol=1e-14)
+    with pytest.raises(ValueError):
+        gradH(X, G, W0, H0, lambda_L=1.0)
+
+
 def test_other_multipliers_known_answers(golden):
     """dichotomy_simplex_acc and dichotomy_simplex_projected_gradient as module-level functions: the reference's root of
     fixture F11, the defining equations, and the reference's own checks (espm/tests/test_updates.py:251-437, :675-731)."""

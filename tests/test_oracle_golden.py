@@ -285,6 +285,23 @@ def test_f14_frobenius_fit(golden):
         np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=2e-5, atol=1e-8, err_msg=name)
 
 
+def test_f15_gradients_and_q_step(golden):
+    """gradW / gradH (KL and l2 branches, vector mu, Laplacian) and update_q (updates.py:225-230, :303-342)."""
+    g = golden("f15_gradients")
+    for name in g["names"]:
+        X, G, W0, H0, mu = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "mu"))
+        L = oc.laplacian_matrix(*(int(v) for v in g[f"{name}_shape"]))
+        np.testing.assert_allclose(oc.gradW(X, G, W0, H0), g[f"{name}_gradW"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(oc.gradW(X, G, W0, H0, l2=True), g[f"{name}_gradW_l2"], rtol=1e-11, atol=1e-10)
+        # (the reference's L is a float32 matrix and `lambda_L * L` rounds 0.8 * 4 to float32: 6e-8 relative)
+        np.testing.assert_allclose(oc.gradH(X, G, W0, H0, mu=mu, lambda_L=0.8, L=L, epsilon_reg=0.7), g[f"{name}_gradH"],
+                                   rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(oc.gradH(X, G, W0, H0), g[f"{name}_gradH_plain"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(oc.gradH(X, G, W0, H0, mu=0.2, lambda_L=0.5, L=L, l2=True), g[f"{name}_gradH_l2"],
+                                   rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(oc.update_q(G @ W0, H0), g[f"{name}_Q"], rtol=1e-12, atol=1e-15)
+
+
 def test_f12_projected_gradient(golden):
     """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W] (updates.py:317-395, dicotomy.py:84-108)."""
     g = golden("f12_projected_gradient")
