@@ -23,9 +23,10 @@ ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = 512, 1024, 10, 144 * 1024
 ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = 8, 4096, 6
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
-MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8
+MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8          # (the default build; `variant(k)` below for the wide one)
 HP_STRIDE, HS_STRIDE, HI_STRIDE = 24, 16, 8
 HS_ROWSUM, HS_MAX = 0, 8
+WIDE_MAX_K = 16
 HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -92,12 +93,12 @@ class EspmError(RuntimeError):
     """HIP runtime failure or unsupported configuration reported by libespm_mu."""
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
+def _load(path=LIB_PATH):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP library is required (no CPU fallback). Build it with "
+            f"{path} is missing: the HIP library is required (no CPU fallback). Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` at the repository root.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here means header and library disagree
         fn.restype, fn.argtypes = res, args
@@ -107,15 +108,15 @@ def _load():
 lib = _load()
 
 
-def last_error() -> str:
-    return lib.espm_mu_last_error().decode()
+def last_error(which=None) -> str:
+    return (which or lib).espm_mu_last_error().decode()
 
 
-def check(rc: int) -> None:
+def check(rc: int, which=None) -> None:
     """Status code -> the exception the reference raises in the same situation."""
     if rc == OK:
         return
-    msg = last_error()
+    msg = last_error(which)
     if rc == ENOSOLUTION:
         raise ValueError(msg)  # espm/estimators/dicotomy.py:22-23
     if rc == EINVAL:
@@ -123,3 +124,31 @@ def check(rc: int) -> None:
     if rc == EUNSUPPORTED:
         raise NotImplementedError(msg)
     raise EspmError(msg)
+
+
+class Variant:
+    """One build of the library (include/espm_mu.h): its handle and the sizes that follow its component stride KP."""
+
+    def __init__(self, handle, kp, min_k, max_k):
+        self.lib, self.KP, self.MIN_K, self.MAX_K = handle, kp, min_k, max_k
+        self.HP_STRIDE, self.HS_STRIDE, self.HS_MAX = 8 + 2 * kp, 2 * kp, kp
+
+    def check(self, rc):
+        check(rc, self.lib)
+
+
+_narrow = Variant(lib, KP, 1, MAX_K)
+_wide = None
+WIDE_LIB_PATH = os.path.join(_HERE, "lib", "libespm_mu_wide.so")
+
+
+def variant(k) -> Variant:
+    """The build that holds the kernels for k components: 1..8 libespm_mu.so, 9..16 libespm_mu_wide.so (dense stores)."""
+    global _wide
+    if k <= MAX_K:
+        return _narrow
+    if k > WIDE_MAX_K:
+        raise NotImplementedError(f"n_components = {k}: the kernels are built for 1..{WIDE_MAX_K} components")
+    if _wide is None:
+        _wide = Variant(_load(WIDE_LIB_PATH), 16, MAX_K + 1, WIDE_MAX_K)
+    return _wide

@@ -8,6 +8,22 @@
 namespace espm {
 
 constexpr int KP = ESPM_KP;
+static_assert(KP == 8 || KP == 16, "ESPM_KP: 8 or 16");
+static_assert(ESPM_MIN_K >= 1 && ESPM_MAX_K <= KP && ESPM_MIN_K <= ESPM_MAX_K, "ESPM_MIN_K .. ESPM_MAX_K must fit the stride");
+
+// the component counts this build instantiates its kernels for: X(1) .. X(8), or X(9) .. X(16) in the wide build
+#if ESPM_MIN_K <= 8
+#define ESPM_K_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#else
+#define ESPM_K_CASES(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#endif
+
+// one KP-strided row (gw_s, h_t) as 16-byte stores
+__device__ __forceinline__ void store_row_kp(float* dst, const float (&row)[KP]) {
+#pragma unroll
+  for (int q = 0; q < KP / 4; ++q)
+    reinterpret_cast<float4*>(dst)[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+}
 constexpr int WAVE = 64;
 
 typedef uint16_t bf16_t;  // raw storage; converted with shifts (exact)

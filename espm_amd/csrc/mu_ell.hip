@@ -51,14 +51,11 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell_tp == 64 || args.ell_tp == 128 || args.ell_tp == 256 || args.ell_tp == 512, "h_step: sparse store tile_px=%d must be 64, 128, 256 or 512", args.ell_tp);
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {
-    case 1: return launch_h_ell_k<1>(args, nblk, stream);
-    case 2: return launch_h_ell_k<2>(args, nblk, stream);
-    case 3: return launch_h_ell_k<3>(args, nblk, stream);
-    case 4: return launch_h_ell_k<4>(args, nblk, stream);
-    case 5: return launch_h_ell_k<5>(args, nblk, stream);
-    case 6: return launch_h_ell_k<6>(args, nblk, stream);
-    case 7: return launch_h_ell_k<7>(args, nblk, stream);
-    case 8: return launch_h_ell_k<8>(args, nblk, stream);
+#if ESPM_MIN_K <= 8   // (the LDS table holds rows of at most 8 floats: the wide build has no sparse store)
+#define ESPM_X(KK) case KK: return launch_h_ell_k<KK>(args, nblk, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
+#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built", args.k);
 }
@@ -95,14 +92,11 @@ int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell && args.ell_off && args.chan_perm && args.n_cg >= 1, "w_accum: the sparse store needs ell_w, ell_w_off, chan_perm");
   ESPM_REQUIRE(nblk == (args.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB, "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, ESPM_ELL_PB);
   switch (k) {
-    case 1: return launch_w_ell_k<1>(args, nblk, stream);
-    case 2: return launch_w_ell_k<2>(args, nblk, stream);
-    case 3: return launch_w_ell_k<3>(args, nblk, stream);
-    case 4: return launch_w_ell_k<4>(args, nblk, stream);
-    case 5: return launch_w_ell_k<5>(args, nblk, stream);
-    case 6: return launch_w_ell_k<6>(args, nblk, stream);
-    case 7: return launch_w_ell_k<7>(args, nblk, stream);
-    case 8: return launch_w_ell_k<8>(args, nblk, stream);
+#if ESPM_MIN_K <= 8
+#define ESPM_X(KK) case KK: return launch_w_ell_k<KK>(args, nblk, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
+#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built", k);
 }

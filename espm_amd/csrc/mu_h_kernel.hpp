@@ -198,9 +198,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         red[R_ROWSUM + kk] += (double)hn;
         red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
       }
-      float4* dstp = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
-      dstp[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
-      dstp[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+      store_row_kp(a.h_t + (size_t)q * KP, ht);
       continue;
     }
     if constexpr (quad) if (a.lambda_l != 0.f) {
@@ -230,9 +228,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         red[R_ROWSUM + kk] += (double)hn;
         red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
       }
-      float4* dstq = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
-      dstq[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
-      dstq[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+      store_row_kp(a.h_t + (size_t)q * KP, ht);
       continue;
     }
 #pragma unroll
@@ -259,9 +255,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       red[R_ROWSUM + kk] += (double)hn;
       red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
     }
-    float4* dst = reinterpret_cast<float4*>(a.h_t + (size_t)q * KP);
-    dst[0] = make_float4(ht[0], ht[1], ht[2], ht[3]);
-    dst[1] = make_float4(ht[4], ht[5], ht[6], ht[7]);
+    store_row_kp(a.h_t + (size_t)q * KP, ht);
   }
 
   __syncthreads();  // smem is reused as reduction scratch

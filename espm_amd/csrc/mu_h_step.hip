@@ -86,16 +86,11 @@ static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nbl
 
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
   switch (args.k) {
-    case 1: return dispatch_h_k<1>(args, x_dtype, tile_px, nblk, stream);
-    case 2: return dispatch_h_k<2>(args, x_dtype, tile_px, nblk, stream);
-    case 3: return dispatch_h_k<3>(args, x_dtype, tile_px, nblk, stream);
-    case 4: return dispatch_h_k<4>(args, x_dtype, tile_px, nblk, stream);
-    case 5: return dispatch_h_k<5>(args, x_dtype, tile_px, nblk, stream);
-    case 6: return dispatch_h_k<6>(args, x_dtype, tile_px, nblk, stream);
-    case 7: return dispatch_h_k<7>(args, x_dtype, tile_px, nblk, stream);
-    case 8: return dispatch_h_k<8>(args, x_dtype, tile_px, nblk, stream);
+#define ESPM_X(KK) case KK: return dispatch_h_k<KK>(args, x_dtype, tile_px, nblk, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
   }
-  return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built (1..%d)", args.k, ESPM_MAX_K);
+  return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built (%d..%d)", args.k, ESPM_MIN_K, ESPM_MAX_K);
 }
 
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream) {

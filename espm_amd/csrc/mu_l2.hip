@@ -14,22 +14,27 @@
 
 namespace espm {
 
-// out[a][b] = sum_r M[r][a] M[r][b] for M (rows, KP) fp32, a, b < k.  Workgroup = 4 row groups x 64 (a, b) pairs;
-// partials [KP * KP][nblk] doubles, then one workgroup sums them in fixed order.
+// out[a][b] = sum_r M[r][a] M[r][b] for M (rows, KP) fp32, a, b < k.  Workgroup = GRAM_GROUPS row groups x KP * KP
+// (a, b) pairs; partials [KP * KP][nblk] doubles, then one workgroup sums them in fixed order.
+constexpr int GRAM_PAIRS = KP * KP, GRAM_GROUPS = 256 / GRAM_PAIRS;   // 64 x 4, or 256 x 1 in the wide build
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ m, int rows, int k, double* __restrict__ part) {
-  __shared__ double s[4][KP * KP];
-  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  __shared__ double s[GRAM_GROUPS][GRAM_PAIRS];
+  const int e = threadIdx.x % GRAM_PAIRS, grp = threadIdx.x / GRAM_PAIRS;
   const int ia = e / KP, ib = e % KP;
   double acc = 0.0;
   if (ia < k && ib < k) {
-    for (int r = blockIdx.x * 4 + grp; r < rows; r += gridDim.x * 4)
+    for (int r = blockIdx.x * GRAM_GROUPS + grp; r < rows; r += gridDim.x * GRAM_GROUPS)
       acc += (double)m[(size_t)r * KP + ia] * (double)m[(size_t)r * KP + ib];
   }
   s[grp][e] = acc;
   __syncthreads();
-  if (grp == 0) part[(size_t)e * gridDim.x + blockIdx.x] = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+  if (grp == 0) {
+    double t = s[0][e];
+    if constexpr (GRAM_GROUPS == 4) t = (s[0][e] + s[1][e]) + (s[2][e] + s[3][e]);
+    part[(size_t)e * gridDim.x + blockIdx.x] = t;
+  }
 }
-__global__ __launch_bounds__(64) void gram_sum_kernel(const double* __restrict__ part, int nblk, float* __restrict__ out) {
+__global__ __launch_bounds__(GRAM_PAIRS) void gram_sum_kernel(const double* __restrict__ part, int nblk, float* __restrict__ out) {
   const int e = threadIdx.x;
   double t = 0.0;
   for (int b = 0; b < nblk; ++b) t += part[(size_t)e * nblk + b];
@@ -44,7 +49,7 @@ int launch_gram(const float* m, int rows, int k, double* part, int part_cap, flo
   if (nblk > 256) nblk = 256;
   if (nblk < 1) nblk = 1;
   hipLaunchKernelGGL(gram_partial_kernel, dim3(nblk), dim3(256), 0, stream, m, rows, k, part);
-  hipLaunchKernelGGL(gram_sum_kernel, dim3(1), dim3(64), 0, stream, part, nblk, out);
+  hipLaunchKernelGGL(gram_sum_kernel, dim3(1), dim3(GRAM_PAIRS), 0, stream, part, nblk, out);
   return check_hip(hipGetLastError(), "gram launch");
 }
 

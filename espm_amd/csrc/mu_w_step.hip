@@ -316,7 +316,7 @@ __device__ __forceinline__ float load_a(const WFinishArgs& a, int kk, int c) {
 template <int KK, int WF_ROWS>
 __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinishArgs a) {
   constexpr int KA = KK;  // per-thread arrays are sized by the real component count (k == KK)
-  __shared__ double scratch[(WF_THREADS / 64 + 1) * 8];
+  __shared__ double scratch[(WF_THREADS / 64 + 1) * KP];
   __shared__ double s_lo[KA], s_hi[KA], s_mid[KA];
   __shared__ int s_go;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // G given: [M*k] new W, [M*k] G^T A
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     for (int kk = 0; kk < KA; ++kk) wn[r][kk] = 0.f;
 
   if (a.update_w) {
-    if (a.g && a.g_t && MK <= WF_GTA_PAR) {
+    if (KA <= 8 && a.g && a.g_t && MK <= WF_GTA_PAR) {   // (the packed sum below is laid out for 4 rows x 8 components)
       // G^T A with the association G^T (R H^T), updates.py:58-59, with every thread busy: thread = channel
       // (its k entries of A in registers), G^T rows read coalesced, the products of a wave summed across its lanes
       // and the per-wave partials by the workgroup.  s_part lives behind s_gta.
@@ -583,9 +583,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       }
     }
     if (c < a.n_pad) {
-      float4* dst = reinterpret_cast<float4*>(a.gw_s + (size_t)c * espm::KP);
-      dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-      dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+      espm::store_row_kp(a.gw_s + (size_t)c * espm::KP, row);
     }
   };
   const int n_rows = a.n_pad;
@@ -758,9 +756,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
       }
       row[kk] = v;
     }
-    float4* dst = reinterpret_cast<float4*>(a.gw_s + (size_t)c * KP);
-    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+    store_row_kp(a.gw_s + (size_t)c * KP, row);
   }
   block_reduce<KP, KP>(cs, scratch);
   if (tid == 0)
@@ -789,16 +785,11 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
 
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream) {
   switch (k) {
-    case 1: return dispatch_w_k<1>(args, x_dtype, nblk, stream);
-    case 2: return dispatch_w_k<2>(args, x_dtype, nblk, stream);
-    case 3: return dispatch_w_k<3>(args, x_dtype, nblk, stream);
-    case 4: return dispatch_w_k<4>(args, x_dtype, nblk, stream);
-    case 5: return dispatch_w_k<5>(args, x_dtype, nblk, stream);
-    case 6: return dispatch_w_k<6>(args, x_dtype, nblk, stream);
-    case 7: return dispatch_w_k<7>(args, x_dtype, nblk, stream);
-    case 8: return dispatch_w_k<8>(args, x_dtype, nblk, stream);
+#define ESPM_X(KK) case KK: return dispatch_w_k<KK>(args, x_dtype, nblk, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
   }
-  return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built (1..%d)", k, ESPM_MAX_K);
+  return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built (%d..%d)", k, ESPM_MIN_K, ESPM_MAX_K);
 }
 
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
@@ -907,14 +898,9 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   if (rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
     const size_t lds = args.g ? (size_t)mk * sizeof(float) * (2 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0)) : 0;
     switch (args.k) {
-      case 1: launch_fast<1>(args, rows, lds, stream); break;
-      case 2: launch_fast<2>(args, rows, lds, stream); break;
-      case 3: launch_fast<3>(args, rows, lds, stream); break;
-      case 4: launch_fast<4>(args, rows, lds, stream); break;
-      case 5: launch_fast<5>(args, rows, lds, stream); break;
-      case 6: launch_fast<6>(args, rows, lds, stream); break;
-      case 7: launch_fast<7>(args, rows, lds, stream); break;
-      case 8: launch_fast<8>(args, rows, lds, stream); break;
+#define ESPM_X(KK) case KK: launch_fast<KK>(args, rows, lds, stream); break;
+      ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
       default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
     }
   } else {

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MUState, check, lib
+from ._lib import MUState
 
 # the sparse count store is chosen (x_store='auto') when at most this fraction of X is non-zero
 ELL_MAX_DENSITY = 0.35
@@ -71,6 +71,8 @@ class MUEngine:
         dev = self.device
         k = int(n_components)
         self.k = k
+        self.V = _lib.variant(k)          # the build with the kernels for k components (1..8, or 9..16 on the dense stores)
+        self.lib, self._check = self.V.lib, self.V.check
 
         # ---- X to the device, zero lines, storage type ------------------------------------------
         Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
@@ -165,7 +167,7 @@ class MUEngine:
             if code == 2:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
-                fits = self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
+                fits = k <= _lib.MAX_K and self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
                 sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
@@ -176,7 +178,7 @@ class MUEngine:
                 set_empty(log_shift)
                 flag.fill_(0)      # (the fill is neither an integer nor a bf16 value)
             if x_store == "ell" and int(flag.item()) != 3:
-                raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS")
+                raise ValueError("x_store='ell' needs integer counts <= 255, k <= 8, n <= 16384 and a GW table that fits in LDS")
             refill = unfilled and int(flag.item()) == 3 and filled_channels is not None  # (the caller's tensor: put the fill back)
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
         if int(h_rule) != 0 and x_store in ("u8", "bf16"):
@@ -196,7 +198,7 @@ class MUEngine:
             st.nx, st.ny, st.grid_mode = nx, ny, 1
         else:
             st.nx, st.ny, st.grid_mode = 0, 0, 0
-        check(lib.espm_mu_query(C.byref(st)))
+        self._check(self.lib.espm_mu_query(C.byref(st)))
         p_total = torch.tensor([p], dtype=torch.int64, device=dev)
         if group is not None:
             torch.distributed.all_reduce(p_total, group=group)
@@ -223,7 +225,7 @@ class MUEngine:
             self.x_cm = torch.empty((st.p_pad // st.x_tile, st.n_cm, st.x_tile), dtype=xt, device=dev)
             self.x_pm = torch.empty((self.p, st.n_pad), dtype=xt, device=dev)
             Xd = Xd.contiguous()
-            check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
+            self._check(self.lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                      _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
                                      _ptr(self.x_cm), _ptr(self.x_pm), st.x_dtype, st.n_pad, st.p_pad, st.x_tile, st.n_cm, _stream()))
             self.x_bytes = self.x_cm.numel() * self.x_cm.element_size() + self.x_pm.numel() * self.x_pm.element_size()
@@ -270,12 +272,12 @@ class MUEngine:
         f64 = dict(dtype=torch.float64, device=dev)
         self.w = [torch.zeros((self.M, k), **f32) for _ in range(2)]
         self.h = [torch.ones((k, st.p_pad), **f32) for _ in range(2)]  # pad columns stay positive
-        self.h_t = torch.zeros((self.p, _lib.KP), **f32)
-        self.gw_s = torch.zeros((st.n_pad, _lib.KP), **f32)
-        self.colsum_gw = torch.zeros(_lib.KP, **f64)
+        self.h_t = torch.zeros((self.p, self.V.KP), **f32)
+        self.gw_s = torch.zeros((st.n_pad, self.V.KP), **f32)
+        self.colsum_gw = torch.zeros(self.V.KP, **f64)
         nblk_h = (self.p + st.tile_px - 1) // st.tile_px
-        self.hpart = torch.zeros((nblk_h, _lib.HP_STRIDE), **f64)
-        self.hstat = [torch.zeros(_lib.HS_STRIDE, **f64) for _ in range(2)]
+        self.hpart = torch.zeros((nblk_h, self.V.HP_STRIDE), **f64)
+        self.hstat = [torch.zeros(self.V.HS_STRIDE, **f64) for _ in range(2)]
         self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
         self.a = torch.zeros((k, st.n_pad), **f32)
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
@@ -332,7 +334,7 @@ class MUEngine:
         if self.world > 1:
             from .sharding import ShardExchange
             self.exchange = ShardExchange(group, k, st.n_pad, st.ny, bool(st.grid_mode and self.lambda_L != 0.0), dev)
-            if self.exchange.layout.nbytes != int(lib.espm_mu_shard_record_bytes(C.byref(st))):
+            if self.exchange.layout.nbytes != int(self.lib.espm_mu_shard_record_bytes(C.byref(st))):
                 raise RuntimeError("record layout of espm_amd.sharding and libespm_mu disagree")
 
     # ------------------------------------------------------------------------------------------------
@@ -342,26 +344,26 @@ class MUEngine:
         st, dev = self.st, self.device
         i32 = dict(dtype=torch.int32, device=dev)
         x8 = torch.empty((self.p, st.n_pad), dtype=torch.uint8, device=dev)
-        check(lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
+        self._check(self.lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                  _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
                                  None, _ptr(x8), _lib.X_U8, st.n_pad, st.p_pad, _lib.PPAD, st.n_cm, _stream()))
         cnt_px = torch.empty((2, st.p_pad), **i32)                    # entries, elements equal to 1
         cnt_bc = torch.empty((2, st.nblk_w, st.n_cg * 64), **i32)
         klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
-        check(lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
+        self._check(self.lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
         chan_perm = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
         pix_perm = torch.empty(st.p_pad, **i32)
         h_off = torch.empty(2 * (st.p_pad // 64) + 1, **i32)          # per group: first unit row, first general row
         w_off = torch.empty(2 * st.nblk_w * st.n_cg + 1, **i32)
         rows = torch.zeros(2, dtype=torch.int64, device=dev)
-        check(lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off),
+        self._check(self.lib.espm_mu_ell_plan(C.byref(st), _ptr(cnt_px), _ptr(cnt_bc), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off),
                                    _ptr(w_off), _ptr(rows), _stream()))
         rows_h, rows_w = (int(v) for v in rows.cpu())
         if max(rows_h, rows_w) * 64 >= 2 ** 31:
             raise ValueError("sparse count store: the lists exceed 2^31 dwords")
         ell_h = torch.zeros(max(rows_h, 1) * 64, **i32)
         ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
-        check(lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
+        self._check(self.lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
                                    _ptr(ell_h), _ptr(ell_w), _stream()))
         nnz = int((x8[:, :self.n] != 0).sum())
         torch.cuda.current_stream().synchronize()
@@ -392,8 +394,8 @@ class MUEngine:
         self.hist.zero_()
         self.w[0].copy_(torch.from_numpy(np.ascontiguousarray(W)))
         self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
-        check(lib.espm_mu_build_gw(C.byref(st), 0, _stream()))
-        check(lib.espm_mu_hstat(C.byref(st), 0, _stream()))
+        self._check(self.lib.espm_mu_build_gw(C.byref(st), 0, _stream()))
+        self._check(self.lib.espm_mu_hstat(C.byref(st), 0, _stream()))
         if self.world > 1:
             self._globalize_hstat(0)
             self._exchange_halo_only(0)
@@ -409,13 +411,13 @@ class MUEngine:
         self.g.copy_(torch.from_numpy(Gh))
         self.g_t[:, :self.n] = self.g.t()
         self.colsum_g.copy_(torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)))
-        check(lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
+        self._check(self.lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
 
     # ---- sharded helpers ---------------------------------------------------------------------------
     def _globalize_hstat(self, which):
         hs = self.hstat[which]
-        torch.distributed.all_reduce(hs[:_lib.HS_MAX], group=self.group)
-        torch.distributed.all_reduce(hs[_lib.HS_MAX:], op=torch.distributed.ReduceOp.MAX, group=self.group)
+        torch.distributed.all_reduce(hs[:self.V.HS_MAX], group=self.group)
+        torch.distributed.all_reduce(hs[self.V.HS_MAX:], op=torch.distributed.ReduceOp.MAX, group=self.group)
 
     def _set_halo_from_records(self):
         top, bot = self.exchange.halo_offsets()
@@ -425,7 +427,7 @@ class MUEngine:
 
     def _exchange_halo_only(self, which):
         """Boundary rows of h[which] to the neighbours (initial state only)."""
-        check(lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.exchange.send), _stream()))
+        self._check(self.lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.exchange.send), _stream()))
         self.exchange.gather()
         self._set_halo_from_records()
 
@@ -441,10 +443,10 @@ class MUEngine:
         if self.frobenius:
             self._frobenius_of_current()
         if advance_h:
-            check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+            self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
             self._pending_finalize = (st.cur, st.it)
         else:
-            check(lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+            self._check(self.lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
 
     def _frobenius_of_current(self, rows=32768):
         """||X - G W H||_F^2 of the current state (espm/measures.py:350-384) into its history slot: residual in fp32 over
@@ -467,9 +469,9 @@ class MUEngine:
         if self.m > 0 and getattr(self, "_gtg", None) is None:
             self._gtg = (self.g.double().t() @ self.g.double()).float().contiguous()
         s = _stream()
-        check(lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(self._gtg) if self.m > 0 else None, _ptr(work), _ptr(scratch),
+        self._check(self.lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(self._gtg) if self.m > 0 else None, _ptr(work), _ptr(scratch),
                                     scratch.numel(), s))
-        check(lib.espm_mu_build_gw(C.byref(st), 1 - cur, s))
+        self._check(self.lib.espm_mu_build_gw(C.byref(st), 1 - cur, s))
         wn, wo = self.w[1 - cur].double(), self.w[cur].double()
         self.hist[slot + 1, _lib.HI_REL_W] = ((wn - wo).abs() / (wn + self.rel_tol * wn.mean())).max()   # base.py:323
         st.cur, st.it = 1 - cur, slot + 1
@@ -478,7 +480,7 @@ class MUEngine:
         pend = getattr(self, "_pending_finalize", None)
         if pend is not None:
             self._pending_finalize = None
-            check(lib.espm_mu_h_finalize(C.byref(self.st), pend[0], pend[1], _stream()))
+            self._check(self.lib.espm_mu_h_finalize(C.byref(self.st), pend[0], pend[1], _stream()))
 
     def finish_iteration(self):
         """W-step with the H produced by ``eval_current`` and the bookkeeping; flips the buffers."""
@@ -489,7 +491,7 @@ class MUEngine:
         if self.frobenius:
             return self._finish_iteration_frobenius()
         s = _stream()
-        check(lib.espm_mu_w_accum(C.byref(st), s))
+        self._check(self.lib.espm_mu_w_accum(C.byref(st), s))
         ride = getattr(self, "_pending_finalize", None) == (cur, slot)   # the H-step's record reduction rides along
         if ride:
             self._pending_finalize = None
@@ -497,16 +499,16 @@ class MUEngine:
             self._flush_finalize()
         if self.world > 1:
             if ride:   # slab reduction + record reduction + this rank's record, one launch
-                check(lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, _ptr(self.exchange.send), s))
+                self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, _ptr(self.exchange.send), s))
             else:
-                check(lib.espm_mu_w_reduce(C.byref(st), s))
-                check(lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
+                self._check(self.lib.espm_mu_w_reduce(C.byref(st), s))
+                self._check(self.lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
             self.exchange.gather()
             # sum over the ranks + W update (one launch when W' needs nothing global, include/espm_mu.h)
-            check(lib.espm_mu_shard_combine_finish(C.byref(st), _ptr(self.exchange.recv), self.world, cur, slot, s))
+            self._check(self.lib.espm_mu_shard_combine_finish(C.byref(st), _ptr(self.exchange.recv), self.world, cur, slot, s))
             self._set_halo_from_records()
         else:
-            check(lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
+            self._check(self.lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
         st.cur, st.it = 1 - cur, slot + 1
 
     def linesearch_step(self, gamma):
@@ -521,13 +523,13 @@ class MUEngine:
             raise ValueError("linesearch needs a completed iteration")
         self._flush_finalize()
         if getattr(self, "_ls_out", None) is None:
-            self._ls_out = torch.zeros(4 + _lib.KP, dtype=torch.float64, device=self.device)
-        check(lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
+            self._ls_out = torch.zeros(4 + self.V.KP, dtype=torch.float64, device=self.device)
+        self._check(self.lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
         t = self._ls_out.cpu().numpy()
         if st.h_rule == 1:     # quadratic surrogate: sigma ||Ht - H||^2 (surrogates.py:6-58)
             t3 = float(t[3])
         else:                  # sigma sum_k max_j H_kj sum_j dgkl(Ht, H) (surrogates.py:65-114)
-            maxh = self.hstat[st.cur][_lib.HS_MAX:_lib.HS_MAX + self.k].cpu().numpy()   # max_j H[k, j] of the new H (global)
+            maxh = self.hstat[st.cur][self.V.HS_MAX:self.V.HS_MAX + self.k].cpu().numpy()   # max_j H[k, j] of the new H (global)
             t3 = float((maxh * t[4:4 + self.k]).sum())
         d = 0.5 * (2.0 * t[1] - t[0] + float(gamma) * t3) - 0.5 * t[2]
         gamma = float(gamma) / 1.05 if d > 0 else float(gamma) * 1.5
@@ -550,7 +552,7 @@ class MUEngine:
         t = st.it
         f_xt = float(self.history(upto=t, average=False)["loss"][t])   # (also reduces the H-step's records: pg_q[t][0])
         scratch = self.hist_len - 1
-        check(lib.espm_mu_loss_only(C.byref(st), 1 - st.cur, scratch, _stream()))   # state (W_t, H_{t+1})
+        self._check(self.lib.espm_mu_loss_only(C.byref(st), 1 - st.cur, scratch, _stream()))   # state (W_t, H_{t+1})
         self._pg_f_mid = self._loss_sum_of_slot(scratch)
         d = f_xt + float(self.pg_q[t, 0]) - self._pg_f_mid
         gamma_h = float(gamma_h) / 1.05 if d > 0 else float(gamma_h) * 1.5
@@ -575,7 +577,7 @@ class MUEngine:
             raise ValueError("history buffer exhausted: raise max_iter")
         self._flush_finalize()
         if self.world == 1 and not self.frobenius:
-            check(lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
+            self._check(self.lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
         else:
             for _ in range(int(n_iter)):
                 self.eval_current(True)
@@ -586,8 +588,8 @@ class MUEngine:
     # ---- single half steps for the module-level functions ----------------------------------------------
     def _l2_buffers(self):
         if getattr(self, "_l2_work", None) is None:
-            self._l2_work = torch.zeros((2, _lib.KP, _lib.KP), dtype=torch.float32, device=self.device)
-            self._l2_scratch = torch.zeros(64 * _lib.KP * _lib.KP, dtype=torch.float64, device=self.device)
+            self._l2_work = torch.zeros((2, self.V.KP, self.V.KP), dtype=torch.float32, device=self.device)
+            self._l2_scratch = torch.zeros(64 * self.V.KP * self.V.KP, dtype=torch.float64, device=self.device)
         return self._l2_work, self._l2_scratch
 
     def step_h_only(self, l2=False):
@@ -595,11 +597,11 @@ class MUEngine:
         self._flush_finalize()
         if l2:  # Frobenius branch, updates.py:109-118
             work, scratch = self._l2_buffers()
-            check(lib.espm_mu_l2_step_h(C.byref(st), st.cur, _ptr(work), _ptr(scratch), scratch.numel(), _stream()))
-            check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+            self._check(self.lib.espm_mu_l2_step_h(C.byref(st), st.cur, _ptr(work), _ptr(scratch), scratch.numel(), _stream()))
+            self._check(self.lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
             return self._h_numpy(1 - st.cur)
-        check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
-        check(lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
+        self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+        self._check(self.lib.espm_mu_h_finalize(C.byref(st), st.cur, st.it, _stream()))
         return self._h_numpy(1 - st.cur)
 
     def step_w_only(self, l2=False):
@@ -615,12 +617,12 @@ class MUEngine:
             gtg = None
             if self.m > 0:
                 gtg = (self.g.double().t() @ self.g.double()).float().contiguous()   # G^T G (m, m): a constant of the fit
-            check(lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(gtg) if gtg is not None else None, _ptr(work), _ptr(scratch),
+            self._check(self.lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(gtg) if gtg is not None else None, _ptr(work), _ptr(scratch),
                                         scratch.numel(), s))
             return self.w[1 - cur].cpu().numpy()
-        check(lib.espm_mu_w_accum(C.byref(st), s))
-        check(lib.espm_mu_w_reduce(C.byref(st), s))
-        check(lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))
+        self._check(self.lib.espm_mu_w_accum(C.byref(st), s))
+        self._check(self.lib.espm_mu_w_reduce(C.byref(st), s))
+        self._check(self.lib.espm_mu_w_finish(C.byref(st), cur, cur, -1, s))
         return self.w[1 - cur].cpu().numpy()
 
     # ---- read-back -----------------------------------------------------------------------------------------

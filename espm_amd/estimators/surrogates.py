@@ -18,18 +18,17 @@ def _terms(Ht, H, L):
     Ht = np.asarray(Ht)
     H = np.asarray(H)
     k, p = Ht.shape
-    if k > _lib.KP:
-        raise NotImplementedError(f"k = {k} > {_lib.KP}")
+    V = _lib.variant(k)   # (raises beyond 16 components)
     kind, shape = classify_laplacian(L, p)
     dev = require_gpu()
     a = torch.from_numpy(np.ascontiguousarray(Ht, dtype=np.float32)).to(dev)
     b = torch.from_numpy(np.ascontiguousarray(H, dtype=np.float32)).to(dev)
-    nparts = (4 + _lib.KP) * ((p + 511) // 512)
+    nparts = (4 + V.KP) * ((p + 511) // 512)
     part = torch.zeros(nparts, dtype=torch.float64, device=dev)
-    out = torch.zeros(4 + _lib.KP, dtype=torch.float64, device=dev)
+    out = torch.zeros(4 + V.KP, dtype=torch.float64, device=dev)
     grid = 0 if kind == "identity" else 1
     nx, ny = (0, 0) if kind == "identity" else shape
-    _lib.check(_lib.lib.espm_surrogate_terms(_ptr(a), _ptr(b), k, p, p, int(nx), int(ny), grid, _ptr(part), nparts, _ptr(out), _stream()))
+    V.check(V.lib.espm_surrogate_terms(_ptr(a), _ptr(b), k, p, p, int(nx), int(ny), grid, _ptr(part), nparts, _ptr(out), _stream()))
     t = out.cpu().numpy()
     return t[0], t[1], t[2], t[3], t[4:4 + k]
 

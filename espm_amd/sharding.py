@@ -22,7 +22,9 @@ from dataclasses import dataclass
 
 import torch
 
-HS_STRIDE = 16  # ESPM_HS_STRIDE
+def hs_stride(k: int) -> int:
+    """ESPM_HS_STRIDE of the build that serves k components (2 KP: KP = 8 up to 8 components, else 16)."""
+    return 16 if k <= 8 else 32
 
 
 def split_rows(nx: int, world: int, rank: int):
@@ -55,7 +57,7 @@ def record_layout(k: int, n_pad: int, ny: int) -> RecordLayout:
     """Byte layout of one rank's record (same arithmetic as espm_mu_shard_record_bytes)."""
     na = k * n_pad
     off_hstat = na * 4
-    off_top = off_hstat + HS_STRIDE * 8
+    off_top = off_hstat + hs_stride(k) * 8
     row = k * max(ny, 0) * 4
     off_bot = off_top + row
     nbytes = (off_bot + row + 15) // 16 * 16
@@ -99,7 +101,7 @@ class ShardExchange:
         lay = self.layout
         base = r * lay.nbytes
         a = buf[base + lay.off_a: base + lay.off_a + lay.na * 4].view(torch.float32)
-        hs = buf[base + lay.off_hstat: base + lay.off_hstat + HS_STRIDE * 8].view(torch.float64)
+        hs = buf[base + lay.off_hstat: base + lay.off_hstat + hs_stride(lay.k) * 8].view(torch.float64)
         row = lay.k * lay.ny * 4
         top = buf[base + lay.off_top: base + lay.off_top + row].view(torch.float32).view(lay.k, max(lay.ny, 0))
         bot = buf[base + lay.off_bot: base + lay.off_bot + row].view(torch.float32).view(lay.k, max(lay.ny, 0))

@@ -72,8 +72,19 @@ enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1, ESPM_X_U8 = 2 /* integer counts <= 255 *
 enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
 enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
 
-#define ESPM_MAX_K 8       /* components supported by the built kernels */
-#define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP) */
+/* The library is built twice from the same sources: libespm_mu.so (1..8 components, the strides below = 8) and
+ * libespm_mu_wide.so (-DESPM_KP=16 -DESPM_MIN_K=9 -DESPM_MAX_K=16: 9..16 components on the dense stores; the
+ * sparse store's LDS table is laid out for rows of at most 8 floats).  Same entry points, same state struct; every
+ * size below that names KP follows the build. */
+#ifndef ESPM_KP
+#define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP): 8 or 16 */
+#endif
+#ifndef ESPM_MAX_K
+#define ESPM_MAX_K ESPM_KP /* components supported by the built kernels */
+#endif
+#ifndef ESPM_MIN_K
+#define ESPM_MIN_K 1
+#endif
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
 #define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
@@ -93,16 +104,16 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_HP_LAP 2      /* sum H_in * (H_in L)                                      */
 #define ESPM_HP_BAD 3      /* count of non-finite H_out entries                        */
 #define ESPM_HP_ROWSUM 4   /* [4, 4+KP): sum_j H_out[k, j]                             */
-#define ESPM_HP_MAX 12     /* [12, 12+KP): max_j H_out[k, j]                           */
-#define ESPM_HP_RELH 20    /* max |H_in - H_prev| / (H_in + tol mean H_in) over the block (base.py:324) */
-#define ESPM_HP_PGQ 21     /* projected-gradient rule only: sum <H' - H, grad> + gamma_H ||H' - H||^2 over the block   */
+#define ESPM_HP_MAX (4 + ESPM_KP)      /* [4+KP, 4+2KP): max_j H_out[k, j]  (12 with KP = 8)           */
+#define ESPM_HP_RELH (4 + 2 * ESPM_KP) /* (20) max |H_in - H_prev| / (H_in + tol mean H_in) over the block (base.py:324) */
+#define ESPM_HP_PGQ (5 + 2 * ESPM_KP)  /* (21) projected-gradient rule only: sum <H' - H, grad> + gamma_H ||H' - H||^2 over the block */
 #define ESPM_HP_NSCALAR 5  /* KL, REG, LAP, BAD, RELH                                  */
-#define ESPM_HP_STRIDE 24
+#define ESPM_HP_STRIDE (8 + 2 * ESPM_KP) /* (24) */
 
 /* per-state statistics of one H buffer (doubles): produced by espm_mu_hstat / h_finalize */
 #define ESPM_HS_ROWSUM 0   /* [0, KP)  */
-#define ESPM_HS_MAX 8      /* [8, 16)  */
-#define ESPM_HS_STRIDE 16
+#define ESPM_HS_MAX ESPM_KP /* [KP, 2 KP)  */
+#define ESPM_HS_STRIDE (2 * ESPM_KP)
 
 /* history record per evaluated state (doubles) */
 #define ESPM_HI_KLX 0      /* xscale * sum X ln(X/Y)   (local pixels)                  */

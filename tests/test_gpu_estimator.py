@@ -330,6 +330,54 @@ def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m):
         MUEngine(Xp, k, G=prob["G"], shape_2d=(nx, ny), x_store="ell", **kw)
 
 
+@pytest.mark.parametrize("k,store,m,kw", [
+    (9, "u8", None, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),
+    (12, "f32", 20, dict(lambda_L=0.5, mu=0.05, simplex_H=True, simplex_W=False)),
+    (16, "u8", None, dict(lambda_L=1.0, simplex_H=False, simplex_W=True)),
+    (11, "bf16", 14, dict(lambda_L=0.0, simplex_H=False, simplex_W=True)),
+    (16, "f32", None, dict(lambda_L=0.3, simplex_H=True, simplex_W=False, fixed=True)),
+    (10, "u8", None, dict(lambda_L=0.0, simplex_H=False, simplex_W=False)),
+])
+def test_nine_to_sixteen_components(k, store, m, kw):
+    """More than 8 components run on the second build of the library (libespm_mu_wide.so: component stride 16, dense
+    stores): engine against the fp64 oracle with simplex over H or W, a dictionary G, mu, the Laplacian and fixed_H."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    kw = dict(kw)
+    n, nx, ny = 150, 19, 23
+    prob = synth.make_problem(n, nx, ny, k, N=120.0, seed=k, m=m)
+    X = np.minimum(synth.sample_numpy(prob, seed=k), 255.0)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    if store == "f32":
+        X = X * 0.37
+    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=k, scale=0.2)
+    fixed_H = None
+    if kw.pop("fixed", False):
+        fixed_H = -np.ones((k, nx * ny))
+        fixed_H[k - 1, ::3] = 0.05
+    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                 max_iter=6, tol=0, fixed_H=fixed_H, **kw)
+    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=6, tol=0, fixed_H=fixed_H, x_store="auto" if store == "f32" else store, **kw)
+    assert eng.x_store == store and eng.V.KP == 16
+    eng.load_state(W0, H0)
+    eng.iterate(6, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(h["rel_H"][1:], ref["rel"][:, 1], rtol=1e-3, atol=1e-5)
+    We, He = eng.get_W().astype(np.float64), eng.get_H().astype(np.float64)
+    if not kw["simplex_H"] and not kw["simplex_W"]:
+        We, He = oc.rescaled_DH(We, He)   # base.py:399-400: what the fit loop returns without a simplex
+    np.testing.assert_allclose(He, ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(We, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
+    with pytest.raises(ValueError):
+        MUEngine(np.round(X), k, shape_2d=(nx, ny), x_store="ell")     # the sparse store is built for k <= 8
+
+
 def test_sparse_store_is_chosen_for_sparse_counts_only():
     from espm_amd import synth
     from espm_amd.engine import MUEngine
@@ -392,7 +440,7 @@ def test_one_dimensional_spectrum_fit(SmoothNMF):
 def test_k_above_build_limit_is_refused(SmoothNMF):
     X = np.random.default_rng(0).random((20, 30))
     with pytest.raises(NotImplementedError):
-        quiet(SmoothNMF(n_components=9, verbose=0, max_iter=2).fit, X)
+        quiet(SmoothNMF(n_components=17, verbose=0, max_iter=2).fit, X)
 
 
 @pytest.mark.parametrize("case", ["all_ones", "no_ones", "wide", "ones_and_bright"])

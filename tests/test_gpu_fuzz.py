@@ -12,11 +12,11 @@ from oracle import mu_oracle as oc
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed):
-    rng = np.random.default_rng(1000 + seed)
+def _case(seed, wide=False):
+    rng = np.random.default_rng((5000 if wide else 1000) + seed)
     n = int(rng.integers(20, 260))
     nx, ny = int(rng.integers(3, 18)), int(rng.integers(3, 18))
-    k = int(rng.integers(1, 9))
+    k = int(rng.integers(9, 17)) if wide else int(rng.integers(1, 9))   # 9..16: the second build of the library
     p = nx * ny
     algo = ["log_surrogate", "log_surrogate", "bmd", "l2_surrogate", "projected_gradient"][seed % 5]
     use_G = algo != "bmd" and rng.random() < 0.45
@@ -66,8 +66,16 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_CASES", "36"))))
 def test_random_configuration_matches_oracle(seed):
+    _run(_case(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_WIDE_CASES", "20"))))
+def test_random_configuration_with_9_to_16_components_matches_oracle(seed):
+    _run(_case(seed, wide=True), seed)
+
+
+def _run(c, seed):
     from espm_amd.estimators import SmoothNMF
-    c = _case(seed)
     iters = 6
     try:
         ref = oc.fit(c["X"], c["k"], G=c["G"], W=c["W0"].copy(), H=c["H0"].copy(), shape_2d=c["shape"], algo=c["algo"], tol=0,

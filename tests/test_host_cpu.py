@@ -32,17 +32,29 @@ def _declared_functions():
 def test_every_declared_symbol_is_exported_and_bound(lib):
     declared = _declared_functions()
     assert len(declared) >= 18
-    cdll = C.CDLL(lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(cdll, name), f"{name} declared in espm_mu.h but not exported"
-        assert name in lib.SYMBOLS, f"{name} has no ctypes prototype in espm_amd/_lib.py"
+    for path in (lib.LIB_PATH, lib.WIDE_LIB_PATH):   # both builds of the sources: 1..8 and 9..16 components
+        cdll = C.CDLL(path)
+        for name in declared:
+            assert hasattr(cdll, name), f"{name} declared in espm_mu.h but not exported by {path}"
+            assert name in lib.SYMBOLS, f"{name} has no ctypes prototype in espm_amd/_lib.py"
     assert sorted(lib.SYMBOLS) == declared
     assert b"gfx950" in lib.lib.espm_mu_version()
+    wide = lib.variant(12)
+    assert wide.lib is not lib.lib and (wide.KP, wide.HP_STRIDE, wide.HS_STRIDE, wide.HS_MAX) == (16, 40, 32, 16)
+    assert lib.variant(8).lib is lib.lib
+    with pytest.raises(NotImplementedError):
+        lib.variant(17)
 
 
 def test_header_constants_and_struct_match_ctypes(lib):
     text = open(HEADER).read()
-    defs = dict(re.findall(r"#define\s+(ESPM_[A-Z_]+)\s+(-?\d+)", text))
+    raw = dict(re.findall(r"#define\s+(ESPM_[A-Z_]+)\s+(\(?[-+*0-9A-Z_ ]+\)?)\s*(?:/\*|$)", text, flags=re.M))
+
+    def value(name, depth=0):   # integer #defines, or arithmetic over other #defines (the sizes that follow ESPM_KP)
+        expr = re.sub(r"ESPM_[A-Z_]+", lambda m: str(value(m.group(0), depth + 1)), raw[name])
+        assert depth < 4 and re.fullmatch(r"[-+*0-9 ()]+", expr), (name, expr)
+        return int(eval(expr))
+    defs = {name: value(name) for name in raw}
     for name, val in (("MAX_K", lib.MAX_K), ("KP", lib.KP), ("PPAD", lib.PPAD), ("NPAD", lib.NPAD),
                       ("HP_STRIDE", lib.HP_STRIDE), ("HS_STRIDE", lib.HS_STRIDE), ("HI_STRIDE", lib.HI_STRIDE),
                       ("HS_MAX", lib.HS_MAX), ("HI_KLX", lib.HI_KLX), ("HI_REG", lib.HI_REG), ("HI_LAP", lib.HI_LAP),

@@ -148,12 +148,14 @@ def test_record_layout_matches_the_library():
     import __graft_entry__ as ge
     ge.build()
     from espm_amd import _lib
-    for n, k, ny, p in ((2048, 5, 512, 512 * 64), (1980, 8, 1024, 1024 * 128), (100, 3, 20, 400), (7, 1, 0, 1)):
+    for n, k, ny, p in ((2048, 5, 512, 512 * 64), (1980, 8, 1024, 1024 * 128), (100, 3, 20, 400), (7, 1, 0, 1),
+                        (2048, 12, 512, 512 * 64), (300, 16, 30, 900)):   # (9..16 components: the wide build's statistics block)
         st = _lib.MUState()
         st.n, st.p, st.k, st.ny, st.x_dtype = n, p, k, ny, 1
-        assert _lib.lib.espm_mu_query(C.byref(st)) == 0
+        lib = _lib.variant(k).lib
+        assert lib.espm_mu_query(C.byref(st)) == 0
         lay = sharding.record_layout(k, st.n_pad, ny)
-        assert lay.nbytes == _lib.lib.espm_mu_shard_record_bytes(C.byref(st))
+        assert lay.nbytes == lib.espm_mu_shard_record_bytes(C.byref(st))
         assert lay.off_hstat % 8 == 0 and lay.off_top % 4 == 0 and lay.nbytes % 16 == 0
 
 
