@@ -106,7 +106,7 @@ int espm_mu_query(espm_mu_state* st) {
     return ESPM_OK;
   }
   // W accumulation: about 2 workgroups per CU, at least 16 pixels each.
-  const int ychunks = st->x_dtype != ESPM_X_F32 ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
+  const int ychunks = (st->x_dtype != ESPM_X_F32 && ESPM_MIN_K <= 8) ? (st->n_pad + 2047) / 2048 : (st->n_pad + 1023) / 1024;
   int target = (2 * cus + ychunks - 1) / ychunks;
   int by_px = (st->p + 15) / 16;
   int nb = target < by_px ? target : by_px;

@@ -288,7 +288,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 // L2: the Frobenius branch (updates.py:109-118): num = GW^T X, no ratio, no loss; the epilogue takes the denominator
 // (GW^T GW) H from a.l2_m.
 template <int K, typename XT, int PX, int NW, bool LOSS, int U, int NBUF, bool L2 = false, int RULE = 0>
-__global__ __launch_bounds__(NW * 64) void h_step_kernel(const HStepArgs a) {
+__global__ __launch_bounds__(NW * 64, (K > 12 && NW == 4) ? 2 : 1) void h_step_kernel(const HStepArgs a) {   // (k > 12: two workgroups per CU, <= 256 registers)
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   constexpr int TP = 64 * PX;
   const int lane = threadIdx.x & 63;

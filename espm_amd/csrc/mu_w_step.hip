@@ -767,12 +767,14 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
 template <int K>
 static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream_t stream) {
   if (args.l2 && x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "the l2 W accumulation needs the f32 store");
+  // channels per lane: 8 up to 8 components; 4 beyond (8 x k accumulators and 8 x k GW entries do not fit the registers)
+  constexpr int CH8 = K <= 8 ? 8 : 4;
   if (x_dtype == ESPM_X_U8) {
-    dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
-    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, 8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
+    dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
+    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, CH8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
   } else if (x_dtype == ESPM_X_BF16) {
-    dim3 grid(nblk, (args.n_pad + 4 * 64 * 8 - 1) / (4 * 64 * 8));
-    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, 8, 4, 0>), grid, dim3(256), 0, stream, args);
+    dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
+    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, CH8, 4, 0>), grid, dim3(256), 0, stream, args);
   } else {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 4 - 1) / (4 * 64 * 4));
     if (args.l2)
