@@ -13,13 +13,25 @@
 //   - row sums / row maxima of H' (updates.py:60, :139 of the NEXT half steps)
 #include "mu_h_kernel.hpp"
 
+// This file holds most of the library's kernel instantiations (component count x store x tile x rule); the build may
+// compile it ESPM_H_PARTS (<= 4) times, part ESPM_H_PART instantiating every ESPM_H_PARTS-th component count, so that
+// the parts compile side by side.  Part 0 carries everything that is not a template.
+#ifndef ESPM_H_PARTS
+#define ESPM_H_PARTS 1
+#define ESPM_H_PART 0
+#endif
+#define ESPM_CAT2(a, b) a##b
+#define ESPM_CAT(a, b) ESPM_CAT2(a, b)
+
 namespace espm {
 
+#if ESPM_H_PART == 0
 // ---- reduction of the per-workgroup records (one workgroup) ---------------------------------
 __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) {
   __shared__ double scratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
   h_finalize_body(a, scratch);
 }
+#endif
 
 // ---- dispatch ---------------------------------------------------------------------------------
 template <int K, typename XT, int PX, int NW, int U, int NBUF>
@@ -84,18 +96,48 @@ static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nbl
   return set_error(ESPM_EINVAL, "h_step: tile_px %d not available for x_dtype %d", tile_px, x_dtype);
 }
 
-int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
+template <int KK>
+static int dispatch_h_part_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
+  if constexpr ((KK - ESPM_MIN_K) % ESPM_H_PARTS == ESPM_H_PART) return dispatch_h_k<KK>(args, x_dtype, tile_px, nblk, stream);
+  else return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d belongs to another part of the build", KK);
+}
+
+int ESPM_CAT(dispatch_h_step_part, ESPM_H_PART)(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
   switch (args.k) {
-#define ESPM_X(KK) case KK: return dispatch_h_k<KK>(args, x_dtype, tile_px, nblk, stream);
+#define ESPM_X(KK) case KK: return dispatch_h_part_k<KK>(args, x_dtype, tile_px, nblk, stream);
     ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
   }
   return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built (%d..%d)", args.k, ESPM_MIN_K, ESPM_MAX_K);
 }
 
+#if ESPM_H_PART == 0
+int dispatch_h_step_part1(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
+int dispatch_h_step_part2(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
+int dispatch_h_step_part3(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
+
+int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
+  static_assert(ESPM_H_PARTS >= 1 && ESPM_H_PARTS <= 4, "ESPM_H_PARTS: 1..4");
+  if (args.k < ESPM_MIN_K || args.k > ESPM_MAX_K)
+    return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built (%d..%d)", args.k, ESPM_MIN_K, ESPM_MAX_K);
+  switch ((args.k - ESPM_MIN_K) % ESPM_H_PARTS) {
+#if ESPM_H_PARTS > 1
+    case 1: return dispatch_h_step_part1(args, x_dtype, tile_px, nblk, stream);
+#endif
+#if ESPM_H_PARTS > 2
+    case 2: return dispatch_h_step_part2(args, x_dtype, tile_px, nblk, stream);
+#endif
+#if ESPM_H_PARTS > 3
+    case 3: return dispatch_h_step_part3(args, x_dtype, tile_px, nblk, stream);
+#endif
+  }
+  return dispatch_h_step_part0(args, x_dtype, tile_px, nblk, stream);
+}
+
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream) {
   hipLaunchKernelGGL(h_finalize_kernel, dim3(1), dim3(256), 0, stream, args);
   return check_hip(hipGetLastError(), "h_finalize launch");
 }
+#endif
 
 }  // namespace espm
