@@ -1,6 +1,7 @@
 """Randomised parity sweep: every solver / option combination the GPU path accepts, on small random problems, against the
 fp64 oracle (which is pinned to the reference by the golden fixtures).  Seeded - the same 36 cases every run
-(ESPM_FUZZ_CASES=240 for a longer sweep: 238 pass, 2 are draws the reference itself refuses)."""
+(ESPM_FUZZ_CASES=400 ESPM_FUZZ_WIDE_CASES=200 for a longer sweep: a handful of draws are skipped - the reference's own
+bisection refuses them, or the drawn projected-gradient step sizes are unstable - and the rest pass)."""
 import contextlib
 import io
 
@@ -85,6 +86,10 @@ def _run(c, seed):
         pytest.skip("the reference's own bisection refuses this draw")
     if not np.isfinite(ref["losses"]).all():
         pytest.skip("the oracle itself diverges on this draw")
+    if c["algo"] == "projected_gradient" and (np.diff(ref["losses"]) > 0).any():
+        # step sizes 1 / gamma too long for this draw: the iterates jump (losses of 1e3, components thrown onto the clamp, after which
+        # rescaled_DH's least squares is degenerate): rounding differences are amplified without bound
+        pytest.skip("unstable projected-gradient step sizes in this draw")
     est = SmoothNMF(n_components=c["k"], G=c["G"], shape_2d=c["shape"], algo=c["algo"], tol=0, no_stop_criterion=True, max_iter=iters,
                     verbose=0, **c["kw"], **c["extra"])
     with contextlib.redirect_stdout(io.StringIO()):
