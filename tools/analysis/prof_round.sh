@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01g
+O=$R/gpurun_out/r01h
 mkdir -p $O
 cd $R && python bench.py > $O/bench_default.log 2>&1
 cd /tmp && export TMPDIR=/tmp
