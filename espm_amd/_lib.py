@@ -49,6 +49,7 @@ class MUState(C.Structure):
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
         ("ell_h", _vp), ("ell_h_off", _vp), ("ell_klc", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
         ("ell_cbits", _i32), ("n_cg", _i32), ("pix_perm", _vp), ("g_t", _vp), ("breg_sr_px", _vp), ("breg_sr_ch", _vp), ("h_rule", _i32), ("pg_gamma_w", _f32), ("pg_q", _vp),
+        ("ell_fill_px", _vp), ("ell_fill_num", _vp), ("ell_fill_n", _i32),
     ]
 
 

@@ -43,6 +43,8 @@ static int check_state(const espm_mu_state* st) {
                  "sparse count store: tile_px must be 64..%d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
                  ESPM_ELL_TILE, ESPM_ELL_PB);
   }
+  ESPM_REQUIRE(st->ell_fill_n >= 0 && (st->ell_fill_n == 0 || (st->x_dtype == ESPM_X_ELL && st->ell_fill_px && st->ell_fill_num)),
+               "ell_fill_n=%d needs the sparse store, ell_fill_px and ell_fill_num", st->ell_fill_n);
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
                "grid %d x %d does not match p=%d", st->nx, st->ny, st->p);
   ESPM_REQUIRE(st->xscale > 0.f, "xscale must be positive");
@@ -217,7 +219,15 @@ int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
 int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
-  if (st->x_dtype == ESPM_X_ELL) return launch_h_ell(make_h_args(st, src, write_h), nblk_h(st), static_cast<hipStream_t>(stream));
+  if (st->x_dtype == ESPM_X_ELL) {
+    HStepArgs a = make_h_args(st, src, write_h);
+    if (a.fill_num) {  // pixels without counts: the numerator of their log_shift fill first (include/espm_mu.h)
+      if (int rc = launch_ell_fill_num(st->gw_s, st->h[src], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad, st->log_shift,
+                                       st->ell_fill_num, static_cast<hipStream_t>(stream)))
+        return rc;
+    }
+    return launch_h_ell(a, nblk_h(st), static_cast<hipStream_t>(stream));
+  }
   return dispatch_h_step(make_h_args(st, src, write_h), st->x_dtype, st->tile_px, nblk_h(st),
                          static_cast<hipStream_t>(stream));
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dichotomy_kernel(const double* __restrict
     const double nn = num[(size_t)i * p + j], dd = den[(size_t)i * den_cols + (den_cols > 1 ? j : 0)];
     if (nn > 0) lo = fmax(lo, nn / 2 - (dd - dstar));
   }
-  double hi = 2.0 * k * nmax - dmin_all + dstar, x = lo, dxold = hi - lo;
+  double hi = 2.0 * k * nmax + (dstar - dmin_all), x = lo, dxold = hi - lo;   // (this order: tiny numerators next to large denominators)
   for (int it = 0; it < maxit; ++it) {
     double f = -1, fp = 0;
     for (int i = 0; i < k; ++i) {

@@ -259,7 +259,7 @@ __device__ __forceinline__ bool simplex_root(const T (&num)[K], const T (&den)[K
     e[i] = i < k ? den[i] - dstar : (T)1;
     if (i < k && num[i] > 0) lo = fmax(lo, num[i] / 2 - e[i]);
   }
-  T hi = (T)(2 * k) * nmax - dmin_all + dstar;  // dicotomy.py:49
+  T hi = (T)(2 * k) * nmax + (dstar - dmin_all);  // dicotomy.py:49 (in this order: numerators of 1e-13 must survive next to den ~ 30)
   // start at nu = 0 (delta = d*) when that lies inside the bracket: multiplicative updates sit close to their
   // fixed point, where sum_i num_i / den_i is already ~1; the safeguards below handle either side of the root
   T x = fmax(lo, fmin(dstar, hi)), dxold = hi - lo;
@@ -402,6 +402,8 @@ struct HStepArgs {
   const float* l2_m; // Frobenius branch: (KP, KP) GW^T GW, else null
   const float* breg_sr; // Bregman variant: per-pixel sums of the stored X (p_pad), else null
   int h_rule;        // 0: log surrogate (multiplicative_step_h), 1: quadratic surrogate (multiplicative_step_hq)
+  const float* fill_num;  // sparse store: numerators of the pixels that hold nothing but the fill (k, fill_n), else null
+  int fill_n;
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -550,6 +552,8 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.l2_m = nullptr;
   a.breg_sr = st->breg_sr_px;
   a.h_rule = st->h_rule;
+  a.fill_num = (st->x_dtype == ESPM_X_ELL && st->ell_fill_n > 0) ? st->ell_fill_num : nullptr;
+  a.fill_n = st->ell_fill_n;
   a.n_pad = st->n_pad;
   return a;
 }
@@ -582,6 +586,8 @@ int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
                     uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
+int launch_ell_fill_num(const float* gw_s, const float* h_in, const int32_t* fill_px, int fill_n, int n, int k, int p_pad, float fill,
+                        float* fill_num, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
                     hipStream_t stream);

@@ -101,4 +101,45 @@ int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built", k);
 }
 
+// Pixels without counts (include/espm_mu.h, ell_fill_*): numerator of the reference's log_shift fill,
+// fill * sum_c GW_c / (GW_c . H_pixel) over the n real channels (updates.py:127-132 restricted to that pixel column); one wave
+// per listed pixel, lanes over the channels, rows of gw_s straight from L2 (n x KP floats).
+__global__ __launch_bounds__(256) void ell_fill_num_kernel(const float* __restrict__ gw_s, const float* __restrict__ h_in,
+                                                           const int32_t* __restrict__ fill_px, int fill_n, int n, int k, int p_pad,
+                                                           float fill, float* __restrict__ fill_num) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= fill_n) return;   // (whole waves)
+  const int px = fill_px[idx];
+  float h[KP], s[KP];
+#pragma unroll
+  for (int kk = 0; kk < KP; ++kk) {
+    h[kk] = kk < k ? h_in[(size_t)kk * p_pad + px] : 0.f;
+    s[kk] = 0.f;
+  }
+  for (int c = lane; c < n; c += 64) {
+    float g[KP], y = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      g[kk] = gw_s[(size_t)c * KP + kk];
+      if (kk < k) y = fmaf(g[kk], h[kk], y);
+    }
+    const float r = 1.f / y;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) s[kk] = fmaf(g[kk], r, s[kk]);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KP; ++kk) {
+    const float t = wave_sum(s[kk]);
+    if (lane == 0 && kk < k) fill_num[(size_t)kk * fill_n + idx] = fill * t;
+  }
+}
+
+int launch_ell_fill_num(const float* gw_s, const float* h_in, const int32_t* fill_px, int fill_n, int n, int k, int p_pad, float fill,
+                        float* fill_num, hipStream_t stream) {
+  hipLaunchKernelGGL(ell_fill_num_kernel, dim3((fill_n + 3) / 4), dim3(256), 0, stream, gw_s, h_in, fill_px, fill_n, n, k, p_pad, fill,
+                     fill_num);
+  return check_hip(hipGetLastError(), "ell_fill_num launch");
+}
+
 }  // namespace espm

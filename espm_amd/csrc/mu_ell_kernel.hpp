@@ -259,7 +259,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HSte
     }
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) part[((size_t)slot * K + kk) * TP + lp] = acc[kk];
-    if (LOSS && slot == 0) kl += a.ell_klc[px];
+    if (LOSS && slot == 0) kl += fmaxf(a.ell_klc[px], 0.f);   // (negative: the mark of a pixel without counts, no constant)
   };
   auto group_rows = [&](int gi) { return a.ell_off[2 * (tile0 / 64 + gi) + 2] - a.ell_off[2 * (tile0 / 64 + gi)]; };
 

@@ -95,6 +95,14 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       nv[kk] = s * a.xscale;
       dv[kk] = (float)a.colsum_gw[kk];
     }
+    if (a.fill_num) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
+      const float mark = a.ell_klc[q];
+      if (mark < 0.f) {
+        const int idx = (int)(-mark) - 1;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) nv[kk] += a.fill_num[(size_t)kk * a.fill_n + idx] * a.xscale;
+      }
+    }
     if (a.breg_sr) {  // Bregman variant, updates.py:120-125: num = sR / H, denum = colsum(GW) - GW^T (X / GWH) + sR / H
       const float sr = a.xscale * a.breg_sr[q];
 #pragma unroll

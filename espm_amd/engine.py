@@ -63,7 +63,7 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None, frobenius=False):
+                 filled_channels=None, filled_pixels=None, frobenius=False):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -99,6 +99,11 @@ class MUEngine:
             empty_ch = torch.as_tensor(filled_channels, dtype=torch.bool).to(dev)
             if empty_ch.shape != (self.n,):
                 raise ValueError("filled_channels must be a boolean mask over the n channels")
+        empty_px = None   # (and the pixels without counts, local to the rank)
+        if filled_pixels is not None:
+            empty_px = torch.as_tensor(filled_pixels, dtype=torch.bool).to(dev)
+            if empty_px.shape != (self.p,):
+                raise ValueError("filled_pixels must be a boolean mask over the p pixels")
         if fix_zero_lines:
             # all-zero channels / pixels become log_shift, base.py:519-528 (channel sums are global)
             ch_sum = Xd.sum(dim=px_axis, dtype=torch.float64)
@@ -108,7 +113,7 @@ class MUEngine:
             zc, zp = ch_sum == 0, px_sum == 0
             if bool(zc.any()) or bool(zp.any()):
                 Xd = Xd.clone()
-                empty_ch = zc
+                empty_ch, empty_px = zc, zp
                 if layout == "cm":
                     Xd[:, zp] = log_shift
                     Xd[zc, :] = log_shift
@@ -145,10 +150,12 @@ class MUEngine:
         refill = False
 
         def set_empty(v):
-            if layout == "cm":
-                Xd[empty_ch, :] = v
-            else:
-                Xd[:, empty_ch] = v
+            for mask, axis in ((empty_px, px_axis), (empty_ch, ch_axis)):   # (the reference's order, base.py:524-525)
+                if mask is not None:
+                    if axis == 0:
+                        Xd[mask, :] = v
+                    else:
+                        Xd[:, mask] = v
         if x_store in ("auto", "ell"):
             # u8 / ell: integer counts <= 255.  All-zero channels / pixels were filled with 1e-14 above (base.py:519-528),
             # which is not an integer: such data keep the bf16 store and the reference's exact semantics.
@@ -156,9 +163,12 @@ class MUEngine:
             # fits in LDS; the decision is taken jointly by all ranks.
             # Channels that are empty in the whole image (common in measured spectra: the bins below the detector's
             # threshold and above the beam energy) do not cost the sparse store: their fill of log_shift = 1e-14 counts
-            # per bin moves W, H and the loss by O(1e-14) and is left out of the lists (DESIGN.md section 6); without
-            # the sparse store the fill stays, as in the reference.
-            unfilled = empty_ch is not None and not self.bregman and bool(empty_ch.any())
+            # per bin moves W, H and the loss by O(1e-14) and is left out of the lists (DESIGN.md section 3); without
+            # the sparse store the fill stays, as in the reference.  Pixels without a single count (holes, vacuum, low
+            # dose) keep empty lists too: what their fill contributes to W and to the loss is of the same order, but under
+            # simplex_H it alone decides their column of H - the H-step adds its numerator (include/espm_mu.h, ell_fill_*).
+            unfilled = (not self.bregman and ((empty_ch is not None and bool(empty_ch.any()))
+                                              or (empty_px is not None and bool(empty_px.any()))))
             if unfilled:
                 set_empty(0)
             is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
@@ -179,7 +189,7 @@ class MUEngine:
                 flag.fill_(0)      # (the fill is neither an integer nor a bf16 value)
             if x_store == "ell" and int(flag.item()) != 3:
                 raise ValueError("x_store='ell' needs integer counts <= 255, k <= 8, n <= 16384 and a GW table that fits in LDS")
-            refill = unfilled and int(flag.item()) == 3 and filled_channels is not None  # (the caller's tensor: put the fill back)
+            refill = unfilled and int(flag.item()) == 3 and (filled_channels is not None or filled_pixels is not None)  # (the caller's tensor: put the fill back)
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
         if int(h_rule) != 0 and x_store in ("u8", "bf16"):
             x_store = "f32"   # the alternate H rules are built for the sparse and the fp32 store
@@ -206,6 +216,7 @@ class MUEngine:
         self.p_total = st.p_total
 
         self.ell = None
+        self.fill_px = self.fill_num = None
         if x_store == "ell":
             from . import ell as _ell
             self.x_cm = self.x_pm = None
@@ -214,6 +225,14 @@ class MUEngine:
             else:
                 self.ell = self._build_ell(Xd.contiguous(), layout)
             assert self.ell["n_cg"] == st.n_cg and self.ell["nblk_w"] == st.nblk_w
+            # pixels without counts: marked in the per-pixel loss constants, their fill's numerator has its own small pass
+            if empty_px is not None and bool(empty_px.any()):
+                idx = torch.nonzero(empty_px).flatten()
+                if idx.numel() >= 1 << 24:
+                    raise NotImplementedError("more than 2^24 pixels without counts")
+                self.fill_px = idx.to(torch.int32).contiguous()
+                self.fill_num = torch.zeros((k, idx.numel()), dtype=torch.float32, device=dev)
+                self.ell["klc"][idx] = -(torch.arange(idx.numel(), device=dev, dtype=torch.float32) + 1.0)
             self.x_bytes = 4 * (self.ell["ell_h"].numel() + self.ell["ell_w"].numel())
         else:
             xt = {"u8": torch.uint8, "bf16": torch.bfloat16, "f32": torch.float32}[x_store]
@@ -301,6 +320,8 @@ class MUEngine:
         else:
             st.x_cm = st.x_pm = None
             st.ell_h, st.ell_h_off, st.ell_klc = (self.ell[key].data_ptr() for key in ("ell_h", "ell_h_off", "klc"))
+            if self.fill_px is not None:
+                st.ell_fill_px, st.ell_fill_num, st.ell_fill_n = self.fill_px.data_ptr(), self.fill_num.data_ptr(), int(self.fill_px.numel())
             st.ell_w, st.ell_w_off, st.chan_perm = (self.ell[key].data_ptr() for key in ("ell_w", "ell_w_off", "chan_perm"))
             st.pix_perm = self.ell["pix_perm"].data_ptr()
         st.g = self.g.data_ptr() if self.g is not None else None

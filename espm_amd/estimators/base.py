@@ -94,7 +94,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None):
         from espm_amd.engine import MUEngine
 
         rows = None
@@ -113,7 +113,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
-                        fix_zero_lines=False, filled_channels=filled_channels, **self._engine_kwargs())
+                        fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -199,16 +199,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             assert_all_finite(Xv, input_name="X")
         self.const_KL_ = None
         xscale = 1.0
-        # (channels without a single count in the image: the engine's sparse store may leave their fill out)
+        # (channels / pixels without a single count in the image: the engine's sparse store leaves their fill out of its lists)
         if Xd is None:
             X_fixed = self.remove_zeros_lines(Xv, self.log_shift)
             mean_x = None
-            empty_ch = Xv.sum(axis=1) == 0
+            empty_ch, empty_px = Xv.sum(axis=1) == 0, Xv.sum(axis=0) == 0
         else:
             if bool((Xd < 0).any()):
                 raise ValueError("Negative values in data")
             zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
-            empty_ch = zc
+            empty_ch, empty_px = zc, zp
             if bool(zp.any()) or bool(zc.any()):
                 X_fixed = Xv.copy()
                 X_fixed[:, zp.cpu().numpy()] = self.log_shift
@@ -251,7 +251,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
 
         out_dtype = self.X_.dtype
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd, xscale, None if self._identity_G else self.G_,
-                                                filled_channels=empty_ch if bool(empty_ch.any()) else None)
+                                                filled_channels=empty_ch if bool(empty_ch.any()) else None,
+                                                filled_pixels=empty_px if bool(empty_px.any()) else None)
         del X_fixed, Xd
         eng.load_state(self.W_, self.H_)
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]

@@ -230,6 +230,15 @@ typedef struct espm_mu_state {
                                :438-447; surrogates.py:153-170).  [t][0] = sum <H' - H, grad_H> + gamma_H ||H' - H||^2 of
                                the H update that STARTS from state t (written by espm_mu_h_finalize(.., slot = t));
                                [t][1] = the same for the W update that PRODUCED state t.  The caller adds the losses. */
+  /* Sparse store, pixels without a single count.  The reference fills them with log_shift in every channel
+   * (base.py:519-528); under simplex_H that fill alone decides their column of H.  The lists stay empty for such a
+   * pixel; instead ell_klc[pixel] = -(1 + i) names entry i of ell_fill_px, and espm_mu_step_h first forms the fill's
+   * numerator log_shift * sum_c GW_c / (GW_c . H_pixel) of the ell_fill_n listed pixels into ell_fill_num
+   * (k, ell_fill_n), which the H-step's epilogue adds.  The fill's part in the W update and in the loss is O(log_shift)
+   * and is left out.  ell_fill_n = 0: no such pixel, both pointers may be NULL. */
+  const int32_t* ell_fill_px;
+  float* ell_fill_num;
+  int32_t ell_fill_n;
 } espm_mu_state;
 
 const char* espm_mu_version(void);

@@ -322,12 +322,6 @@ def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m):
                   max_iter=8, tol=0, normalize=True, **kw)
     np.testing.assert_allclose(est.losses_, refn["losses"], rtol=LOSS_RTOL)
     np.testing.assert_allclose(est.H_, refn["H"], rtol=2e-4, atol=2e-5)
-    # an empty pixel (or the Bregman variant's channel sums) keeps the reference's fill and a dense store
-    Xp = X.copy()
-    Xp[:, 5] = 0
-    assert MUEngine(Xp, k, G=prob["G"], shape_2d=(nx, ny), **kw).x_store == "f32"
-    with pytest.raises(ValueError):
-        MUEngine(Xp, k, G=prob["G"], shape_2d=(nx, ny), x_store="ell", **kw)
 
 
 @pytest.mark.parametrize("k,store,m,kw", [
@@ -376,6 +370,58 @@ def test_nine_to_sixteen_components(k, store, m, kw):
     assert h["bad"].sum() == 0
     with pytest.raises(ValueError):
         MUEngine(np.round(X), k, shape_2d=(nx, ny), x_store="ell")     # the sparse store is built for k <= 8
+
+
+@pytest.mark.parametrize("kw", [dict(simplex_H=True, simplex_W=False, mu=0.2, lambda_L=1.5), dict(simplex_H=True, simplex_W=False),
+                                dict(simplex_H=False, simplex_W=True, lambda_L=0.5), dict(simplex_H=False, simplex_W=False)])
+@pytest.mark.parametrize("m", [None, 6])
+def test_pixels_without_counts_keep_the_sparse_store(SmoothNMF, kw, m):
+    """Holes, vacuum and low doses leave pixels without a single count.  The reference fills them with log_shift in every
+    channel (base.py:519-528) and, under simplex_H, that fill alone decides their column of H.  The sparse store keeps
+    their lists empty and the H-step adds the fill's numerator from a small pass of its own (ell_fill_* in espm_mu.h).
+    Engine and estimator against the fp64 oracle, which fills like the reference; scattered pixels, a whole image row,
+    image corners, together with empty channels."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    n, nx, ny, k = 130, 18, 21, 4
+    prob = synth.make_problem(n, nx, ny, k, N=30.0, seed=8, m=m)
+    X = synth.sample_numpy(prob, seed=8)
+    X[0, X.sum(axis=0) == 0] = 1.0
+    X[:3] = 0                                 # empty channels as well
+    empty = np.zeros(nx * ny, dtype=bool)
+    empty[[0, ny - 1, nx * ny - 1, 100, 101, 233]] = True
+    empty[5 * ny:6 * ny] = True               # a whole image row
+    X[:, empty] = 0
+    W0, H0 = synth.random_init(m if m else n, k, nx * ny, seed=8, scale=0.2)
+    ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                 max_iter=8, tol=0, **kw)
+    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=8, tol=0, **kw)
+    assert eng.x_store == "ell" and int(eng.st.ell_fill_n) == int(empty.sum())
+    eng.load_state(W0, H0)
+    eng.iterate(8, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    We, He = eng.get_W().astype(np.float64), eng.get_H().astype(np.float64)
+    if not kw["simplex_H"] and not kw["simplex_W"]:
+        We, He = oc.rescaled_DH(We, He)
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(h["rel_H"][1:], ref["rel"][:, 1], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(He[:, ~empty], ref["H"][:, ~empty], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(He[:, empty], ref["H"][:, empty], rtol=5e-4, atol=5e-5)     # the columns the fill decides
+    np.testing.assert_allclose(We, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
+    if kw["simplex_H"]:
+        np.testing.assert_allclose(He[:, empty].sum(axis=0), 1.0, atol=1e-5)
+    est = SmoothNMF(n_components=k, G=prob["G"], shape_2d=(nx, ny), max_iter=8, tol=0, no_stop_criterion=True, verbose=0,
+                    normalize=True, **kw)
+    Xin = X.copy()
+    quiet(est.fit, Xin, W=W0.copy(), H=H0.copy())
+    assert est._engine.x_store == "ell" and (Xin == X).all()
+    refn = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
+                  max_iter=8, tol=0, normalize=True, **kw)
+    np.testing.assert_allclose(est.losses_, refn["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(est.H_, refn["H"], rtol=5e-4, atol=5e-5)
 
 
 def test_sparse_store_is_chosen_for_sparse_counts_only():

@@ -358,6 +358,25 @@ def test_gradients_and_q_step_golden(golden):
         gradH(X, G, W0, H0, lambda_L=1.0)
 
 
+def test_simplex_multiplier_with_tiny_numerators():
+    """All numerators ~1e-13 next to denominators ~30 (a pixel without counts: only the reference's log_shift fill feeds
+    its column, base.py:519-528): the bracket's upper end 2 k max(num) - min(den) + d* must not cancel to zero."""
+    from espm_amd.estimators.dicotomy import dichotomy_simplex
+    rng = np.random.default_rng(3)
+    num = rng.random((4, 50)) * 1e-13 + 1e-14
+    den = 25.0 + 10.0 * rng.random((4, 50))
+    nu = dichotomy_simplex(num, den, 1e-14, tol=1e-9)
+    # the root sits ~num_k* right of the pole -min(den) and nu (fp64) resolves that distance to ulp(30) = 3.6e-15 only - the
+    # reference has the same limit (test_host_cpu.py::test_reference_loses_the_simplex_next_to_a_pole); the H-step works with the
+    # distance itself.  Here: the distance returned is the numerator of the component at the pole, to that resolution.
+    dist = nu + den.min(axis=0)
+    k_star = np.argmin(den, axis=0)
+    assert np.all(dist > 0)
+    np.testing.assert_allclose(dist, num[k_star, np.arange(50)], atol=8e-15, rtol=0)
+    nu_ref = oc.dichotomy_simplex(num, den, 1e-14, tol=1e-12, maxit=200)
+    np.testing.assert_allclose(nu, nu_ref, atol=8e-15, rtol=0)
+
+
 def test_other_multipliers_known_answers(golden):
     """dichotomy_simplex_acc and dichotomy_simplex_projected_gradient as module-level functions: the reference's root of
     fixture F11, the defining equations, and the reference's own checks (espm/tests/test_updates.py:251-437, :675-731)."""
