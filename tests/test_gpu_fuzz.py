@@ -62,6 +62,15 @@ def _case(seed, wide=False):
         fH = -np.ones((k, p))
         fH[0, ::4] = 0.2
         extra["fixed_H"] = fH
+    # empty lines (base.py:519-528: filled with log_shift by the reference; the sparse store keeps its lists empty): one draw
+    # in four has channels, one in four pixels without a single count (a generator of its own: the draws above stay as they were)
+    rz = np.random.default_rng(77000 + seed + (500 if wide else 0))
+    if rz.random() < 0.25:
+        X[rz.choice(n, size=int(rz.integers(1, 6)), replace=False), :] = 0
+    if rz.random() < 0.25 and algo != "bmd" and not (algo == "l2_surrogate" and kw["lambda_L"] == 0 and kw["simplex_H"]):
+        # (that combination is the classic rule with the reference's own bisection, which the oracle restates without the exact
+        #  root: next to the pole where an empty pixel's multiplier sits it is off by 1e-3, test_host_cpu.py::test_reference_loses_...)
+        X[:, rz.choice(p, size=int(rz.integers(1, max(2, p // 10))), replace=False)] = 0
     return dict(X=X, G=G, W0=W0, H0=H0, k=k, shape=(nx, ny), algo=algo, kw=kw, extra=extra, counts=counts)
 
 
