@@ -19,8 +19,10 @@ KW = dict(lambda_L=1.0, mu=0.1, simplex_H=True, simplex_W=False, tol=0.0)
 
 def _data():
     from espm_amd import synth
-    prob = synth.make_problem(N, NX, NY, K, N=120.0, seed=2)
+    prob = synth.make_problem(N, NX, NY, K, N=40.0, seed=2)
     X = synth.sample_numpy(prob, seed=2)
+    X[7] = 0                       # a channel without counts in the whole image, pixels without counts in two shards
+    X[:, [3, NY + 1, (NX - 1) * NY + 5]] = 0
     W0, H0 = synth.random_init(N, K, NX * NY, seed=2, scale=0.5)
     return X, W0, H0
 
@@ -56,6 +58,7 @@ def test_sharded_engine_matches_single_gpu(world):
     from espm_amd.engine import MUEngine
     X, W0, H0 = _data()
     eng = MUEngine(X, K, shape_2d=(NX, NY), max_iter=ITERS, device="cuda:0", **KW)
+    assert eng.x_store == "ell" and eng.st.ell_fill_n == 3    # the sparse store, with its pass for the pixels without counts
     eng.load_state(W0, H0)
     eng.iterate(ITERS, final_loss=True)
     torch.cuda.synchronize()
