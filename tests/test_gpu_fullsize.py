@@ -147,3 +147,37 @@ def test_other_solvers_on_full_tiles(algo):
     np.testing.assert_allclose(est.losses_, ref["losses"], rtol=1e-4)
     np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-3, atol=2e-3 * np.abs(ref["W"]).mean())
+
+
+def test_pixels_without_counts_at_full_size():
+    """A low dose (5 counts per pixel) leaves ~1700 of the 262144 pixels without a single count, and some channels too.  The
+    sparse store (lists walked in pairs at this size, the fill's numerator from its own pass) against the fp32 store, which
+    holds the reference's log_shift fill as data (base.py:519-528): three iterations, every column of H - the ones the fill
+    alone decides included - W and the loss."""
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(N, NX, NY, K, N=5.0, seed=0)
+    X = synth.sample_torch(prob, "cuda", seed=1000)
+    empty = (X.sum(dim=1) == 0).cpu().numpy()
+    assert 500 < empty.sum() < 5000
+    W0, H0 = synth.random_init(N, K, NX * NY, seed=0, scale=5.0 / N)
+    kw = dict(layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4)
+    out = {}
+    for store in ("auto", "f32"):
+        eng = MUEngine(X, K, x_store=store, **kw)
+        assert eng.x_store == ("ell" if store == "auto" else "f32")
+        if store == "auto":
+            assert int(eng.st.ell_fill_n) == int(empty.sum()) and eng.st.tile_px == 512
+        eng.load_state(W0, H0)
+        eng.iterate(3, final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        assert h["bad"].sum() == 0
+        out[store] = (eng.get_W(), eng.get_H(), h["loss"])
+        del eng
+    (Ws, Hs, ls), (Wd, Hd, ld) = out["auto"], out["f32"]
+    np.testing.assert_allclose(ls, ld, rtol=2e-6)
+    np.testing.assert_allclose(Hs[:, ~empty], Hd[:, ~empty], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(Hs[:, empty], Hd[:, empty], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(Hs[:, empty].sum(axis=0), 1.0, atol=1e-5)
+    np.testing.assert_allclose(Ws, Wd, rtol=2e-4, atol=2e-4 * np.abs(Wd).mean())
