@@ -337,16 +337,45 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
   ESPM_REQUIRE(st->it + n_iter < st->hist_len, "history too short: it=%d + %d >= %d", st->it, n_iter, st->hist_len);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // Sparse store with a local W update: the tail of the W update (column sums of G W', rel_W: one small workgroup, 8 us as
+  // a launch of its own) rides in the NEXT H-step's launch as an extra workgroup; that H-step sums the partial column sums
+  // itself, and the slab reduction that follows finds colsum_gw written.  The last tail is a launch of its own.
+  const bool defer = st->x_dtype == ESPM_X_ELL && w_update_is_local(st) && !(st->pg_q && st->pg_gamma_w > 0.f);
+  bool pending = false;
+  WTailArgs tail;
   for (int i = 0; i < n_iter; ++i) {
     const int cur = st->cur, slot = st->it;
     int rc;
-    if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
-    if ((rc = espm_mu_w_accum(st, stream))) return rc;
-    // slab reduction with the H-step's finalize riding in the same launch, then (or, when W' is local, in it) the W update
-    if ((rc = espm_mu_w_reduce_finish(st, cur, slot, 1, stream))) return rc;
+    if (defer) {
+      HStepArgs a = make_h_args(st, cur, 1);
+      if (a.fill_num && (rc = launch_ell_fill_num(st->gw_s, st->h[cur], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad,
+                                                  st->log_shift, st->ell_fill_num, s)))
+        return rc;
+      if (pending) {
+        a.cs_parts = tail.parts;
+        a.cs_nbk = tail.nbk;
+        a.tail_on = 1;
+        a.tail = tail;
+      }
+      if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
+      if ((rc = espm_mu_w_accum(st, stream))) return rc;
+      const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
+      if ((rc = launch_w_reduce_update(finish_args(st, cur, 1 - cur, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
+                                       st->nblk_w, st->a, st->hpart, nblk_h(st), nullptr, 0, nullptr, &fin, s, &tail)))
+        return rc;
+      pending = true;
+    } else {
+      if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
+      if ((rc = espm_mu_w_accum(st, stream))) return rc;
+      // slab reduction with the H-step's finalize riding in the same launch, then (or, when W' is local, in it) the W update
+      if ((rc = espm_mu_w_reduce_finish(st, cur, slot, 1, stream))) return rc;
+    }
     st->cur = 1 - cur;
     st->it = slot + 1;
   }
+  if (pending)
+    if (int rc = launch_w_update_tail(tail, s)) return rc;
   if (final_loss) return espm_mu_loss_only(st, st->cur, st->it, stream);
   return ESPM_OK;
 }

@@ -211,6 +211,72 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
   __syncthreads();
 }
 
+// ---- tail of the local W update: column sums of G W' and rel_W (base.py:323) from the partials and W', W -----------------
+// One workgroup of any size (a kernel of its own, or an extra workgroup of the next H-step, which then does not wait for
+// it: mu_ell_kernel.hpp).  `scratch`: (blockDim.x / 64 + 1) * (KP + 1) + 1 doubles.  HELD entries of W per thread are
+// requested up front, before the partials are reduced.
+struct WTailArgs {
+  const double* parts;
+  const float* w_old;
+  const float* w_new;
+  double* colsum_gw;
+  double* hist_slot;
+  double* pg_q;   // projected gradient: sum of the third row of partials goes here, else null
+  int n, k, nbk;
+  float rel_tol;
+};
+template <int HELD>
+__device__ __forceinline__ void w_tail_body(const WTailArgs& a, double* scratch) {
+  const int tid = threadIdx.x, nt = blockDim.x, nwg = a.k * a.nbk, mk = a.n * a.k;
+  double* s_mean = scratch + (nt / 64 + 1) * (KP + 1);
+  float wn[HELD], wo[HELD];
+  if (a.hist_slot) {
+#pragma unroll
+    for (int u = 0; u < HELD; ++u) {
+      const int i = tid + u * nt;
+      wn[u] = i < mk ? a.w_new[i] : 1.f;
+      wo[u] = i < mk ? a.w_old[i] : 1.f;
+    }
+  }
+  double v[KP + 1];
+#pragma unroll
+  for (int i = 0; i <= KP; ++i) v[i] = 0.0;
+  for (int j = tid; j < a.nbk; j += nt) {
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+      if (kk < a.k) {
+        v[kk] += a.parts[kk * a.nbk + j];
+        v[KP] += a.parts[nwg + kk * a.nbk + j];
+      }
+  }
+  block_reduce<KP + 1, KP + 1>(v, scratch);
+  if (tid == 0) {
+    for (int kk = 0; kk < KP; ++kk) a.colsum_gw[kk] = kk < a.k ? v[kk] : 0.0;
+    *s_mean = v[KP] / (double)mk;
+  }
+  __syncthreads();
+  if (a.pg_q) {
+    double q1[1] = {0.0};
+    for (int j = tid; j < nwg; j += nt) q1[0] += a.parts[2 * nwg + j];
+    block_reduce<1, 1>(q1, scratch);
+    if (tid == 0) *a.pg_q = q1[0];
+  }
+  if (!a.hist_slot) return;
+  const float shift = (float)((double)a.rel_tol * *s_mean);
+  float rel = 0.f;   // fp32 like the register-resident W finish compares doubles of fp32 values: the quotient of two
+                     // fp32 numbers rounded once is within 1 ulp of that; rel_W is a stop-rule statistic (base.py:323)
+#pragma unroll
+  for (int u = 0; u < HELD; ++u)
+    if (tid + u * nt < mk) rel = fmaxf(rel, fabsf(wn[u] - wo[u]) / (wn[u] + shift));
+  for (int i = tid + HELD * nt; i < mk; i += nt) {
+    const float x = a.w_new[i], y = a.w_old[i];
+    rel = fmaxf(rel, fabsf(x - y) / (x + shift));
+  }
+  double r1[1] = {(double)rel};
+  block_reduce<1, 0>(r1, scratch);
+  if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = r1[0];
+}
+
 // ---- per-column simplex multiplier ----------------------------------------------------------
 // Root of f(nu) = sum_i max(num_i / (nu + den_i), eps) - 1 inside the reference's bracket
 // (espm/estimators/dicotomy.py:29-49).
@@ -404,6 +470,12 @@ struct HStepArgs {
   int h_rule;        // 0: log surrogate (multiplicative_step_h), 1: quadratic surrogate (multiplicative_step_hq)
   const float* fill_num;  // sparse store: numerators of the pixels that hold nothing but the fill (k, fill_n), else null
   int fill_n;
+  // espm_mu_iterate, sparse store, local W update: the tail of the previous W update rides in this launch as one extra
+  // workgroup (tail_on), and the workgroups sum the partial column sums of G W' themselves (cs_parts: (k, cs_nbk) doubles,
+  // into k doubles of LDS at byte offset cs_lds_off) instead of waiting for colsum_gw
+  const double* cs_parts;
+  int cs_nbk, cs_lds_off, tail_on;
+  WTailArgs tail;
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -554,6 +626,8 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.h_rule = st->h_rule;
   a.fill_num = (st->x_dtype == ESPM_X_ELL && st->ell_fill_n > 0) ? st->ell_fill_num : nullptr;
   a.fill_n = st->ell_fill_n;
+  a.cs_parts = nullptr;
+  a.cs_nbk = a.cs_lds_off = a.tail_on = 0;
   a.n_pad = st->n_pad;
   return a;
 }
@@ -599,7 +673,8 @@ int launch_w_finish_l2(const float* a, int n, int n_pad, int m, int k, const flo
                        float* w_new, const float* fixed_w, float log_shift, hipStream_t stream);
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
                            const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
-                           const HFinalizeArgs* fused_finalize, hipStream_t stream);
+                           const HFinalizeArgs* fused_finalize, hipStream_t stream, WTailArgs* defer_tail = nullptr);
+int launch_w_update_tail(const WTailArgs& t, hipStream_t stream);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                   int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream);
 int launch_hstat(const float* h, int k, int p, int p_pad, double* out, hipStream_t stream);

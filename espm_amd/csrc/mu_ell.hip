@@ -19,17 +19,25 @@ static int allow_lds(KernelT kern, size_t bytes, const char* what) {
 }
 
 template <int K>
-static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
+static int launch_h_ell_k(const HStepArgs& args_in, int nblk, hipStream_t stream) {
   constexpr int UNR = ESPM_ELL_UNR_H;
   const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   // [nsplit][K][tile_px]: K * 512 floats whatever the split; two such sets when the groups of a 512-pixel window are walked in pairs
-  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
+  size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args_in.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
   if (red > part) part = red;
-  const size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
+  const size_t tail_scratch = (size_t)((ESPM_ELL_TILE / 64 + 1) * (KP + 1) + 1) * sizeof(double);
+  if (tail_scratch > part) part = tail_scratch;
+  HStepArgs args = args_in;
+  size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
+  if (args.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
+    args.cs_lds_off = (int)bytes;
+    bytes += KP * sizeof(double);
+  }
+  const dim3 grid(nblk + (args.tail_on ? 1 : 0));   // (+ the tail of the previous W update, espm_mu_iterate)
   if (args.h_rule == 1 || args.h_rule == 2) {  // quadratic surrogate of the Laplacian term / projected gradient
     auto go = [&](auto kern) -> int {
       if (int rc = allow_lds(kern, bytes, "h_step (ell)")) return rc;
-      hipLaunchKernelGGL(kern, dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+      hipLaunchKernelGGL(kern, grid, dim3(ESPM_ELL_TILE), bytes, stream, args);
       return ESPM_OK;
     };
     int rc;
@@ -38,10 +46,10 @@ static int launch_h_ell_k(const HStepArgs& args, int nblk, hipStream_t stream) {
     if (rc) return rc;
   } else if (args.compute_loss) {
     if (int rc = allow_lds(h_step_ell_kernel<K, true, UNR>, bytes, "h_step (ell)")) return rc;
-    hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+    hipLaunchKernelGGL((h_step_ell_kernel<K, true, UNR>), grid, dim3(ESPM_ELL_TILE), bytes, stream, args);
   } else {
     if (int rc = allow_lds(h_step_ell_kernel<K, false, UNR>, bytes, "h_step (ell)")) return rc;
-    hipLaunchKernelGGL((h_step_ell_kernel<K, false, UNR>), dim3(nblk), dim3(ESPM_ELL_TILE), bytes, stream, args);
+    hipLaunchKernelGGL((h_step_ell_kernel<K, false, UNR>), grid, dim3(ESPM_ELL_TILE), bytes, stream, args);
   }
   return check_hip(hipGetLastError(), "h_step (ell) launch");
 }

@@ -211,6 +211,18 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HSte
   const int TP = a.ell_tp;             // pixels of this workgroup: 64 * (8 / nsplit)
   const int gpw = TP >> 6;             // list groups per workgroup
   const bool pairs = PAIRS_OK && gpw == NT / 64;
+  if (a.tail_on && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
+    w_tail_body<20>(a.tail, reinterpret_cast<double*>(smem));
+    return;
+  }
+  double* cs_lds = a.cs_parts ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + a.cs_lds_off) : nullptr;
+  if (cs_lds && (int)(threadIdx.x >> 6) < K) {      // wave kk: column sum kk of G W' from the W update's partials
+    const int kk = threadIdx.x >> 6;
+    double v = 0.0;
+    for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
+  }
   for (int r = threadIdx.x; r < a.n_pad; r += NT) {
     const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
     EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HSte
     walk_rows(gi, (int)((long)len * si / nsplit), (int)((long)len * (si + 1) / nsplit), si);
     nparts = nsplit;
   }
-  h_epilogue<K, true, RULE>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f);
+  h_epilogue<K, true, RULE>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f, cs_lds);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------

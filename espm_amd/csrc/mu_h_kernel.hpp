@@ -54,7 +54,8 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // RULE: the H rule (a.h_rule) - 0 log surrogate, 1 quadratic surrogate, 2 projected gradient - as a compile-time switch,
 // so that the default rule does not carry the registers of the others.
 template <int K, bool EARLY = true, int RULE = 0>
-__device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane) {
+__device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
+                                           const double* colsum = nullptr) {   // colsum: the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
 #pragma unroll
@@ -93,7 +94,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * K + kk) * TP + jj];
       hin[kk] = in.hin[kk];
       nv[kk] = s * a.xscale;
-      dv[kk] = (float)a.colsum_gw[kk];
+      dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
     }
     if (a.fill_num) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
       const float mark = a.ell_klc[q];
@@ -271,12 +272,12 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   if constexpr (RULE == 2) {
     double one[1] = {pg_q};
     block_reduce<1, 1>(one, reinterpret_cast<double*>(smem));
-    if (threadIdx.x == 0) a.hpart[(size_t)ESPM_HP_PGQ * gridDim.x + blockIdx.x] = one[0];
+    if (threadIdx.x == 0) a.hpart[(size_t)ESPM_HP_PGQ * (gridDim.x - a.tail_on) + blockIdx.x] = one[0];
   }
   if (threadIdx.x == 0) {
     // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
     double* out = a.hpart + blockIdx.x;
-    const size_t nb = gridDim.x;
+    const size_t nb = gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
     out[ESPM_HP_KL * nb] = red[ESPM_HP_KL];
     out[ESPM_HP_REG * nb] = red[ESPM_HP_REG];
     out[ESPM_HP_LAP * nb] = red[ESPM_HP_LAP];

@@ -201,72 +201,14 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
   }
 }
 
-// Column sums of G W' and rel_W (base.py:323) from the partials and W', W: one workgroup.
-struct WTailArgs {
-  const double* parts;
-  const float* w_old;
-  const float* w_new;
-  double* colsum_gw;
-  double* hist_slot;
-  double* pg_q;   // projected gradient: sum of the third row of partials goes here, else null
-  int n, k, nbk;
-  float rel_tol;
-};
+// Column sums of G W' and rel_W (base.py:323) from the partials and W', W: one workgroup (w_tail_body, mu_common.hpp).
 // 256 threads: the cross-wave stage of a block reduction costs per wave, and everything here is latency - the
 // entries of W are requested up front, before the partials are reduced, so that only one memory round trip and
 // two short reductions separate the launch from the result.
 constexpr int WT_THREADS = 256;
-constexpr int WT_HELD = 40;  // entries of W per thread held in registers (10240 = the headline size); more take the loop
 __global__ __launch_bounds__(WT_THREADS) void w_update_tail_kernel(const WTailArgs a) {
-  __shared__ double scratch[(WT_THREADS / 64 + 1) * (KP + 1)];
-  __shared__ double s_mean;
-  const int tid = threadIdx.x, nwg = a.k * a.nbk, mk = a.n * a.k;
-  float wn[WT_HELD], wo[WT_HELD];
-  if (a.hist_slot) {
-#pragma unroll
-    for (int u = 0; u < WT_HELD; ++u) {
-      const int i = tid + u * WT_THREADS;
-      wn[u] = i < mk ? a.w_new[i] : 1.f;
-      wo[u] = i < mk ? a.w_old[i] : 1.f;
-    }
-  }
-  double v[KP + 1];
-#pragma unroll
-  for (int i = 0; i <= KP; ++i) v[i] = 0.0;
-  for (int j = tid; j < a.nbk; j += WT_THREADS) {
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk)
-      if (kk < a.k) {
-        v[kk] += a.parts[kk * a.nbk + j];
-        v[KP] += a.parts[nwg + kk * a.nbk + j];
-      }
-  }
-  block_reduce<KP + 1, KP + 1>(v, scratch);
-  if (tid == 0) {
-    for (int kk = 0; kk < KP; ++kk) a.colsum_gw[kk] = kk < a.k ? v[kk] : 0.0;
-    s_mean = v[KP] / (double)mk;
-  }
-  __syncthreads();
-  if (a.pg_q) {
-    double q1[1] = {0.0};
-    for (int j = tid; j < nwg; j += WT_THREADS) q1[0] += a.parts[2 * nwg + j];
-    block_reduce<1, 1>(q1, scratch);
-    if (tid == 0) *a.pg_q = q1[0];
-  }
-  if (!a.hist_slot) return;
-  const float shift = (float)((double)a.rel_tol * s_mean);
-  float rel = 0.f;   // fp32 like the register-resident W finish compares doubles of fp32 values: the quotient of two
-                     // fp32 numbers rounded once is within 1 ulp of that; rel_W is a stop-rule statistic (base.py:323)
-#pragma unroll
-  for (int u = 0; u < WT_HELD; ++u)
-    if (tid + u * WT_THREADS < mk) rel = fmaxf(rel, fabsf(wn[u] - wo[u]) / (wn[u] + shift));
-  for (int i = tid + WT_HELD * WT_THREADS; i < mk; i += WT_THREADS) {
-    const float x = a.w_new[i], y = a.w_old[i];
-    rel = fmaxf(rel, fabsf(x - y) / (x + shift));
-  }
-  double r1[1] = {(double)rel};
-  block_reduce<1, 0>(r1, scratch);
-  if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = r1[0];
+  __shared__ double scratch[(WT_THREADS / 64 + 1) * (KP + 1) + 1];
+  w_tail_body<40>(a, scratch);   // 40 x 256 = 10240 entries of W held in registers (the headline size); more take the loop
 }
 
 // ---- W finish: one workgroup of 1024 threads --------------------------------------------------
@@ -838,7 +780,7 @@ int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HF
 
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
                            const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
-                           const HFinalizeArgs* fused_finalize, hipStream_t stream) {
+                           const HFinalizeArgs* fused_finalize, hipStream_t stream, WTailArgs* defer_tail) {
   WUpdateArgs a;
   a.src = static_cast<const unsigned char*>(src);
   a.src_stride = src_stride;
@@ -878,8 +820,16 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   t.k = f.k;
   t.nbk = a.nbk;
   t.rel_tol = f.rel_tol;
-  hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
+  if (defer_tail)   // (espm_mu_iterate: the tail rides in the next H-step's launch, or in launch_w_update_tail at the end)
+    *defer_tail = t;
+  else
+    hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
   return check_hip(hipGetLastError(), "w_reduce_update launch");
+}
+
+int launch_w_update_tail(const WTailArgs& t, hipStream_t stream) {
+  hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
+  return check_hip(hipGetLastError(), "w_update_tail launch");
 }
 
 template <int KK>
