@@ -27,6 +27,7 @@ MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8          # (the default build; `variant(k)`
 HP_STRIDE, HS_STRIDE, HI_STRIDE = 24, 16, 8
 HS_ROWSUM, HS_MAX = 0, 8
 WIDE_MAX_K = 16
+TAIL_DEFER, TAIL_RIDE = 1, 2
 HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -49,7 +50,7 @@ class MUState(C.Structure):
         ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
         ("ell_h", _vp), ("ell_h_off", _vp), ("ell_klc", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
         ("ell_cbits", _i32), ("n_cg", _i32), ("pix_perm", _vp), ("g_t", _vp), ("breg_sr_px", _vp), ("breg_sr_ch", _vp), ("h_rule", _i32), ("pg_gamma_w", _f32), ("pg_q", _vp),
-        ("ell_fill_px", _vp), ("ell_fill_num", _vp), ("ell_fill_n", _i32),
+        ("ell_fill_px", _vp), ("ell_fill_num", _vp), ("ell_fill_n", _i32), ("tail_mode", _i32),
     ]
 
 
@@ -59,6 +60,8 @@ SYMBOLS = {
     "espm_mu_version": (C.c_char_p, []),
     "espm_mu_last_error": (C.c_char_p, []),
     "espm_mu_query": (C.c_int, [_SP]),
+    "espm_mu_w_update_is_local": (C.c_int, [_SP]),
+    "espm_mu_w_update_tail": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_ell_count": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_ell_plan": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

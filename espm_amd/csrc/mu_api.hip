@@ -175,6 +175,11 @@ int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
   return launch_hstat(st->h[which], st->k, st->p, st->p_pad, st->hstat[which], static_cast<hipStream_t>(stream));
 }
 
+// W' needs nothing global but the row sums of the new H: the reduction workgroups finish W themselves
+static bool w_update_is_local(const espm_mu_state* st) {
+  return st->m == 0 && !st->simplex_w && st->n >= 64 && st->w_scratch != nullptr;
+}
+
 static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
   WFinishArgs a;
   a.g = st->m > 0 ? st->g : nullptr;
@@ -221,6 +226,13 @@ int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t 
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
   if (st->x_dtype == ESPM_X_ELL) {
     HStepArgs a = make_h_args(st, src, write_h);
+    if (st->tail_mode & ESPM_TAIL_RIDE) {  // the tail of the W update that produced this state rides along (include/espm_mu.h)
+      ESPM_REQUIRE(st->it >= 1 && w_update_is_local(st), "tail_mode: no local W update produced state %d", st->it);
+      a.tail = make_w_tail_args(finish_args(st, 1 - src, src, st->it, 1));
+      a.cs_parts = a.tail.parts;
+      a.cs_nbk = a.tail.nbk;
+      a.tail_on = 1;
+    }
     if (a.fill_num) {  // pixels without counts: the numerator of their log_shift fill first (include/espm_mu.h)
       if (int rc = launch_ell_fill_num(st->gw_s, st->h[src], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad, st->log_shift,
                                        st->ell_fill_num, static_cast<hipStream_t>(stream)))
@@ -299,21 +311,18 @@ int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_
   return launch_w_finish(finish_args(st, src, hsrc, slot, 1), static_cast<hipStream_t>(stream));
 }
 
-// W' needs nothing global but the row sums of the new H: the reduction workgroups finish W themselves
-static bool w_update_is_local(const espm_mu_state* st) {
-  return st->m == 0 && !st->simplex_w && st->n >= 64 && st->w_scratch != nullptr;
-}
-
 int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with_finalize, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
   ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const HFinalizeArgs fin = finalize_args(st, src, slot, true);
+  WTailArgs left_out;   // ESPM_TAIL_DEFER: the caller has the tail carried by the next H-step (or espm_mu_w_update_tail)
   if (w_update_is_local(st)) {
     return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
                                   st->nblk_w, st->a, with_finalize ? st->hpart : nullptr, nblk_h(st), with_finalize ? nullptr : st->hstat[1 - src],
-                                  0, nullptr, with_finalize ? &fin : nullptr, s);   // (no riding finalize: hstat[1-src] is already reduced)
+                                  0, nullptr, with_finalize ? &fin : nullptr, s,   // (no riding finalize: hstat[1-src] is already reduced)
+                                  (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
   }
   if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, with_finalize ? &fin : nullptr, s)) return rc;
   return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
@@ -324,13 +333,25 @@ int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, i
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(records && world >= 1 && (src == 0 || src == 1), "shard_combine_finish: bad arguments");
   ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
+  WTailArgs left_out;
   if (w_update_is_local(st)) {
     return launch_w_reduce_update(finish_args(st, src, 1 - src, slot + 1, 1), records, espm_mu_shard_record_bytes(st), world, st->a,
                                   nullptr, 0, nullptr, (size_t)st->k * st->n_pad * sizeof(float), st->hstat[1 - src], nullptr,
-                                  static_cast<hipStream_t>(stream));
+                                  static_cast<hipStream_t>(stream), (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
   }
   if (int rc = espm_mu_shard_combine(st, records, world, 1 - src, stream)) return rc;
   return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
+}
+
+int espm_mu_w_update_is_local(const espm_mu_state* st) {
+  if (check_state(st)) return 0;
+  return w_update_is_local(st) ? 1 : 0;
+}
+
+int espm_mu_w_update_tail(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE((src == 0 || src == 1) && slot >= 0 && slot + 1 < st->hist_len && w_update_is_local(st), "w_update_tail: bad arguments");
+  return launch_w_update_tail(make_w_tail_args(finish_args(st, src, 1 - src, slot + 1, 1)), static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {

@@ -778,6 +778,22 @@ int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HF
   return check_hip(hipGetLastError(), "w_reduce_pack launch");
 }
 
+// the tail's view of a local W update: partials in f.scratch, W before / after, where the results go
+WTailArgs make_w_tail_args(const WFinishArgs& f) {
+  WTailArgs t;
+  t.parts = reinterpret_cast<const double*>(f.scratch);
+  t.w_old = f.w_old;
+  t.w_new = f.w_new;
+  t.colsum_gw = f.colsum_gw;
+  t.hist_slot = f.hist_slot;
+  t.pg_q = f.pg_q;
+  t.n = f.n;
+  t.k = f.k;
+  t.nbk = (f.n_pad + 31) / 32;
+  t.rel_tol = f.rel_tol;
+  return t;
+}
+
 int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_stride, int nsrc, float* a_out,
                            const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream, WTailArgs* defer_tail) {
@@ -809,17 +825,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.fuse_finalize = fused_finalize != nullptr;
   if (fused_finalize) a.fin = *fused_finalize;
   hipLaunchKernelGGL(w_reduce_update_kernel, dim3(a.k * a.nbk + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
-  WTailArgs t;
-  t.parts = a.parts;
-  t.w_old = f.w_old;
-  t.w_new = f.w_new;
-  t.colsum_gw = f.colsum_gw;
-  t.hist_slot = f.hist_slot;
-  t.pg_q = f.pg_q;
-  t.n = f.n;
-  t.k = f.k;
-  t.nbk = a.nbk;
-  t.rel_tol = f.rel_tol;
+  const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)   // (espm_mu_iterate: the tail rides in the next H-step's launch, or in launch_w_update_tail at the end)
     *defer_tail = t;
   else

@@ -412,6 +412,7 @@ class MUEngine:
             raise ValueError(f"H must be {(self.k, self.p)}, got {H.shape}")
         st.cur, st.it = 0, 0
         self._pending_finalize = None
+        self._pending_tail = False
         self.hist.zero_()
         self.w[0].copy_(torch.from_numpy(np.ascontiguousarray(W)))
         self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
@@ -460,14 +461,22 @@ class MUEngine:
         With advance_h the reduction of the H-step's records is deferred: ``finish_iteration`` folds it into its
         slab-reduction launch; any other consumer (``history``, ``step_*_only``, ...) flushes it first."""
         st = self.st
-        self._flush_finalize()
+        self._flush_finalize(tail=False)
         if self.frobenius:
             self._frobenius_of_current()
-        if advance_h:
-            self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
-            self._pending_finalize = (st.cur, st.it)
-        else:
-            self._check(self.lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+        # the tail of the W update that produced this state (column sums of G W', rel_W) rides in this launch (tail_mode,
+        # include/espm_mu.h) instead of costing one of its own
+        carry = getattr(self, "_pending_tail", False)
+        st.tail_mode = _lib.TAIL_RIDE if carry else 0
+        self._pending_tail = False
+        try:
+            if advance_h:
+                self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+                self._pending_finalize = (st.cur, st.it)
+            else:
+                self._check(self.lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
+        finally:
+            st.tail_mode = 0
 
     def _frobenius_of_current(self, rows=32768):
         """||X - G W H||_F^2 of the current state (espm/measures.py:350-384) into its history slot: residual in fp32 over
@@ -497,11 +506,14 @@ class MUEngine:
         self.hist[slot + 1, _lib.HI_REL_W] = ((wn - wo).abs() / (wn + self.rel_tol * wn.mean())).max()   # base.py:323
         st.cur, st.it = 1 - cur, slot + 1
 
-    def _flush_finalize(self):
+    def _flush_finalize(self, tail=True):
         pend = getattr(self, "_pending_finalize", None)
         if pend is not None:
             self._pending_finalize = None
             self._check(self.lib.espm_mu_h_finalize(C.byref(self.st), pend[0], pend[1], _stream()))
+        if tail and getattr(self, "_pending_tail", False):   # no H-step will carry the tail of the last W update: a launch of its own
+            self._pending_tail = False
+            self._check(self.lib.espm_mu_w_update_tail(C.byref(self.st), 1 - self.st.cur, self.st.it - 1, _stream()))
 
     def finish_iteration(self):
         """W-step with the H produced by ``eval_current`` and the bookkeeping; flips the buffers."""
@@ -518,6 +530,9 @@ class MUEngine:
             self._pending_finalize = None
         else:
             self._flush_finalize()
+        # sparse store, local W update: its tail is left to the next H-step's launch (eval_current) or to _flush_finalize
+        defer = (self.ell is not None and self.pg_q is None and bool(self.lib.espm_mu_w_update_is_local(C.byref(st))))
+        st.tail_mode = _lib.TAIL_DEFER if defer else 0
         if self.world > 1:
             if ride:   # slab reduction + record reduction + this rank's record, one launch
                 self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, _ptr(self.exchange.send), s))
@@ -530,6 +545,8 @@ class MUEngine:
             self._set_halo_from_records()
         else:
             self._check(self.lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
+        st.tail_mode = 0
+        self._pending_tail = defer
         st.cur, st.it = 1 - cur, slot + 1
 
     def linesearch_step(self, gamma):

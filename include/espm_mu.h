@@ -96,6 +96,8 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
+#define ESPM_TAIL_DEFER 1  /* espm_mu_state.tail_mode bits */
+#define ESPM_TAIL_RIDE 2
 
 /* per-workgroup partial record written by the H-step (doubles), stored field-major:
  * hpart[field * nblk + block] */
@@ -239,6 +241,13 @@ typedef struct espm_mu_state {
   const int32_t* ell_fill_px;
   float* ell_fill_num;
   int32_t ell_fill_n;
+  /* Tail of the local W update (espm_mu_w_update_is_local: column sums of G W' -> colsum_gw, rel_W -> hist): one small
+   * workgroup, 8 us as a launch of its own.  bit 0 (ESPM_TAIL_DEFER): espm_mu_w_reduce_finish / espm_mu_shard_combine_finish
+   * leave it out.  bit 1 (ESPM_TAIL_RIDE): the next espm_mu_step_h / espm_mu_loss_only (sparse store) carries the tail of
+   * the update that PRODUCED state `it` (w[1 - src] -> w[src]) as an extra workgroup and sums the partial column sums
+   * itself; the caller sets the bit for that one call, or flushes with espm_mu_w_update_tail.  espm_mu_iterate does all
+   * this internally and ignores the field. */
+  int32_t tail_mode;
 } espm_mu_state;
 
 const char* espm_mu_version(void);
@@ -313,6 +322,12 @@ int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with
  * changes of the update that produced it.  A final loss-only H-step fills the last slot when
  * final_loss != 0. */
 int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream);
+/* 1 when the W update needs nothing global (G = identity, no simplex over W, ...): the slab / record reduction updates W
+ * itself and a tail workgroup finishes (tail_mode above); 0: espm_mu_w_finish does the update, there is no tail. */
+int espm_mu_w_update_is_local(const espm_mu_state* st);
+/* The tail of the update w[src] -> w[1 - src] that produced state slot + 1, as a launch of its own (after a finish call
+ * with ESPM_TAIL_DEFER when no H-step will carry it). */
+int espm_mu_w_update_tail(const espm_mu_state* st, int src, int slot, espm_stream_t stream);
 
 /* Sharded image (pixel rows split over ranks).  Per iteration every rank packs one
  * record [A | hstat of the new H | first and last owned image row of the new H], the caller
