@@ -181,3 +181,22 @@ def test_pixels_without_counts_at_full_size():
     np.testing.assert_allclose(Hs[:, empty], Hd[:, empty], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(Hs[:, empty].sum(axis=0), 1.0, atol=1e-5)
     np.testing.assert_allclose(Ws, Wd, rtol=2e-4, atol=2e-4 * np.abs(Wd).mean())
+
+
+def test_iteration_loop_is_reproducible_across_chunkings(big):
+    """espm_mu_iterate lets the W update's tail ride in the next H-step's launch and flushes it at the end of a call: the same
+    8 iterations in one call, and in uneven chunks, give bit-identical W, H and history (loss, rel_W, rel_H)."""
+    eng = big["engs"]["ell"]
+    out = []
+    for chunks in ((8,), (1, 2, 5), (3, 1, 1, 3)):
+        eng.load_state(big["W0"], big["H0"])
+        for c in chunks:
+            eng.iterate(c, final_loss=False)
+        eng.eval_current(advance_h=False)
+        torch.cuda.synchronize()
+        out.append((eng.get_W(), eng.get_H(), eng.history()))
+    for W, H, h in out[1:]:
+        assert np.array_equal(W, out[0][0]) and np.array_equal(H, out[0][1])
+        for key in ("loss", "rel_W", "rel_H", "bad"):
+            assert np.array_equal(h[key], out[0][2][key]), key
+    assert out[0][2]["bad"].sum() == 0 and np.isfinite(out[0][2]["rel_W"][1:]).all()
