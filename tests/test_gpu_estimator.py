@@ -728,3 +728,33 @@ def test_projected_gradient_linesearch_golden(SmoothNMF, golden):
         np.testing.assert_allclose(np.array(est.losses_)[:n_ok], ref_l[:n_ok], rtol=3 * LOSS_RTOL, err_msg=name)
         if n_ok < len(ref_l):
             assert est.losses_[n_ok] > 1e3 and (np.diff(gam[n_ok - 1:, 0]) > 0).any() and np.isfinite(est.losses_).all()
+
+
+def test_sparse_store_at_its_lds_limit():
+    """The widest spectrum whose GW table, numerators, riding tail scratch and column-sum copy still fit the sparse H-step's LDS
+    budget (k = 5: 6344 channels), and one channel more (dense store): iterations in the C loop against the oracle."""
+    import torch
+    from espm_amd import _lib, ell, synth
+    from espm_amd.engine import MUEngine
+    k, nx, ny = 5, 16, 20
+    n = 6344
+    assert ell.lds_bytes_h(n, k) <= _lib.ELL_LDS_MAX < ell.lds_bytes_h(n + 8, k)
+    rng = np.random.default_rng(4)
+    for nn, store in ((n, "ell"), (n + 8, "u8")):
+        prob = synth.make_problem(nn, nx, ny, k, N=400.0, seed=4)
+        X = np.minimum(synth.sample_numpy(prob, seed=4), 255.0)
+        X[X.sum(axis=1) == 0, 0] = 1.0
+        X[0, X.sum(axis=0) == 0] = 1.0
+        W0, H0 = synth.random_init(nn, k, nx * ny, seed=4, scale=0.05)
+        kw = dict(shape_2d=(nx, ny), lambda_L=0.8, simplex_H=True, simplex_W=False)
+        eng = MUEngine(X, k, max_iter=5, tol=0, **kw)
+        assert eng.x_store == store
+        eng.load_state(W0, H0)
+        eng.iterate(5, final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        ref = oc.fit(X, k, W=W0.copy(), H=H0.copy(), exact_root=True, no_stop_criterion=True, max_iter=5, tol=0, **kw)
+        np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+        np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+        assert h["bad"].sum() == 0
