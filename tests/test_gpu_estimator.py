@@ -758,3 +758,32 @@ def test_sparse_store_at_its_lds_limit():
         np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
         assert h["bad"].sum() == 0
+
+
+@pytest.mark.parametrize("nx,ny,tile", [(300, 300, 128), (400, 401, 256), (250, 180, 64)])
+def test_sparse_store_mid_size_tiles(nx, ny, tile):
+    """Images between 256 x 256 and 512 x 512 pixels run the sparse H-step with 128- and 256-pixel windows (two or four waves
+    share a list group), several W blocks and pixels past the last full window: whole iterations against the oracle."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    n, k = 96, 4
+    prob = synth.make_problem(n, nx, ny, k, N=25.0, seed=nx)
+    X = synth.sample_numpy(prob, seed=nx)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[:, 1000:1003] = 0                       # a few pixels without counts
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=nx, scale=0.2)
+    kw = dict(shape_2d=(nx, ny), lambda_L=0.7, mu=0.05, simplex_H=True, simplex_W=False)
+    eng = MUEngine(X, k, max_iter=4, tol=0, **kw)
+    assert eng.x_store == "ell" and eng.st.tile_px == tile and eng.st.nblk_w == -(-nx * ny // 1024)
+    eng.load_state(W0, H0)
+    eng.iterate(4, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    ref = oc.fit(X, k, W=W0.copy(), H=H0.copy(), exact_root=True, no_stop_criterion=True, max_iter=4, tol=0, **kw)
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(h["rel_H"][1:], ref["rel"][:, 1], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    assert h["bad"].sum() == 0
