@@ -164,20 +164,49 @@ __device__ __forceinline__ void load_f32(const float* p, float (&x)[PX]) {
 }
 
 // ---- wave / block reductions ----------------------------------------------------------------
+// Reductions over the 64 lanes with DPP moves (vector-ALU lane permutes) instead of ds_bpermute: a scan inside every row
+// of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into
+// the upper half (row_bcast:31): lane 63 holds the result, which v_readlane hands to every lane.  The LDS crossbar the
+// shuffles went through was what a one-workgroup kernel with 16 waves waited for (380 ds_bpermute in the W finish).
+// Lanes without a source keep the identity (sum: 0, max: -inf).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v, float ident) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v, double ident) {
+  const long long vb = __double_as_longlong(v), ib = __double_as_longlong(ident);
+  const int lo = __builtin_amdgcn_update_dpp((int)ib, (int)vb, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(ib >> 32), (int)(vb >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double lane63(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
+  v += dpp_move<0x111, 0xf>(v, (T)0);   // row_shr:1
+  v += dpp_move<0x112, 0xf>(v, (T)0);   // row_shr:2
+  v += dpp_move<0x114, 0xf>(v, (T)0);   // row_shr:4
+  v += dpp_move<0x118, 0xf>(v, (T)0);   // row_shr:8
+  v += dpp_move<0x142, 0xa>(v, (T)0);   // row_bcast:15 -> rows 1, 3
+  v += dpp_move<0x143, 0xc>(v, (T)0);   // row_bcast:31 -> rows 2, 3
+  return lane63(v);
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    T o = __shfl_xor(v, off, WAVE);
-    v = o > v ? o : v;
-  }
-  return v;
+  const T ninf = -(T)INFINITY;
+  T o;
+  o = dpp_move<0x111, 0xf>(v, ninf); v = o > v ? o : v;
+  o = dpp_move<0x112, 0xf>(v, ninf); v = o > v ? o : v;
+  o = dpp_move<0x114, 0xf>(v, ninf); v = o > v ? o : v;
+  o = dpp_move<0x118, 0xf>(v, ninf); v = o > v ? o : v;
+  o = dpp_move<0x142, 0xa>(v, ninf); v = o > v ? o : v;
+  o = dpp_move<0x143, 0xc>(v, ninf); v = o > v ? o : v;
+  return lane63(v);
 }
 
 // Block-wide reduction of NV doubles (sum for the first NSUM, max for the rest).  `scratch` holds at

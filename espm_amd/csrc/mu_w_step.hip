@@ -255,10 +255,20 @@ __device__ __forceinline__ float load_a(const WFinishArgs& a, int kk, int c) {
   return a.a[(size_t)kk * a.n_pad + c];
 }
 
+// 1 / x for the bisection's sum_c num_c / (nu + den_c): v_rcp_f64 and two Newton steps (a few ulp; an IEEE division is
+// three times the instructions, and 10 of them per thread and step were what the one-workgroup W finish spent its time on)
+__device__ __forceinline__ double rcp_f64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 template <int KK, int WF_ROWS>
 __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinishArgs a) {
   constexpr int KA = KK;  // per-thread arrays are sized by the real component count (k == KK)
   __shared__ double scratch[(WF_THREADS / 64 + 1) * KP];
+  __shared__ double bis[2][(WF_THREADS / 64) * KA];   // per-wave partial sums of the bisection, two alternating buffers
   __shared__ double s_lo[KA], s_hi[KA], s_mid[KA];
   __shared__ int s_go;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // G given: [M*k] new W, [M*k] G^T A
@@ -406,33 +416,57 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
           s_hi[kk] = rows * b2[kk] / 0.5 + b3[kk];
         }
       __syncthreads();
-      for (int it = 0; it <= 100; ++it) {  // dicotomy.py:146-171, global stop rule
-        if (tid < k) s_mid[tid] = (s_lo[tid] + s_hi[tid]) / 2;
-        __syncthreads();
+      // dicotomy.py:146-171, global stop rule.  Every thread keeps the brackets of all components and takes the decisions
+      // itself from the per-wave partial sums (summed in wave order, like block_reduce: the same values in every thread), on
+      // two alternating buffers: ONE barrier per bisection step instead of five and no single-thread section - the ~40 steps
+      // of a simplex over W were 120 us of the iteration with the reference's default constraints.
+      double lo[KA], hi[KA], mid[KA];
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) {
+        lo[kk] = kk < k ? s_lo[kk] : 0.0;
+        hi[kk] = kk < k ? s_hi[kk] : 0.0;
+        mid[kk] = 0.0;
+      }
+      constexpr int NWV = WF_THREADS / 64;
+      for (int it = 0; it <= 100; ++it) {
         double f[KA];
 #pragma unroll
-        for (int kk = 0; kk < KA; ++kk) f[kk] = 0.0;
+        for (int kk = 0; kk < KA; ++kk) {
+          mid[kk] = (lo[kk] + hi[kk]) / 2;
+          f[kk] = 0.0;
+        }
 #pragma unroll
         for (int r = 0; r < WF_ROWS; ++r) {
           if (tid + r * WF_THREADS < M && in_set[r]) {
 #pragma unroll
             for (int kk = 0; kk < KA; ++kk)
-              if (kk < k) f[kk] += fmax((double)nv[r][kk] / (s_mid[kk] + (double)dv[r][kk]), (double)a.log_shift);
+              if (kk < k) f[kk] += fmax((double)nv[r][kk] * rcp_f64(mid[kk] + (double)dv[r][kk]), (double)a.log_shift);
           }
         }
-        block_reduce<KA, KA>(f, scratch);
-        if (tid == 0) {
-          double worst = 0.0;
-          for (int kk = 0; kk < k; ++kk) worst = fmax(worst, fabs(f[kk] - 1.0));
-          s_go = (worst > (double)a.tol) && (it < 100);
-          if (s_go)
-            for (int kk = 0; kk < k; ++kk) {
-              if (f[kk] - 1.0 <= 0.0) s_hi[kk] = s_mid[kk]; else s_lo[kk] = s_mid[kk];
-            }
+        double* sc = bis[it & 1];
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          f[kk] = wave_sum(f[kk]);
+          if (lane == 0) sc[wave * KA + kk] = f[kk];
         }
         __syncthreads();
-        if (!s_go) break;
+        double worst = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          double acc = sc[kk];
+          for (int w = 1; w < NWV; ++w) acc = acc + sc[w * KA + kk];
+          f[kk] = acc;
+          if (kk < k) worst = fmax(worst, fabs(acc - 1.0));
+        }
+        if (!((worst > (double)a.tol) && (it < 100))) break;
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) {
+          if (f[kk] - 1.0 <= 0.0) hi[kk] = mid[kk]; else lo[kk] = mid[kk];
+        }
       }
+      if (tid == 0)
+        for (int kk = 0; kk < k; ++kk) s_mid[kk] = mid[kk];
+      __syncthreads();
     }
     // W' = max(num / (den + nu), eps), fixed entries (updates.py:70-76); rel_W (base.py:323)
     double sum_l = 0.0;
