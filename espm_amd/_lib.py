@@ -16,42 +16,38 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ESPM_MU_LIB", os.path.join(_HERE, "lib", "libespm_mu.so"))
 
-# mirrors of the header's constants
-OK, EINVAL, ENOSOLUTION, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4
-X_F32, X_BF16, X_U8, X_ELL = 0, 1, 2, 3
-ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = 512, 1024, 10, 144 * 1024
-ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = 8, 4096, 6
+from . import _abi
+
+# ---- constants and the state layout come from include/espm_mu.h itself (espm_amd/_abi.py parses it): no hand-kept copy ----
+_HEADER_TEXT = _abi.header_text()
+_D = _abi.parse_defines(_HEADER_TEXT)
+OK, EINVAL, ENOSOLUTION, EHIP, EUNSUPPORTED = 0, -1, -2, -3, -4          # enum espm_status
+X_F32, X_BF16, X_U8, X_ELL = 0, 1, 2, 3                                  # enum ESPM_X_*
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
-MAX_K, KP, PPAD, NPAD = 8, 8, 512, 8          # (the default build; `variant(k)` below for the wide one)
-HP_STRIDE, HS_STRIDE, HI_STRIDE = 24, 16, 8
-HS_ROWSUM, HS_MAX = 0, 8
+ABI_VERSION = _D["ESPM_MU_ABI_VERSION"]
+ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = _D["ESPM_ELL_TILE"], _D["ESPM_ELL_PB"], _D["ESPM_ELL_PBITS"], _D["ESPM_ELL_LDS_MAX"]
+ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = _D["ESPM_ELL_UNIT_ROWS"], _D["ESPM_ELL_UNIT_MAX_N"], _D["ESPM_ELL_PAIR_MAX_K"]
+KP, PPAD, NPAD = _D["ESPM_KP"], _D["ESPM_PPAD"], _D["ESPM_NPAD"]         # (the default build; `variant(k)` below for the wide one)
+MAX_K = KP
+HP_STRIDE, HS_STRIDE, HI_STRIDE = 8 + 2 * KP, 2 * KP, _D["ESPM_HI_STRIDE"]
+HS_ROWSUM, HS_MAX = 0, KP
 WIDE_MAX_K = 16
-TAIL_DEFER, TAIL_RIDE = 1, 2
-HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = 0, 1, 2, 3, 4, 5, 6
+TAIL_DEFER, TAIL_RIDE = _D["ESPM_TAIL_DEFER"], _D["ESPM_TAIL_RIDE"]
+HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = (_D["ESPM_HI_" + n] for n in ("KLX", "REG", "LAP", "SUMY", "BAD", "REL_W", "REL_H"))
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
 class MUState(C.Structure):
-    """struct espm_mu_state (same field order as include/espm_mu.h)."""
-    _fields_ = [
-        ("n", _i32), ("m", _i32), ("k", _i32), ("p", _i32), ("nx", _i32), ("ny", _i32),
-        ("n_pad", _i32), ("p_pad", _i32), ("x_dtype", _i32), ("tile_px", _i32), ("nblk_w", _i32), ("x_tile", _i32), ("n_cm", _i32), ("h_variant", _i32),
-        ("p_total", _i64),
-        ("simplex_h", _i32), ("simplex_w", _i32), ("grid_mode", _i32), ("compute_loss", _i32),
-        ("lambda_l", _f32), ("sigma_l", _f32), ("eps_reg", _f32), ("log_shift", _f32),
-        ("dicotomy_tol", _f32), ("rel_tol", _f32), ("xscale", _f32), ("gw_floor", _f32),
-        ("x_cm", _vp), ("x_pm", _vp), ("g", _vp), ("colsum_g", _vp),
-        ("w", _vp * 2), ("gw_s", _vp), ("colsum_gw", _vp), ("gw_a", _vp), ("gw_p", _vp), ("h", _vp * 2), ("h_t", _vp),
-        ("mu", _vp), ("fixed_h", _vp), ("fixed_w", _vp), ("simplex_rows", _vp),
-        ("halo_top", _vp), ("halo_bot", _vp),
-        ("hpart", _vp), ("hstat", _vp * 2), ("a_slab", _vp), ("a", _vp), ("w_scratch", _vp),
-        ("hist", _vp), ("hist_len", _i32), ("cur", _i32), ("it", _i32),
-        ("ell_h", _vp), ("ell_h_off", _vp), ("ell_klc", _vp), ("ell_w", _vp), ("ell_w_off", _vp), ("chan_perm", _vp),
-        ("ell_cbits", _i32), ("n_cg", _i32), ("pix_perm", _vp), ("g_t", _vp), ("breg_sr_px", _vp), ("breg_sr_ch", _vp), ("h_rule", _i32), ("pg_gamma_w", _f32), ("pg_q", _vp),
-        ("ell_fill_px", _vp), ("ell_fill_num", _vp), ("ell_fill_n", _i32), ("tail_mode", _i32),
-    ]
+    """struct espm_mu_state: fields, order and types parsed from include/espm_mu.h.  A fresh instance carries
+    struct_size / abi_version, which every entry point checks (ESPM_EINVAL on a mismatch)."""
+    _fields_ = _abi.parse_struct(_HEADER_TEXT)
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(type(self))
+        self.abi_version = ABI_VERSION
 
 
 # every symbol include/espm_mu.h declares: name -> (restype, argtypes)
@@ -59,6 +55,9 @@ _SP = C.POINTER(MUState)
 SYMBOLS = {
     "espm_mu_version": (C.c_char_p, []),
     "espm_mu_last_error": (C.c_char_p, []),
+    "espm_mu_state_size": (C.c_size_t, []),
+    "espm_mu_abi_version": (C.c_int, []),
+    "espm_mu_state_layout": (C.c_char_p, []),
     "espm_mu_query": (C.c_int, [_SP]),
     "espm_mu_w_update_is_local": (C.c_int, [_SP]),
     "espm_mu_w_update_tail": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
@@ -72,6 +71,8 @@ SYMBOLS = {
     "espm_mu_h_finalize": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_loss_only": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_accum": (C.c_int, [_SP, _vp]),
+    "espm_mu_step_hw": (C.c_int, [_SP, C.c_int, _vp]),
+    "espm_mu_fused_applies": (C.c_int, [_SP]),
     "espm_mu_w_reduce": (C.c_int, [_SP, _vp]),
     "espm_mu_w_reduce_finalize": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
@@ -106,6 +107,11 @@ def _load(path=LIB_PATH):
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here means header and library disagree
         fn.restype, fn.argtypes = res, args
+    # the library's view of the state against the header's: size, version, and every field's name, offset and size
+    theirs, ours = lib.espm_mu_state_layout().decode(), _abi.layout_string(MUState)
+    if lib.espm_mu_state_size() != C.sizeof(MUState) or lib.espm_mu_abi_version() != ABI_VERSION or theirs != ours:
+        raise ImportError(f"{path} was built from another include/espm_mu.h (ABI {lib.espm_mu_abi_version()} / {lib.espm_mu_state_size()} bytes "
+                          f"against {ABI_VERSION} / {C.sizeof(MUState)}): rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
     return lib
 
 

@@ -24,8 +24,27 @@ int check_hip(hipError_t e, const char* what) {
 
 static int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
-static int check_state(const espm_mu_state* st) {
+// every field of espm_mu_state, in declaration order (tests compare espm_mu_state_layout() with the header: a field missing here fails them)
+#define ESPM_MU_STATE_FIELDS(F) \
+  F(struct_size) F(abi_version) F(n) F(m) F(k) F(p) F(nx) F(ny) F(n_pad) F(p_pad) F(x_dtype) F(tile_px) F(nblk_w) \
+  F(x_tile) F(n_cm) F(h_variant) F(p_total) F(simplex_h) F(simplex_w) F(grid_mode) F(compute_loss) F(lambda_l) \
+  F(sigma_l) F(eps_reg) F(log_shift) F(dicotomy_tol) F(rel_tol) F(xscale) F(gw_floor) F(x_cm) F(x_pm) F(g) \
+  F(colsum_g) F(w) F(gw_s) F(colsum_gw) F(gw_a) F(gw_p) F(h) F(h_t) F(mu) F(fixed_h) F(fixed_w) F(simplex_rows) \
+  F(halo_top) F(halo_bot) F(hpart) F(hstat) F(a_slab) F(a) F(w_scratch) F(hist) F(hist_len) F(cur) F(it) F(ell_h) \
+  F(ell_h_off) F(ell_klc) F(ell_w) F(ell_w_off) F(chan_perm) F(ell_cbits) F(n_cg) F(pix_perm) F(g_t) F(breg_sr_px) \
+  F(breg_sr_ch) F(h_rule) F(pg_gamma_w) F(pg_q) F(ell_fill_px) F(ell_fill_num) F(ell_fill_n) F(tail_mode) F(no_fused)
+
+// the caller's view of the state must be this library's (include/espm_mu.h, ESPM_MU_ABI_VERSION): checked before any field is read
+static int check_abi(const espm_mu_state* st) {
   ESPM_REQUIRE(st != nullptr, "state is NULL");
+  ESPM_REQUIRE(st->struct_size == (uint32_t)sizeof(espm_mu_state) && st->abi_version == (uint32_t)ESPM_MU_ABI_VERSION,
+               "espm_mu_state of %u bytes, ABI %u handed to a library built for %zu bytes, ABI %d: the binding's copy of the layout has drifted",
+               st->struct_size, st->abi_version, sizeof(espm_mu_state), ESPM_MU_ABI_VERSION);
+  return ESPM_OK;
+}
+
+static int check_state(const espm_mu_state* st) {
+  if (int rc = check_abi(st)) return rc;
   ESPM_REQUIRE(st->n >= 1 && st->p >= 1, "n=%d, p=%d must be >= 1", st->n, st->p);
   if (st->k < ESPM_MIN_K || st->k > ESPM_MAX_K)
     return set_error(ESPM_EUNSUPPORTED, "k=%d: this build supports %d..%d components", st->k, ESPM_MIN_K, ESPM_MAX_K);
@@ -67,6 +86,18 @@ static int check_state(const espm_mu_state* st) {
 
 static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / st->tile_px; }
 
+// Both half-steps in one launch (mu_fused_kernel.hpp): sparse store at its full geometry (512-pixel H tiles, i.e. an image
+// that fills the chip), the default H rule, LDS for the table and the numerators of 1024 pixels.  One record per pixel BLOCK.
+static bool fused_ok(const espm_mu_state* st) {
+  return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->tile_px == ESPM_ELL_TILE && st->h_rule == 0 && !st->no_fused &&
+         fused_ell_lds_bytes(st->n_pad, st->k) <= ESPM_ELL_LDS_MAX;
+}
+static HStepArgs fused_h_args(const espm_mu_state* st, int src) {
+  HStepArgs a = make_h_args(st, src, 1);
+  a.rec_nb = nblk_h(st);
+  return a;
+}
+
 }  // namespace espm
 
 using namespace espm;
@@ -76,8 +107,26 @@ extern "C" {
 const char* espm_mu_version(void) { return "espm_mu 0.1 (gfx950)"; }
 const char* espm_mu_last_error(void) { return g_err; }
 
+size_t espm_mu_state_size(void) { return sizeof(espm_mu_state); }
+int espm_mu_abi_version(void) { return ESPM_MU_ABI_VERSION; }
+
+const char* espm_mu_state_layout(void) {
+  static char text[4096];
+  static bool done = false;
+  if (!done) {
+    size_t len = 0;
+#define F(name)                                                                                                      \
+  len += (size_t)snprintf(text + len, sizeof(text) - len, #name ":%zu:%zu;", offsetof(espm_mu_state, name), \
+                          sizeof(((espm_mu_state*)nullptr)->name));
+    ESPM_MU_STATE_FIELDS(F)
+#undef F
+    done = true;
+  }
+  return text;
+}
+
 int espm_mu_query(espm_mu_state* st) {
-  ESPM_REQUIRE(st != nullptr, "state is NULL");
+  if (int rc = check_abi(st)) return rc;
   ESPM_REQUIRE(st->n >= 1 && st->p >= 1, "n=%d, p=%d must be >= 1", st->n, st->p);
   st->n_pad = roundup(st->n, ESPM_NPAD);
   st->p_pad = roundup(st->p, ESPM_PPAD);
@@ -133,7 +182,7 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
 }
 
 static int check_ell_geometry(const espm_mu_state* st) {
-  ESPM_REQUIRE(st != nullptr, "state is NULL");
+  if (int rc = check_abi(st)) return rc;
   ESPM_REQUIRE(st->x_dtype == ESPM_X_ELL && st->n >= 1 && st->p >= 1 && st->n_pad == roundup(st->n, ESPM_NPAD) &&
                    st->p_pad == roundup(st->p, ESPM_PPAD) && st->n_cg == (st->n + 63) / 64 &&
                    st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->ell_cbits >= 1 && st->ell_cbits <= 14 &&
@@ -286,6 +335,34 @@ int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream) {
   return dispatch_w_accum(make_w_args(st), st->k, st->x_dtype, st->nblk_w, static_cast<hipStream_t>(stream));
 }
 
+int espm_mu_fused_applies(const espm_mu_state* st) {
+  if (check_state(st)) return 0;
+  return fused_ok(st) ? 1 : 0;
+}
+
+int espm_mu_step_hw(const espm_mu_state* st, int src, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
+  if (!fused_ok(st)) {
+    if (int rc = espm_mu_step_h(st, src, 1, stream)) return rc;
+    return espm_mu_w_accum(st, stream);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HStepArgs a = fused_h_args(st, src);
+  if (st->tail_mode & ESPM_TAIL_RIDE) {  // the tail of the W update that produced this state rides along (include/espm_mu.h)
+    ESPM_REQUIRE(st->it >= 1 && w_update_is_local(st), "tail_mode: no local W update produced state %d", st->it);
+    a.tail = make_w_tail_args(finish_args(st, 1 - src, src, st->it, 1));
+    a.cs_parts = a.tail.parts;
+    a.cs_nbk = a.tail.nbk;
+    a.tail_on = 1;
+  }
+  if (a.fill_num)
+    if (int rc = launch_ell_fill_num(st->gw_s, st->h[src], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad, st->log_shift,
+                                     st->ell_fill_num, s))
+      return rc;
+  return launch_fused_ell(a, make_w_args(st), st->nblk_w, s);
+}
+
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, static_cast<hipStream_t>(stream));
@@ -363,13 +440,15 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
   // a launch of its own) rides in the NEXT H-step's launch as an extra workgroup; that H-step sums the partial column sums
   // itself, and the slab reduction that follows finds colsum_gw written.  The last tail is a launch of its own.
   const bool defer = st->x_dtype == ESPM_X_ELL && w_update_is_local(st) && !(st->pg_q && st->pg_gamma_w > 0.f);
+  // Both half-steps in one launch where the fused kernel applies (mu_fused_kernel.hpp): 2 launches per iteration instead of 3.
+  const bool fused = fused_ok(st);
   bool pending = false;
   WTailArgs tail;
   for (int i = 0; i < n_iter; ++i) {
     const int cur = st->cur, slot = st->it;
     int rc;
     if (defer) {
-      HStepArgs a = make_h_args(st, cur, 1);
+      HStepArgs a = fused ? fused_h_args(st, cur) : make_h_args(st, cur, 1);
       if (a.fill_num && (rc = launch_ell_fill_num(st->gw_s, st->h[cur], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad,
                                                   st->log_shift, st->ell_fill_num, s)))
         return rc;
@@ -379,16 +458,19 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
         a.tail_on = 1;
         a.tail = tail;
       }
-      if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
-      if ((rc = espm_mu_w_accum(st, stream))) return rc;
+      if (fused) {
+        if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s))) return rc;
+      } else {
+        if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
+        if ((rc = espm_mu_w_accum(st, stream))) return rc;
+      }
       const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
       if ((rc = launch_w_reduce_update(finish_args(st, cur, 1 - cur, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
                                        st->nblk_w, st->a, st->hpart, nblk_h(st), nullptr, 0, nullptr, &fin, s, &tail)))
         return rc;
       pending = true;
     } else {
-      if ((rc = espm_mu_step_h(st, cur, 1, stream))) return rc;
-      if ((rc = espm_mu_w_accum(st, stream))) return rc;
+      if ((rc = espm_mu_step_hw(st, cur, stream))) return rc;   // (one launch where the fused kernel applies, else H-step + W accumulation)
       // slab reduction with the H-step's finalize riding in the same launch, then (or, when W' is local, in it) the W update
       if ((rc = espm_mu_w_reduce_finish(st, cur, slot, 1, stream))) return rc;
     }
@@ -490,7 +572,7 @@ int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double
 }
 
 size_t espm_mu_shard_record_bytes(const espm_mu_state* st) {
-  if (!st) return 0;
+  if (check_abi(st)) return 0;
   size_t b = (size_t)st->k * st->n_pad * 4 + ESPM_HS_STRIDE * 8 + 2 * (size_t)st->k * (st->ny > 0 ? st->ny : 0) * 4;
   return (b + 15) / 16 * 16;
 }

@@ -505,6 +505,9 @@ struct HStepArgs {
   const double* cs_parts;
   int cs_nbk, cs_lds_off, tail_on;
   WTailArgs tail;
+  // fused half-steps (mu_fused_kernel.hpp): a workgroup covers TWO record slots of hpart - its record goes to slot
+  // 2 * blockIdx.x of rec_nb, zeros (neutral for every field) to the next; 0: one record per workgroup
+  int rec_nb;
 };
 struct HFinalizeArgs {
   const double* hpart;
@@ -657,6 +660,7 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   a.fill_n = st->ell_fill_n;
   a.cs_parts = nullptr;
   a.cs_nbk = a.cs_lds_off = a.tail_on = 0;
+  a.rec_nb = 0;
   a.n_pad = st->n_pad;
   return a;
 }
@@ -681,6 +685,8 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream);
+size_t fused_ell_lds_bytes(int n_pad, int k);
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);
 int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,

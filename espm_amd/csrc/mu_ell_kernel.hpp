@@ -58,10 +58,7 @@ struct EllTab {
   static __device__ __forceinline__ const float* quad(const float* tab, int rows) { return tab + (size_t)WB * rows; }
   // row r from 8 consecutive floats (the KP-strided gw_s / h_t rows)
   static __device__ __forceinline__ void put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
-    reinterpret_cast<float4*>(tab + (size_t)WB * rows)[r] = lo;
-    if constexpr (WB == 1) tab[r] = hi.x;
-    if constexpr (WB == 2) reinterpret_cast<float2*>(tab)[r] = make_float2(hi.x, hi.y);
-    if constexpr (WB == 4) reinterpret_cast<float4*>(tab)[r] = hi;
+    lds_table_put<K>(tab, rows, r, lo, hi);   // (mu_h_kernel.hpp: the epilogue of the fused half-steps writes rows too)
   }
   static __device__ __forceinline__ void get(const float* tab, int rows, uint32_t r, float (&g)[K]) {
     const float4 lo = reinterpret_cast<const float4*>(quad(tab, rows))[r];

@@ -1,0 +1,66 @@
+// Launcher of the fused half-steps of the sparse count store (mu_fused_kernel.hpp).
+#include "mu_fused_kernel.hpp"
+
+#ifndef ESPM_ELL_UNR_H
+#define ESPM_ELL_UNR_H 4
+#endif
+#ifndef ESPM_ELL_UNR_W
+#define ESPM_ELL_UNR_W 4
+#endif
+
+namespace espm {
+
+#if ESPM_MIN_K <= 8
+template <int K>
+static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream) {
+  FusedArgs args = args_in;
+  const int tab_rows = args.h.n_pad > ESPM_ELL_PB ? args.h.n_pad : ESPM_ELL_PB;
+  size_t part = (size_t)K * ESPM_ELL_PB * sizeof(float) * (K <= ESPM_ELL_PAIR_MAX_K ? 2 : 1);
+  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
+  if (red > part) part = red;
+  if (tail_scratch > part) part = tail_scratch;
+  size_t bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
+  if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
+    args.h.cs_lds_off = (int)bytes;
+    bytes += KP * sizeof(double);
+  }
+  if (bytes > ESPM_ELL_LDS_MAX) return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
+  auto go = [&](auto kern) -> int {
+    if (bytes > 64 * 1024)
+      if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                             "fused half-steps"))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(nblk + (args.h.tail_on ? 1 : 0)), dim3(ESPM_ELL_WTHREADS), bytes, stream, args);
+    return check_hip(hipGetLastError(), "fused half-steps launch");
+  };
+  return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W>)
+                             : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W>);
+}
+#endif
+
+// LDS the fused kernel needs for (n_pad, k): the caller decides with it whether the fused path applies
+size_t fused_ell_lds_bytes(int n_pad, int k) {
+  const int tab_rows = n_pad > ESPM_ELL_PB ? n_pad : ESPM_ELL_PB;
+  const int tabf = 4 + (k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4)));
+  return (size_t)tab_rows * tabf * 4 + (size_t)k * ESPM_ELL_PB * 4 * (k <= ESPM_ELL_PAIR_MAX_K ? 2 : 1) + KP * sizeof(double);
+}
+
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream) {
+  ESPM_REQUIRE(h.ell && h.ell_off && h.ell_klc && h.ell_pix && w.ell && w.ell_off && w.chan_perm, "fused half-steps: the sparse store's lists are missing");
+  ESPM_REQUIRE(h.ell_tp == ESPM_ELL_TILE && h.h_rule == 0 && h.write_h && !h.l2_m, "fused half-steps: 512-pixel tiles, the default H rule, write_h");
+  ESPM_REQUIRE(nblk == (h.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && w.n_cg >= 1, "fused half-steps: nblk_w=%d must be ceil(p / %d)", nblk, ESPM_ELL_PB);
+  FusedArgs fa;
+  fa.h = h;
+  fa.w = w;
+  switch (h.k) {
+#if ESPM_MIN_K <= 8
+#define ESPM_X(KK) case KK: return launch_fused_k<KK>(fa, nblk, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
+#endif
+  }
+  return set_error(ESPM_EUNSUPPORTED, "fused half-steps: k=%d not built", h.k);
+}
+
+}  // namespace espm

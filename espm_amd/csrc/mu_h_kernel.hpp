@@ -5,6 +5,17 @@
 
 namespace espm {
 
+// Row r of an LDS gather table of `rows` rows of K floats, in the layout of EllTab<K> (mu_ell_kernel.hpp): components 4..
+// first (1, 2 or 4 floats per row), then the float4 part.
+template <int K>
+__device__ __forceinline__ void lds_table_put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
+  constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : 4));
+  reinterpret_cast<float4*>(tab + (size_t)WB * rows)[r] = lo;
+  if constexpr (WB == 1) tab[r] = hi.x;
+  if constexpr (WB == 2) reinterpret_cast<float2*>(tab)[r] = make_float2(hi.x, hi.y);
+  if constexpr (WB == 4) reinterpret_cast<float4*>(tab)[r] = hi;
+}
+
 // What the epilogue needs of one pixel besides its numerators: requested in one go (no branch between the
 // loads, so they are all in flight together) BEFORE the barrier that ends the accumulation phase - a wave that
 // finishes its part early has them by the time the slowest wave arrives.
@@ -53,9 +64,12 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // EARLY = false requests the pixel's inputs after the barrier (for a kernel that cannot spare the registers across it).
 // RULE: the H rule (a.h_rule) - 0 log surrogate, 1 quadratic surrogate, 2 projected gradient - as a compile-time switch,
 // so that the default rule does not carry the registers of the others.
+// lds_tab (fused half-steps, mu_fused_kernel.hpp): the row H'[:, pixel] goes into this LDS table of `lds_rows` rows (the W
+// walk's gather table: row = place of the pixel in the tile, ones for the pixels beyond p) instead of the copy h_t in memory.
 template <int K, bool EARLY = true, int RULE = 0>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
-                                           const double* colsum = nullptr) {   // colsum: the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
+                                           const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
+                                           float* lds_tab = nullptr, int lds_rows = 0) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
   double red[NRED];
 #pragma unroll
@@ -74,6 +88,15 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   __syncthreads();
 
   // ---- epilogue: one thread per pixel -------------------------------------------------------
+  auto emit_ht = [&](int q, int jj, const float (&ht)[KP]) {   // the transposed copy of the new column: memory, or the W walk's LDS table
+    if (lds_tab) {
+      float4 hi = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (KP > 4 && K > 4) hi = make_float4(ht[4], ht[5], ht[6], ht[7]);
+      lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(ht[0], ht[1], ht[2], ht[3]), hi);
+    } else {
+      store_row_kp(a.h_t + (size_t)q * KP, ht);
+    }
+  };
   const float ls = a.lambda_l * a.sigma_l;
   float rel_shift = 0.f;
   if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
@@ -84,7 +107,10 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
   for (int jj = threadIdx.x; jj < TP; jj += (int)blockDim.x) {
     const int q = tile0 + jj;
-    if (q >= a.p) continue;
+    if (q >= a.p) {
+      if (lds_tab) lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f));
+      continue;
+    }
     if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
     loaded = false;
     float hin[K], nv[K], dv[K];
@@ -207,7 +233,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         red[R_ROWSUM + kk] += (double)hn;
         red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
       }
-      store_row_kp(a.h_t + (size_t)q * KP, ht);
+      emit_ht(q, jj, ht);
       continue;
     }
     if constexpr (quad) if (a.lambda_l != 0.f) {
@@ -237,7 +263,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         red[R_ROWSUM + kk] += (double)hn;
         red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
       }
-      store_row_kp(a.h_t + (size_t)q * KP, ht);
+      emit_ht(q, jj, ht);
       continue;
     }
 #pragma unroll
@@ -264,7 +290,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       red[R_ROWSUM + kk] += (double)hn;
       red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
     }
-    store_row_kp(a.h_t + (size_t)q * KP, ht);
+    emit_ht(q, jj, ht);
   }
 
   __syncthreads();  // smem is reused as reduction scratch
@@ -276,8 +302,8 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
   if (threadIdx.x == 0) {
     // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
-    double* out = a.hpart + blockIdx.x;
-    const size_t nb = gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
+    const size_t nb = a.rec_nb ? (size_t)a.rec_nb : gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
+    double* out = a.hpart + (a.rec_nb ? 2 * blockIdx.x : blockIdx.x);
     out[ESPM_HP_KL * nb] = red[ESPM_HP_KL];
     out[ESPM_HP_REG * nb] = red[ESPM_HP_REG];
     out[ESPM_HP_LAP * nb] = red[ESPM_HP_LAP];
@@ -287,6 +313,10 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     for (int kk = 0; kk < KP; ++kk) {
       out[(ESPM_HP_ROWSUM + kk) * nb] = kk < K ? red[R_ROWSUM + kk] : 0.0;
       out[(ESPM_HP_MAX + kk) * nb] = kk < K ? red[R_MAX + kk] : 0.0;
+    }
+    if (a.rec_nb && 2 * blockIdx.x + 1 < nb) {   // the slot of the block's second tile: sums + 0, maxima of non-negative values with 0
+#pragma unroll
+      for (int f = 0; f <= ESPM_HP_RELH; ++f) out[f * nb + 1] = 0.0;
     }
   }
 }

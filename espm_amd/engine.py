@@ -63,7 +63,7 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None, filled_pixels=None, frobenius=False):
+                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -350,6 +350,10 @@ class MUEngine:
         self.pg_q = torch.zeros((self.hist_len, 2), **f64) if float(pg_gamma_w) > 0 or int(h_rule) == 2 else None
         st.pg_q = self.pg_q.data_ptr() if self.pg_q is not None else None
         st.cur, st.it = 0, 0
+        # both half-steps of an iteration in one launch where the library's fused kernel applies (sparse store at 512-pixel
+        # tiles, default H rule: include/espm_mu.h, no_fused); `fused=False` keeps the two launches (A/B, tests)
+        st.no_fused = 0 if fused else 1
+        self._accum_done = False
 
         # ---- sharding -----------------------------------------------------------------------------------
         if self.world > 1:
@@ -433,6 +437,7 @@ class MUEngine:
         self.g.copy_(torch.from_numpy(Gh))
         self.g_t[:, :self.n] = self.g.t()
         self.colsum_g.copy_(torch.from_numpy(np.asarray(G, dtype=np.float64).sum(axis=0).astype(np.float32)))
+        self._gtg = None   # G^T G of the Frobenius W step (updates.py:31-36) belongs to the old G
         self._check(self.lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
 
     # ---- sharded helpers ---------------------------------------------------------------------------
@@ -471,7 +476,12 @@ class MUEngine:
         self._pending_tail = False
         try:
             if advance_h:
-                self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
+                # (the W accumulation rides in the same launch where the fused kernel applies; finish_iteration then skips it)
+                self._accum_done = (not self.frobenius) and bool(self.lib.espm_mu_fused_applies(C.byref(st)))
+                if self._accum_done:
+                    self._check(self.lib.espm_mu_step_hw(C.byref(st), st.cur, _stream()))
+                else:
+                    self._check(self.lib.espm_mu_step_h(C.byref(st), st.cur, 1, _stream()))
                 self._pending_finalize = (st.cur, st.it)
             else:
                 self._check(self.lib.espm_mu_loss_only(C.byref(st), st.cur, st.it, _stream()))
@@ -524,7 +534,9 @@ class MUEngine:
         if self.frobenius:
             return self._finish_iteration_frobenius()
         s = _stream()
-        self._check(self.lib.espm_mu_w_accum(C.byref(st), s))
+        if not (self._accum_done and getattr(self, "_pending_finalize", None) == (cur, slot)):
+            self._check(self.lib.espm_mu_w_accum(C.byref(st), s))
+        self._accum_done = False
         ride = getattr(self, "_pending_finalize", None) == (cur, slot)   # the H-step's record reduction rides along
         if ride:
             self._pending_finalize = None

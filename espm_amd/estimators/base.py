@@ -79,7 +79,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
     def __getstate__(self):
         state = super().__getstate__()
         state = dict(state)
-        state.pop("_engine", None)  # device buffers / ctypes pointers are not picklable
+        for key in ("_engine", "_truth_engine"):  # device buffers / ctypes pointers are not picklable
+            state.pop(key, None)
         return state
 
     # ---- hooks implemented by the concrete estimator -------------------------------------------------
@@ -133,8 +134,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         eng.load_state(W, H)
         eng.eval_current(advance_h=False)
         h = eng.history(upto=0, average=average)
-        self.detailed_loss_ = self._detailed(float(h["kl"][0]), float(h["reg"][0]), float(h["lap"][0]))
-        return float(h["loss"][0])
+        kl, loss = float(h["kl"][0]), float(h["loss"][0])
+        if X is not None and not self.l2 and self.const_KL_ is not None:
+            # base.py:196-203: the constant of the KL term is the one cached for the FITTED data, also when another X is
+            # handed in (the reference never recomputes it): replace the engine's own constant of `X`
+            Xa = np.asarray(X, dtype=np.float64)
+            own = float(np.sum(Xa * np.log(np.maximum(Xa, self.log_shift))) - np.sum(Xa))
+            shift = (self.const_KL_ - own) / (float(self.GWH_numel_) if average else 1.0)
+            kl, loss = kl + shift, loss + shift
+        self.detailed_loss_ = self._detailed(kl, float(h["reg"][0]), float(h["lap"][0]))
+        return loss
 
     def _get_engine(self):
         eng = getattr(self, "_engine", None)
@@ -216,7 +225,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 Xd[:, zp] = self.log_shift
                 Xd[zc, :] = self.log_shift
             else:
-                X_fixed = Xv
+                X_fixed = Xv.copy()   # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies)
             mean_x = float(Xd.mean(dtype=torch.float64))
         if self.normalize:
             self.norm_factor_ = (normalization_factor(X_fixed, self.n_components) if mean_x is None

@@ -121,9 +121,13 @@ class SmoothNMF(NMFEstimator):
 
     # ---- hooks of the base fit loop ---------------------------------------------------------------------
     def _gamma_value(self):
-        if self.algo == "projected_gradient" and self.gamma is None:
-            return self._pg_gamma()[0]
-        g = self.gamma_ if getattr(self, "gamma_", None) is not None else (sigmaL if self.gamma is None else self.gamma)
+        # the adapted gamma_ first (smooth_nmf.py:470-473 reports gamma_[0] after the linesearch moved it); the initial
+        # Lipschitz bound of the projected gradient only while gamma_ is not set yet
+        g = getattr(self, "gamma_", None)
+        if g is None:
+            if self.algo == "projected_gradient" and self.gamma is None:
+                return self._pg_gamma()[0]
+            g = sigmaL if self.gamma is None else self.gamma
         return g[0] if isinstance(g, list) else g
 
     def _engine_kwargs(self):

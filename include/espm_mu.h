@@ -17,6 +17,8 @@
  *                            + updates.py:38 / base.py:189 (GW = G @ W) + base.py:323 (rel_W)
  *   (rel_H, base.py:324, is produced by espm_mu_step_h / espm_mu_h_finalize of the NEXT state evaluation)
  *   espm_mu_hstat         <- updates.py:139 (max_j H), updates.py:60 (sum_j H)
+ *   espm_mu_step_hw       <- smooth_nmf.py:324-339 + :404-414 up to the sum over pixels: the H update and, with the new H, the
+ *                            pixel contraction of the W update (updates.py:38-39, :53-59) in one launch
  *   espm_mu_iterate       <- espm/estimators/smooth_nmf.py:284-455 (_iteration, log_surrogate)
  *                            driven by base.py:313-394 (single GPU, no host sync)
  *   espm_mu_shard_*       <- (new) pixel-row sharding over the GPUs of a node; no reference analogue
@@ -128,7 +130,15 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
                               starts FROM this state (local max; max-reduce over ranks) */
 #define ESPM_HI_STRIDE 8
 
+/* Version of this header's binary interface: the layout of espm_mu_state and the meaning of its fields.  Every entry
+ * point that takes a state checks st->struct_size == sizeof(espm_mu_state) and st->abi_version == ESPM_MU_ABI_VERSION
+ * first and fails with ESPM_EINVAL otherwise: a binding whose copy of the layout has drifted is refused instead of
+ * having its pointers misread.  A binding can also compare its layout field by field with espm_mu_state_layout(). */
+#define ESPM_MU_ABI_VERSION 2
+
 typedef struct espm_mu_state {
+  uint32_t struct_size;   /* sizeof(espm_mu_state) as the CALLER sees it                  */
+  uint32_t abi_version;   /* ESPM_MU_ABI_VERSION the caller was written against            */
   /* geometry */
   int32_t n;        /* energy channels: rows of X                                       */
   int32_t m;        /* columns of G; 0 means G = identity (then W is (n, k))            */
@@ -248,10 +258,20 @@ typedef struct espm_mu_state {
    * itself; the caller sets the bit for that one call, or flushes with espm_mu_w_update_tail.  espm_mu_iterate does all
    * this internally and ignores the field. */
   int32_t tail_mode;
+  /* Sparse store at its full geometry (tile_px = ESPM_ELL_TILE: an image that fills the chip), default H rule:
+   * espm_mu_iterate and espm_mu_step_hw run both half-steps of an iteration in ONE launch - the workgroup that has
+   * updated the 1024 pixels of a block goes straight on with that block's part of R H^T, which needs no other pixel's
+   * new H (updates.py:38-39, :53-59); h_t is then not written.  no_fused != 0 keeps the two launches (A/B, tests). */
+  int32_t no_fused;
 } espm_mu_state;
 
 const char* espm_mu_version(void);
 const char* espm_mu_last_error(void);
+/* sizeof(espm_mu_state) and ESPM_MU_ABI_VERSION of the library, and its view of the layout as text:
+ * "name:offset:size;" for every field in declaration order (arrays: the whole array), NUL-terminated, static storage. */
+size_t espm_mu_state_size(void);
+int espm_mu_abi_version(void);
+const char* espm_mu_state_layout(void);
 
 /* Fills n_pad, p_pad, tile_px, x_tile, nblk_w of `st` from n, p, k, x_dtype and the device's CU count. */
 int espm_mu_query(espm_mu_state* st);
@@ -300,6 +320,12 @@ int espm_mu_loss_only(const espm_mu_state* st, int src, int slot, espm_stream_t 
 
 /* A_slab[b] = sum over the pixels of block b of R[:, j] H[:, j]^T with R = X / (GW H), H = h_t. */
 int espm_mu_w_accum(const espm_mu_state* st, espm_stream_t stream);
+/* espm_mu_step_h(st, src, 1) and espm_mu_w_accum as ONE launch where espm_mu_fused_applies(st) (see no_fused above), else
+ * as those two calls: reads h[src]; writes h[1 - src], the records of hpart and a_slab.  (Fused: one record per block of
+ * 1024 pixels in every other record slot, zeros - neutral for every field - in between, so that espm_mu_h_finalize and
+ * the reduction calls read the records as they always do; h_t is left alone.) */
+int espm_mu_step_hw(const espm_mu_state* st, int src, espm_stream_t stream);
+int espm_mu_fused_applies(const espm_mu_state* st);
 /* a = sum_b a_slab[b] in fixed order (one pass, bit-reproducible). */
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream);
 /* espm_mu_w_reduce and espm_mu_h_finalize(st, src, slot) in ONE launch (the reduction of the H-step's records

@@ -47,6 +47,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_header_constants_and_struct_match_ctypes(lib):
+    """The binding takes the layout of espm_mu_state and the sizes from include/espm_mu.h itself; here an independent
+    (regex) reading of the header and the LIBRARY's own view (offsetof / sizeof of every field) must both agree with it."""
     text = open(HEADER).read()
     raw = dict(re.findall(r"#define\s+(ESPM_[A-Z_]+)\s+(\(?[-+*0-9A-Z_ ]+\)?)\s*(?:/\*|$)", text, flags=re.M))
 
@@ -59,7 +61,7 @@ def test_header_constants_and_struct_match_ctypes(lib):
                       ("HP_STRIDE", lib.HP_STRIDE), ("HS_STRIDE", lib.HS_STRIDE), ("HI_STRIDE", lib.HI_STRIDE),
                       ("HS_MAX", lib.HS_MAX), ("HI_KLX", lib.HI_KLX), ("HI_REG", lib.HI_REG), ("HI_LAP", lib.HI_LAP),
                       ("HI_SUMY", lib.HI_SUMY), ("HI_BAD", lib.HI_BAD), ("HI_REL_W", lib.HI_REL_W),
-                      ("HI_REL_H", lib.HI_REL_H)):
+                      ("HI_REL_H", lib.HI_REL_H), ("MU_ABI_VERSION", lib.ABI_VERSION)):
         assert int(defs["ESPM_" + name]) == val, name
     body = re.sub(r"/\*.*?\*/", "", text[text.index("typedef struct espm_mu_state {"):text.index("} espm_mu_state;")], flags=re.S)
     names = []
@@ -70,6 +72,49 @@ def test_header_constants_and_struct_match_ctypes(lib):
         for part in decl.split(","):
             names.append(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:\[\d+\])?\s*$", part.strip())[0])
     assert names == [f[0] for f in lib.MUState._fields_]
+    assert names[:2] == ["struct_size", "abi_version"]
+    from espm_amd import _abi
+    for handle in (lib.lib, lib.variant(12).lib):   # both builds
+        assert handle.espm_mu_state_size() == C.sizeof(lib.MUState) and handle.espm_mu_abi_version() == lib.ABI_VERSION
+        assert handle.espm_mu_state_layout().decode() == _abi.layout_string(lib.MUState)
+
+
+def test_a_drifted_layout_is_refused(lib):
+    """A binding whose copy of the struct lost, gained or reordered a field must fail loudly, not have its pointers
+    misread: every entry point checks struct_size / abi_version, and the loader compares the layouts field by field."""
+    from espm_amd import _abi
+    fields = list(lib.MUState._fields_)
+    i = [n for n, _ in fields].index("x_cm")
+
+    class Dropped(C.Structure):        # one pointer missing: everything behind it moves by 8 bytes
+        _fields_ = fields[:i] + fields[i + 1:]
+
+    class Swapped(C.Structure):        # same size, two pointers traded places
+        _fields_ = fields[:i] + [fields[i + 1], fields[i]] + fields[i + 2:]
+
+    st = Dropped()
+    st.struct_size, st.abi_version = C.sizeof(Dropped), lib.ABI_VERSION
+    st.n, st.p, st.k = 64, 512, 3
+    raw = C.CDLL(lib.LIB_PATH)        # (untyped handle: the typed one would refuse the foreign struct before the call)
+    raw.espm_mu_last_error.restype = C.c_char_p
+    assert raw.espm_mu_query(C.byref(st)) == lib.EINVAL and b"drifted" in raw.espm_mu_last_error()
+    assert raw.espm_mu_step_h(C.byref(st), 0, 1, None) == lib.EINVAL
+    assert raw.espm_mu_iterate(C.byref(st), 1, 0, None) == lib.EINVAL
+    good = lib.MUState()
+    good.n, good.p, good.k = 64, 512, 3
+    assert raw.espm_mu_query(C.byref(good)) == 0
+    good.abi_version = lib.ABI_VERSION - 1
+    assert raw.espm_mu_query(C.byref(good)) == lib.EINVAL
+    # same size, wrong offsets: only the field-by-field comparison of the loader sees it
+    assert C.sizeof(Swapped) == C.sizeof(lib.MUState)
+    assert _abi.layout_string(Swapped) != lib.lib.espm_mu_state_layout().decode()
+
+
+def test_integration_binding_is_generated_from_the_header():
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_integration.py"), "--check"]) == 0, \
+        "INTEGRATION.md's espm_mu_state block is stale: run python tools/gen_integration.py"
 
 
 def test_query_layout_without_gpu(lib):

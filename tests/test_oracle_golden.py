@@ -340,3 +340,37 @@ def test_f13_projected_gradient_linesearch(golden):
         np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-6, err_msg=name)
         if name == "lx":
             assert (np.diff(g[f"{name}_gammas"][:, 0]) > 0).any(), "the fixture must contain an increase of gamma"
+
+
+def test_sparse_oracle_on_f6(golden):
+    """The sparse-aware fp64 variant (oracle/mu_oracle_sparse.py: Y only at the non-zero entries of X, sum(Y) by
+    colsum . rowsum, G^T (R H^T)) that the full-size GPU parity tests use is pinned here: on every F6 problem it must
+    reproduce the reference-generated trajectories (free mode) like the faithful oracle does."""
+    from oracle import mu_oracle_sparse as osp
+    g = golden("f6_trajectories")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        G = g.get(f"{name}_G")
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        kw = dict(c["kw"])
+        if kw.pop("normalize", False):
+            continue
+        X_ = oc.remove_zeros_lines(np.asarray(g[f"{name}_X"]), oc.LOG_SHIFT)
+        _, W0, H0 = oc.initialize_algorithms(X_, G, g[f"{name}_W0"].copy(), g[f"{name}_H0"].copy(), c["k"], None, None,
+                                             kw.get("simplex_H", False), kw.get("simplex_W", True))
+        r = osp.fit(osp.SparseX.from_dense(X_), c["k"], G=G, W=W0, H=H0, shape_2d=shape, record_at=(1, 2, 5, 50),
+                    tol=0, max_iter=50, **kw)
+        pre = f"{name}_free"
+        np.testing.assert_allclose(r["losses"], g[f"{pre}_losses"], rtol=1e-9, err_msg=pre)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{pre}_detailed"][:, :3], rtol=1e-9, atol=1e-18, err_msg=pre)
+        np.testing.assert_allclose(r["rel"], g[f"{pre}_rel"], rtol=1e-7, atol=1e-12, err_msg=pre)
+        Wf, Hf = r["W"], r["H"]
+        if not kw.get("simplex_H", False) and not kw.get("simplex_W", True):
+            Wf, Hf = oc.rescaled_DH(Wf, Hf)      # base.py:399-400, outside the loop
+        np.testing.assert_allclose(Wf, g[f"{pre}_W"], rtol=1e-8, atol=1e-14, err_msg=pre)
+        np.testing.assert_allclose(Hf, g[f"{pre}_H"], rtol=1e-8, atol=1e-14, err_msg=pre)
+        for t, (Wt, Ht) in r["snapshots"].items():
+            np.testing.assert_allclose(Wt, g[f"{pre}_W{t}"], rtol=1e-8, atol=1e-14)
+            np.testing.assert_allclose(Ht, g[f"{pre}_H{t}"], rtol=1e-8, atol=1e-14)
+        assert osp.dropped_eps_logy(osp.SparseX.from_dense(X_), G, r["W"], r["H"]) < 1e-9 * abs(r["losses"][-1]) * X_.size
