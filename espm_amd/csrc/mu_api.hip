@@ -89,7 +89,7 @@ static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / 
 // Both half-steps in one launch (mu_fused_kernel.hpp): sparse store at its full geometry (512-pixel H tiles, i.e. an image
 // that fills the chip), the default H rule, LDS for the table and the numerators of 1024 pixels.  One record per pixel BLOCK.
 static bool fused_ok(const espm_mu_state* st) {
-  return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->tile_px == ESPM_ELL_TILE && st->h_rule == 0 && !st->no_fused &&
+  return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->tile_px == ESPM_ELL_TILE && st->h_rule == 0 && st->no_fused != 1 &&
          fused_ell_lds_bytes(st->n_pad, st->k) <= ESPM_ELL_LDS_MAX;
 }
 static HStepArgs fused_h_args(const espm_mu_state* st, int src) {
@@ -360,7 +360,7 @@ int espm_mu_step_hw(const espm_mu_state* st, int src, espm_stream_t stream) {
     if (int rc = launch_ell_fill_num(st->gw_s, st->h[src], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad, st->log_shift,
                                      st->ell_fill_num, s))
       return rc;
-  return launch_fused_ell(a, make_w_args(st), st->nblk_w, s);
+  return launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2);
 }
 
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
@@ -459,7 +459,7 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
         a.tail = tail;
       }
       if (fused) {
-        if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s))) return rc;
+        if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2))) return rc;
       } else {
         if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
         if ((rc = espm_mu_w_accum(st, stream))) return rc;

@@ -26,6 +26,29 @@ __device__ __forceinline__ void store_row_kp(float* dst, const float (&row)[KP])
 }
 constexpr int WAVE = 64;
 
+// Phase stamps of the fused kernel for tools/analysis/phase_clock.py: only in a library built with -DESPM_PHASE_CLOCK (never
+// the product's build).  Thread 0 of a workgroup writes the 100 MHz wall clock into slot `id` of its 8 slots.
+#ifdef ESPM_PHASE_CLOCK
+static __device__ unsigned long long* espm_phase_buf = nullptr;
+#define ESPM_PHASE_SLOTS 40   // 8 workgroup stamps, then one per wave (16) for the end of the H walk and of the W walk
+#define ESPM_PHASE_STAMP(id)                                                                                                 \
+  do {                                                                                                                       \
+    if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[(size_t)blockIdx.x * ESPM_PHASE_SLOTS + (id)] = wall_clock64();   \
+  } while (0)
+#define ESPM_WAVE_STAMP(base)                                                                                                              \
+  do {                                                                                                                                     \
+    if ((threadIdx.x & 63) == 0 && espm_phase_buf)                                                                                         \
+      espm_phase_buf[(size_t)blockIdx.x * ESPM_PHASE_SLOTS + (base) + (threadIdx.x >> 6)] = wall_clock64();                                 \
+  } while (0)
+#else
+#define ESPM_PHASE_STAMP(id) \
+  do {                       \
+  } while (0)
+#define ESPM_WAVE_STAMP(base) \
+  do {                        \
+  } while (0)
+#endif
+
 typedef uint16_t bf16_t;  // raw storage; converted with shifts (exact)
 typedef float f2 __attribute__((ext_vector_type(2)));  // pairs of fp32: v_pk_fma_f32 / v_pk_mul_f32
 
@@ -238,6 +261,33 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
     for (int i = 0; i < NV; ++i) v[i] = scratch[nw * NV + i];
   }
   __syncthreads();
+}
+
+// Block-wide reduction of NV fp32 values (sum for the first NSUM, max for the rest) with ONE barrier: fp32 DPP reductions
+// inside each wave (6 moves + 6 adds per value, a third of the double version), the per-wave results as doubles in
+// `scratch` ((blockDim.x / 64) * NV doubles), then thread i < NV combines value i over the waves in wave order
+// (deterministic, fp64) and hands it to emit(i, value) - no gathering thread, no second and third barrier.  The other
+// threads leave after the barrier; `scratch` must not be reused before the next barrier of the caller.
+template <int NV, int NSUM, typename Emit>
+__device__ __forceinline__ void block_reduce_f32(const float (&v)[NV], double* scratch, Emit emit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = (double)r[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    double acc = scratch[i];
+    for (int w = 1; w < nw; ++w) {
+      const double o = scratch[w * NV + i];
+      acc = (i < NSUM) ? acc + o : (o > acc ? o : acc);
+    }
+    emit(i, acc);
+  }
 }
 
 // ---- tail of the local W update: column sums of G W' and rel_W (base.py:323) from the partials and W', W -----------------
@@ -685,7 +735,7 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
-int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream);
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units = 0);
 size_t fused_ell_lds_bytes(int n_pad, int k);
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);

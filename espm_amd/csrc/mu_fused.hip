@@ -15,12 +15,14 @@ template <int K>
 static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream) {
   FusedArgs args = args_in;
   const int tab_rows = args.h.n_pad > ESPM_ELL_PB ? args.h.n_pad : ESPM_ELL_PB;
-  size_t part = (size_t)K * ESPM_ELL_PB * sizeof(float) * (K <= ESPM_ELL_PAIR_MAX_K ? 2 : 1);
+  size_t part = (size_t)FusedGeom<K>::S * FusedGeom<K>::PROWS * ESPM_ELL_PB * sizeof(float);
   const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
   if (red > part) part = red;
   if (tail_scratch > part) part = tail_scratch;
   size_t bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
+  args.cnt_lds_off = (int)bytes;   // the two unit counters
+  bytes += 16;
   if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
     args.h.cs_lds_off = (int)bytes;
     bytes += KP * sizeof(double);
@@ -43,16 +45,18 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
 size_t fused_ell_lds_bytes(int n_pad, int k) {
   const int tab_rows = n_pad > ESPM_ELL_PB ? n_pad : ESPM_ELL_PB;
   const int tabf = 4 + (k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4)));
-  return (size_t)tab_rows * tabf * 4 + (size_t)k * ESPM_ELL_PB * 4 * (k <= ESPM_ELL_PAIR_MAX_K ? 2 : 1) + KP * sizeof(double);
+  const int seg = k <= 5 ? 4 : (k == 6 ? 3 : 2);   // FusedGeom<K>::S
+  return (size_t)tab_rows * tabf * 4 + (size_t)seg * (k + 1) * ESPM_ELL_PB * 4 + 16 + KP * sizeof(double);
 }
 
-int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream) {
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units) {
   ESPM_REQUIRE(h.ell && h.ell_off && h.ell_klc && h.ell_pix && w.ell && w.ell_off && w.chan_perm, "fused half-steps: the sparse store's lists are missing");
   ESPM_REQUIRE(h.ell_tp == ESPM_ELL_TILE && h.h_rule == 0 && h.write_h && !h.l2_m, "fused half-steps: 512-pixel tiles, the default H rule, write_h");
   ESPM_REQUIRE(nblk == (h.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && w.n_cg >= 1, "fused half-steps: nblk_w=%d must be ceil(p / %d)", nblk, ESPM_ELL_PB);
   FusedArgs fa;
   fa.h = h;
   fa.w = w;
+  fa.static_units = static_units;
   switch (h.k) {
 #if ESPM_MIN_K <= 8
 #define ESPM_X(KK) case KK: return launch_fused_k<KK>(fa, nblk, stream);
@@ -64,3 +68,11 @@ int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStrea
 }
 
 }  // namespace espm
+
+#ifdef ESPM_PHASE_CLOCK
+// debug build only (tools/analysis/phase_clock.py): where the fused kernel's workgroups write their phase stamps (8 x uint64 per workgroup)
+extern "C" int espm_debug_phase_buffer(void* dev_ptr) {
+  unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+  return espm::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm::espm_phase_buf), &p, sizeof(p)), "phase buffer");
+}
+#endif

@@ -6,14 +6,20 @@
 // What IS global - the row sums of H' in the denominator of W', the sum of the slabs - stays in the reduction launch
 // that follows (w_reduce_update_kernel / w_reduce_kernel, mu_w_step.hip).
 //
-//   workgroup = 16 waves = one block of ESPM_ELL_PB = 1024 pixels = two H tiles of 512 pixels
+//   workgroup = 16 waves = one block of ESPM_ELL_PB = 1024 pixels = two H tiles of 512 pixels (16 pixel-list groups)
 //   1. GW table -> LDS (address 0), as in h_step_ell_kernel
-//   2. H walk: waves 0..7 tile 2b, waves 8..15 tile 2b + 1, each half exactly as h_step_ell_kernel walks its window
-//      (pairs of list groups, two partial numerators per pixel)
+//   2. H walk, DYNAMIC: the rows of every list group are cut into S segments; the 16 S (group, segment) units are handed
+//      out through a counter in LDS, so a wave that is done takes the next unit.  A unit's partial numerators (and its
+//      part of the KL sum) go to slot `segment` of its pixels, and a pixel's slots are summed in slot order: the result
+//      does not depend on which wave walked what (bit-reproducible), only the time does.
+//      Why: the four waves of a SIMD do not share it evenly - with equal shares of the rows, waves 0-3 of the workgroup
+//      finished their walk after 42 us, waves 12-15 after 71 (tools/analysis/phase_clock.py), and the tail ran one wave
+//      per SIMD deep.
 //   3. epilogue, one thread per pixel (h_epilogue): H' -> h[1 - src] (the next iteration's stencil and rel_H need it in
 //      memory) and, instead of the transposed copy h_t in memory, straight into the LDS table of the W walk, which
 //      takes the place of the GW table (address 0: the unit entries of both list sets address their table without a base)
-//   4. W walk: w_accum_ell_kernel's body; the GW row of a lane's channel comes from gw_s (L2)
+//   4. W walk, dynamic too: the block's channel groups (in order of decreasing length) through a second counter; a group
+//      is walked by one wave, so its rows of the slab have one writer whoever that is.
 //
 // Against the two launches this saves a kernel boundary, the table prologue of the W accumulation (1024 rows of h_t
 // from memory, a barrier), and 2 x 4 KP p bytes of h_t traffic.  The block's record goes to the hpart slot of its first
@@ -26,22 +32,40 @@ namespace espm {
 struct FusedArgs {
   HStepArgs h;      // write_h = 1, ell_tp = 512; h_t unused
   WAccumArgs w;     // h_t unused
+  int cnt_lds_off;  // byte offset of the two unit counters in LDS
+  int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
+};
+
+// segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of 1024 floats each)
+template <int K>
+struct FusedGeom {
+  static constexpr int S = K <= 5 ? 4 : (K == 6 ? 3 : 2);
+  static constexpr int PROWS = K + 1;   // K numerators + the KL part
+  // first row of segment s of a group of `len` rows: the segments shrink (35 / 30 / 20 / 15 % of the rows), so that the
+  // units handed out last are the short ones and the waves end close together
+  static __device__ __forceinline__ int seg_begin(int len, int s) {
+    constexpr int cut4[5] = {0, 35, 65, 85, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, 60, 100};
+    const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
+    return (int)((long)len * c / 100);
+  }
 };
 
 template <int K, bool LOSS, int UNR_H, int UNR_W>
 __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const FusedArgs fa) {
   constexpr int NT = ESPM_ELL_WTHREADS;       // 1024 threads
-  constexpr int TP = ESPM_ELL_TILE;           // 512 pixels per half
+  constexpr int TP = ESPM_ELL_TILE;           // 512 pixels per H tile
   constexpr int PB = ESPM_ELL_PB;             // 1024 pixels per workgroup
   static_assert(PB == 2 * TP && NT == PB, "a workgroup is two H tiles and one thread per pixel");
-  constexpr bool PAIRS_OK = K <= ESPM_ELL_PAIR_MAX_K;
-  constexpr int NPARTS = PAIRS_OK ? 2 : 1;
+  constexpr int S = FusedGeom<K>::S, PROWS = FusedGeom<K>::PROWS;
+  constexpr int NGRP = PB / 64;               // 16 pixel-list groups
   const HStepArgs& a = fa.h;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;   // [n_pad] rows of GW, later [PB] rows of H'
   ell_table_at_lds_zero(tab);
+  ESPM_PHASE_STAMP(0);
   const int tab_rows = a.n_pad > PB ? a.n_pad : PB;
-  float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [NPARTS][K][PB] numerators (pixel = its place in the block), then reduction scratch
+  float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
+  int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk
   if (a.tail_on && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
     w_tail_body<10>(a.tail, reinterpret_cast<double*>(smem));
     return;
@@ -58,83 +82,75 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
     const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
     EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
   }
-  if constexpr (PAIRS_OK) {  // second partial numerator: only the pixels of the longer group of a pair receive one
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) part[((size_t)K + kk) * PB + threadIdx.x] = 0.f;
-  }
+  if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
   __syncthreads();
+  ESPM_PHASE_STAMP(1);
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = wave >> 3, hw = wave & 7;          // H tile of this wave, its number inside the tile's eight
   const int blk0 = blockIdx.x * PB;
-  const int tile0 = blk0 + half * TP;
-  const bool tile_ok = tile0 < a.p_pad;               // (an odd number of tiles: the last block has one)
-  float kl = 0.f;
-
-  // rows [x0, x1) of list group gi of the tile -> partial numerator `slot` of its pixels
-  auto walk_rows = [&](int gi, int x0, int x1, int slot) {
-    const int grp = tile0 / 64 + gi;
-    const int lp = a.ell_pix[tile0 + gi * 64 + lane];   // slot -> pixel of the window (lists ordered by length)
-    const int px = tile0 + lp;
-    float hk[K], acc[K];
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
-      acc[kk] = 0.f;
+  int own_next[2] = {(int)(threadIdx.x >> 6), (int)(threadIdx.x >> 6)};
+  auto next_unit = [&](int which) {
+    if (fa.static_units) {
+      const int u = own_next[which];
+      own_next[which] += NT / 64;
+      return __builtin_amdgcn_readfirstlane(u);
     }
-    const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg;
-    const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-    if (x0 < mid) {
-      ell_walk<K, UNR_H>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
-        const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
-        ell_axpy<K>(acc, g, r);
-        if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
-      });
-    }
-    if (x1 > mid) {
-      const int g0 = max(x0, mid);
-      ell_walk<K, UNR_H>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
-        const float y = ell_dot<K>(g, hk);
-        const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-        ell_axpy<K>(acc, g, r);
-        if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-      });
-    }
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) part[((size_t)slot * K + kk) * PB + half * TP + lp] = acc[kk];
-    if (LOSS && slot == 0) kl += fmaxf(a.ell_klc[px], 0.f);
+    int u = 0;
+    if (lane == 0) u = __hip_atomic_fetch_add(cnt + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(u);
   };
-  auto group_rows = [&](int gi) { return a.ell_off[2 * (tile0 / 64 + gi) + 2] - a.ell_off[2 * (tile0 / 64 + gi)]; };
 
-  if (tile_ok) {
-    if constexpr (PAIRS_OK) {
-      const int gl = hw < 4 ? hw : 7 - hw;           // the longer group of this wave's pair
-      const int len_l = group_rows(gl), len_s = group_rows(7 - gl);
-      const int hrows = min(len_l, (len_l + len_s + 1) / 2);
-      if (hw < 4) {
-        walk_rows(gl, 0, hrows, 0);
-      } else {
-        walk_rows(hw, 0, len_s, 0);
-        if (hrows < len_l) walk_rows(gl, hrows, len_l, 1);
-      }
-    } else {
-      walk_rows(hw, 0, group_rows(hw), 0);
-    }
-  } else {
+  // ---- H walk: units u = segment * 16 + group (segment-major: every group is started early) ----
+  for (int u = next_unit(0); u < NGRP * S; u = next_unit(0)) {
+    const int seg = u / NGRP, gi = u - seg * NGRP;     // group gi of the block: tile gi >> 3, its group gi & 7
+    const int grp = blk0 / 64 + gi;
+    float acc[K];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) part[(size_t)kk * PB + threadIdx.x] = 0.f;   // (no tile: its pixels lie beyond p, never read)
+    for (int kk = 0; kk < K; ++kk) acc[kk] = 0.f;
+    float kl = 0.f;
+    int lp = lane;   // place of the lane's pixel inside its tile
+    if (blk0 + (gi >> 3) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
+      lp = a.ell_pix[grp * 64 + lane];       // slot -> pixel of the window (lists ordered by length)
+      const int px = blk0 + (gi >> 3) * TP + lp;
+      float hk[K];
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
+      const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg, len = a.ell_off[2 * grp + 2] - beg;
+      const int x0 = FusedGeom<K>::seg_begin(len, seg), x1 = FusedGeom<K>::seg_begin(len, seg + 1);
+      const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
+      if (x0 < mid) {
+        ell_walk<K, UNR_H>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
+          const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+          ell_axpy<K>(acc, g, r);
+          if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
+        });
+      }
+      if (x1 > mid) {
+        const int g0 = max(x0, mid);
+        ell_walk<K, UNR_H>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
+          const float y = ell_dot<K>(g, hk);
+          // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+          const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+          ell_axpy<K>(acc, g, r);
+          if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+        });
+      }
+    }
+    float* dst = part + (size_t)seg * PROWS * PB + (gi >> 3) * TP + lp;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) dst[(size_t)kk * PB] = acc[kk];
+    dst[(size_t)K * PB] = kl;
   }
+  ESPM_PHASE_STAMP(2);   // wave 0 found no unit left
+  ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the 1024 pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0>(a, part, NPARTS, PB, blk0, LOSS ? kl : 0.f, cs_lds, tab, PB);
+  h_epilogue<K, true, 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true);
 
-  // ---- W accumulation over the block's channel lists (w_accum_ell_kernel's body with csplit = 1) ----
+  ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
+  // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
   const WAccumArgs& w = fa.w;
   const int b = blockIdx.x;
-  constexpr int nw = NT / 64;
-  for (int t = 0; t * nw < w.n_cg; ++t) {
-    const int cg = t * nw + ((t & 1) ? nw - 1 - wave : wave);
-    if (cg >= w.n_cg) continue;
+  for (int cg = next_unit(1); cg < w.n_cg; cg = next_unit(1)) {
     const int c = w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane];
     const float* gsrc = w.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
@@ -158,6 +174,12 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
       for (int kk = 0; kk < K; ++kk) w.a_slab[((size_t)b * K + kk) * w.n_pad + c] = acc[kk];
     }
   }
+  ESPM_PHASE_STAMP(6);   // wave 0 found no channel group left
+  ESPM_WAVE_STAMP(24);
+#ifdef ESPM_PHASE_CLOCK
+  __syncthreads();
+  ESPM_PHASE_STAMP(7);   // the workgroup is done
+#endif
 }
 
 }  // namespace espm

@@ -66,17 +66,20 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // so that the default rule does not carry the registers of the others.
 // lds_tab (fused half-steps, mu_fused_kernel.hpp): the row H'[:, pixel] goes into this LDS table of `lds_rows` rows (the W
 // walk's gather table: row = place of the pixel in the tile, ones for the pixels beyond p) instead of the copy h_t in memory.
+// kl_rows (fused half-steps): every partial carries K + 1 rows of TP floats, the last being the pixel's part of
+// sum X log2(X / Y) (summed per pixel in slot order: the loss does not depend on which wave walked which slot); kl_lane
+// is then unused and the per-pixel loss constant ell_klc is added here.
 template <int K, bool EARLY = true, int RULE = 0>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
-                                           float* lds_tab = nullptr, int lds_rows = 0) {
+                                           float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
-  double red[NRED];
+  float red[NRED];   // per-thread partials in fp32 (one or two pixels per thread); fp64 from the wave results on (block_reduce_f32)
 #pragma unroll
-  for (int i = 0; i < NRED; ++i) red[i] = 0.0;
+  for (int i = 0; i < NRED; ++i) red[i] = 0.f;
   // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
   constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
-  red[ESPM_HP_KL] = (double)kl_lane;
+  red[ESPM_HP_KL] = kl_lane;
   double pg_q = 0.0;   // rule 2: <H' - H, grad> + gamma ||H' - H||^2 of this thread's pixels (the linesearch's quadratic bound)
   const bool stencil = a.lambda_l != 0.f && a.grid_mode;
   HEpiIn<K> in;
@@ -86,6 +89,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     loaded = true;
   }
   __syncthreads();
+  ESPM_PHASE_STAMP(3);
 
   // ---- epilogue: one thread per pixel -------------------------------------------------------
   auto emit_ht = [&](int q, int jj, const float (&ht)[KP]) {   // the transposed copy of the new column: memory, or the W walk's LDS table
@@ -114,10 +118,16 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
     loaded = false;
     float hin[K], nv[K], dv[K];
+    const int prows = kl_rows ? K + 1 : K;   // rows of TP floats per partial
+    if (kl_rows) {
+      float s = fmaxf(a.ell_klc[q], 0.f);   // (negative: the mark of a pixel without counts, no constant)
+      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + K) * TP + jj];
+      red[ESPM_HP_KL] += s;
+    }
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
       float s = 0.f;
-      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * K + kk) * TP + jj];
+      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + kk) * TP + jj];
       hin[kk] = in.hin[kk];
       nv[kk] = s * a.xscale;
       dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
@@ -154,7 +164,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       float worst = 0.f;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) worst = fmaxf(worst, fabsf(hin[kk] - in.hprev[kk]) * __builtin_amdgcn_rcpf(hin[kk] + rel_shift));   // (a stop-rule statistic: 1 ulp reciprocal)
-      red[R_RELH] = fmax(red[R_RELH], (double)worst);
+      red[R_RELH] = fmaxf(red[R_RELH], worst);
     }
     constexpr bool quad = RULE == 1;   // quadratic surrogate of the Laplacian term (multiplicative_step_hq, updates.py:263-315)
     constexpr bool pgrad = RULE == 2;  // projected gradient (proj_grad_step_h, updates.py:372-395)
@@ -163,7 +173,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       for (int kk = 0; kk < K; ++kk) {
         const float m = a.mu[kk];
         if (!quad) dv[kk] += m * __builtin_amdgcn_rcpf(hin[kk] + a.eps_reg);   // updates.py:134-137 (mu is not in the hq update)
-        red[ESPM_HP_REG] += (double)(m * logf(hin[kk] + a.eps_reg));  // measures.py:543-548
+        red[ESPM_HP_REG] += m * logf(hin[kk] + a.eps_reg);  // measures.py:543-548
       }
     }
     float hlv[K];
@@ -177,7 +187,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
                                            (((in.wl * in.l[kk] + in.wr * in.r[kk]) + in.wu * in.u[kk]) + in.wd * in.d[kk])
                                      : hin[kk];
         hlv[kk] = hl;
-        red[ESPM_HP_LAP] += (double)(hin[kk] * hl);             // measures.py:574-577
+        red[ESPM_HP_LAP] += hin[kk] * hl;             // measures.py:574-577
         if constexpr (RULE == 0) {
           const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
           nv[kk] += ls * mh;                                      // updates.py:140
@@ -227,11 +237,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
           const double dh = (double)hn - (double)hin[kk];
           pg_q += dh * (double)(dv[kk] - nv[kk]) + (double)a.sigma_l * dh * dh;
         }
-        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;
+        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.f;
         a.h_out[(size_t)kk * a.p_pad + q] = hn;
         ht[kk] = hn;
-        red[R_ROWSUM + kk] += (double)hn;
-        red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+        red[R_ROWSUM + kk] += hn;
+        red[R_MAX + kk] = fmaxf(red[R_MAX + kk], hn);
       }
       emit_ht(q, jj, ht);
       continue;
@@ -246,7 +256,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       }
       const float inv2a = __builtin_amdgcn_rcpf(2.f * ls);
       float nu = 0.f;
-      if (a.simplex_h && !simplex_root_hq<K>(ls, bq, cq, a.log_shift, 100, nu)) red[ESPM_HP_BAD] += 1.0;
+      if (a.simplex_h && !simplex_root_hq<K>(ls, bq, cq, a.log_shift, 100, nu)) red[ESPM_HP_BAD] += 1.f;
       float ht[KP];
 #pragma unroll
       for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
@@ -257,11 +267,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
           const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
           if (f >= 0.f) hn = f;
         }
-        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;
+        if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.f;
         a.h_out[(size_t)kk * a.p_pad + q] = hn;
         ht[kk] = hn;
-        red[R_ROWSUM + kk] += (double)hn;
-        red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+        red[R_ROWSUM + kk] += hn;
+        red[R_MAX + kk] = fmaxf(red[R_MAX + kk], hn);
       }
       emit_ht(q, jj, ht);
       continue;
@@ -270,7 +280,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
     if (a.simplex_h) {
       float delta, e[K];
-      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.0;
+      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.f;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
     }
@@ -284,40 +294,37 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
         if (f >= 0.f) hn = f;                                   // updates.py:154-155
       }
-      if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.0;            // NaN or inf
+      if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.f;            // NaN or inf
       a.h_out[(size_t)kk * a.p_pad + q] = hn;
       ht[kk] = hn;
-      red[R_ROWSUM + kk] += (double)hn;
-      red[R_MAX + kk] = fmax(red[R_MAX + kk], (double)hn);
+      red[R_ROWSUM + kk] += hn;
+      red[R_MAX + kk] = fmaxf(red[R_MAX + kk], hn);
     }
     emit_ht(q, jj, ht);
   }
 
+  ESPM_PHASE_STAMP(4);
   __syncthreads();  // smem is reused as reduction scratch
-  block_reduce<NRED, R_RELH, true>(red, reinterpret_cast<double*>(smem));   // rel_H and the row maxima are fp32 values
+  // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced; thread i of the
+  // workgroup finishes and writes value i itself
+  const size_t nb = a.rec_nb ? (size_t)a.rec_nb : gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
+  double* out = a.hpart + (a.rec_nb ? 2 * blockIdx.x : blockIdx.x);
+  block_reduce_f32<NRED, R_RELH>(red, reinterpret_cast<double*>(smem), [&](int i, double v) {
+    // red[]: [0..3] KL, REG, LAP, BAD, [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima -> record fields
+    const int field = i < R_RELH ? i : (i == R_RELH ? ESPM_HP_RELH : ESPM_HP_MAX + (i - R_MAX));
+    out[(size_t)field * nb] = v;
+  });
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 2 * (KP - K)) {   // the unused component slots of the record: zeros (second wave: off the reducing lanes' path)
+    const int j = threadIdx.x - 64;
+    out[(size_t)((j < KP - K ? ESPM_HP_ROWSUM + K + j : ESPM_HP_MAX + K + (j - (KP - K)))) * nb] = 0.0;
+  }
+  if (a.rec_nb && 2 * blockIdx.x + 1 < nb && threadIdx.x >= 128 && threadIdx.x <= 128 + ESPM_HP_RELH)   // the slot of the block's second tile: sums + 0, maxima of non-negative values with 0
+    out[(size_t)(threadIdx.x - 128) * nb + 1] = 0.0;
   if constexpr (RULE == 2) {
+    __syncthreads();
     double one[1] = {pg_q};
     block_reduce<1, 1>(one, reinterpret_cast<double*>(smem));
-    if (threadIdx.x == 0) a.hpart[(size_t)ESPM_HP_PGQ * (gridDim.x - a.tail_on) + blockIdx.x] = one[0];
-  }
-  if (threadIdx.x == 0) {
-    // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced
-    const size_t nb = a.rec_nb ? (size_t)a.rec_nb : gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
-    double* out = a.hpart + (a.rec_nb ? 2 * blockIdx.x : blockIdx.x);
-    out[ESPM_HP_KL * nb] = red[ESPM_HP_KL];
-    out[ESPM_HP_REG * nb] = red[ESPM_HP_REG];
-    out[ESPM_HP_LAP * nb] = red[ESPM_HP_LAP];
-    out[ESPM_HP_BAD * nb] = red[ESPM_HP_BAD];
-    out[ESPM_HP_RELH * nb] = red[R_RELH];
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk) {
-      out[(ESPM_HP_ROWSUM + kk) * nb] = kk < K ? red[R_ROWSUM + kk] : 0.0;
-      out[(ESPM_HP_MAX + kk) * nb] = kk < K ? red[R_MAX + kk] : 0.0;
-    }
-    if (a.rec_nb && 2 * blockIdx.x + 1 < nb) {   // the slot of the block's second tile: sums + 0, maxima of non-negative values with 0
-#pragma unroll
-      for (int f = 0; f <= ESPM_HP_RELH; ++f) out[f * nb + 1] = 0.0;
-    }
+    if (threadIdx.x == 0) a.hpart[(size_t)ESPM_HP_PGQ * nb + blockIdx.x] = one[0];
   }
 }
 

@@ -108,7 +108,7 @@ struct WUpdateArgs {
 __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs a) {
   __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
   __shared__ float s_part[8][32];
-  __shared__ double s_rs;
+  __shared__ double s_rsw[4];
   const int nwg = a.k * a.nbk;
   if ((int)blockIdx.x >= nwg) {  // the extra workgroup
     h_finalize_body(a.fin, fscratch);
@@ -118,12 +118,28 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = 32 * j + col;
   const int e = kk * a.n_pad + c;
+  auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
+  // Everything this workgroup needs from memory is requested up front - 32 sources per thread (256 slabs), its share of
+  // the H-step's records - so that ONE memory round trip and ONE barrier separate the launch from the update: the kernel
+  // is pure latency (8 us before, of an iteration of 150).
+  constexpr int INFLIGHT = 32;
+  float v[INFLIGHT];
+  const bool live = c < a.n_pad;
+#pragma unroll
+  for (int u = 0; u < INFLIGHT; ++u) {
+    const int b = grp + 8 * u;
+    v[u] = (live && b < a.nsrc) ? src(b) : 0.f;
+  }
+  double rsp = 0.0;   // slab mode: this thread's share of row sum kk of the new H (the order of h_finalize_body: same value as hstat's)
+  if (a.hpart) {
+    const size_t nb = a.nblk_h;
+    for (int b = threadIdx.x; b < a.nblk_h; b += 256) rsp += a.hpart[(ESPM_HP_ROWSUM + kk) * nb + b];
+  }
   float acc[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-  auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
-  if (c < a.n_pad) {
-    int b = grp;
+  for (int u = 0; u < 8; ++u) acc[u] = ((v[u] + v[u + 8]) + v[u + 16]) + v[u + 24];   // (the order of the loop below: source b ascending per partial)
+  if (live) {
+    int b = grp + 8 * INFLIGHT;
     for (; b + 56 < a.nsrc; b += 64) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] += src(b + 8 * u);
@@ -134,13 +150,10 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
   // row sum of component kk of the new H
   double rs = 0.0;
   if (a.hpart) {
-    double v[1] = {0.0};
-    const size_t nb = a.nblk_h;
-    for (int b = threadIdx.x; b < a.nblk_h; b += 256) v[0] += a.hpart[(ESPM_HP_ROWSUM + kk) * nb + b];
-    block_reduce<1, 1>(v, fscratch);   // (its barriers also order s_part)
-    if (threadIdx.x == 0) s_rs = v[0];
-    __syncthreads();
-    rs = s_rs;
+    rsp = wave_sum(rsp);
+    if ((threadIdx.x & 63) == 0) s_rsw[threadIdx.x >> 6] = rsp;
+    __syncthreads();   // (also orders s_part)
+    rs = ((s_rsw[0] + s_rsw[1]) + s_rsw[2]) + s_rsw[3];   // wave order, like block_reduce
   } else if (a.hstat_rs) {
     rs = a.hstat_rs[ESPM_HS_ROWSUM + kk];
     __syncthreads();
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     if (blockIdx.x == 0 && threadIdx.x < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
       double t = 0.0;
       for (int r = 0; r < a.nsrc; ++r) {
-        const double v = reinterpret_cast<const double*>(a.src + (size_t)r * a.src_stride + a.rec_hstat_off)[threadIdx.x];
-        t = (int)threadIdx.x < ESPM_HS_MAX ? t + v : fmax(t, v);
+        const double v2 = reinterpret_cast<const double*>(a.src + (size_t)r * a.src_stride + a.rec_hstat_off)[threadIdx.x];
+        t = (int)threadIdx.x < ESPM_HS_MAX ? t + v2 : fmax(t, v2);
       }
       a.hstat_out[threadIdx.x] = t;
     }
@@ -268,8 +281,11 @@ template <int KK, int WF_ROWS>
 __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinishArgs a) {
   constexpr int KA = KK;  // per-thread arrays are sized by the real component count (k == KK)
   __shared__ double scratch[(WF_THREADS / 64 + 1) * KP];
-  __shared__ double bis[2][(WF_THREADS / 64) * KA];   // per-wave partial sums of the bisection, two alternating buffers
-  __shared__ double s_lo[KA], s_hi[KA], s_mid[KA];
+  __shared__ double bis[2][(WF_THREADS / 64) * 2 * KA];   // per-wave partial sums (f, f') of the root finder, two alternating buffers
+  __shared__ double s_lo[KA], s_hi[KA], s_mid[KA], s_dstar[KA], s_sum[KA];
+  __shared__ double s_x[KA], s_root[KA], s_fder[KA], s_ad[KA], s_width[KA], s_u[KA];
+  __shared__ int s_flag[KA];
+  __shared__ unsigned long long s_mask[4];
   __shared__ int s_go;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // G given: [M*k] new W, [M*k] G^T A
   const int M = a.m > 0 ? a.m : a.n;
@@ -386,86 +402,224 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       }
     }
     if (a.simplex_w) {
+      // Multipliers of the simplex over W, all components at once.  The reference bisects the bracket [a, b] of every
+      // column with a GLOBAL stop rule (dicotomy.py:146-171): all columns stop at the first sweep t in which every column's
+      // midpoint has |f| <= tol, so its nu is the t-th midpoint of the bisection path towards the root - accurate to tol
+      // only, and W' inherits that (column sums 1 +- 1e-5).  Walking those ~40 sweeps on one CU was 90 us of a 260 us
+      // iteration.  The same nu in ~5 evaluations of f instead of ~40:
+      //   1. the ROOT by Newton in the shifted unknown delta = nu + d* (as the H-step's simplex_root): f is convex and
+      //      decreasing, sum(num) bounds the root from the right (every e = den - d* >= 0), so the first step lands left of
+      //      the root and the rest converges monotonically; safeguarded by the running bracket;
+      //   2. the bisection path needs no sweeps once the root is known: the t-th midpoint towards a root at fraction u of
+      //      the bracket is a + (b - a) (2 floor(u 2^(t-1)) + 1) / 2^t;
+      //   3. the sweep the reference stops at: the first t with max_k |f_k(mid_t)| <= tol - decided from the linearisation
+      //      f ~ f'(root) (mid - root) (its relative error is |mid - root| / delta ~ tol there), and by a real evaluation of
+      //      f where the estimate is within 1 % of tol.
+      // Thread kk < k OWNS component kk (bracket, iterate, decisions); the evaluation points travel through LDS (two
+      // barriers per evaluation): per-thread copies of the state of all components cost more registers than a wave has.
       double cnt_l = 0.0;
 #pragma unroll
       for (int r = 0; r < WF_ROWS; ++r) cnt_l += (tid + r * WF_THREADS < M && in_set[r]) ? 1.0 : 0.0;
       const double rows = block_sum1(cnt_l, scratch);
-      double b1[KA], b2[KA], b3[KA];  // per column: max(num/2 - den), max num, max(-den)   (dicotomy.py:29-49)
+      {  // per column: max(num/2 - den), max num, max(-den) (dicotomy.py:29-49); max(-den | num > 0), sum num
+        double b1[KA], b2[KA], b3[KA];
 #pragma unroll
-      for (int kk = 0; kk < KA; ++kk) { b1[kk] = -INFINITY; b2[kk] = 0.0; b3[kk] = -INFINITY; }
-#pragma unroll
-      for (int r = 0; r < WF_ROWS; ++r) {
-        if (tid + r * WF_THREADS < M && in_set[r]) {
-#pragma unroll
-          for (int kk = 0; kk < KA; ++kk) {
-            if (kk < k) {
-              const double nn = nv[r][kk], dd = dv[r][kk];
-              if (nn > 0) b1[kk] = fmax(b1[kk], nn / 2 - dd);
-              b2[kk] = fmax(b2[kk], nn);
-              b3[kk] = fmax(b3[kk], -dd);
-            }
-          }
-        }
-      }
-      block_reduce<KA, 0>(b1, scratch);
-      block_reduce<KA, 0>(b2, scratch);
-      block_reduce<KA, 0>(b3, scratch);
-      if (tid == 0)
-        for (int kk = 0; kk < k; ++kk) {
-          s_lo[kk] = b1[kk];
-          s_hi[kk] = rows * b2[kk] / 0.5 + b3[kk];
-        }
-      __syncthreads();
-      // dicotomy.py:146-171, global stop rule.  Every thread keeps the brackets of all components and takes the decisions
-      // itself from the per-wave partial sums (summed in wave order, like block_reduce: the same values in every thread), on
-      // two alternating buffers: ONE barrier per bisection step instead of five and no single-thread section - the ~40 steps
-      // of a simplex over W were 120 us of the iteration with the reference's default constraints.
-      double lo[KA], hi[KA], mid[KA];
-#pragma unroll
-      for (int kk = 0; kk < KA; ++kk) {
-        lo[kk] = kk < k ? s_lo[kk] : 0.0;
-        hi[kk] = kk < k ? s_hi[kk] : 0.0;
-        mid[kk] = 0.0;
-      }
-      constexpr int NWV = WF_THREADS / 64;
-      for (int it = 0; it <= 100; ++it) {
-        double f[KA];
-#pragma unroll
-        for (int kk = 0; kk < KA; ++kk) {
-          mid[kk] = (lo[kk] + hi[kk]) / 2;
-          f[kk] = 0.0;
-        }
+        for (int kk = 0; kk < KA; ++kk) { b1[kk] = -INFINITY; b2[kk] = 0.0; b3[kk] = -INFINITY; }
 #pragma unroll
         for (int r = 0; r < WF_ROWS; ++r) {
           if (tid + r * WF_THREADS < M && in_set[r]) {
 #pragma unroll
-            for (int kk = 0; kk < KA; ++kk)
-              if (kk < k) f[kk] += fmax((double)nv[r][kk] * rcp_f64(mid[kk] + (double)dv[r][kk]), (double)a.log_shift);
+            for (int kk = 0; kk < KA; ++kk) {
+              if (kk < k) {
+                const double nn = nv[r][kk], dd = dv[r][kk];
+                if (nn > 0) b1[kk] = fmax(b1[kk], nn / 2 - dd);
+                b2[kk] = fmax(b2[kk], nn);
+                b3[kk] = fmax(b3[kk], -dd);
+              }
+            }
           }
         }
-        double* sc = bis[it & 1];
+        block_reduce<KA, 0>(b1, scratch);
+        block_reduce<KA, 0>(b2, scratch);
+        block_reduce<KA, 0>(b3, scratch);
+        if (tid == 0)
+          for (int kk = 0; kk < k; ++kk) {
+            s_lo[kk] = b1[kk];                          // a, dicotomy.py:29-43
+            s_hi[kk] = rows * b2[kk] / 0.5 + b3[kk];    // b, dicotomy.py:49
+          }
+      }
+      {
+        double b4[KA], b5[KA];
+#pragma unroll
+        for (int kk = 0; kk < KA; ++kk) { b4[kk] = -INFINITY; b5[kk] = 0.0; }
+#pragma unroll
+        for (int r = 0; r < WF_ROWS; ++r) {
+          if (tid + r * WF_THREADS < M && in_set[r]) {
+#pragma unroll
+            for (int kk = 0; kk < KA; ++kk) {
+              if (kk < k && nv[r][kk] > 0.f) {
+                b4[kk] = fmax(b4[kk], -(double)dv[r][kk]);
+                b5[kk] += (double)nv[r][kk];
+              }
+            }
+          }
+        }
+        block_reduce<KA, 0>(b4, scratch);
+        block_reduce<KA, KA>(b5, scratch);
+        if (tid == 0)
+          for (int kk = 0; kk < k; ++kk) {
+            s_dstar[kk] = b5[kk] > 0.0 ? -b4[kk] : 0.0;   // d* = min{den : num > 0}: the last pole of f is at nu = -d*
+            s_sum[kk] = b5[kk];
+          }
+      }
+      __syncthreads();
+      constexpr int NWV = WF_THREADS / 64;
+      const double tol = (double)a.tol;
+      // owner state (threads kk < k); a column without a positive numerator has no multiplier (dicotomy.py:19)
+      const bool owner = tid < k;
+      const bool solve = owner && s_sum[owner ? tid : 0] > 0.0 && s_sum[owner ? tid : 0] < INFINITY;
+      double o_x = 1.0, o_lo = 0.0, o_hi = 1.0, o_dxold = 1.0, o_fder = 0.0;
+      bool o_done = true;
+      if (owner) {
+        const double dstar = s_dstar[tid];
+        if (solve) {
+          o_lo = fmax(s_lo[tid] + dstar, 0.0);
+          o_hi = s_hi[tid] + dstar;
+          o_x = fmin(fmax(s_sum[tid], o_lo), o_hi);
+          o_dxold = o_hi - o_lo;
+          o_done = false;
+        }
+        s_x[tid] = o_x;
+        s_flag[tid] = o_done ? 1 : 0;
+      }
+      __syncthreads();
+      int evals = 0;
+      // per-wave partial sums of f_kk and f_kk' at delta = s_x[kk] into bis[evals & 1]; ends with a barrier
+      auto evaluate = [&]() {
+        double* sc = bis[evals & 1];
+        ++evals;
 #pragma unroll
         for (int kk = 0; kk < KA; ++kk) {
-          f[kk] = wave_sum(f[kk]);
-          if (lane == 0) sc[wave * KA + kk] = f[kk];
+          double f = 0.0, fp = 0.0;
+          if (kk < k) {
+            const double at = s_x[kk] - s_dstar[kk];   // (delta + den - d*: den - d* >= 0 is exact in fp64 for fp32 inputs of one scale)
+#pragma unroll
+            for (int r = 0; r < WF_ROWS; ++r) {
+              if (tid + r * WF_THREADS < M && in_set[r]) {
+                const double inv = rcp_f64(at + (double)dv[r][kk]);
+                const double t = nv[r][kk] > 0.f ? (double)nv[r][kk] * inv : 0.0;
+                if (t > (double)a.log_shift) {
+                  f += t;
+                  fp -= t * inv;
+                } else {
+                  f += (double)a.log_shift;
+                }
+              }
+            }
+          }
+          f = wave_sum(f);
+          fp = wave_sum(fp);
+          if (lane == 0) {
+            sc[wave * 2 * KA + kk] = f;
+            sc[wave * 2 * KA + KA + kk] = fp;
+          }
         }
         __syncthreads();
-        double worst = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < KA; ++kk) {
-          double acc = sc[kk];
-          for (int w = 1; w < NWV; ++w) acc = acc + sc[w * KA + kk];
-          f[kk] = acc;
-          if (kk < k) worst = fmax(worst, fabs(acc - 1.0));
+        return sc;
+      };
+      auto combine = [&](const double* sc, int kk, double& fs, double& fps) {   // wave order: deterministic
+        fs = sc[kk];
+        fps = sc[KA + kk];
+        for (int w = 1; w < NWV; ++w) {
+          fs += sc[w * 2 * KA + kk];
+          fps += sc[w * 2 * KA + KA + kk];
         }
-        if (!((worst > (double)a.tol) && (it < 100))) break;
-#pragma unroll
-        for (int kk = 0; kk < KA; ++kk) {
-          if (f[kk] - 1.0 <= 0.0) hi[kk] = mid[kk]; else lo[kk] = mid[kk];
+        fs -= 1.0;
+      };
+      for (int it = 0; it < 100; ++it) {   // 1. the roots
+        const double* sc = evaluate();
+        if (owner && !o_done) {
+          double fs, fps;
+          combine(sc, tid, fs, fps);
+          o_fder = fps;
+          if (fabs(fs) <= 1e-11) {
+            o_done = true;
+          } else {
+            if (fs > 0) o_lo = o_x; else o_hi = o_x;
+            double dx = fps < 0 ? -fs / fps : 0.0;
+            double xn = o_x + dx;
+            if (!(fps < 0) || !(xn > o_lo && xn < o_hi) || fabs(dx) > 0.5 * fabs(o_dxold)) {
+              dx = (o_hi - o_lo) / 2;
+              xn = o_lo + dx;
+            }
+            o_dxold = dx;
+            if (xn == o_x || fabs(dx) <= 1e-15 * fabs(o_x)) o_done = true;
+            o_x = xn;
+          }
+          s_x[tid] = o_x;
+          s_flag[tid] = o_done ? 1 : 0;
+        }
+        __syncthreads();
+        bool all_done = true;
+        for (int kk = 0; kk < k; ++kk) all_done = all_done && s_flag[kk] != 0;
+        if (all_done) break;
+      }
+      // 2., 3. the reference's sweep count and its midpoints (in delta: a + d* + (b - a) frac)
+      if (owner) {
+        const double ad = s_lo[tid] + s_dstar[tid], width = s_hi[tid] - s_lo[tid];
+        s_root[tid] = o_x;
+        s_fder[tid] = solve ? o_fder : 0.0;
+        s_ad[tid] = ad;
+        s_width[tid] = width;
+        s_u[tid] = solve ? fmin(fmax((o_x - ad) / width, 0.0), 1.0) : 0.5;
+      }
+      __syncthreads();
+      // midpoint of sweep t (the first midpoint is t = 1) on the way to a root at fraction u of the bracket, as a fraction
+      auto mid_frac = [](double uu, int t) {
+        const double scale = ldexp(1.0, t - 1);
+        const double cell = fmin(floor(uu * scale), scale - 1.0);
+        return ldexp(2.0 * cell + 1.0, -t);
+      };
+      // the sweeps are independent given the roots: lane l of wave 0 looks at sweeps l + 1 and l + 65 (dicotomy.py:152: at
+      // most maxit = 100 sweeps after the first midpoint); two bit masks - "certainly stops here", "within 1 % of tol"
+      if (wave == 0) {
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 1 + lane + 64 * hf;
+          double est = 0.0;
+          for (int kk = 0; kk < k; ++kk)
+            est = fmax(est, fabs(s_fder[kk] * ((s_ad[kk] + s_width[kk] * mid_frac(s_u[kk], t)) - s_root[kk])));
+          const bool certain = t <= 101 && (est <= 0.99 * tol || t == 101);
+          const bool band = t <= 101 && !certain && est <= 1.01 * tol;
+          const unsigned long long mc = __ballot(certain), mb = __ballot(band);
+          if (lane == 0) {
+            s_mask[hf] = mc;
+            s_mask[2 + hf] = mb;
+          }
         }
       }
-      if (tid == 0)
-        for (int kk = 0; kk < k; ++kk) s_mid[kk] = mid[kk];
+      __syncthreads();
+      unsigned long long mc[2] = {s_mask[0], s_mask[1]}, mb[2] = {s_mask[2], s_mask[3]};
+      int t_stop = 101;
+      for (;;) {   // (uniform: every thread reads the same masks and the same sums)
+        const unsigned long long w0 = mc[0] | mb[0], w1 = mc[1] | mb[1];
+        if (!w0 && !w1) break;
+        const int hf = w0 ? 0 : 1;
+        const int bit = __ffsll((long long)(hf ? w1 : w0)) - 1;
+        const int t = 1 + bit + 64 * hf;
+        if ((mc[hf] >> bit) & 1ull) { t_stop = t; break; }
+        if (owner) s_x[tid] = s_ad[tid] + s_width[tid] * mid_frac(s_u[tid], t);
+        __syncthreads();
+        const double* sc = evaluate();
+        double worst = 0.0;
+        for (int kk = 0; kk < k; ++kk) {
+          double fs, fps;
+          combine(sc, kk, fs, fps);
+          if (s_fder[kk] != 0.0) worst = fmax(worst, fabs(fs));
+        }
+        if (worst <= tol) { t_stop = t; break; }
+        mb[hf] &= ~(1ull << bit);
+      }
+      if (owner) s_mid[tid] = solve ? s_ad[tid] + s_width[tid] * mid_frac(s_u[tid], t_stop) : s_dstar[tid];   // delta = nu + d* (no multiplier: nu = 0)
       __syncthreads();
     }
     // W' = max(num / (den + nu), eps), fixed entries (updates.py:70-76); rel_W (base.py:323)
@@ -478,7 +632,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         for (int kk = 0; kk < KA; ++kk) {
           if (kk < k) {
             float den = dv[r][kk];
-            if (a.simplex_w && in_set[r]) den += (float)s_mid[kk];
+            if (a.simplex_w && in_set[r]) den = (float)(((double)den - s_dstar[kk]) + s_mid[kk]);
             float v = fmaxf(nv[r][kk] / den, a.log_shift);
             if (a.fixed_w) {
               const float fx = a.fixed_w[mm * k + kk];

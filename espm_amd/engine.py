@@ -352,7 +352,7 @@ class MUEngine:
         st.cur, st.it = 0, 0
         # both half-steps of an iteration in one launch where the library's fused kernel applies (sparse store at 512-pixel
         # tiles, default H rule: include/espm_mu.h, no_fused); `fused=False` keeps the two launches (A/B, tests)
-        st.no_fused = 0 if fused else 1
+        st.no_fused = 2 if fused == "static" else (0 if fused else 1)
         self._accum_done = False
 
         # ---- sharding -----------------------------------------------------------------------------------

@@ -261,7 +261,8 @@ typedef struct espm_mu_state {
   /* Sparse store at its full geometry (tile_px = ESPM_ELL_TILE: an image that fills the chip), default H rule:
    * espm_mu_iterate and espm_mu_step_hw run both half-steps of an iteration in ONE launch - the workgroup that has
    * updated the 1024 pixels of a block goes straight on with that block's part of R H^T, which needs no other pixel's
-   * new H (updates.py:38-39, :53-59); h_t is then not written.  no_fused != 0 keeps the two launches (A/B, tests). */
+   * new H (updates.py:38-39, :53-59); h_t is then not written.  no_fused = 1 keeps the two launches (A/B, tests); 2 runs the
+   * fused kernel with a fixed assignment of its work units to waves instead of the dynamic one (A/B only). */
   int32_t no_fused;
 } espm_mu_state;
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where a workgroup of the fused kernel spends its time at the headline size: phase stamps (100 MHz wall clock) written
+by the instrumented build tools/analysis/libespm_mu_phase.so (build_phase_lib.sh).
+
+stamps per workgroup: 0 entry | 1 GW table in LDS | 2 wave 0 walked its pixel lists | 3 every wave did | 4 wave 0 finished its
+pixel's update | 5 records reduced, H' table complete | 6 wave 0 walked its channel lists | 7 every wave did
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ESPM_MU_LIB"] = os.path.join(ROOT, "tools", "analysis", "libespm_mu_phase.so")
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from espm_amd import _lib, synth  # noqa: E402
+from espm_amd.engine import MUEngine  # noqa: E402
+
+N_CH, NX, NY, K = 2048, 512, 512, int(os.environ.get("K", "5"))
+dev = torch.device("cuda", 0)
+prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0)
+X = synth.sample_torch(prob, dev, seed=1000)
+W0, H0 = synth.random_init(N_CH, K, NX * NY, seed=0, scale=500.0 / N_CH)
+eng = MUEngine(X, K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=600, device=dev)
+del X
+eng.load_state(W0, H0)
+eng.iterate(300, final_loss=False)
+torch.cuda.synchronize()
+nblk = eng.st.nblk_w
+SLOTS = 40
+buf = torch.zeros((nblk + 1, SLOTS), dtype=torch.int64, device=dev)
+fn = _lib.lib.espm_debug_phase_buffer
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+_lib.check(fn(C.c_void_p(buf.data_ptr())))
+eng.iterate(3, final_loss=False)          # the stamps of the last of these stay
+torch.cuda.synchronize()
+t = buf[:nblk].cpu().numpy().astype(np.float64) * 0.01    # us
+t0 = t[:, 0].min()
+names = ["table -> LDS", "H walk (wave 0)", "H walk, slowest wave - wave 0", "per-pixel update", "record reduction + barrier", "W walk (wave 0)",
+         "W walk, slowest wave - wave 0"]
+print(f"{nblk} workgroups; kernel span (first entry -> last exit) {t[:, 7].max() - t0:7.2f} us; entries spread over {t[:, 0].max() - t0:5.2f} us")
+for i, nm in enumerate(names):
+    d = t[:, i + 1] - t[:, i]
+    print(f"  {nm:36s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+tot = t[:, 7] - t[:, 0]
+print(f"  {'workgroup total':36s} mean {tot.mean():7.2f}  min {tot.min():7.2f}  max {tot.max():7.2f} us")
+print(f"  exits spread over {t[:, 7].max() - t[:, 7].min():5.2f} us")
+# per wave: end of the H walk / of the W walk relative to the stamp that started it (1: table ready, 5: H' table ready)
+hw = t[:, 8:24] - t[:, 1:2]
+ww = t[:, 24:40] - t[:, 5:6]
+print("H walk per wave (mean over workgroups, us): " + " ".join(f"{v:5.1f}" for v in hw.mean(axis=0)))
+print("W walk per wave (mean over workgroups, us): " + " ".join(f"{v:5.1f}" for v in ww.mean(axis=0)))
+ell = eng.ell
+off = ell["ell_h_off"].cpu().numpy()
+rows = off[2::2] - off[0:-1:2]
+unit = off[1::2] - off[0:-1:2]
+g = rows.reshape(-1, 8)
+u = unit.reshape(-1, 8)
+print("H list groups of a 512-pixel window, rows (mean over windows):        " + " ".join(f"{v:6.1f}" for v in g.mean(axis=0)))
+print("                                   of which unit rows:                " + " ".join(f"{v:6.1f}" for v in u.mean(axis=0)))
