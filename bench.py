@@ -3,16 +3,27 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Metric (BASELINE.json): MU iterations / second on the 2048-channel x (512*512)-pixel X, k = 5,
-SmoothNMF with simplex on H and Laplacian smoothness (lambda = 1), fp32 arithmetic; the counts are
-held in the store the engine selects for them (--x-store auto: the sparse count store, 16 bits per non-zero
-entry; u8 / bf16 / f32 are the dense stores).  One "step" = one full iteration (H update + W update + the loss of the state and
-the relative changes the reference book-keeps every iteration, espm/estimators/base.py:316-351).
-With N > 1 the image rows are sharded over the ranks (strong scaling: same total problem).
+Metric (BASELINE.json): MU iterations / second on the 2048-channel x (512*512)-pixel X, k = 5, SmoothNMF with simplex
+on H and Laplacian smoothness (lambda = 1), fp32 arithmetic; the counts are held in the store the engine selects for
+them (--x-store auto: the sparse count store, 16 bits per non-zero entry - lossless, checked on ingest; u8 / bf16 / f32
+are the dense stores).  One "step" = one full iteration: H update + W update + the loss of the state and the relative
+changes the reference book-keeps every iteration (espm/estimators/base.py:316-351).  With N > 1 the image rows are
+sharded over the ranks (strong scaling: same total problem).  W warm-up iterations, then exactly K timed iterations
+between barrier + synchronize on both sides, maximum over ranks.
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     - the H-step kernel (dominant): algorithmic bytes / launch over its HIP-event time
-  cpu_baseline - the numpy oracle (reference-faithful op sequence) on a pixel crop, on the host
+Prints ONE JSON line on rank 0.  Beside the contract's fields:
+  roofline      the dominant kernel (the fused H update + W accumulation launch): algorithmic bytes per launch over its
+                mean duration from HIP events on the launch stream.  `frac` follows SURVEY 8(d)'s definition (X ONCE per
+                iteration + H read + written, X = its stored form: 2 bytes per non-zero entry); `frac_lists_twice` counts
+                both list sets the kernel streams (X is held once per half-step's access order).  `traffic`: HBM bytes per
+                launch from the PMC counters (rocprofv3, separate passes), read from profiles/hbm_traffic.json with the
+                binaries' round named in `traffic_source`.
+  dense_store   the same iteration on the dense 8-bit and bf16 stores (the sparse rate depends on the 21 % non-zero
+                entries of this dose; the dense rates do not)
+  steady_state  300 further iterations timed the same way: the first tens of milliseconds after an idle phase run
+                8-15 % slower (clocks), which a 20-step timed region sits inside
+  cpu_baseline  the numpy oracle (reference-faithful op sequence) on the host cores, on a crop of the SAME image
+  loss_parity_rel  final loss of the HIP path against the oracle's on that crop, same W0 / H0
 """
 import argparse
 import json
@@ -31,22 +42,27 @@ COUNTS, LAMBDA_L = 500.0, 1.0
 HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
 BF16_PEAK = 2.5e15      # dense bf16 MFMA FLOP/s (spec)
 VALU_F32_PEAK = 157.3e12
+CROP_ROWS, CROP_ITERS = 64, 8
 
 
-def cpu_baseline(prob, rows=64, iters=8):
-    """Oracle (numpy fp64, reference op sequence incl. the dense identity G) on the first `rows`
-    image rows; time scales linearly with pixels, so it/s(full) = it/s(crop) * crop / full."""
+def cpu_baseline_and_parity(X_crop_pm, device):
+    """Oracle (numpy fp64, the reference's op sequence incl. the dense identity G and (G^T R) H^T) on the first CROP_ROWS
+    image rows of the benchmark's own X, and the HIP path on the same crop from the same W0 / H0.
+
+    Why a crop and not SURVEY 8(d)'s three full-size iterations: the reference-faithful loop forms Y and X / Y as dense
+    (n, p) fp64 arrays (4.3 GB each at full size, plus the (n, n) identity products): ~13 s per iteration on this host
+    and ~25 GB of temporaries.  Time is linear in the pixels (every op is), so it/s(full) = it/s(crop) * crop / full."""
     from oracle import mu_oracle as oc
     from espm_amd import synth
+    from espm_amd.engine import MUEngine
 
-    sub = dict(prob)
-    ny = prob["shape_2d"][1]
-    sub["weights"] = prob["weights"][:rows * ny]
-    X = synth.sample_numpy(sub, seed=0)
-    W0, H0 = synth.random_init(N_CH, K, rows * ny, seed=0, scale=COUNTS / N_CH)
+    ny = NY
+    X = np.ascontiguousarray(X_crop_pm.T.astype(np.float64))            # (n, p_crop)
+    p_crop = X.shape[1]
+    W0, H0 = synth.random_init(N_CH, K, p_crop, seed=0, scale=COUNTS / N_CH)
     t0 = time.perf_counter()
-    r = oc.fit(X, K, W=W0, H=H0, lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(rows, ny),
-               tol=0, no_stop_criterion=True, max_iter=iters)
+    r = oc.fit(X, K, W=W0.copy(), H=H0.copy(), lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(CROP_ROWS, ny),
+               tol=0, no_stop_criterion=True, max_iter=CROP_ITERS)
     dt = time.perf_counter() - t0
     its_crop = r["n_iter"] / dt
     threads = os.cpu_count()
@@ -57,9 +73,21 @@ def cpu_baseline(prob, rows=64, iters=8):
                 threads = info.get("num_threads", threads)
     except Exception:
         pass
-    return dict(value=its_crop * rows / NX, unit="it/s", cores=int(threads), kind="port",
-                sample=f"numpy fp64 oracle, {iters} iterations on the first {rows} of {NX} image rows "
-                       f"({rows * ny} px x {N_CH} ch, {dt:.1f} s), scaled by {rows}/{NX}")
+    eng = MUEngine(X, K, layout="cm", shape_2d=(CROP_ROWS, ny), lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, tol=0.0,
+                   max_iter=CROP_ITERS + 2, device=device)
+    eng.load_state(W0, H0)
+    eng.iterate(CROP_ITERS, final_loss=True)
+    torch.cuda.synchronize()
+    ours = eng.history()["loss"]
+    parity = dict(rel=float(abs(ours[-1] - r["losses"][-1]) / abs(r["losses"][-1])),
+                  worst_rel_over_trajectory=float(np.max(np.abs(ours[1:] - r["losses"]) / np.abs(r["losses"]))),
+                  max_abs_dH=float(np.abs(eng.get_H() - r["H"]).max()),
+                  sample=f"{CROP_ITERS} iterations on the first {CROP_ROWS} image rows of the benchmark's X, same W0 / H0; x_store {eng.x_store}")
+    base = dict(value=its_crop * CROP_ROWS / NX, unit="it/s", cores=int(threads), kind="port",
+                sample=f"numpy fp64 oracle (reference op sequence), {CROP_ITERS} iterations on the first {CROP_ROWS} of {NX} image rows of the "
+                       f"benchmark's own X ({p_crop} px x {N_CH} ch, {dt:.1f} s), scaled by {CROP_ROWS}/{NX}; a crop because the faithful loop "
+                       f"needs ~25 GB of dense fp64 temporaries and ~{dt / CROP_ITERS * NX / CROP_ROWS:.0f} s per full-size iteration")
+    return base, parity
 
 
 def main():
@@ -67,9 +95,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense-store and steady-state legs (profiling runs)")
     ap.add_argument("--lambda-l", type=float, default=LAMBDA_L)
     ap.add_argument("--x-store", default="auto", choices=["auto", "ell", "u8", "bf16", "f32"])
+    ap.add_argument("--no-fused", action="store_true", help="two launches per iteration pair instead of the fused kernel (A/B)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,19 +128,21 @@ def main():
     from espm_amd.engine import MUEngine, _stream
     import ctypes as C
 
-    # ---- synthetic data: this rank's block of image rows ------------------------------------------
+    # ---- synthetic data: this rank's block of image rows.  Host-side preparation first, the device work (sampling, list
+    # building) last, so that the timed loop starts on a busy device rather than after an idle phase ----
     rows = NX // world
     row0 = rank * rows
     if rank == world - 1:
         rows = NX - row0
     prob = synth.make_problem(N_CH, rows, NY, K, N=COUNTS, seed=0, row0=row0, nx_total=NX)
-    X = synth.sample_torch(prob, device, seed=1000, row0=row0)            # (p_local, n) f32 counts
     W0, H0_full = synth.random_init(N_CH, K, NX * NY, seed=0, scale=COUNTS / N_CH)
     H0 = H0_full[:, row0 * NY:(row0 + rows) * NY]
+    del H0_full
     total_iters = args.warmup + args.steps
+    X = synth.sample_torch(prob, device, seed=1000, row0=row0)            # (p_local, n) f32 counts
+    X_crop = X[:CROP_ROWS * NY].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
     eng = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=total_iters + 40, group=group, device=device, x_store=args.x_store)
-    del X
+                   tol=0.0, max_iter=total_iters + 400, group=group, device=device, x_store=args.x_store, fused=not args.no_fused)
     eng.load_state(W0, H0)
 
     def barrier():
@@ -119,17 +151,26 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        eng.iterate(n, final_loss=False)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     eng.iterate(args.warmup, final_loss=False)
-    barrier()
-    t0 = time.perf_counter()
-    eng.iterate(args.steps, final_loss=False)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(args.steps)
     its = args.steps / dt
+    steady = None
+    if not args.no_extras:
+        n_ss = 300
+        steady = dict(steps=n_ss, value=n_ss / timed(n_ss), unit="it/s",
+                      note="300 further iterations, same bracket: the device clocks have ramped by then")
 
     # ---- loss sanity + per-kernel timing with HIP events on the launch stream (rank-local) --------
     eng.eval_current(advance_h=False)
@@ -151,44 +192,79 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
 
-    s = _stream()
-    t_h = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_step_h(C.byref(st), st.cur, 0, s)))
-    t_h_upd = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_step_h(C.byref(st), st.cur, 1, s)))
-    t_w = time_kernel(lambda: _lib.check(_lib.lib.espm_mu_w_accum(C.byref(st), s)))
+    s = _stream()   # torch's current stream IS the launch stream of every call below
+    lib = eng.lib
+    fused = bool(lib.espm_mu_fused_applies(C.byref(st)))
     p_loc = eng.p
     if eng.x_store == "ell":
-        # sparse count store: 16 bits per non-zero entry of X (list padding is overhead, not algorithmic work);
-        # the H-step also reads the per-pixel loss constant
         e_h, e_w = eng.ell["entries_h"], eng.ell["entries_w"]
-        bytes_h = 2 * e_h + 2 * K * p_loc * 4 + p_loc * 4        # lists once, H read + written, sum x log2 x
-        bytes_w = 2 * e_w + K * p_loc * 4                        # lists once, H read
-        nnz = torch.tensor([float(eng.ell["nnz"])], dtype=torch.float64, device=device)
+        nnz_loc = float(eng.ell["nnz"])
+        nnz = torch.tensor([nnz_loc], dtype=torch.float64, device=device)
         if world > 1:
             torch.distributed.all_reduce(nnz)
-        bytes_it = 2 * float(nnz.item()) + 2 * K * NX * NY * 4   # SURVEY 8(d) with X = its non-zero entries, once
-        flops_it = 8.0 * K * float(nnz.item())                   # four products restricted to the non-zero entries
+        nnz_total = float(nnz.item())
+        bytes_it = 2 * nnz_total + 2 * K * NX * NY * 4             # SURVEY 8(d) with X = its non-zero entries (2 B each), once; H read + written
+        flops_it = 8.0 * K * nnz_total                             # four products restricted to the non-zero entries
+        bytes_h = 2 * e_h + 2 * K * p_loc * 4 + p_loc * 4          # H-step alone: its lists once, H read + written, the loss constants
+        bytes_w = 2 * e_w + K * p_loc * 4                          # W accumulation alone: its lists once, H read
+        bytes_fused_once = 2 * nnz_loc + 2 * K * p_loc * 4         # the fused launch by 8(d)'s count: X once, H read + written
+        bytes_fused_lists = 2 * (e_h + e_w) + 2 * K * p_loc * 4 + p_loc * 4   # what it streams: both list sets (splits of counts > their field included)
+        nnz_frac = nnz_total / (float(N_CH) * NX * NY)
     else:
         xbytes = {"u8": 1, "bf16": 2, "f32": 4}[eng.x_store]
-        bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4          # X once, H read + written
-        bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4              # X once, H read
-        bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4     # X once per iteration
+        bytes_h = N_CH * p_loc * xbytes + 2 * K * p_loc * 4
+        bytes_w = N_CH * p_loc * xbytes + K * p_loc * 4
+        bytes_it = N_CH * NX * NY * xbytes + 2 * K * NX * NY * 4
         flops_it = 8.0 * N_CH * K * NX * NY
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, corrected as
-    # MI355X_MICROARCH.md prescribes); measured once per kernel version and committed under profiles/
-    traffic = None
+        bytes_fused_once = bytes_fused_lists = None
+        nnz_frac = None
+    traffic = traffic_source = None
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            if world == 1:
-                traffic = json.load(f)["stores"][eng.x_store]["h_step"]["hbm_bytes_per_launch"]
+            tj = json.load(f)
+        if world == 1:
+            entry = tj["stores"][eng.x_store]["fused" if fused else "h_step"]
+            traffic = entry["hbm_bytes_per_launch"]
+            traffic_source = f"profiles/hbm_traffic.json ({entry.get('round', 'r01')} binaries, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
-    roofline = dict(bound="hbm", kernel=("h_step_ell_kernel<5,loss>" if eng.x_store == "ell" else "h_step_kernel<5,%s,...,loss>" % eng.x_store), achieved=bytes_h / t_h_upd / 1e9,
-                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK, traffic=traffic,
-                    bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3, launch_ms_loss_only=t_h * 1e3,
-                    w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3),
-                    iteration=dict(algorithmic_GB=bytes_it / 1e9, hbm_frac=bytes_it * its / HBM_PEAK,
-                                   valu_f32_frac=flops_it * its / VALU_F32_PEAK,
-                                   bf16_mfma_frac=flops_it * its / BF16_PEAK))
+    if fused:
+        t_f = time_kernel(lambda: _lib.check(lib.espm_mu_step_hw(C.byref(st), st.cur, s)))
+        roofline = dict(bound="hbm", kernel="mu_fused_ell_kernel<5, loss> (H update + W accumulation of a 1024-pixel block per workgroup)",
+                        achieved=bytes_fused_once / t_f / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_fused_once / t_f / HBM_PEAK,
+                        traffic=traffic, traffic_source=traffic_source,
+                        bytes_per_launch=bytes_fused_once, launch_ms=t_f * 1e3,
+                        bytes_definition="SURVEY 8(d): X once (sparse store: 2 B per non-zero entry, lossless) + H read + H written",
+                        frac_lists_twice=bytes_fused_lists / t_f / HBM_PEAK, bytes_lists_twice=bytes_fused_lists)
+    else:
+        t_h_upd = time_kernel(lambda: _lib.check(lib.espm_mu_step_h(C.byref(st), st.cur, 1, s)))
+        t_w = time_kernel(lambda: _lib.check(lib.espm_mu_w_accum(C.byref(st), s)))
+        roofline = dict(bound="hbm", kernel=("h_step_ell_kernel<5,loss>" if eng.x_store == "ell" else "h_step_kernel<5,%s,...,loss>" % eng.x_store),
+                        achieved=bytes_h / t_h_upd / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=bytes_h / t_h_upd / HBM_PEAK,
+                        traffic=traffic, traffic_source=traffic_source, bytes_per_launch=bytes_h, launch_ms=t_h_upd * 1e3,
+                        bytes_definition="this launch's own streams: X once in its stored form + H read + H written",
+                        w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3))
+    roofline["iteration"] = dict(algorithmic_GB=bytes_it / 1e9, hbm_frac=bytes_it * its / HBM_PEAK,
+                                 traffic_GB=(traffic + 12.0e6) / 1e9 if (traffic and fused) else None,   # + ~12 MB of the slab reduction (profiles/README.md)
+                                 valu_f32_frac=flops_it * its / VALU_F32_PEAK, bf16_mfma_frac=flops_it * its / BF16_PEAK)
+
+    # ---- the same iteration on the dense stores (N = 1 only): the sparse rate is a property of the dose ----
+    dense = None
+    if world == 1 and not args.no_extras and eng.x_store == "ell":
+        dense = {}
+        for name in ("u8", "bf16"):
+            e2 = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
+                          tol=0.0, max_iter=260, device=device, x_store=name)
+            e2.load_state(W0, H0)
+            e2.iterate(20, final_loss=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e2.iterate(100, final_loss=False)
+            torch.cuda.synchronize()
+            dense[name + "_its"] = 100 / (time.perf_counter() - t0)
+            del e2
+        dense["note"] = "dense 8-bit / bf16 stores, 100 iterations after 20 warm-up, same image and state"
+    del X
 
     out = None
     if rank == 0:
@@ -201,13 +277,19 @@ def main():
                                    "X stored %s, W/H fp32" % (args.lambda_l, eng.x_store),
                        "n": N_CH, "shape_2d": [NX, NY], "k": K, "lambda_L": args.lambda_l, "simplex_H": True,
                        "parallelism": f"pixel-row shard x{world}" if world > 1 else "single GPU",
-                       "loss_every_iteration": True},
+                       "loss_every_iteration": True, "launches_per_iteration": 2 if fused else 3,
+                       "nnz_frac": nnz_frac, "counts_per_pixel": COUNTS},
             "loss_first": loss_first, "loss_last": loss_last, "nonfinite": bad,
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu:
-            full = synth.make_problem(N_CH, NX, NY, K, N=COUNTS, seed=0)
-            out["cpu_baseline"] = cpu_baseline(full)
+        if steady:
+            out["steady_state"] = steady
+        if dense:
+            out["dense_store"] = dense
+        if X_crop is not None:
+            out["cpu_baseline"], parity = cpu_baseline_and_parity(X_crop, device)
+            out["loss_parity_rel"] = parity["rel"]
+            out["loss_parity"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -95,7 +95,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm"):
         from espm_amd.engine import MUEngine
 
         rows = None
@@ -114,7 +114,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
-                        fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, **self._engine_kwargs())
+                        fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, layout=layout,
+                        **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -196,11 +197,22 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         # Large X: ONE upload; the passes the reference makes over X on the host before the loop (sign check, zero
         # lines base.py:519-528, mean for normalize, const_KL_ base.py:200-201, the NNDSVD's products) run on that
         # device copy, which then feeds the engine.  Small X: the host path, like the reference.
-        Xd = None
+        # A (pixels, channels) array - what hyperspy's decomposition hands over, hspy_comp=True - is uploaded AS IT IS
+        # (pixel-major is also the layout the engine ingests natively: no host transpose, no device transpose); Xd below
+        # is the logical (n, p) view of the device copy either way.
+        Xd = Xd_raw = None
+        dev_layout = "cm"
         if Xv.size >= _DEVICE_PREP_MIN_SIZE:
             import torch
             if torch.cuda.is_available():
-                Xd = torch.from_numpy(np.ascontiguousarray(Xv)).to(f"cuda:{torch.cuda.current_device()}")
+                if Xv.flags.c_contiguous:
+                    host = Xv
+                elif Xv.T.flags.c_contiguous:
+                    host, dev_layout = Xv.T, "pm"
+                else:
+                    host = np.ascontiguousarray(Xv)
+                Xd_raw = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
+                Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
                 if big and not bool(torch.isfinite(Xd).all()):   # the scan validate_data was told to skip, same message
                     raise ValueError(f"Input X contains {'NaN' if bool(torch.isnan(Xd).any()) else 'infinity'}.")
         if big and Xd is None:   # (no device after all: scikit-learn's own check)
@@ -218,14 +230,14 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 raise ValueError("Negative values in data")
             zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
             empty_ch, empty_px = zc, zp
+            # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies): a straight copy of the
+            # memory as it lies (for a pixel-major input: its transposed view), not a strided gather
+            X_fixed = Xv.copy() if dev_layout == "cm" else Xv.T.copy().T
             if bool(zp.any()) or bool(zc.any()):
-                X_fixed = Xv.copy()
                 X_fixed[:, zp.cpu().numpy()] = self.log_shift
                 X_fixed[zc.cpu().numpy(), :] = self.log_shift
                 Xd[:, zp] = self.log_shift
                 Xd[zc, :] = self.log_shift
-            else:
-                X_fixed = Xv.copy()   # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies)
             mean_x = float(Xd.mean(dtype=torch.float64))
         if self.normalize:
             self.norm_factor_ = (normalization_factor(X_fixed, self.n_components) if mean_x is None
@@ -259,10 +271,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._L_pixels = int(self.X_.shape[1])
 
         out_dtype = self.X_.dtype
-        self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd, xscale, None if self._identity_G else self.G_,
+        self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
                                                 filled_channels=empty_ch if bool(empty_ch.any()) else None,
-                                                filled_pixels=empty_px if bool(empty_px.any()) else None)
-        del X_fixed, Xd
+                                                filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout)
+        self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
+        del X_fixed, Xd, Xd_raw
         eng.load_state(self.W_, self.H_)
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]
         self.const_KL_ = (getattr(self, "_const_KL_dev", None) if Xv.size >= _DEVICE_PREP_MIN_SIZE else None)

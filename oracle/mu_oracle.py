@@ -561,13 +561,20 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
         random_state=None, normalize=False, log_shift=LOG_SHIFT, dicotomy_tol=DICOTOMY_TOL,
         gamma=None, fixed_H=None, fixed_W=None, no_stop_criterion=False, safe=False,
         record_at=(), time_iterations=False, exact_root=False, linesearch=False, true_D=None, true_H=None,
-        algo="log_surrogate", l2=False):
+        algo="log_surrogate", l2=False, physics_model=None):
     """Reference-faithful fit loop: NMFEstimator.fit_transform (base.py:209-420) driving
     SmoothNMF._iteration (smooth_nmf.py:284-455, algo="log_surrogate", "bmd", "l2_surrogate" or "projected_gradient" with a given gamma; linesearch: smooth_nmf.py:376-381;
     true_D / true_H tracking: base.py:301-347).
 
+    ``physics_model`` (base.py:269-274, :388-392; interface espm/models/base.py:217-264): an object with ``NMF_update(W=None)
+    -> G``, ``NMF_simplex() -> rows under the simplex over W`` and ``NMF_initialize_W(D)``; G comes from it, is refreshed
+    from the current W after every third iteration, and the loss is re-evaluated with the new G before the next stop test.
+
     Returns a dict with W, H, G, GW, losses, detailed_losses, rel, n_iter, exit, snapshots.
     """
+    if physics_model is not None:
+        G = physics_model.NMF_update()
+    simplex_rows = physics_model.NMF_simplex() if physics_model is not None else None
     if simplex_H and simplex_W:  # smooth_nmf.py:218-222
         simplex_W, simplex_H = True, False
     X_ = remove_zeros_lines(np.asarray(X), log_shift)
@@ -639,7 +646,7 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
                 gamma_[1] = gamma_[1] / 1.05 if quadratic_surrogate(W_, old_W, f_xt, grad, gamma_[1]) - f_x > 0 else gamma_[1] * 1.5
         else:
             W_ = multiplicative_step_w(X_, G_, W_, H_, log_shift=log_shift, safe=safe, l2=l2,
-                                       simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg)
+                                       simplex_W=simplex_W, fixed_W=fixed_W, use_bregman=breg, simplex_rows=simplex_rows)
         eval_after, det = loss(W_, H_)
         n_iter += 1
         gammas.append(list(gamma_) if isinstance(gamma_, list) else gamma_)
@@ -672,7 +679,11 @@ def fit(X, n_components, G=None, W=None, H=None, *, lambda_L=0.0, mu=0, epsilon_
             elif (eval_before - eval_after) < 0:
                 reason = "increase"
                 break
-        eval_before = eval_after
+        if physics_model is not None and n_iter % 3 == 0:  # base.py:388-392
+            G_ = physics_model.NMF_update(W_)
+            eval_before = loss(W_, H_)[0]
+        else:
+            eval_before = eval_after
     elapsed = time.perf_counter() - t0
     if not simplex_H and not simplex_W:
         W_, H_ = rescaled_DH(W_, H_)  # base.py:399-400

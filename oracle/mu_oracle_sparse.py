@@ -19,55 +19,107 @@ fixture F6) to 1e-9.
 """
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from . import mu_oracle as oc
 
 
-class SparseX:
-    """The non-zero entries of X (n, p): ``ch``, ``px`` (int64), ``val`` (float64), sorted by pixel."""
+def _workers():
+    return max(1, min(16, os.cpu_count() or 1))
 
-    def __init__(self, ch, px, val, n, p):
-        order = np.argsort(px, kind="stable")
-        self.ch = np.ascontiguousarray(np.asarray(ch)[order], dtype=np.int64)
-        self.px = np.ascontiguousarray(np.asarray(px)[order], dtype=np.int64)
-        self.val = np.ascontiguousarray(np.asarray(val, dtype=np.float64)[order])
+
+class SparseX:
+    """The non-zero entries of X (n, p): ``ch``, ``px`` (int32), ``val`` (float64), sorted by pixel, cut into chunks at
+    pixel boundaries.  The three passes over the entries are mapped over the chunks by a thread pool (numpy releases the
+    GIL in take / multiply / bincount): at 2048 x 512^2 with 21 % non-zero entries an iteration takes seconds, not a minute."""
+
+    def __init__(self, ch, px, val, n, p, chunk=1 << 22):
+        px = np.asarray(px)
+        if px.size > 1 and not bool(np.all(px[1:] >= px[:-1])):
+            order = np.argsort(px, kind="stable")
+            ch, px, val = np.asarray(ch)[order], px[order], np.asarray(val)[order]
+        self.ch = np.ascontiguousarray(ch, dtype=np.int32)
+        self.px = np.ascontiguousarray(px, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
         self.n, self.p = int(n), int(p)
         self.sum_x = float(self.val.sum())
         self.const_kl = float(np.sum(self.val * np.log(self.val)) - self.sum_x)   # base.py:200-201 (0 log 0 = 0)
+        # chunks [lo, hi) of entries that end at pixel boundaries, with their pixel ranges [q0, q1)
+        nnz = self.val.shape[0]
+        cuts = [0]
+        while cuts[-1] < nnz:
+            hi = min(nnz, cuts[-1] + chunk)
+            if hi < nnz:
+                hi = int(np.searchsorted(self.px, self.px[hi], side="left"))   # back to the start of that pixel
+                if hi <= cuts[-1]:
+                    hi = int(np.searchsorted(self.px, self.px[cuts[-1]], side="right"))
+            cuts.append(hi)
+        self.chunks = [(lo, hi, int(self.px[lo]), int(self.px[hi - 1]) + 1) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
 
     @classmethod
     def from_dense(cls, X):
         X = np.asarray(X)
-        ch, px = np.nonzero(X)
+        px, ch = np.nonzero(X.T)          # pixel-major walk: sorted by pixel
         return cls(ch, px, X[ch, px], X.shape[0], X.shape[1])
 
-    def y_at_nonzeros(self, GW, H, chunk=1 << 24):
-        """(GW @ H)[ch, px] for every stored entry."""
-        out = np.empty(self.val.shape[0])
-        for lo in range(0, out.shape[0], chunk):
-            c, q = self.ch[lo:lo + chunk], self.px[lo:lo + chunk]
-            acc = GW[c, 0] * H[0, q]
-            for kk in range(1, H.shape[0]):
-                acc += GW[c, kk] * H[kk, q]
-            out[lo:lo + chunk] = acc
-        return out
+    def _map(self, fn):
+        if len(self.chunks) == 1 or _workers() == 1:
+            return [fn(c) for c in self.chunks]
+        with ThreadPoolExecutor(_workers()) as ex:
+            return list(ex.map(fn, self.chunks))
 
-    def gwt_r(self, GW, r):
-        """GW^T R (k, p) with R given at the stored entries."""
-        k = GW.shape[1]
-        out = np.empty((k, self.p))
-        for kk in range(k):
-            out[kk] = np.bincount(self.px, weights=GW[self.ch, kk] * r, minlength=self.p)
-        return out
+    def _rows(self, GW, HT, lo, hi):
+        """The GW rows and the H columns of the entries [lo, hi) as (m, k) arrays, and (GW @ H) there."""
+        Gc = np.take(GW, self.ch[lo:hi], axis=0)
+        Hq = np.take(HT, self.px[lo:hi], axis=0)
+        return Gc, Hq, np.einsum("ik,ik->i", Gc, Hq)
 
-    def r_ht(self, r, H):
-        """R H^T (n, k)."""
-        k = H.shape[0]
-        out = np.empty((self.n, k))
-        for kk in range(k):
-            out[:, kk] = np.bincount(self.ch, weights=r * H[kk, self.px], minlength=self.n)
-        return out
+    def _starts(self, lo, hi, q0, q1):
+        """First entry (relative to lo) of every pixel q0..q1 (the entries are sorted by pixel)."""
+        return np.searchsorted(self.px[lo:hi], np.arange(q0, q1 + 1, dtype=np.int32), side="left")
+
+    def gwt_r(self, GW, H):
+        """GW^T (X / (GW H)) (k, p)."""
+        GW, HT = np.ascontiguousarray(GW), np.ascontiguousarray(H.T)
+        out = np.zeros((self.p, GW.shape[1]))
+
+        def work(chunk):
+            lo, hi, q0, q1 = chunk
+            Gc, _, y = self._rows(GW, HT, lo, hi)
+            Gc *= (self.val[lo:hi] / y)[:, None]
+            st = self._starts(lo, hi, q0, q1)
+            seg = np.add.reduceat(Gc, np.minimum(st[:-1], hi - lo - 1), axis=0)
+            seg[st[1:] == st[:-1]] = 0.0                     # pixels without an entry (reduceat returns a row there)
+            out[q0:q1] = seg
+        self._map(work)
+        return np.ascontiguousarray(out.T)
+
+    def r_ht(self, GW, H):
+        """(X / (GW H)) H^T (n, k)."""
+        GW, HT = np.ascontiguousarray(GW), np.ascontiguousarray(H.T)
+
+        def work(chunk):
+            lo, hi, _, _ = chunk
+            _, Hq, y = self._rows(GW, HT, lo, hi)
+            Hq *= (self.val[lo:hi] / y)[:, None]
+            c = self.ch[lo:hi]
+            part = np.empty((self.n, HT.shape[1]))
+            for kk in range(HT.shape[1]):
+                part[:, kk] = np.bincount(c, weights=Hq[:, kk], minlength=self.n)
+            return part
+        return np.sum(self._map(work), axis=0)
+
+    def x_log_y(self, GW, H):
+        """sum X log(GW H) over the stored entries."""
+        GW, HT = np.ascontiguousarray(GW), np.ascontiguousarray(H.T)
+
+        def work(chunk):
+            lo, hi, _, _ = chunk
+            return float(np.dot(self.val[lo:hi], np.log(self._rows(GW, HT, lo, hi)[2])))
+        return float(np.sum(self._map(work)))
 
 
 def step_h(sx, G, W, H, simplex_H=False, mu=0, log_shift=oc.LOG_SHIFT, epsilon_reg=1, dicotomy_tol=oc.DICOTOMY_TOL,
@@ -78,8 +130,7 @@ def step_h(sx, G, W, H, simplex_H=False, mu=0, log_shift=oc.LOG_SHIFT, epsilon_r
             raise ValueError("Please provide the laplacian")
         HL = H @ L
     GW = W if G is None else G @ W
-    y = sx.y_at_nonzeros(GW, H)
-    num = sx.gwt_r(GW, sx.val / y)
+    num = sx.gwt_r(GW, H)
     den = GW.sum(axis=0)[:, None]
     if not (np.isscalar(mu) and mu == 0):
         mu_col = np.asarray(mu, dtype=float)
@@ -107,8 +158,7 @@ def step_h(sx, G, W, H, simplex_H=False, mu=0, log_shift=oc.LOG_SHIFT, epsilon_r
 def step_w(sx, G, W, H, simplex_W=False, log_shift=oc.LOG_SHIFT, fixed_W=None, simplex_rows=None):
     """multiplicative_step_w, KL branch (updates.py:6-78)."""
     GW = W if G is None else G @ W
-    y = sx.y_at_nonzeros(GW, H)
-    A = sx.r_ht(sx.val / y, H)                      # R H^T (n, k)
+    A = sx.r_ht(GW, H)                               # R H^T (n, k)
     gta = A if G is None else G.T @ A                # G^T (R H^T) == (G^T R) H^T
     num = W * gta
     colsum_g = np.ones(W.shape[0]) if G is None else G.sum(axis=0)
@@ -130,9 +180,8 @@ def loss(sx, G, W, H, L, mu=0, epsilon_reg=1, lambda_L=0.0, log_shift=oc.LOG_SHI
     """SmoothNMF.loss (smooth_nmf.py:457-475, base.py:196-203): (total, [lkl, reg, lap])."""
     GW = np.maximum(W if G is None else G @ W, log_shift)
     Hc = np.maximum(H, log_shift)
-    y = sx.y_at_nonzeros(GW, Hc)
     sum_y = float(GW.sum(axis=0) @ Hc.sum(axis=1))
-    lkl = sum_y - float(np.sum(sx.val * np.log(y))) + sx.const_kl
+    lkl = sum_y - sx.x_log_y(GW, Hc) + sx.const_kl
     reg = oc.log_reg(H, mu, epsilon_reg)
     lap = 0.5 * lambda_L * oc.trace_xtLx(L, H.T)
     numel = float(sx.n) * float(sx.p) if average else 1.0

@@ -644,7 +644,72 @@ def f15():
     save("f15_gradients", **out)
 
 
+# ------------------------------------------------------------------ F16: a physics model that refreshes G every third iteration
+PHYS = {
+    # the reference's default constraint (simplex over the rows NMF_simplex() names), Laplacian
+    "pw": dict(n=56, nx=8, ny=9, k=3, m=8, m0=6, iters=13, kw=dict(simplex_H=False, simplex_W=True, lambda_L=0.5)),
+    # simplex over H, Laplacian, log sparsity (the C5 analogue with a live model)
+    "ph": dict(n=60, nx=10, ny=9, k=4, m=9, m0=7, iters=13, kw=dict(simplex_H=True, simplex_W=False, lambda_L=1.0, mu=0.05)),
+    # default stop rules: eval_before is re-evaluated after every refresh (base.py:388-392), which decides n_iter_
+    "ps": dict(n=48, nx=8, ny=8, k=3, m=7, m0=5, iters=80, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.3, tol=3e-4), stop=True),
+    # Frobenius data term with a live model: the W step divides by G^T G W H H^T of the CURRENT G (updates.py:31-36)
+    "pl2": dict(n=44, nx=7, ny=8, k=3, m=6, m0=4, iters=12, kw=dict(simplex_H=True, simplex_W=False, lambda_L=0.6, algo="l2_surrogate", l2=True)),
+}
+
+
+def f16():
+    from espm.models.base import PhysicalModel
+    sys.path.insert(0, os.path.dirname(HERE))
+    from physics_double import AbsorbingModel
+
+    class RefModel(AbsorbingModel, PhysicalModel):   # the reference asks isinstance(G, PhysicalModel) (base.py:269)
+        def __init__(self, G0, Abs, strength, m0):
+            PhysicalModel.__init__(self, 0.0, G0.shape[0], 0.01, {}, db_name=None)
+            AbsorbingModel.__init__(self, G0, Abs, strength, m0)
+
+        def generate_g_matr(self, *a, **k):
+            pass
+
+        def generate_phases(self, *a, **k):
+            pass
+
+    rng = np.random.default_rng(1616)
+    out = {}
+    for name, c_ in PHYS.items():
+        X, G0, W, H = synth(rng, c_["n"], c_["nx"], c_["ny"], c_["k"], c_["m"])
+        p = c_["nx"] * c_["ny"]
+        Abs = rng.random((c_["n"], c_["m0"])) * (rng.random((c_["n"], c_["m0"])) < 0.5)
+        strength = 0.8
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        if c_["kw"].get("simplex_W"):
+            W0[:c_["m0"]] /= W0[:c_["m0"]].sum(axis=0, keepdims=True)
+        H0 = rng.random((c_["k"], p)) + 0.05
+        if c_["kw"].get("simplex_H"):
+            H0 /= H0.sum(axis=0, keepdims=True)
+        else:
+            H0 *= X.sum() / (G0 @ W0 @ H0).sum()
+        model = RefModel(G0, Abs, strength, c_["m0"])
+        kw = dict(c_["kw"])
+        if not c_.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        est = SmoothNMF(n_components=c_["k"], G=model, shape_2d=(c_["nx"], c_["ny"]), verbose=0, max_iter=c_["iters"], **kw)
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        assert est.physics_model_ is model and model.updates in (est.n_iter_ // 3, est.n_iter_ // 3 - 1) and not np.allclose(est.G_, G0)   # (the loop ends before the refresh of its last iteration)
+        out[f"{name}_X"], out[f"{name}_G0"], out[f"{name}_Abs"], out[f"{name}_W0"], out[f"{name}_H0"] = X, G0, Abs, W0, H0
+        out[f"{name}_strength"] = np.array(strength)
+        out[f"{name}_shape"] = np.array([c_["nx"], c_["ny"]])
+        out[f"{name}_GW"], out[f"{name}_W"], out[f"{name}_H"], out[f"{name}_G"] = GW, est.W_, est.H_, est.G_
+        out[f"{name}_losses"] = np.array(est.losses_)
+        out[f"{name}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{name}_rel"] = np.array(est.rel_)
+        out[f"{name}_n_iter"] = np.array(est.n_iter_)
+        out[f"{name}_updates"] = np.array(model.updates)
+    out["names"] = np.array(list(PHYS))
+    out["configs"] = np.array(json.dumps(PHYS))
+    save("f16_physics_model", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

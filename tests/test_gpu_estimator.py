@@ -662,6 +662,37 @@ def test_frobenius_fit_golden(SmoothNMF, golden):
                                    rtol=1e-5, err_msg=name)
 
 
+def test_physics_model_trajectories_golden(SmoothNMF, golden):
+    """Fits with a physics model whose G changes with W (fixture F16, generated from the reference with
+    tests/physics_double.py mixed into its abstract PhysicalModel): G refreshed after every third iteration and the loss
+    re-evaluated with it before the next stop test (base.py:388-392), simplex over the NMF_simplex() rows, the same
+    n_iter_ under the default stop rules, and the Frobenius W step with the CURRENT G^T G (l2=True, updates.py:31-36)."""
+    from physics_double import AbsorbingModel
+    g = golden("f16_physics_model")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        model = AbsorbingModel(g[f"{name}_G0"], g[f"{name}_Abs"], float(g[f"{name}_strength"]), c["m0"])
+        kw = dict(c["kw"])
+        if not c.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        est = SmoothNMF(n_components=c["k"], G=model, shape_2d=shape, verbose=0, max_iter=c["iters"], **kw)
+        GW = quiet(est.fit_transform, g[f"{name}_X"], W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy())
+        assert est.physics_model_ is model and est.n_iter_ == int(g[f"{name}_n_iter"]) and model.updates == int(g[f"{name}_updates"]), name
+        l2 = bool(kw.get("l2"))
+        np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=(3 if l2 else 1) * LOSS_RTOL, err_msg=name)
+        det = np.array(est.detailed_losses_, dtype=float)
+        np.testing.assert_allclose(det[:, :3], g[f"{name}_detailed"][:, :3], rtol=1e-3 if l2 else 2e-5, atol=1e-7 if l2 else 1e-12, err_msg=name)
+        np.testing.assert_allclose(np.array(est.rel_), g[f"{name}_rel"], rtol=2e-2, atol=1e-4, err_msg=name)
+        np.testing.assert_allclose(est.G_, g[f"{name}_G"], rtol=2e-5, err_msg=name)
+        np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=1e-3, atol=1e-4 if l2 else 5e-5, err_msg=name)
+        np.testing.assert_allclose(est.W_, g[f"{name}_W"], rtol=1e-3, atol=2e-4 * np.abs(g[f"{name}_W"]).max(), err_msg=name)
+        np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=1e-3, atol=1e-3 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
+        if kw.get("simplex_W"):
+            np.testing.assert_allclose(est.W_[:c["m0"]].sum(axis=0), 1.0, atol=2e-5)
+
+
 def test_projected_gradient_golden(SmoothNMF, golden):
     """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W]: both steps as direct calls and whole fits (G
     given, mu, lambda, entries at the clamp) against the reference (fixture F12)."""

@@ -374,3 +374,28 @@ def test_sparse_oracle_on_f6(golden):
             np.testing.assert_allclose(Wt, g[f"{pre}_W{t}"], rtol=1e-8, atol=1e-14)
             np.testing.assert_allclose(Ht, g[f"{pre}_H{t}"], rtol=1e-8, atol=1e-14)
         assert osp.dropped_eps_logy(osp.SparseX.from_dense(X_), G, r["W"], r["H"]) < 1e-9 * abs(r["losses"][-1]) * X_.size
+
+
+def test_f16_physics_model_refreshes_g(golden):
+    """Fixture F16: fits with a PhysicalModel whose G depends on W (tests/physics_double.py mixed into the reference's
+    abstract class by the generator): NMF_update every third iteration, the loss re-evaluated with the new G before the
+    next stop test (base.py:388-392), simplex over the NMF_simplex() rows only, and the Frobenius W step with a live G."""
+    from physics_double import AbsorbingModel
+    g = golden("f16_physics_model")
+    cfgs = json.loads(str(g["configs"]))
+    for name in g["names"]:
+        c = cfgs[name]
+        shape = tuple(int(v) for v in g[f"{name}_shape"])
+        model = AbsorbingModel(g[f"{name}_G0"], g[f"{name}_Abs"], float(g[f"{name}_strength"]), c["m0"])
+        kw = dict(c["kw"])
+        if not c.get("stop"):
+            kw.update(tol=0, no_stop_criterion=True)
+        r = oc.fit(g[f"{name}_X"], c["k"], W=g[f"{name}_W0"].copy(), H=g[f"{name}_H0"].copy(), shape_2d=shape, max_iter=c["iters"],
+                   physics_model=model, **kw)
+        assert r["n_iter"] == int(g[f"{name}_n_iter"]) and model.updates == int(g[f"{name}_updates"]), name
+        np.testing.assert_allclose(r["losses"], g[f"{name}_losses"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(r["detailed_losses"], g[f"{name}_detailed"], rtol=1e-9, atol=1e-18, err_msg=name)
+        np.testing.assert_allclose(r["rel"], g[f"{name}_rel"], rtol=1e-7, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(r["W"], g[f"{name}_W"], rtol=1e-8, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(r["H"], g[f"{name}_H"], rtol=1e-8, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(r["G"], g[f"{name}_G"], rtol=1e-10, err_msg=name)
