@@ -26,6 +26,7 @@ X_F32, X_BF16, X_U8, X_ELL = 0, 1, 2, 3                                  # enum 
 SRC_F32, SRC_F64 = 0, 1
 LAYOUT_CM, LAYOUT_PM = 0, 1
 ABI_VERSION = _D["ESPM_MU_ABI_VERSION"]
+XCHG_HANDLE_BYTES = _D["ESPM_XCHG_HANDLE_BYTES"]
 ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = _D["ESPM_ELL_TILE"], _D["ESPM_ELL_PB"], _D["ESPM_ELL_PBITS"], _D["ESPM_ELL_LDS_MAX"]
 ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = _D["ESPM_ELL_UNIT_ROWS"], _D["ESPM_ELL_UNIT_MAX_N"], _D["ESPM_ELL_PAIR_MAX_K"]
 KP, PPAD, NPAD = _D["ESPM_KP"], _D["ESPM_PPAD"], _D["ESPM_NPAD"]         # (the default build; `variant(k)` below for the wide one)
@@ -83,6 +84,16 @@ SYMBOLS = {
     "espm_mu_shard_combine_finish": (C.c_int, [_SP, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_w_reduce_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_w_reduce_pack": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
+    "espm_xchg_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    "espm_xchg_handle": (C.c_int, [_vp, _vp]),
+    "espm_xchg_connect": (C.c_int, [_vp, _vp]),
+    "espm_xchg_staging": (_vp, [_vp]),
+    "espm_xchg_records": (_vp, [_vp, C.c_int]),
+    "espm_xchg_post": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "espm_xchg_wait": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "espm_xchg_timeouts": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "espm_xchg_destroy": (C.c_int, [_vp]),
+    "espm_mu_iterate_sharded": (C.c_int, [_SP, _vp, C.POINTER(C.c_uint32), C.c_int, C.c_int, _vp]),
     "espm_mu_linesearch_terms": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
     "espm_surrogate_terms": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "espm_dichotomy_simplex_acc": (C.c_int, [C.c_double, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),

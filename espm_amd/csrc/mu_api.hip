@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include "mu_common.hpp"
+#include "mu_xchg.hpp"
 
 namespace espm {
 
@@ -479,6 +480,46 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
   }
   if (pending)
     if (int rc = launch_w_update_tail(tail, s)) return rc;
+  if (final_loss) return espm_mu_loss_only(st, st->cur, st->it, stream);
+  return ESPM_OK;
+}
+
+int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int n_iter, int final_loss, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(x && seq && n_iter >= 0, "iterate_sharded: bad arguments");
+  ESPM_REQUIRE(st->it + n_iter < st->hist_len, "history too short: it=%d + %d >= %d", st->it, n_iter, st->hist_len);
+  ESPM_REQUIRE(x->record_bytes == espm_mu_shard_record_bytes(st), "iterate_sharded: the exchange was created for records of %zu bytes, the state packs %zu",
+               x->record_bytes, espm_mu_shard_record_bytes(st));
+  const bool defer = st->x_dtype == ESPM_X_ELL && w_update_is_local(st) && !(st->pg_q && st->pg_gamma_w > 0.f);
+  const bool with_halo = st->grid_mode && st->lambda_l != 0.f;
+  // byte offsets inside a record: [A | statistics | first owned image row | last owned image row]
+  const size_t off_top = (size_t)st->k * st->n_pad * 4 + ESPM_HS_STRIDE * 8, off_bot = off_top + (size_t)st->k * (st->ny > 0 ? st->ny : 0) * 4;
+  bool pending = (st->tail_mode & ESPM_TAIL_RIDE) != 0;   // the caller may hand over a deferred tail of its own last update
+  int rc = ESPM_OK;
+  for (int i = 0; i < n_iter && !rc; ++i) {
+    const int cur = st->cur, slot = st->it;
+    st->tail_mode = pending ? ESPM_TAIL_RIDE : 0;
+    rc = espm_mu_step_hw(st, cur, stream);
+    st->tail_mode = 0;
+    if (!rc) rc = espm_mu_w_reduce_pack(st, cur, slot, x->staging, stream);
+    const uint32_t s = ++*seq;
+    if (!rc) rc = espm_xchg_post(x, s, stream);
+    if (!rc) rc = espm_xchg_wait(x, s, stream);
+    const unsigned char* recs = static_cast<const unsigned char*>(espm_xchg_records(x, (int)(s & 1u)));
+    st->tail_mode = defer ? ESPM_TAIL_DEFER : 0;
+    if (!rc) rc = espm_mu_shard_combine_finish(st, recs, x->world, cur, slot, stream);
+    st->tail_mode = 0;
+    pending = defer;
+    if (with_halo) {   // the row above this block is the LAST owned row of rank - 1, the row below the FIRST of rank + 1
+      st->halo_top = x->rank > 0 ? reinterpret_cast<const float*>(recs + (size_t)(x->rank - 1) * x->record_bytes + off_bot) : nullptr;
+      st->halo_bot = x->rank < x->world - 1 ? reinterpret_cast<const float*>(recs + (size_t)(x->rank + 1) * x->record_bytes + off_top) : nullptr;
+    }
+    st->cur = 1 - cur;
+    st->it = slot + 1;
+  }
+  if (rc) return rc;
+  if (pending)
+    if ((rc = espm_mu_w_update_tail(st, 1 - st->cur, st->it - 1, stream))) return rc;
   if (final_loss) return espm_mu_loss_only(st, st->cur, st->it, stream);
   return ESPM_OK;
 }

@@ -1,0 +1,12 @@
+// Private layout of the exchange context (mu_xchg.hip, mu_api.hip); the public type is opaque (include/espm_mu.h).
+#pragma once
+#include <stddef.h>
+
+struct espm_xchg {
+  int world, rank;
+  size_t record_bytes, mailbox_bytes, off_flags, off_err;
+  unsigned char* mailbox;        // this rank's mailbox (device)
+  unsigned char* staging;        // where the rank packs its record before post (device)
+  unsigned char* peers[16];      // mailbox of every rank as mapped here (peers[rank] == mailbox)
+  bool opened[16];
+};

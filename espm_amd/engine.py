@@ -358,7 +358,8 @@ class MUEngine:
         # ---- sharding -----------------------------------------------------------------------------------
         if self.world > 1:
             from .sharding import ShardExchange
-            self.exchange = ShardExchange(group, k, st.n_pad, st.ny, bool(st.grid_mode and self.lambda_L != 0.0), dev)
+            self.exchange = ShardExchange(group, k, st.n_pad, st.ny, bool(st.grid_mode and self.lambda_L != 0.0), dev, lib=self.lib,
+                                          stream_fn=_stream)
             if self.exchange.layout.nbytes != int(self.lib.espm_mu_shard_record_bytes(C.byref(st))):
                 raise RuntimeError("record layout of espm_amd.sharding and libespm_mu disagree")
 
@@ -448,13 +449,13 @@ class MUEngine:
 
     def _set_halo_from_records(self):
         top, bot = self.exchange.halo_offsets()
-        base = self.exchange.recv.data_ptr()
+        base = self.exchange.recv_ptr
         self.st.halo_top = base + top if top is not None else None
         self.st.halo_bot = base + bot if bot is not None else None
 
     def _exchange_halo_only(self, which):
         """Boundary rows of h[which] to the neighbours (initial state only)."""
-        self._check(self.lib.espm_mu_shard_pack(C.byref(self.st), which, _ptr(self.exchange.send), _stream()))
+        self._check(self.lib.espm_mu_shard_pack(C.byref(self.st), which, C.c_void_p(self.exchange.send_ptr), _stream()))
         self.exchange.gather()
         self._set_halo_from_records()
 
@@ -547,13 +548,13 @@ class MUEngine:
         st.tail_mode = _lib.TAIL_DEFER if defer else 0
         if self.world > 1:
             if ride:   # slab reduction + record reduction + this rank's record, one launch
-                self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, _ptr(self.exchange.send), s))
+                self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, C.c_void_p(self.exchange.send_ptr), s))
             else:
                 self._check(self.lib.espm_mu_w_reduce(C.byref(st), s))
-                self._check(self.lib.espm_mu_shard_pack(C.byref(st), 1 - cur, _ptr(self.exchange.send), s))
+                self._check(self.lib.espm_mu_shard_pack(C.byref(st), 1 - cur, C.c_void_p(self.exchange.send_ptr), s))
             self.exchange.gather()
             # sum over the ranks + W update (one launch when W' needs nothing global, include/espm_mu.h)
-            self._check(self.lib.espm_mu_shard_combine_finish(C.byref(st), _ptr(self.exchange.recv), self.world, cur, slot, s))
+            self._check(self.lib.espm_mu_shard_combine_finish(C.byref(st), C.c_void_p(self.exchange.recv_ptr), self.world, cur, slot, s))
             self._set_halo_from_records()
         else:
             self._check(self.lib.espm_mu_w_reduce_finish(C.byref(st), cur, slot, int(ride), s))
@@ -628,6 +629,10 @@ class MUEngine:
         self._flush_finalize()
         if self.world == 1 and not self.frobenius:
             self._check(self.lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
+        elif self.world > 1 and self.exchange.ctx is not None and not self.frobenius:
+            # sharded, one-shot exchange: the whole batch is enqueued by the library (no host-side collective per iteration)
+            self._check(self.lib.espm_mu_iterate_sharded(C.byref(st), self.exchange.ctx, C.byref(self.exchange.seq), int(n_iter),
+                                                         int(bool(final_loss)), _stream()))
         else:
             for _ in range(int(n_iter)):
                 self.eval_current(True)

@@ -18,6 +18,8 @@ kernels; the CPU tests do the same with numpy to check the protocol under gloo.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -65,28 +67,115 @@ def record_layout(k: int, n_pad: int, ny: int) -> RecordLayout:
 
 
 class ShardExchange:
-    """Send / receive buffers of the per-iteration all-gather and the neighbour bookkeeping."""
+    """Send / receive side of the per-iteration record exchange and the neighbour bookkeeping.
 
-    def __init__(self, group, k, n_pad, ny, with_halo, device):
+    Two transports, same record layout, same result (world records in rank order):
+
+    * ``p2p`` (default on GPUs): the library's one-shot exchange (``espm_xchg_*``, csrc/mu_xchg.hip) - every rank writes its
+      record into every peer's mailbox over the direct links and raises a flag; no host-side collective, no host
+      synchronisation, and ``espm_mu_iterate_sharded`` runs whole batches of iterations on it.  The mailboxes are mapped
+      through hipIpc; the 64-byte handles travel once through the process group.  A start-up hand-shake (one exchange of a
+      known pattern) decides - jointly - whether the transport works; if not, every rank falls back to
+    * ``collective``: ``torch.distributed.all_gather_into_tensor`` (RCCL over xGMI on the GPU box, gloo in the CPU tests).
+    """
+
+    def __init__(self, group, k, n_pad, ny, with_halo, device, lib=None, stream_fn=None, mode=None):
         self.group = group
         self.world = torch.distributed.get_world_size(group)
         self.rank = torch.distributed.get_rank(group)
         self.layout = record_layout(k, n_pad, ny)
         self.with_halo = bool(with_halo)
-        self.send = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=device)
-        self.recv = torch.zeros(self.world * self.layout.nbytes, dtype=torch.uint8, device=device)
         self._use_list = torch.distributed.get_backend(group) == "gloo"
+        self.lib, self._stream_fn = lib, stream_fn
+        self.ctx = None          # espm_xchg* when the one-shot transport is up
+        self.seq = C.c_uint32(0)
+        self.send = self.recv = None
+        mode = mode or os.environ.get("ESPM_XCHG", "p2p")
+        if mode == "p2p" and lib is not None and torch.device(device).type == "cuda":
+            self._open_p2p(device)
+        if self.ctx is None:
+            self.send = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=device)
+            self.recv = torch.zeros(self.world * self.layout.nbytes, dtype=torch.uint8, device=device)
+
+    # ---- one-shot transport -------------------------------------------------------------------------------------------
+    def _open_p2p(self, device):
+        lib, nb = self.lib, self.layout.nbytes
+        ctx = C.c_void_p()
+        ok = lib.espm_xchg_create(self.world, self.rank, nb, C.byref(ctx)) == 0
+        handle = (C.c_ubyte * 64)()
+        ok = ok and lib.espm_xchg_handle(ctx, handle) == 0
+        gathered = [None] * self.world
+        torch.distributed.all_gather_object(gathered, (bool(ok), bytes(handle)), group=self.group)
+        ok = all(g[0] for g in gathered)
+        if ok:
+            blob = b"".join(g[1] for g in gathered)
+            ok = lib.espm_xchg_connect(ctx, C.create_string_buffer(blob, len(blob))) == 0
+        if ok:   # hand-shake: one exchange of a pattern every rank can check
+            stage = _as_tensor(lib.espm_xchg_staging(ctx), nb, device)
+            stage.fill_(self.rank + 1)
+            torch.cuda.synchronize()
+            s = self._stream_fn()
+            self.seq.value += 1
+            ok = lib.espm_xchg_post(ctx, self.seq, s) == 0 and lib.espm_xchg_wait(ctx, self.seq, s) == 0
+            torch.cuda.synchronize()
+            if ok:
+                recs = _as_tensor(lib.espm_xchg_records(ctx, self.seq.value & 1), nb * self.world, device).view(self.world, nb)
+                lost = C.c_uint32(0)
+                lib.espm_xchg_timeouts(ctx, C.byref(lost))
+                ok = lost.value == 0 and all(bool((recs[r] == r + 1).all()) for r in range(self.world))
+            stage.zero_()
+        flags = [None] * self.world
+        torch.distributed.all_gather_object(flags, bool(ok), group=self.group)
+        if all(flags):
+            self.ctx = ctx
+        else:   # every rank takes the collective
+            if ctx:
+                lib.espm_xchg_destroy(ctx)
+            self.seq.value = 0
+
+    @property
+    def transport(self):
+        return "p2p" if self.ctx is not None else "collective"
+
+    @property
+    def send_ptr(self):
+        """Where this rank's record is packed."""
+        return int(self.lib.espm_xchg_staging(self.ctx)) if self.ctx is not None else self.send.data_ptr()
+
+    @property
+    def recv_ptr(self):
+        """The records of all ranks, in rank order, after ``gather``."""
+        return int(self.lib.espm_xchg_records(self.ctx, self.seq.value & 1)) if self.ctx is not None else self.recv.data_ptr()
 
     def gather(self):
-        """All ranks' records, in rank order, into ``recv`` (stream-ordered on the current stream)."""
-        if self._use_list:
+        """All ranks' records, in rank order (stream-ordered on the current stream)."""
+        if self.ctx is not None:
+            s = self._stream_fn()
+            self.seq.value += 1
+            rc = self.lib.espm_xchg_post(self.ctx, self.seq, s) or self.lib.espm_xchg_wait(self.ctx, self.seq, s)
+            if rc:
+                raise RuntimeError(self.lib.espm_mu_last_error().decode())
+        elif self._use_list:
             parts = list(self.recv.view(self.world, self.layout.nbytes).unbind(0))
             torch.distributed.all_gather(parts, self.send, group=self.group)
         else:
             torch.distributed.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
+    def lost_peers(self):
+        """Waits that gave up (a peer never delivered) since the exchange was opened: 0 on a healthy node."""
+        if self.ctx is None:
+            return 0
+        lost = C.c_uint32(0)
+        self.lib.espm_xchg_timeouts(self.ctx, C.byref(lost))
+        return int(lost.value)
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.espm_xchg_destroy(self.ctx)
+            self.ctx = None
+
     def halo_offsets(self):
-        """Byte offsets into ``recv`` of (row above my block, row below my block); None at the image edge.
+        """Byte offsets into the gathered records of (row above my block, row below my block); None at the image edge.
 
         The row above is the LAST owned row of rank-1, the row below the FIRST owned row of rank+1."""
         if not self.with_halo:
@@ -106,3 +195,12 @@ class ShardExchange:
         top = buf[base + lay.off_top: base + lay.off_top + row].view(torch.float32).view(lay.k, max(lay.ny, 0))
         bot = buf[base + lay.off_bot: base + lay.off_bot + row].view(torch.float32).view(lay.k, max(lay.ny, 0))
         return a, hs, top, bot
+
+
+def _as_tensor(ptr, nbytes, device):
+    """A uint8 torch view of `nbytes` of device memory the library owns (the exchange's staging record / mailbox)."""
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(m, device=device)

@@ -21,7 +21,8 @@
  *                            pixel contraction of the W update (updates.py:38-39, :53-59) in one launch
  *   espm_mu_iterate       <- espm/estimators/smooth_nmf.py:284-455 (_iteration, log_surrogate)
  *                            driven by base.py:313-394 (single GPU, no host sync)
- *   espm_mu_shard_*       <- (new) pixel-row sharding over the GPUs of a node; no reference analogue
+ *   espm_mu_shard_*, espm_xchg_*, espm_mu_iterate_sharded
+ *                         <- (new) pixel-row sharding over the GPUs of a node and its record exchange; no reference analogue
  *   espm_dichotomy_simplex<- espm/estimators/dicotomy.py:4-55 (module-level function)
  *   espm_mu_pack_x        <- base.py:243-247 (validate_data / hspy_comp transpose) as a layout step
  *   espm_mu_laplacian     <- espm/utils.py:39-76 applied to H (H @ L), measures.py:560-577
@@ -373,6 +374,32 @@ int espm_mu_shard_combine(const espm_mu_state* st, const void* records, int worl
  * the ranks and the W update share a launch when W' needs nothing global (see espm_mu_w_reduce_finish). */
 int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, int world, int src, int slot,
                                  espm_stream_t stream);
+
+/* ---- one-shot record exchange between the ranks of a node (SURVEY 8b "espm_allreduce", 8e) --------------------------
+ * Every rank owns a mailbox in uncached device memory, mapped into every peer through hipIpc (espm_xchg_handle ->
+ * exchange the 64-byte handles by any means -> espm_xchg_connect).  espm_xchg_post copies the record staged at
+ * espm_xchg_staging() into slot [seq & 1][rank] of EVERY rank's mailbox over the direct links and raises a flag there;
+ * espm_xchg_wait returns (on the stream) once the flags of all ranks have reached seq - bounded: a peer that never
+ * delivers is counted (espm_xchg_timeouts), not waited for.  espm_xchg_records(parity) is then what an all-gather would
+ * have produced: world records in rank order.  Sequence numbers start at 1 and grow by one per exchange on every rank.
+ * Contexts are opaque and owned by the library (the one allocation it makes: peers must be able to map it). */
+typedef struct espm_xchg espm_xchg;
+#define ESPM_XCHG_HANDLE_BYTES 64
+int espm_xchg_create(int world, int rank, size_t record_bytes, espm_xchg** out);
+int espm_xchg_handle(const espm_xchg* x, void* handle_out /* ESPM_XCHG_HANDLE_BYTES */);
+int espm_xchg_connect(espm_xchg* x, const void* handles /* world * ESPM_XCHG_HANDLE_BYTES, rank order */);
+void* espm_xchg_staging(const espm_xchg* x);
+const void* espm_xchg_records(const espm_xchg* x, int parity);
+int espm_xchg_post(espm_xchg* x, uint32_t seq, espm_stream_t stream);
+int espm_xchg_wait(espm_xchg* x, uint32_t seq, espm_stream_t stream);
+int espm_xchg_timeouts(const espm_xchg* x, uint32_t* count_out);   /* host-synchronous read of the give-up counter */
+int espm_xchg_destroy(espm_xchg* x);
+
+/* n_iter iterations of a SHARDED image (pixel rows split over the ranks of x) without host synchronisation and without a
+ * host-side collective: per iteration espm_mu_step_hw, espm_mu_w_reduce_pack into the staged record, espm_xchg_post /
+ * _wait, espm_mu_shard_combine_finish on the gathered records; the halo rows of the next H-step are the neighbours'
+ * records in the mailbox.  *seq is the exchange counter (in: last used, out: last used); every rank makes the same calls. */
+int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int n_iter, int final_loss, espm_stream_t stream);
 
 /* nu (p) with sum_i max(num_ij / (nu_j + den_ij), log_shift) = 1.  num (k, p), den (k, den_cols)
  * with den_cols in {1, p}, fp64 device arrays.  status_out (device int32): number of columns

@@ -1,7 +1,11 @@
-"""Sharded HIP path end to end on ONE GPU: two / three ranks (gloo transport, both on cuda:0) each own a
+"""Sharded HIP path end to end on ONE GPU: two / three ranks (process group: gloo, all on cuda:0) each own a
 block of image rows and run the real kernels with halo rows, global statistics and the per-iteration
-record exchange; the result must match the unsharded engine.  (RCCL itself needs one GPU per rank; the
-driver's multi-GPU bench exercises that transport.)"""
+record exchange; the result must match the unsharded engine AND the oracle on the whole image.
+
+Both transports of the exchange (espm_amd/sharding.py): the library's one-shot P2P exchange (mailboxes mapped through
+hipIpc - which also works between processes that share a GPU - flags, bounded waits; the batch loop
+espm_mu_iterate_sharded and the granular loop of the stop-criteria path) and the collective (here gloo; RCCL itself
+needs one GPU per rank: the driver's multi-GPU bench exercises it)."""
 import os
 import socket
 
@@ -27,8 +31,8 @@ def _data():
     return X, W0, H0
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, out, transport, granular):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESPM_XCHG=transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from espm_amd import sharding
@@ -39,10 +43,17 @@ def _worker(rank, world, port, out):
         sl = slice(row0 * NY, (row0 + rows) * NY)
         eng = MUEngine(X[:, sl], K, shape_2d=(rows, NY), max_iter=ITERS, group=dist.group.WORLD, device="cuda:0", **KW)
         eng.load_state(W0, H0[:, sl])
-        eng.iterate(ITERS, final_loss=True)
+        if granular:      # the loop of the stop-criteria path: one exchange per call, host-sequenced
+            for _ in range(ITERS):
+                eng.eval_current(True)
+                eng.finish_iteration()
+            eng.eval_current(False)
+        else:
+            eng.iterate(ITERS, final_loss=True)
         torch.cuda.synchronize()
         h = eng.history()
-        out[rank] = (eng.get_W(), eng.get_H(), h["loss"], h["rel_W"], h["rel_H"])
+        out[rank] = (eng.get_W(), eng.get_H(), h["loss"], h["rel_W"], h["rel_H"], eng.exchange.transport, eng.exchange.lost_peers())
+        eng.exchange.close()
     finally:
         dist.destroy_process_group()
 
@@ -53,9 +64,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_engine_matches_single_gpu(world):
+@pytest.mark.parametrize("world,transport,granular", [(2, "p2p", False), (3, "p2p", False), (3, "p2p", True), (2, "collective", False),
+                                                      (3, "collective", True)])
+def test_sharded_engine_matches_single_gpu(world, transport, granular):
     from espm_amd.engine import MUEngine
+    from oracle import mu_oracle as oc
     X, W0, H0 = _data()
     eng = MUEngine(X, K, shape_2d=(NX, NY), max_iter=ITERS, device="cuda:0", **KW)
     assert eng.x_store == "ell" and eng.st.ell_fill_n == 3    # the sparse store, with its pass for the pixels without counts
@@ -65,8 +78,9 @@ def test_sharded_engine_matches_single_gpu(world):
     ref_W, ref_H, ref = eng.get_W(), eng.get_H(), eng.history()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, transport, granular), nprocs=world, join=True)
         res = dict(out)
+    assert all(res[r][5] == transport and res[r][6] == 0 for r in range(world)), [(res[r][5], res[r][6]) for r in range(world)]
     for r in range(1, world):
         np.testing.assert_array_equal(res[r][0], res[0][0])       # replicated W bit-identical across ranks
         np.testing.assert_array_equal(res[r][2], res[0][2])       # and so is the assembled loss history
@@ -76,3 +90,8 @@ def test_sharded_engine_matches_single_gpu(world):
     np.testing.assert_allclose(res[0][2], ref["loss"], rtol=1e-6)
     np.testing.assert_allclose(res[0][3][1:], ref["rel_W"][1:], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(res[0][4][1:], ref["rel_H"][1:], rtol=1e-3, atol=1e-6)
+    # and against the oracle on the whole image (the data hold lines without counts: the faithful loop with its 1e-14 fill)
+    ora = oc.fit(X, K, W=W0.copy(), H=H0.copy(), shape_2d=(NX, NY), no_stop_criterion=True, max_iter=ITERS, **KW)
+    np.testing.assert_allclose(res[0][2][1:], ora["losses"], rtol=1e-5)
+    np.testing.assert_allclose(H, ora["H"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(res[0][0], ora["W"], rtol=2e-4, atol=2e-4 * np.abs(ora["W"]).max())
