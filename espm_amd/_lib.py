@@ -93,6 +93,7 @@ SYMBOLS = {
     "espm_xchg_wait": (C.c_int, [_vp, C.c_uint32, _vp]),
     "espm_xchg_timeouts": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "espm_xchg_destroy": (C.c_int, [_vp]),
+    "espm_mu_shard_exchange_finish": (C.c_int, [_SP, _vp, C.c_uint32, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate_sharded": (C.c_int, [_SP, _vp, C.POINTER(C.c_uint32), C.c_int, C.c_int, _vp]),
     "espm_mu_linesearch_terms": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
     "espm_surrogate_terms": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),

@@ -484,6 +484,26 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
   return ESPM_OK;
 }
 
+int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_t seq, int src, int slot, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(x && (src == 0 || src == 1), "shard_exchange_finish: bad arguments");
+  ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
+  ESPM_REQUIRE(x->record_bytes == espm_mu_shard_record_bytes(st), "shard_exchange_finish: the exchange was created for records of %zu bytes, the state packs %zu",
+               x->record_bytes, espm_mu_shard_record_bytes(st));
+  if (!w_update_is_local(st) || st->no_fused == 1) {   // W' needs a global finish (G given, simplex over W): the four steps
+    if (int rc = espm_mu_w_reduce_pack(st, src, slot, x->staging, stream)) return rc;
+    if (int rc = espm_xchg_post(x, seq, stream)) return rc;
+    if (int rc = espm_xchg_wait(x, seq, stream)) return rc;
+    return espm_mu_shard_combine_finish(st, espm_xchg_records(x, (int)(seq & 1u)), x->world, src, slot, stream);
+  }
+  const HFinalizeArgs fin = finalize_args(st, src, slot, true);
+  WTailArgs left_out;
+  const int with_halo = st->grid_mode && st->lambda_l != 0.f;
+  return launch_w_exchange_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float), st->nblk_w,
+                                  st->a, st->hstat[1 - src], fin, x, seq, st->h[1 - src], st->nx, st->ny, st->p_pad, with_halo,
+                                  static_cast<hipStream_t>(stream), (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
+}
+
 int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int n_iter, int final_loss, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(x && seq && n_iter >= 0, "iterate_sharded: bad arguments");
@@ -501,13 +521,11 @@ int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int 
     st->tail_mode = pending ? ESPM_TAIL_RIDE : 0;
     rc = espm_mu_step_hw(st, cur, stream);
     st->tail_mode = 0;
-    if (!rc) rc = espm_mu_w_reduce_pack(st, cur, slot, x->staging, stream);
     const uint32_t s = ++*seq;
-    if (!rc) rc = espm_xchg_post(x, s, stream);
-    if (!rc) rc = espm_xchg_wait(x, s, stream);
     const unsigned char* recs = static_cast<const unsigned char*>(espm_xchg_records(x, (int)(s & 1u)));
     st->tail_mode = defer ? ESPM_TAIL_DEFER : 0;
-    if (!rc) rc = espm_mu_shard_combine_finish(st, recs, x->world, cur, slot, stream);
+    // slab reduction, exchange of the records and W update: one launch when W' needs nothing but the global row sums
+    if (!rc) rc = espm_mu_shard_exchange_finish(st, x, s, cur, slot, stream);
     st->tail_mode = 0;
     pending = defer;
     if (with_halo) {   // the row above this block is the LAST owned row of rank - 1, the row below the FIRST of rank + 1

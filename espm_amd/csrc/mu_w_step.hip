@@ -10,6 +10,7 @@
 //             global-stop bisection (dicotomy.py:111-173), clamp, fixed_W, then GW = G W for the
 //             next half step, its column sums, and rel_W (base.py:323).
 #include "mu_w_kernel.hpp"
+#include "mu_xchg.hpp"
 
 namespace espm {
 
@@ -105,6 +106,48 @@ struct WUpdateArgs {
   HFinalizeArgs fin;
 };
 
+// The update of the 32 entries of W (component kk, channels c of the lanes that own one) from their summed A and the row
+// sum rs of the new H, by wave 0 of a reduction workgroup; the per-workgroup partials of what is global go to a.parts.
+__device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, int c, int e, bool owns, float t, double rs, int nwg) {
+  double cs = 0.0, sw = 0.0, qw = 0.0;
+  if (owns) {
+    a.a_out[e] = t;
+    if (c < a.n) {
+      const float wo = a.w_old[(size_t)c * a.k + kk];
+      float v;
+      if (a.pg_gamma_w > 0.f) {  // W - grad / gamma with grad = rowsum(H) - (X / GWH) H^T (G = I), updates.py:353-362
+        v = fmaxf(wo - ((float)rs - t) / a.pg_gamma_w, a.log_shift);
+        const double dw = (double)v - (double)wo;   // (fixed_W is not part of a projected-gradient fit, smooth_nmf.py:430-437)
+        qw = dw * (double)((float)rs - t) + (double)a.pg_gamma_w * dw * dw;
+      } else if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
+        const float sr = a.xscale * a.breg_sr[c];
+        v = fmaxf((sr * wo) / (((float)rs - t) * wo + sr), a.log_shift);
+      } else {
+        v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
+      }
+      if (a.fixed_w) {
+        const float fx = a.fixed_w[(size_t)c * a.k + kk];
+        if (fx >= 0.f) v = fx;                              // updates.py:75-76
+      }
+      a.w_new[(size_t)c * a.k + kk] = v;
+      const float gv = fmaxf(v, a.gw_floor);
+      a.gw_s[(size_t)c * KP + kk] = gv * (1.f / a.xscale);
+      cs = (double)gv;
+      sw = (double)v;
+    } else {
+      a.gw_s[(size_t)c * KP + kk] = 1.f;  // padding channels: X = 0 there
+    }
+  }
+  cs = wave_sum(cs);
+  sw = wave_sum(sw);
+  if (a.pg_track) qw = wave_sum(qw);
+  if (threadIdx.x == 0) {
+    a.parts[blockIdx.x] = cs;
+    a.parts[nwg + blockIdx.x] = sw;
+    if (a.pg_track) a.parts[2 * nwg + blockIdx.x] = qw;
+  }
+}
+
 __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs a) {
   __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
   __shared__ float s_part[8][32];
@@ -171,46 +214,147 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     __syncthreads();
   }
   if (threadIdx.x < 64) {  // wave 0; its first 32 lanes own the 32 entries
-    double cs = 0.0, sw = 0.0, qw = 0.0;
-    if (grp == 0 && c < a.n_pad) {
-      float t = 0.f;
+    float t = 0.f;
+    const bool owns = grp == 0 && c < a.n_pad;
+    if (owns) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += s_part[g][col];
-      a.a_out[e] = t;
-      if (c < a.n) {
-        const float wo = a.w_old[(size_t)c * a.k + kk];
-        float v;
-        if (a.pg_gamma_w > 0.f) {  // W - grad / gamma with grad = rowsum(H) - (X / GWH) H^T (G = I), updates.py:353-362
-          v = fmaxf(wo - ((float)rs - t) / a.pg_gamma_w, a.log_shift);
-          const double dw = (double)v - (double)wo;   // (fixed_W is not part of a projected-gradient fit, smooth_nmf.py:430-437)
-          qw = dw * (double)((float)rs - t) + (double)a.pg_gamma_w * dw * dw;
-        } else if (a.breg_sr) {  // W' = sR W / ((rowsum(H) - (X / GWH) H^T) W + sR), updates.py:41-48
-          const float sr = a.xscale * a.breg_sr[c];
-          v = fmaxf((sr * wo) / (((float)rs - t) * wo + sr), a.log_shift);
-        } else {
-          v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
+    }
+    w_update_entries(a, kk, c, e, owns, t, rs, nwg);
+  }
+}
+
+// ---- Slab reduction, record exchange and W update of a SHARDED image in ONE launch (espm_mu_shard_exchange_finish) ----------
+// The sharded W step after the accumulation used to be four launches - slab reduction into the rank's record, post, wait,
+// sum over the ranks' records + update - i.e. ~17 us of launch latencies around 100 KB of traffic.  Here the reduction
+// workgroup (kk, j) that has summed the slabs for ITS 32 entries of A delivers that 128-byte piece to every rank's mailbox
+// itself (P2P stores), raises ITS flag there, waits for the same piece of every other rank, sums the pieces in rank order
+// (bit-identical W on all ranks) and updates its entries of W: the exchange is as fine-grained as the dependency.  The extra
+// workgroup reduces the H-step's records, delivers the statistics of the new H block to every rank and its boundary rows
+// to the neighbours (and to itself), and raises flag `nwg`; every reduction workgroup also waits for that flag of every
+// rank (the global row sums are in the denominator of W'), so by the end of the launch the halo rows of the next H-step
+// have arrived too.  Every workgroup posts before it waits and the grid (k n_pad / 32 + 1 workgroups of 256 threads) is
+// resident at once: no deadlock; waits are bounded (a lost peer is counted in the mailbox's error word).
+struct WExchangeArgs {
+  WUpdateArgs u;
+  unsigned char* mbox[16];   // every rank's mailbox as mapped here
+  int world, rank, nfl, with_halo;
+  size_t rec_bytes, slot_base, wgflags_off, err_off, hstat_off, top_off, bot_off;
+  unsigned int seq;
+  long long max_ticks;
+  const float* halo_h;
+  int halo_k, halo_nx, halo_ny, halo_ppad;
+};
+
+__device__ __forceinline__ void xchg_wait_flag(const unsigned int* flag, unsigned int seq, long long max_ticks, unsigned int* err) {
+  const long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {   // (polling with acquire loads would invalidate the caches per poll)
+    if (wall_clock64() - t0 > max_ticks) {
+      atomicAdd(err, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+__global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeArgs x) {
+  const WUpdateArgs& a = x.u;
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ float s_part[8][32];
+  const int nwg = a.k * a.nbk;
+  auto record = [&](int dst, int src_rank) { return x.mbox[dst] + x.slot_base + (size_t)src_rank * x.rec_bytes; };
+  auto flag = [&](int dst, int src_rank, int idx) {
+    return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + idx) * sizeof(unsigned int));
+  };
+  if ((int)blockIdx.x >= nwg) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
+    h_finalize_body(a.fin, fscratch);   // (fin.hstat_out = the statistics of this rank's record in its OWN mailbox)
+    __syncthreads();
+    const double* mine = reinterpret_cast<const double*>(record(x.rank, x.rank) + x.hstat_off);
+    for (int i = threadIdx.x; i < x.world * ESPM_HS_STRIDE; i += 256) {
+      const int r = i / ESPM_HS_STRIDE, j = i - r * ESPM_HS_STRIDE;
+      if (r != x.rank) reinterpret_cast<double*>(record(r, x.rank) + x.hstat_off)[j] = mine[j];
+    }
+    if (x.with_halo) {
+      for (int d = -1; d <= 1; ++d) {   // the neighbours read these rows as their halo; this rank keeps a copy (record layout)
+        const int r = x.rank + d;
+        if (r < 0 || r >= x.world) continue;
+        float* top = reinterpret_cast<float*>(record(r, x.rank) + x.top_off);
+        float* bot = reinterpret_cast<float*>(record(r, x.rank) + x.bot_off);
+        for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += 256) {
+          const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+          top[e] = x.halo_h[(size_t)kk * x.halo_ppad + j];
+          bot[e] = x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j];
         }
-        if (a.fixed_w) {
-          const float fx = a.fixed_w[(size_t)c * a.k + kk];
-          if (fx >= 0.f) v = fx;                              // updates.py:75-76
-        }
-        a.w_new[(size_t)c * a.k + kk] = v;
-        const float gv = fmaxf(v, a.gw_floor);
-        a.gw_s[(size_t)c * KP + kk] = gv * (1.f / a.xscale);
-        cs = (double)gv;
-        sw = (double)v;
-      } else {
-        a.gw_s[(size_t)c * KP + kk] = 1.f;  // padding channels: X = 0 there
       }
     }
-    cs = wave_sum(cs);
-    sw = wave_sum(sw);
-    if (a.pg_track) qw = wave_sum(qw);
-    if (threadIdx.x == 0) {
-      a.parts[blockIdx.x] = cs;
-      a.parts[nwg + blockIdx.x] = sw;
-      if (a.pg_track) a.parts[2 * nwg + blockIdx.x] = qw;
+    // (the mailboxes are uncached memory: a store is delivered once it is acknowledged - no cache to write back, so no
+    //  system-scope fence, which would flush this XCD's whole L2 - only ORDER: every thread's stores before any flag)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const int kk = blockIdx.x / a.nbk, j = blockIdx.x - kk * a.nbk;
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = 32 * j + col;
+  const int e = kk * a.n_pad + c;
+  auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
+  constexpr int INFLIGHT = 32;
+  float v[INFLIGHT];
+  const bool live = c < a.n_pad;
+#pragma unroll
+  for (int u = 0; u < INFLIGHT; ++u) {
+    const int b = grp + 8 * u;
+    v[u] = (live && b < a.nsrc) ? src(b) : 0.f;
+  }
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = ((v[u] + v[u + 8]) + v[u + 16]) + v[u + 24];
+  if (live) {
+    int b = grp + 8 * INFLIGHT;
+    for (; b + 56 < a.nsrc; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src(b + 8 * u);
     }
+    for (int u = 0; b < a.nsrc; b += 8, ++u) acc[u & 7] += src(b);
+  }
+  s_part[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (threadIdx.x < 64) {  // wave 0: lanes 0..31 own the 32 entries, lane r < world watches rank r
+    const int lane = threadIdx.x;
+    const bool owns = grp == 0 && live;
+    float t = 0.f;
+    if (owns) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += s_part[g][col];
+      for (int r = 0; r < x.world; ++r)   // this rank's piece, to every rank (write-through, system scope)
+        __hip_atomic_store(reinterpret_cast<float*>(record(r, x.rank)) + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's pieces are delivered before its flags are issued (order, not a cache flush)
+    if (lane < x.world) __hip_atomic_store(flag(lane, x.rank, blockIdx.x), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane < x.world) {
+      unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
+      xchg_wait_flag(flag(x.rank, lane, blockIdx.x), x.seq, x.max_ticks, err);
+      xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
+    }
+    // (every lane's polls are done when the wave goes on: one program counter; the loads below bypass the caches)
+    float tt = 0.f;
+    double rs = 0.0;
+    for (int r = 0; r < x.world; ++r) {   // fixed rank order: the same sums on every rank
+      if (owns) tt += __hip_atomic_load(reinterpret_cast<const float*>(record(x.rank, r)) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      rs += __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + ESPM_HS_ROWSUM + kk, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (blockIdx.x == 0 && lane < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
+      double g = 0.0;
+      for (int r = 0; r < x.world; ++r) {
+        const double v2 = __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + lane, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM);
+        g = lane < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+      }
+      a.hstat_out[lane] = g;
+    }
+    w_update_entries(a, kk, c, e, owns, tt, rs, nwg);
   }
 }
 
@@ -1019,6 +1163,69 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   else
     hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
   return check_hip(hipGetLastError(), "w_reduce_update launch");
+}
+
+int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
+                             const HFinalizeArgs& fin, const espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny, int p_pad,
+                             int with_halo, hipStream_t stream, WTailArgs* defer_tail) {
+  WExchangeArgs x;
+  WUpdateArgs& a = x.u;
+  a.src = static_cast<const unsigned char*>(slabs);
+  a.src_stride = slab_stride;
+  a.nsrc = nslab;
+  a.n = f.n;
+  a.n_pad = f.n_pad;
+  a.k = f.k;
+  a.nbk = (f.n_pad + 31) / 32;
+  a.a_out = a_out;
+  a.hpart = nullptr;
+  a.hstat_rs = nullptr;
+  a.nblk_h = 0;
+  a.rec_hstat_off = 0;
+  a.hstat_out = hstat_out;
+  a.w_old = f.w_old;
+  a.w_new = f.w_new;
+  a.fixed_w = f.fixed_w;
+  a.breg_sr = f.breg_sr;
+  a.pg_gamma_w = f.pg_gamma_w;
+  a.pg_track = f.pg_q != nullptr;
+  a.gw_s = f.gw_s;
+  a.parts = reinterpret_cast<double*>(f.scratch);
+  a.log_shift = f.log_shift;
+  a.gw_floor = f.gw_floor;
+  a.xscale = f.xscale;
+  a.fuse_finalize = 1;
+  a.fin = fin;
+  const int nwg = a.k * a.nbk;
+  ESPM_REQUIRE(nwg + 1 <= xc->wgflags, "exchange: %d reduction workgroups, the mailbox holds flags for %d", nwg, xc->wgflags - 1);
+  for (int r = 0; r < 16; ++r) x.mbox[r] = r < xc->world ? xc->peers[r] : nullptr;
+  for (int r = 0; r < xc->world; ++r) ESPM_REQUIRE(x.mbox[r], "exchange: rank %d is not connected (espm_xchg_connect)", r);
+  x.world = xc->world;
+  x.rank = xc->rank;
+  x.nfl = xc->wgflags;
+  x.with_halo = with_halo;
+  x.rec_bytes = xc->record_bytes;
+  x.slot_base = (size_t)(seq & 1u) * xc->world * xc->record_bytes;
+  x.wgflags_off = xc->off_wgflags;
+  x.err_off = xc->off_err;
+  x.hstat_off = (size_t)f.k * f.n_pad * 4;
+  x.top_off = x.hstat_off + ESPM_HS_STRIDE * 8;
+  x.bot_off = x.top_off + (size_t)f.k * (ny > 0 ? ny : 0) * 4;
+  x.seq = seq;
+  x.max_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  x.halo_h = h_new;
+  x.halo_k = f.k;
+  x.halo_nx = nx;
+  x.halo_ny = ny;
+  x.halo_ppad = p_pad;
+  a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
+  hipLaunchKernelGGL(w_exchange_update_kernel, dim3(nwg + 1), dim3(256), 0, stream, x);
+  const WTailArgs t = make_w_tail_args(f);
+  if (defer_tail)
+    *defer_tail = t;
+  else
+    hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
+  return check_hip(hipGetLastError(), "w_exchange_update launch");
 }
 
 int launch_w_update_tail(const WTailArgs& t, hipStream_t stream) {

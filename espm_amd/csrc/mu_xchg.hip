@@ -13,6 +13,8 @@
 //     errors  1 x uint32                 waits that gave up (bounded spin: a lost peer must not hang the device)
 //   post(seq): one workgroup per destination copies the staged record into slot [seq & 1][rank] of that destination with
 //              16-byte stores, fences at system scope, then one lane stores the flag (release, system scope).
+//   (espm_mu_shard_exchange_finish, mu_w_step.hip, does all of this INSIDE the slab-reduction launch, piece by piece, with
+//    one flag per reduction workgroup: wgflags)
 //   wait(seq): one workgroup, lane r polls flag[r] (system-scope loads, s_sleep between polls) until it reaches seq or
 //              ~2 s have passed; the kernels that read the records are launched behind it on the same stream.
 // Why the records of sequence s are safe to read until s + 2 is posted: a peer posts s + 2 only after its wait(s + 1)
@@ -40,10 +42,12 @@ __global__ __launch_bounds__(256) void xchg_post_kernel(const XchgPostArgs a) {
   uint4* d = reinterpret_cast<uint4*>(mb + a.slot_off);
   const size_t n16 = a.record_bytes / 16;
   for (size_t i = threadIdx.x; i < n16; i += 256) d[i] = s[i];
-  __threadfence_system();      // every thread: its stores are visible system-wide before the barrier lets the flag go
+  // the mailbox is uncached memory: a store is delivered once acknowledged; what is needed is ORDER (every thread's stores
+  // before the flag), not a system-scope fence, which would write back this XCD's whole L2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned int*>(mb + a.flag_off), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(mb + a.flag_off), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void xchg_wait_kernel(unsigned char* mailbox, size_t off_flags, size_t off_err, int world,
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(64) void xchg_wait_kernel(unsigned char* mailbox, s
     const unsigned int* flag = reinterpret_cast<const unsigned int*>(mailbox + off_flags + (size_t)r * XCHG_FLAG_STRIDE);
     const long long t0 = wall_clock64();
     // (sequence numbers only grow: >= also accepts a peer that is already one exchange ahead)
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (wall_clock64() - t0 > max_ticks) {   // a peer that never delivers must not hang the device: give up, count it
         atomicAdd(reinterpret_cast<unsigned int*>(mailbox + off_err), 1u);
         break;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(64) void xchg_wait_kernel(unsigned char* mailbox, s
       __builtin_amdgcn_s_sleep(8);
     }
   }
-  __threadfence_system();
+  // (the kernels that read the records start behind this one on the stream: a kernel boundary, and the mailbox is uncached)
 }
 
 }  // namespace espm
@@ -80,7 +84,10 @@ int espm_xchg_create(int world, int rank, size_t record_bytes, espm_xchg** out) 
   x->record_bytes = record_bytes;
   x->off_flags = 2 * (size_t)world * record_bytes;
   x->off_err = x->off_flags + (size_t)world * XCHG_FLAG_STRIDE;
-  x->mailbox_bytes = x->off_err + XCHG_FLAG_STRIDE;
+  x->off_wgflags = x->off_err + XCHG_FLAG_STRIDE;
+  x->wgflags = (int)(record_bytes / 128) + 2;   // >= k * ceil(n_pad / 32) + 1 for any record that holds k * n_pad floats
+  x->mailbox_bytes = x->off_wgflags + (size_t)world * x->wgflags * sizeof(uint32_t);
+  x->mailbox_bytes = (x->mailbox_bytes + 255) / 256 * 256;
   for (int r = 0; r < XCHG_MAX_WORLD; ++r) {
     x->peers[r] = nullptr;
     x->opened[r] = false;

@@ -63,11 +63,14 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True):
+                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True, force_sharded=False):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
         self.rank = torch.distributed.get_rank(group) if group is not None else 0
+        # the sharded code path (records, exchange, combine) also for a group of ONE rank: what a rank of an N-GPU run does
+        # per iteration, measurable on one GPU (tools/analysis/shard_iter.py)
+        self.sharded = self.world > 1 or (bool(force_sharded) and group is not None)
         dev = self.device
         k = int(n_components)
         self.k = k
@@ -356,7 +359,7 @@ class MUEngine:
         self._accum_done = False
 
         # ---- sharding -----------------------------------------------------------------------------------
-        if self.world > 1:
+        if self.sharded:
             from .sharding import ShardExchange
             self.exchange = ShardExchange(group, k, st.n_pad, st.ny, bool(st.grid_mode and self.lambda_L != 0.0), dev, lib=self.lib,
                                           stream_fn=_stream)
@@ -423,7 +426,7 @@ class MUEngine:
         self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
         self._check(self.lib.espm_mu_build_gw(C.byref(st), 0, _stream()))
         self._check(self.lib.espm_mu_hstat(C.byref(st), 0, _stream()))
-        if self.world > 1:
+        if self.sharded:
             self._globalize_hstat(0)
             self._exchange_halo_only(0)
 
@@ -546,7 +549,7 @@ class MUEngine:
         # sparse store, local W update: its tail is left to the next H-step's launch (eval_current) or to _flush_finalize
         defer = (self.ell is not None and self.pg_q is None and bool(self.lib.espm_mu_w_update_is_local(C.byref(st))))
         st.tail_mode = _lib.TAIL_DEFER if defer else 0
-        if self.world > 1:
+        if self.sharded:
             if ride:   # slab reduction + record reduction + this rank's record, one launch
                 self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, C.c_void_p(self.exchange.send_ptr), s))
             else:
@@ -567,7 +570,7 @@ class MUEngine:
         H before the last update and H the current one, d = g(H, Ht) - 1/2 tr(H L H^T) (lambda_L = 1, as the reference
         calls it); gamma / 1.05 when d > 0, else gamma * 1.5.  Call after ``finish_iteration``; returns the new gamma
         (already in effect for the next H-step).  One host synchronisation."""
-        if self.world > 1:
+        if self.sharded:
             raise NotImplementedError("linesearch is not built for a sharded image")
         st = self.st
         if st.it < 1:
@@ -597,7 +600,7 @@ class MUEngine:
         """After the H-step from state t (``eval_current(True)``), before the W-step: d = f(W, Ht) + <H - Ht, grad> +
         gamma ||H - Ht||^2 - f(W, H) with the losses not averaged; gamma_H / 1.05 when d > 0, else gamma_H * 1.5 (in effect
         from the next H-step).  Costs one loss-only pass over X (the loss of (W_t, H_{t+1})) and two host synchronisations."""
-        if self.world > 1 or self.pg_q is None:
+        if self.sharded or self.pg_q is None:
             raise NotImplementedError("the projected gradient's linesearch needs one GPU and an engine built with h_rule=2")
         st = self.st
         t = st.it
@@ -627,9 +630,9 @@ class MUEngine:
         if st.it + n_iter + 1 > self.hist_len:
             raise ValueError("history buffer exhausted: raise max_iter")
         self._flush_finalize()
-        if self.world == 1 and not self.frobenius:
+        if not self.sharded and not self.frobenius:
             self._check(self.lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
-        elif self.world > 1 and self.exchange.ctx is not None and not self.frobenius:
+        elif self.sharded and self.exchange.ctx is not None and not self.frobenius:
             # sharded, one-shot exchange: the whole batch is enqueued by the library (no host-side collective per iteration)
             self._check(self.lib.espm_mu_iterate_sharded(C.byref(st), self.exchange.ctx, C.byref(self.exchange.seq), int(n_iter),
                                                          int(bool(final_loss)), _stream()))
@@ -700,7 +703,7 @@ class MUEngine:
         upto = self.st.it if upto is None else upto
         self._flush_finalize()
         hist = self.hist[:upto + 1].clone()
-        if self.world > 1:
+        if self.sharded:
             sums = hist[:, [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP, _lib.HI_BAD]].contiguous()
             torch.distributed.all_reduce(sums, group=self.group)
             relh = hist[:, _lib.HI_REL_H].contiguous()

@@ -395,6 +395,13 @@ int espm_xchg_wait(espm_xchg* x, uint32_t seq, espm_stream_t stream);
 int espm_xchg_timeouts(const espm_xchg* x, uint32_t* count_out);   /* host-synchronous read of the give-up counter */
 int espm_xchg_destroy(espm_xchg* x);
 
+/* The sharded W step after the accumulation in ONE launch (where espm_mu_w_update_is_local; otherwise the four calls
+ * espm_mu_w_reduce_pack -> espm_xchg_post -> espm_xchg_wait -> espm_mu_shard_combine_finish): every workgroup of the slab
+ * reduction delivers its 32 entries of A to all ranks itself, waits for the same piece of every rank, sums them in rank
+ * order and updates its entries of W; the statistics of the new H block go to every rank, its boundary rows to the
+ * neighbours.  Afterwards espm_xchg_records(x, seq & 1) holds the gathered records like after an exchange. */
+int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_t seq, int src, int slot, espm_stream_t stream);
+
 /* n_iter iterations of a SHARDED image (pixel rows split over the ranks of x) without host synchronisation and without a
  * host-side collective: per iteration espm_mu_step_hw, espm_mu_w_reduce_pack into the staged record, espm_xchg_post /
  * _wait, espm_mu_shard_combine_finish on the gathered records; the halo rows of the next H-step are the neighbours'

@@ -1,17 +1,23 @@
+# Profiles of a round (rocprofv3 on the GPU box): kernel stats of the default bench, HBM traffic and SQ counters of its
+# kernels (separate --pmc passes, --kernel-trace only), kernel stats of C5 and of a wide-build k.  TAG=r02a bash tools/analysis/prof_round.sh
 set -e
+TAG=${TAG:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01h
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R && python bench.py > $O/bench_default.log 2>&1
+python bench.py --steps 20 --warmup 5 > $O/bench_20_5.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu --no-extras > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu --steps 20 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --no-cpu --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --no-cpu --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_c5 -- python3 $R/tools/analysis/c5_iter.py > $O/c5_iter.log 2>&1
+K="12" rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_wide -- python3 $R/tools/analysis/wide_iter.py > $O/wide_iter.log 2>&1
 cd $R
-for d in ks pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2; do
+for d in ks ks_c5 ks_wide pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2; do
   for f in $O/$d/*/*_kernel_stats.csv $O/$d/*/*_counter_collection.csv; do
     [ -f "$f" ] || continue
     (head -1 $f; grep "espm::" $f) > $O/${d}_$(basename $f | sed 's/^[0-9]*_//')
@@ -19,4 +25,4 @@ for d in ks pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_sq1 pmc_sq2; do
   rm -rf $O/$d
 done
 ls -la $O
-tail -1 $O/bench_default.log
+tail -1 $O/bench_default.log | cut -c1-300
