@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-store and steady-state legs (profiling runs)")
     ap.add_argument("--lambda-l", type=float, default=LAMBDA_L)
     ap.add_argument("--x-store", default="auto", choices=["auto", "ell", "u8", "bf16", "f32"])
+    ap.add_argument("--no-autotune", action="store_true", help="keep the default launch plan instead of timing the candidates at set-up")
     ap.add_argument("--no-fused", action="store_true", help="two launches per iteration pair instead of the fused kernel (A/B)")
     args = ap.parse_args()
 
@@ -139,11 +140,14 @@ def main():
     H0 = H0_full[:, row0 * NY:(row0 + rows) * NY]
     del H0_full
     total_iters = args.warmup + args.steps
+    W0d, H0d = torch.from_numpy(W0).to(device, torch.float32), torch.from_numpy(H0).to(device, torch.float32)
     X = synth.sample_torch(prob, device, seed=1000, row0=row0)            # (p_local, n) f32 counts
     X_crop = X[:CROP_ROWS * NY].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
     eng = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=total_iters + 400, group=group, device=device, x_store=args.x_store, fused=not args.no_fused)
-    eng.load_state(W0, H0)
+                   tol=0.0, max_iter=total_iters + 400, group=group, device=device, x_store=args.x_store, fused=not args.no_fused,
+                   autotune=not (args.no_fused or args.no_autotune))
+    # (W0 / H0 go up before the engine is built and load_state takes device tensors: nothing crosses the host here)
+    eng.load_state(W0d, H0d)
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,7 +249,7 @@ def main():
                         bytes_definition="this launch's own streams: X once in its stored form + H read + H written",
                         w_accum=dict(achieved=bytes_w / t_w / 1e9, frac=bytes_w / t_w / HBM_PEAK, launch_ms=t_w * 1e3))
     roofline["iteration"] = dict(algorithmic_GB=bytes_it / 1e9, hbm_frac=bytes_it * its / HBM_PEAK,
-                                 traffic_GB=(traffic + 12.0e6) / 1e9 if (traffic and fused) else None,   # + ~12 MB of the slab reduction (profiles/README.md)
+                                 traffic_GB=(traffic + 11.1e6) / 1e9 if (traffic and fused) else None,   # + 11.1 MB of the slab reduction launch (profiles/hbm_traffic.json)
                                  valu_f32_frac=flops_it * its / VALU_F32_PEAK, bf16_mfma_frac=flops_it * its / BF16_PEAK)
 
     # ---- the same iteration on the dense stores (N = 1 only): the sparse rate is a property of the dose ----
@@ -255,7 +259,7 @@ def main():
         for name in ("u8", "bf16"):
             e2 = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
                           tol=0.0, max_iter=260, device=device, x_store=name)
-            e2.load_state(W0, H0)
+            e2.load_state(W0d, H0d)
             e2.iterate(20, final_loss=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -278,6 +282,7 @@ def main():
                        "n": N_CH, "shape_2d": [NX, NY], "k": K, "lambda_L": args.lambda_l, "simplex_H": True,
                        "parallelism": f"pixel-row shard x{world}" if world > 1 else "single GPU",
                        "loss_every_iteration": True, "launches_per_iteration": 2 if fused else 3,
+                       "launch_plan": getattr(eng, "plan", None), "launch_plan_timings_us": eng.plan_timings,
                        "nnz_frac": nnz_frac, "counts_per_pixel": COUNTS},
             "loss_first": loss_first, "loss_last": loss_last, "nonfinite": bad,
             "roofline": roofline,

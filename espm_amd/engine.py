@@ -63,7 +63,7 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True, force_sharded=False):
+                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True, force_sharded=False, autotune=False):
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -357,6 +357,10 @@ class MUEngine:
         # tiles, default H rule: include/espm_mu.h, no_fused); `fused=False` keeps the two launches (A/B, tests)
         st.no_fused = 2 if fused == "static" else (0 if fused else 1)
         self._accum_done = False
+        # autotune: at the first load_state the launch plans that apply to this problem are timed on the ingested image and
+        # the fastest is kept (see autotune_plan)
+        self._autotune = bool(autotune)
+        self.plan_timings = None
 
         # ---- sharding -----------------------------------------------------------------------------------
         if self.sharded:
@@ -410,26 +414,77 @@ class MUEngine:
         return out
 
     def load_state(self, W, H):
-        """Install (W, H) as the current state: builds GW, its column sums and the statistics of H."""
+        """Install (W, H) as the current state: builds GW, its column sums and the statistics of H.  numpy arrays, or torch
+        tensors (already on the device: nothing crosses the host then)."""
         st = self.st
-        W = np.asarray(W, dtype=np.float32)
-        H = np.asarray(H, dtype=np.float32)
-        if W.shape != (self.M, self.k):
-            raise ValueError(f"W must be {(self.M, self.k)}, got {W.shape}")
-        if H.shape != (self.k, self.p):
-            raise ValueError(f"H must be {(self.k, self.p)}, got {H.shape}")
+
+        def as_f32(a, shape, name):
+            if isinstance(a, torch.Tensor):
+                t = a.to(device=self.device, dtype=torch.float32)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name} must be {shape}, got {tuple(t.shape)}")
+            return t
+        Wt = as_f32(W, (self.M, self.k), "W")
+        Ht = as_f32(H, (self.k, self.p), "H")
         st.cur, st.it = 0, 0
         self._pending_finalize = None
         self._pending_tail = False
         self.hist.zero_()
-        self.w[0].copy_(torch.from_numpy(np.ascontiguousarray(W)))
-        self.h[0][:, :self.p].copy_(torch.from_numpy(np.ascontiguousarray(H)))
+        self.w[0].copy_(Wt)
+        self.h[0][:, :self.p].copy_(Ht)
         self._check(self.lib.espm_mu_build_gw(C.byref(st), 0, _stream()))
         self._check(self.lib.espm_mu_hstat(C.byref(st), 0, _stream()))
         if self.sharded:
             self._globalize_hstat(0)
             self._exchange_halo_only(0)
+        if self._autotune:
+            self._autotune = False
+            self.autotune_plan()
 
+    PLANS = {0: "fused, units handed out dynamically", 2: "fused, fixed unit assignment", 1: "H-step and W accumulation as two launches"}
+
+    def autotune_plan(self, iters=24, warm=4):
+        """Times the launch plans of the iteration that apply to this problem - the fused kernel with dynamic or fixed
+        assignment of its work units, the two-launch path (include/espm_mu.h: no_fused) - on the ingested image from the
+        loaded state, keeps the fastest and restores the state.  Which plan wins depends on the component count (the fused
+        kernel has fewer segments per list group from k = 6 on), the dose and the image size; at the headline problem the
+        dynamic fused plan does.  ~(3 plans) x (warm + iters) iterations of device time, once per fit.  One GPU only."""
+        st = self.st
+        if self.sharded or self.frobenius or self.ell is None:
+            return None
+        keep = st.no_fused
+        st.no_fused = 0
+        if not bool(self.lib.espm_mu_fused_applies(C.byref(st))):
+            st.no_fused = keep
+            return None
+        iters = min(iters, self.hist_len - st.it - 2 - warm)
+        if iters < 4:   # (a fit of a few iterations: nothing to gain)
+            st.no_fused = keep
+            return None
+        tensors = [self.w[0], self.w[1], self.h[0], self.h[1], self.gw_s, self.colsum_gw, self.hstat[0], self.hstat[1], self.hist,
+                   self.w_scratch, self.hpart]
+        saved = [t.clone() for t in tensors]
+        state = (st.cur, st.it)
+        timings = {}
+        for plan in self.PLANS:
+            st.no_fused = plan
+            self._check(self.lib.espm_mu_iterate(C.byref(st), warm, 0, _stream()))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._check(self.lib.espm_mu_iterate(C.byref(st), iters, 0, _stream()))
+            e1.record()
+            e1.synchronize()
+            timings[plan] = e0.elapsed_time(e1) * 1e3 / iters
+            for t, sv in zip(tensors, saved):
+                t.copy_(sv)
+            st.cur, st.it = state
+        best = min(timings, key=timings.get)
+        st.no_fused = best
+        self.plan_timings = {self.PLANS[p]: v for p, v in timings.items()}
+        self.plan = self.PLANS[best]
+        return self.plan
     def set_G(self, G):
         """Replace G (physics model refreshed it, espm/estimators/base.py:388-390) and rebuild G W."""
         if self.m == 0:

@@ -95,7 +95,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm"):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False):
         from espm_amd.engine import MUEngine
 
         rows = None
@@ -115,7 +115,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
                         fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, layout=layout,
-                        **self._engine_kwargs())
+                        autotune=autotune, **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -273,7 +273,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         out_dtype = self.X_.dtype
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
                                                 filled_channels=empty_ch if bool(empty_ch.any()) else None,
-                                                filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout)
+                                                filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout,
+                                                autotune=Xd is not None and self.max_iter >= 100)   # (a long fit of a large image: time the launch plans once)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         del X_fixed, Xd, Xd_raw
         eng.load_state(self.W_, self.H_)
