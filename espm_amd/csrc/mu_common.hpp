@@ -571,6 +571,8 @@ struct HFinalizeArgs {
 };
 struct WAccumArgs {
   const void* x_pm;
+  const void* x_cm;  // tile-major X (the matrix-core kernel of the wide build streams this copy)
+  int x_tile, n_cm, p_pad, mfma;
   const float* gw_s;
   const float* h_t;
   float* a_slab;
@@ -718,6 +720,11 @@ inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
 inline WAccumArgs make_w_args(const espm_mu_state* st) {
   WAccumArgs a;
   a.x_pm = st->x_pm;
+  a.x_cm = st->x_cm;
+  a.x_tile = st->x_tile;
+  a.n_cm = st->n_cm;
+  a.p_pad = st->p_pad;
+  a.mfma = st->no_fused == 0;   // (no_fused != 0: the vector-ALU kernels, for A/B)
   a.gw_s = st->gw_s;
   a.h_t = st->h_t;
   a.a_slab = st->a_slab;

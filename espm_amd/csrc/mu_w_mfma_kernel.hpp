@@ -1,0 +1,185 @@
+// Dense W accumulation on the matrix cores: 9..16 components (the wide build, KP = 16) and, with half-empty tiles, 7..8.
+//
+// updates.py:38-39, :53, :59 on a dense store: Y = GW H', R = X / Y, A = R H'^T.  With k <= 8 the two contractions are
+// 2 k of the ~2 k + 6 vector instructions an element costs, and padding k to a matrix-core tile wastes most of the tile:
+// the matrix-core H-step measured slower at k = 5.  From k = 9 on the balance tips: the wide build's vector
+// kernels spend 2 k + 6 = 24..38 instructions per element, while a 16-wide tile is 56..100 % full.  Both contractions of
+// the W accumulation run here as v_mfma_f32_16x16x16_bf16 with every fp32 operand split into bf16 hi + lo (three products:
+// hi hi + hi lo + lo hi, relative error ~2^-16 per product, random sign: the sums over 10^5 pixels are fp32-grade), and
+// what stays on the vector ALU per element is the count -> float conversion, one reciprocal, one multiply and the split of
+// R (~6 instructions).
+//
+// Tiling (one wave): CT = 8 channel tiles of 16 channels against groups of 64 pixels = 4 steps of 16 pixel slots.
+//   step s, slot m = 4 q + r  <->  pixel 16 q + 4 s + r of the group (so that a lane's 16 pixels of a channel row are ONE
+//   16-byte load of the tile-major X for all four steps).
+//   1. Y^T (16 pixel slots x 16 channels) = H'^T (slots x k) . GW^T (k x channels):
+//        A operand: lane l holds H'[4 (l / 16) .. + 3, pixel of slot l % 16]   (16 bytes of h_t)
+//        B operand: lane l holds GW[channel l % 16, 4 (l / 16) .. + 3]          (registers, constant over the pixels)
+//        result   : lane l holds Y[channel l % 16, slots 4 (l / 16) + r]       - the A-operand layout of step 3
+//   2. R = X / Y in that layout (X: the lane's channel row, pixels of slots 4 (l / 16) + r: one dword of its 16-byte load)
+//   3. A (16 channels x 16 components) += R (channels x slots) . H'^T (slots x k):
+//        B operand: lane l holds H'[component l % 16, pixels of slots 4 (l / 16) + r]   (four dwords of h_t)
+//        result   : lane l holds A[channels 4 (l / 16) + r, component l % 16]  -> one 16-byte store into the slab
+// The H' operands of a pixel group are loaded and split once and serve all eight channel tiles.
+#pragma once
+#include "mu_common.hpp"
+
+namespace espm {
+
+typedef short mf_s4 __attribute__((ext_vector_type(4)));
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+typedef float mf_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mf_b2 __attribute__((ext_vector_type(2)));
+typedef unsigned mf_u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned mf_pack(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(mf_f2{a, b}, mf_b2));
+}
+// v = hi + lo + O(2^-17 |v|) with hi, lo bf16
+__device__ __forceinline__ void mf_split(const float (&v)[4], mf_s4& hi, mf_s4& lo) {
+  const unsigned h0 = mf_pack(v[0], v[1]), h1 = mf_pack(v[2], v[3]);
+  const unsigned l0 = mf_pack(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+  const unsigned l1 = mf_pack(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+  hi = __builtin_bit_cast(mf_s4, mf_u2{h0, h1});
+  lo = __builtin_bit_cast(mf_s4, mf_u2{l0, l1});
+}
+__device__ __forceinline__ mf_f4 mf_mma3(const mf_s4 ah, const mf_s4 al, const mf_s4 bh, const mf_s4 bl, mf_f4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);   // small terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+}
+
+// 16 consecutive pixels of one channel row of the tile-major X; quad(s) = the 4 pixels of step s as floats
+template <typename XT>
+struct MfRow;
+template <>
+struct MfRow<uint8_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void quad(int s, float (&x)[4]) const {
+    const uint32_t w = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
+    x[0] = ub0(w); x[1] = ub1(w); x[2] = ub2(w); x[3] = ub3(w);
+  }
+};
+template <>
+struct MfRow<bf16_t> {
+  uint4 v[2];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    v[0] = reinterpret_cast<const uint4*>(p)[0];
+    v[1] = reinterpret_cast<const uint4*>(p)[1];
+  }
+  __device__ __forceinline__ void quad(int s, float (&x)[4]) const {
+    const uint4 q = v[s >> 1];
+    const uint32_t a = (s & 1) ? q.z : q.x, b = (s & 1) ? q.w : q.y;
+    x[0] = __uint_as_float(a << 16); x[1] = __uint_as_float(a & 0xffff0000u);
+    x[2] = __uint_as_float(b << 16); x[3] = __uint_as_float(b & 0xffff0000u);
+  }
+};
+template <>
+struct MfRow<float> {
+  float4 v[4];
+  __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = reinterpret_cast<const float4*>(p)[i];
+  }
+  __device__ __forceinline__ void quad(int s, float (&x)[4]) const {
+    const float4 q = v[s];
+    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+  }
+};
+
+template <int K, typename XT, bool L2 = false>
+__global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
+  static_assert(KP == 16 || KP == 8, "component stride 8 or 16: the 16-wide tile is zero-filled beyond it");
+  constexpr int CT = 8;                          // channel tiles of 16 per wave
+  const int lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cbase = (blockIdx.y * 4 + wave) * 16 * CT;
+  if (cbase >= a.n_pad) return;                  // (whole waves)
+
+  // B operand of step 1: GW[channel, 4 q .. 4 q + 3] per channel tile, split once
+  mf_s4 gh[CT], gl[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int c = min(cbase + 16 * t + l16, a.n_pad - 1);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * q < KP) g = *reinterpret_cast<const float4*>(a.gw_s + (size_t)c * KP + 4 * q);
+    const float gv[4] = {g.x, g.y, g.z, g.w};
+    mf_split(gv, gh[t], gl[t]);
+  }
+  mf_f4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = mf_f4{0.f, 0.f, 0.f, 0.f};
+
+  const int groups = a.p_pad / 64;
+  const int gpb = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int g_begin = blockIdx.x * gpb, g_end = min(groups, g_begin + gpb);
+  const XT* x_cm = static_cast<const XT*>(a.x_cm);
+  // raw H' operands of a pixel group (both layouts, four steps): requested one group ahead of their use
+  struct HRaw {
+    float4 a[4];      // step s: H'[4 q .. 4 q + 3, pixel of slot l16]
+    float b[4][4];    // step s: H'[component l16, pixels of slots 4 q + r]
+  };
+  auto load_h = [&](HRaw& h, int g) {
+    const int px0 = g * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int pa = min(px0 + 16 * (l16 >> 2) + 4 * s + (l16 & 3), a.p - 1);      // pixel of slot l16 (rows beyond p: X = 0)
+      h.a[s] = (4 * q < KP) ? *reinterpret_cast<const float4*>(a.h_t + (size_t)pa * KP + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h.b[s][r] = l16 < KP ? a.h_t[(size_t)min(px0 + 16 * q + 4 * s + r, a.p - 1) * KP + l16] : 0.f;
+    }
+  };
+  HRaw hn;
+  if (g_begin < g_end) load_h(hn, g_begin);
+  for (int g = g_begin; g < g_end; ++g) {
+    const int px0 = g * 64;
+    if (px0 >= a.p) break;                       // (only padding beyond: X = 0 there)
+    mf_s4 a1h[4], a1l[4], b3h[4], b3l[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float hav[4] = {hn.a[s].x, hn.a[s].y, hn.a[s].z, hn.a[s].w};
+      mf_split(hav, a1h[s], a1l[s]);
+      mf_split(hn.b[s], b3h[s], b3l[s]);
+    }
+    if (g + 1 < g_end) load_h(hn, g + 1);        // in flight while this group's tiles are worked
+    const size_t xoff = (size_t)(px0 / a.x_tile) * a.n_cm * a.x_tile + (px0 % a.x_tile) + 16 * q;
+    MfRow<XT> xr[2];
+    xr[0].load(x_cm + xoff + (size_t)min(cbase + l16, a.n_cm - 1) * a.x_tile);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      if (t + 1 < CT) xr[(t + 1) & 1].load(x_cm + xoff + (size_t)min(cbase + 16 * (t + 1) + l16, a.n_cm - 1) * a.x_tile);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float x[4], r[4];
+        xr[t & 1].quad(s, x);
+        if constexpr (L2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = x[i];
+        } else {
+          mf_f4 y = mf_mma3(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float yi = y[i];
+            asm volatile("v_rcp_f32 %0, %0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard)
+            r[i] = x[i] * yi;
+          }
+        }
+        mf_s4 rh, rl;
+        mf_split(r, rh, rl);
+        acc[t] = mf_mma3(rh, rl, b3h[s], b3l[s], acc[t]);
+      }
+    }
+  }
+  // A[channels cbase + 16 t + 4 q + r, component l16] -> slab (k, n_pad): 4 consecutive channels per lane
+  if (l16 < K) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c0 = cbase + 16 * t + 4 * q;
+      if (c0 < a.n_pad)   // (n_pad is a multiple of 8: a quad is inside or outside as a whole)
+        *reinterpret_cast<float4*>(a.a_slab + ((size_t)blockIdx.x * K + l16) * a.n_pad + c0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+  }
+}
+
+}  // namespace espm

@@ -10,7 +10,12 @@
 //             global-stop bisection (dicotomy.py:111-173), clamp, fixed_W, then GW = G W for the
 //             next half step, its column sums, and rel_W (base.py:323).
 #include "mu_w_kernel.hpp"
+#include "mu_w_mfma_kernel.hpp"
 #include "mu_xchg.hpp"
+
+#ifndef ESPM_MFMA_MIN_K
+#define ESPM_MFMA_MIN_K 9   // measured at the headline image, 8-bit store: k = 7 493 vs 499 us per iteration, k = 8 519 vs 522 (no gain), k = 12 642 vs 761, k = 16 750 vs 992
+#endif
 
 namespace espm {
 
@@ -1043,6 +1048,21 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
   if (args.l2 && x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "the l2 W accumulation needs the f32 store");
   // channels per lane: 8 up to 8 components; 4 beyond (8 x k accumulators and 8 x k GW entries do not fit the registers)
   constexpr int CH8 = K <= 8 ? 8 : 4;
+  // both contractions on the matrix cores (mu_w_mfma_kernel.hpp) from MFMA_MIN_K components on: below, the vector kernel's 2 k + 6
+  // instructions per element are fewer than what the split operands and the tile traffic cost
+  if (K >= ESPM_MFMA_MIN_K && args.mfma && args.x_cm && args.n_pad % 8 == 0) {
+    const dim3 grid(nblk, (args.n_pad + 4 * 16 * 8 - 1) / (4 * 16 * 8));
+    if (x_dtype == ESPM_X_U8) {
+      hipLaunchKernelGGL((w_accum_mfma_kernel<K, uint8_t>), grid, dim3(256), 0, stream, args);
+    } else if (x_dtype == ESPM_X_BF16) {
+      hipLaunchKernelGGL((w_accum_mfma_kernel<K, bf16_t>), grid, dim3(256), 0, stream, args);
+    } else if (args.l2) {
+      hipLaunchKernelGGL((w_accum_mfma_kernel<K, float, true>), grid, dim3(256), 0, stream, args);
+    } else {
+      hipLaunchKernelGGL((w_accum_mfma_kernel<K, float>), grid, dim3(256), 0, stream, args);
+    }
+    return check_hip(hipGetLastError(), "w_accum (mfma) launch");
+  }
   if (x_dtype == ESPM_X_U8) {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
     hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, CH8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune

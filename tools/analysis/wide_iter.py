@@ -15,9 +15,9 @@ for k in [int(v) for v in os.environ.get("K", "8 12 16").split()]:
     prob = synth.make_problem(n, nx, ny, k, N=500.0, seed=0)
     X = synth.sample_torch(prob, dev, seed=1000)
     W0, H0 = synth.random_init(n, k, nx * ny, seed=0, scale=500.0 / n)
-    for store in (["ell", "u8"] if k <= 8 else ["u8"]):
+    for store, fused in ([("ell", True), ("u8", False), ("u8", True)] if k <= 8 else [("u8", False), ("u8", True)]):   # (wide build: fused=False = the vector-ALU W accumulation, True = matrix cores)
         eng = MUEngine(X, k, layout="pm", shape_2d=(nx, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=200,
-                       device=dev, x_store=store)
+                       device=dev, x_store=store, fused=fused)
         eng.load_state(W0, H0)
         eng.iterate(10, final_loss=False)
         torch.cuda.synchronize()
@@ -28,7 +28,7 @@ for k in [int(v) for v in os.environ.get("K", "8 12 16").split()]:
         eng.eval_current(advance_h=False)
         h = eng.history()
         dense = 2 * n * nx * ny   # both copies of the 8-bit X are read once per iteration
-        print(f"k={k:2d} store={eng.x_store:3s} (stride {eng.V.KP}): {dt * 1e6:7.1f} us/iteration = {1 / dt:6.0f} it/s"
+        print(f"k={k:2d} store={eng.x_store:3s} {'mfma' if (fused and k >= 7 and store != 'ell') else 'valu'} (stride {eng.V.KP}): {dt * 1e6:7.1f} us/iteration = {1 / dt:6.0f} it/s"
               + (f"; X stream {dense / dt / 1e12:.2f} TB/s" if store == "u8" else "")
               + f"; loss {h['loss'][0]:.6f} -> {h['loss'][-1]:.6f}; nonfinite {h['bad'].sum():.0f}", flush=True)
         del eng
