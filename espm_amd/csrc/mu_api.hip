@@ -49,8 +49,6 @@ static int check_state(const espm_mu_state* st) {
   ESPM_REQUIRE(st->n >= 1 && st->p >= 1, "n=%d, p=%d must be >= 1", st->n, st->p);
   if (st->k < ESPM_MIN_K || st->k > ESPM_MAX_K)
     return set_error(ESPM_EUNSUPPORTED, "k=%d: this build supports %d..%d components", st->k, ESPM_MIN_K, ESPM_MAX_K);
-  if (ESPM_MIN_K > 8 && st->x_dtype == ESPM_X_ELL)
-    return set_error(ESPM_EUNSUPPORTED, "the sparse count store is built for k <= 8");
   ESPM_REQUIRE(st->n_pad == roundup(st->n, ESPM_NPAD) && st->p_pad == roundup(st->p, ESPM_PPAD),
                "n_pad/p_pad (%d, %d) do not match n, p (%d, %d); call espm_mu_query", st->n_pad, st->p_pad, st->n,
                st->p);

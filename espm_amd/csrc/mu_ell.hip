@@ -20,7 +20,7 @@ static int allow_lds(KernelT kern, size_t bytes, const char* what) {
 
 template <int K>
 static int launch_h_ell_k(const HStepArgs& args_in, int nblk, hipStream_t stream) {
-  constexpr int UNR = ESPM_ELL_UNR_H;
+  constexpr int UNR = K > 8 ? 2 : ESPM_ELL_UNR_H;   // (a batch holds 2 UNR gathered rows of K floats)
   const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   // [nsplit][K][tile_px]: K * 512 floats whatever the split; two such sets when the groups of a 512-pixel window are walked in pairs
   size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args_in.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
@@ -59,11 +59,9 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell_tp == 64 || args.ell_tp == 128 || args.ell_tp == 256 || args.ell_tp == 512, "h_step: sparse store tile_px=%d must be 64, 128, 256 or 512", args.ell_tp);
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {
-#if ESPM_MIN_K <= 8   // (the LDS table holds rows of at most 8 floats: the wide build has no sparse store)
 #define ESPM_X(KK) case KK: return launch_h_ell_k<KK>(args, nblk, stream);
     ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
-#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built", args.k);
 }
@@ -81,7 +79,7 @@ static int device_cus() {
 
 template <int K>
 static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) {
-  constexpr int UNR = ESPM_ELL_UNR_W;
+  constexpr int UNR = K > 8 ? 2 : ESPM_ELL_UNR_W;
   // one workgroup per pixel block while the blocks alone cover the chip; otherwise the channel groups of a
   // block are dealt to `csplit` workgroups, each with as many waves (<= 16) as it has groups (two per wave
   // when csplit = 1: heavy / light pairing)
@@ -92,6 +90,7 @@ static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) 
   if (nw > ESPM_ELL_WTHREADS / 64) nw = ESPM_ELL_WTHREADS / 64;
   if (nw < 1) nw = 1;
   const size_t bytes = (size_t)ESPM_ELL_PB * EllTab<K>::FLOATS * sizeof(float);
+  if (int rc = allow_lds(w_accum_ell_kernel<K, UNR>, bytes, "w_accum (ell)")) return rc;
   hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk, csplit), dim3(64 * nw), bytes, stream, args);
   return check_hip(hipGetLastError(), "w_accum (ell) launch");
 }
@@ -100,11 +99,9 @@ int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell && args.ell_off && args.chan_perm && args.n_cg >= 1, "w_accum: the sparse store needs ell_w, ell_w_off, chan_perm");
   ESPM_REQUIRE(nblk == (args.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB, "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, ESPM_ELL_PB);
   switch (k) {
-#if ESPM_MIN_K <= 8
 #define ESPM_X(KK) case KK: return launch_w_ell_k<KK>(args, nblk, stream);
     ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
-#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built", k);
 }

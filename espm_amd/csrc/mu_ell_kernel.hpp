@@ -53,12 +53,19 @@ __device__ __forceinline__ void ell_table_at_lds_zero(const float* tab) {
 }
 template <int K>
 struct EllTab {
-  static constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : 4));
+  static constexpr int WB = LdsTabGeom<K>::WB;   // (mu_h_kernel.hpp) 0, 1, 2, 4 | 8 | 12 floats beyond the float4 part
   static constexpr int FLOATS = 4 + WB;
+  static constexpr int WQ = WB / 4;              // float4 of the second array per row (from 7 components on)
   static __device__ __forceinline__ const float* quad(const float* tab, int rows) { return tab + (size_t)WB * rows; }
-  // row r from 8 consecutive floats (the KP-strided gw_s / h_t rows)
-  static __device__ __forceinline__ void put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
-    lds_table_put<K>(tab, rows, r, lo, hi);   // (mu_h_kernel.hpp: the epilogue of the fused half-steps writes rows too)
+  // row r from a KP-strided row of gw_s / h_t
+  static __device__ __forceinline__ void put(float* tab, int rows, int r, const float* src) {
+    float row[(K + 3) / 4 * 4];   // (16-byte loads of the quads that hold a component)
+#pragma unroll
+    for (int i = 0; i < (K + 3) / 4 * 4; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      row[i] = v.x; row[i + 1] = v.y; row[i + 2] = v.z; row[i + 3] = v.w;
+    }
+    lds_table_put_row<K>(tab, rows, r, row);
   }
   static __device__ __forceinline__ void get(const float* tab, int rows, uint32_t r, float (&g)[K]) {
     const float4 lo = reinterpret_cast<const float4*>(quad(tab, rows))[r];
@@ -71,15 +78,19 @@ struct EllTab {
       g[4] = v.x;
       g[5] = v.y;
     }
-    if constexpr (WB == 4) {
-      const float4 v = reinterpret_cast<const float4*>(tab)[r];
-      const float h[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (WB >= 4) {
 #pragma unroll
-      for (int i = 4; i < K; ++i) g[i] = h[i - 4];
+      for (int q = 0; q < WQ; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(tab)[(size_t)r * WQ + q];
+        const float h[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 + 4 * q + i < K) g[4 + 4 * q + i] = h[i];
+      }
     }
   }
   // unit entry: off = 16 * row.  The table sits at LDS address 0 (ell_table_at_lds_zero), lds_q = LDS address of its
-  // float4 part: the address of the second array is a shift of the entry, with no base to add.
+  // float4 part: the address of the second array is a shift (or a small multiple) of the entry, with no base to add.
   static __device__ __forceinline__ void get_unit(uint32_t lds_q, uint32_t off, float (&g)[K]) {
     const lds_v4f lo = *(ESPM_LDS(lds_v4f))(uintptr_t)(lds_q + off);
 #pragma unroll
@@ -90,10 +101,15 @@ struct EllTab {
       g[4] = v[0];
       g[5] = v[1];
     }
-    if constexpr (WB == 4) {
-      const lds_v4f v = *(ESPM_LDS(lds_v4f))(uintptr_t)(off);
+    if constexpr (WB >= 4) {
+      const uint32_t base = off * WQ;   // (x 1, 2: a shift, or x 3)
 #pragma unroll
-      for (int i = 4; i < K; ++i) g[i] = v[i - 4];
+      for (int q = 0; q < WQ; ++q) {
+        const lds_v4f v = *(ESPM_LDS(lds_v4f))(uintptr_t)(base + 16 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 + 4 * q + i < K) g[4 + 4 * q + i] = v[i];
+      }
     }
   }
 };
@@ -198,7 +214,7 @@ struct EllGetUnit {
 //   otherwise every 64-pixel list group is walked by `nsplit` waves, each taking a contiguous slice of its rows
 //     (small images use nsplit = 2, 4 or 8 so that the grid still covers the chip).
 template <int K, bool LOSS, int UNR, int RULE = 0>
-__global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HStepArgs a) {
+__global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_kernel(const HStepArgs a) {   // (more than 8 components: 256 registers, one workgroup per CU by its LDS anyway)
   constexpr int NT = ESPM_ELL_TILE;
   constexpr bool PAIRS_OK = K <= ESPM_ELL_PAIR_MAX_K;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -213,17 +229,15 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, 4) void h_step_ell_kernel(const HSte
     return;
   }
   double* cs_lds = a.cs_parts ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + a.cs_lds_off) : nullptr;
-  if (cs_lds && (int)(threadIdx.x >> 6) < K) {      // wave kk: column sum kk of G W' from the W update's partials
-    const int kk = threadIdx.x >> 6;
-    double v = 0.0;
-    for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
+  if (cs_lds) {      // wave w: column sums w, w + 8, ... of G W' from the W update's partials
+    for (int kk = threadIdx.x >> 6; kk < K; kk += NT / 64) {
+      double v = 0.0;
+      for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
+      v = wave_sum(v);
+      if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
+    }
   }
-  for (int r = threadIdx.x; r < a.n_pad; r += NT) {
-    const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
-    EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
-  }
+  for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
   if (pairs) {  // second partial numerator: only the pixels of the longer group of a pair receive one
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) part[((size_t)K + kk) * TP + threadIdx.x] = 0.f;
@@ -310,13 +324,8 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WA
   const int nw = (int)blockDim.x >> 6;
   for (int r = threadIdx.x; r < PB; r += (int)blockDim.x) {
     const int q = b * PB + r;
-    float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // pixels past the end: never referenced by an entry with a count
-    if (q < a.p) {
-      const float4* src = reinterpret_cast<const float4*>(a.h_t + (size_t)q * KP);
-      lo = src[0];
-      hi = src[1];
-    }
-    EllTab<K>::put(tab, PB, r, lo, hi);
+    // (pixels past the end: the row of the last pixel - never referenced by an entry with a count, and positive)
+    EllTab<K>::put(tab, PB, r, a.h_t + (size_t)min(q, a.p - 1) * KP);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;

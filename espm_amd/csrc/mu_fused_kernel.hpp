@@ -78,10 +78,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
   }
-  for (int r = threadIdx.x; r < a.n_pad; r += NT) {
-    const float4* src = reinterpret_cast<const float4*>(a.gw_s + (size_t)r * KP);
-    EllTab<K>::put(tab, a.n_pad, r, src[0], src[1]);
-  }
+  for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
   if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
   __syncthreads();
   ESPM_PHASE_STAMP(1);

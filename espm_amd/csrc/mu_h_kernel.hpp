@@ -8,12 +8,31 @@ namespace espm {
 // Row r of an LDS gather table of `rows` rows of K floats, in the layout of EllTab<K> (mu_ell_kernel.hpp): components 4..
 // first (1, 2 or 4 floats per row), then the float4 part.
 template <int K>
+struct LdsTabGeom {
+  // floats of a row beyond the float4 part: 0, 1, 2, 4 up to 8 components; 8 (two float4) up to 12, 12 (three) up to 16
+  static constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : (K <= 8 ? 4 : (K <= 12 ? 8 : 12))));
+};
+// row r from the first K of `src` (a KP-strided row of gw_s / h_t, or registers)
+template <int K>
+__device__ __forceinline__ void lds_table_put_row(float* tab, int rows, int r, const float* src) {
+  constexpr int WB = LdsTabGeom<K>::WB;
+  reinterpret_cast<float4*>(tab + (size_t)WB * rows)[r] = make_float4(src[0], K > 1 ? src[1] : 0.f, K > 2 ? src[2] : 0.f, K > 3 ? src[3] : 0.f);
+  if constexpr (WB == 1) tab[r] = src[4];
+  if constexpr (WB == 2) reinterpret_cast<float2*>(tab)[r] = make_float2(src[4], src[5]);
+  if constexpr (WB >= 4) {
+#pragma unroll
+    for (int q = 0; q < WB / 4; ++q)
+      reinterpret_cast<float4*>(tab)[(size_t)r * (WB / 4) + q] =
+          make_float4(4 + 4 * q < K ? src[4 + 4 * q] : 0.f, 5 + 4 * q < K ? src[5 + 4 * q] : 0.f, 6 + 4 * q < K ? src[6 + 4 * q] : 0.f, 7 + 4 * q < K ? src[7 + 4 * q] : 0.f);
+  }
+}
+template <int K>
 __device__ __forceinline__ void lds_table_put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
-  constexpr int WB = K <= 4 ? 0 : (K == 5 ? 1 : (K == 6 ? 2 : 4));
-  reinterpret_cast<float4*>(tab + (size_t)WB * rows)[r] = lo;
-  if constexpr (WB == 1) tab[r] = hi.x;
-  if constexpr (WB == 2) reinterpret_cast<float2*>(tab)[r] = make_float2(hi.x, hi.y);
-  if constexpr (WB == 4) reinterpret_cast<float4*>(tab)[r] = hi;
+  static_assert(K >= 1, "");
+  if constexpr (K <= 8) {
+    const float src[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    lds_table_put_row<K>(tab, rows, r, src);
+  }   // (more than 8 components: the fused kernel, the only caller with two float4, is not built for them)
 }
 
 // What the epilogue needs of one pixel besides its numerators: requested in one go (no branch between the

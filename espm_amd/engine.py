@@ -180,7 +180,7 @@ class MUEngine:
             if code == 2:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
-                fits = k <= _lib.MAX_K and self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
+                fits = k <= _lib.WIDE_MAX_K and self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
                 sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
@@ -191,7 +191,7 @@ class MUEngine:
                 set_empty(log_shift)
                 flag.fill_(0)      # (the fill is neither an integer nor a bf16 value)
             if x_store == "ell" and int(flag.item()) != 3:
-                raise ValueError("x_store='ell' needs integer counts <= 255, k <= 8, n <= 16384 and a GW table that fits in LDS")
+                raise ValueError("x_store='ell' needs integer counts <= 255, n <= 16384 and a GW table that fits in LDS (12- or 16-float rows from 9 components on)")
             refill = unfilled and int(flag.item()) == 3 and (filled_channels is not None or filled_pixels is not None)  # (the caller's tensor: put the fill back)
             x_store = ("f32", "bf16", "u8", "ell")[int(flag.item())]
         if int(h_rule) != 0 and x_store in ("u8", "bf16"):

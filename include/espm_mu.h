@@ -76,8 +76,8 @@ enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
 enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
 
 /* The library is built twice from the same sources: libespm_mu.so (1..8 components, the strides below = 8) and
- * libespm_mu_wide.so (-DESPM_KP=16 -DESPM_MIN_K=9 -DESPM_MAX_K=16: 9..16 components on the dense stores; the
- * sparse store's LDS table is laid out for rows of at most 8 floats).  Same entry points, same state struct; every
+ * libespm_mu_wide.so (-DESPM_KP=16 -DESPM_MIN_K=9 -DESPM_MAX_K=16: 9..16 components; the sparse store's LDS table then has
+ * rows of 12 or 16 floats and must fit ESPM_ELL_LDS_MAX together with the numerators of a tile).  Same entry points, same state struct; every
  * size below that names KP follows the build. */
 #ifndef ESPM_KP
 #define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP): 8 or 16 */

@@ -335,10 +335,15 @@ def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m):
     (11, "bf16", 14, dict(lambda_L=0.0, simplex_H=False, simplex_W=True)),
     (16, "f32", None, dict(lambda_L=0.3, simplex_H=True, simplex_W=False, fixed=True)),
     (10, "u8", None, dict(lambda_L=0.0, simplex_H=False, simplex_W=False)),
+    # the sparse count store with 12- and 16-float table rows (round 2)
+    (9, "ell", None, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),
+    (12, "ell", 20, dict(lambda_L=0.5, mu=0.05, simplex_H=True, simplex_W=False)),
+    (13, "ell", None, dict(lambda_L=1.0, simplex_H=False, simplex_W=True)),
+    (16, "ell", None, dict(lambda_L=0.3, simplex_H=True, simplex_W=False, fixed=True)),
 ])
 def test_nine_to_sixteen_components(k, store, m, kw):
-    """More than 8 components run on the second build of the library (libespm_mu_wide.so: component stride 16, dense
-    stores): engine against the fp64 oracle with simplex over H or W, a dictionary G, mu, the Laplacian and fixed_H."""
+    """More than 8 components run on the second build of the library (libespm_mu_wide.so: component stride 16, every
+    store): engine against the fp64 oracle with simplex over H or W, a dictionary G, mu, the Laplacian and fixed_H."""
     import torch
     from espm_amd import synth
     from espm_amd.engine import MUEngine
@@ -372,8 +377,6 @@ def test_nine_to_sixteen_components(k, store, m, kw):
     np.testing.assert_allclose(He, ref["H"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(We, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
     assert h["bad"].sum() == 0
-    with pytest.raises(ValueError):
-        MUEngine(np.round(X), k, shape_2d=(nx, ny), x_store="ell")     # the sparse store is built for k <= 8
 
 
 @pytest.mark.parametrize("kw", [dict(simplex_H=True, simplex_W=False, mu=0.2, lambda_L=1.5), dict(simplex_H=True, simplex_W=False),

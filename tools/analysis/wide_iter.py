@@ -15,9 +15,11 @@ for k in [int(v) for v in os.environ.get("K", "8 12 16").split()]:
     prob = synth.make_problem(n, nx, ny, k, N=500.0, seed=0)
     X = synth.sample_torch(prob, dev, seed=1000)
     W0, H0 = synth.random_init(n, k, nx * ny, seed=0, scale=500.0 / n)
-    for store, fused in ([("ell", True), ("u8", False), ("u8", True)] if k <= 8 else [("u8", False), ("u8", True)]):   # (wide build: fused=False = the vector-ALU W accumulation, True = matrix cores)
+    for store, fused in ([("ell", True), ("u8", False), ("u8", True)] if k <= 8 else [("ell", True), ("u8", False), ("u8", True)]):   # (wide build: fused=False = the vector-ALU W accumulation, True = matrix cores)
         eng = MUEngine(X, k, layout="pm", shape_2d=(nx, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=200,
-                       device=dev, x_store=store, fused=fused)
+                       device=dev, x_store=store, fused=fused) if not (store == "ell" and k > 12) else None
+        if eng is None:
+            continue
         eng.load_state(W0, H0)
         eng.iterate(10, final_loss=False)
         torch.cuda.synchronize()
