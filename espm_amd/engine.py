@@ -499,6 +499,24 @@ class MUEngine:
         self._gtg = None   # G^T G of the Frobenius W step (updates.py:31-36) belongs to the old G
         self._check(self.lib.espm_mu_build_gw(C.byref(self.st), self.st.cur, _stream()))
 
+    def exchange_health(self):
+        """Sharded engines: the number of bounded waits of the one-shot exchange that gave up, maximum over the ranks (0 on a
+        healthy node; a peer that never delivers is counted, not waited for - the iterates are garbage from there on)."""
+        if not self.sharded:
+            return 0
+        lost = torch.tensor([self.exchange.lost_peers()], dtype=torch.int64, device=self.device)
+        torch.distributed.all_reduce(lost, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        return int(lost.item())
+
+    def use_collective_exchange(self):
+        """Replaces the one-shot exchange by the collective transport on every rank (call it on all of them); the state has to
+        be loaded again afterwards."""
+        from .sharding import ShardExchange
+        torch.cuda.synchronize()
+        self.exchange.close()
+        self.exchange = ShardExchange(self.group, self.k, self.st.n_pad, self.st.ny, bool(self.st.grid_mode and self.lambda_L != 0.0),
+                                      self.device, lib=self.lib, stream_fn=_stream, mode="collective")
+
     # ---- sharded helpers ---------------------------------------------------------------------------
     def _globalize_hstat(self, which):
         hs = self.hstat[which]
@@ -758,6 +776,9 @@ class MUEngine:
         upto = self.st.it if upto is None else upto
         self._flush_finalize()
         hist = self.hist[:upto + 1].clone()
+        if self.sharded and self.exchange.ctx is not None and self.exchange_health() > 0:
+            raise _lib.EspmError("the record exchange between the ranks lost a peer (a bounded wait gave up): the iterates since "
+                                 "then are not valid; ESPM_XCHG=collective selects the collective transport")
         if self.sharded:
             sums = hist[:, [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP, _lib.HI_BAD]].contiguous()
             torch.distributed.all_reduce(sums, group=self.group)

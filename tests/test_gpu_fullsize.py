@@ -200,3 +200,33 @@ def test_iteration_loop_is_reproducible_across_chunkings(big):
         for key in ("loss", "rel_W", "rel_H", "bad"):
             assert np.array_equal(h[key], out[0][2][key]), key
     assert out[0][2]["bad"].sum() == 0 and np.isfinite(out[0][2]["rel_W"][1:]).all()
+
+
+def test_launch_plan_autotune_restores_the_state(big):
+    """MUEngine(autotune=True) times the launch plans at the first load_state (fused with dynamic / fixed units, two
+    launches) on the ingested image and keeps the fastest; the loaded state must come back bit for bit, and the fit that
+    follows must equal the fit of an engine that never timed anything."""
+    from espm_amd.engine import MUEngine
+    eng = big["engs"]["ell"]
+    X = None
+    # an engine of its own on the same lists would need X again: reuse the fixture's engine, toggling the switch by hand
+    eng.load_state(big["W0"], big["H0"])
+    eng.iterate(4, final_loss=True)
+    torch.cuda.synchronize()
+    ref = (eng.get_W(), eng.get_H(), eng.history()["loss"].copy())
+    W0d = torch.from_numpy(big["W0"]).to("cuda", torch.float32)
+    H0d = torch.from_numpy(big["H0"]).to("cuda", torch.float32)
+    eng.load_state(W0d, H0d)                                   # device tensors: nothing crosses the host
+    before = [t.clone() for t in (eng.w[0], eng.h[0], eng.gw_s, eng.colsum_gw, eng.hstat[0], eng.hist)]
+    plan = eng.autotune_plan(iters=8, warm=2)
+    assert plan in MUEngine.PLANS.values() and set(eng.plan_timings) == set(MUEngine.PLANS.values())
+    assert all(5.0 < v < 2000.0 for v in eng.plan_timings.values()), eng.plan_timings
+    after = (eng.w[0], eng.h[0], eng.gw_s, eng.colsum_gw, eng.hstat[0], eng.hist)
+    assert all(torch.equal(a, b) for a, b in zip(before, after)) and (eng.st.cur, eng.st.it) == (0, 0)
+    eng.iterate(4, final_loss=True)
+    torch.cuda.synchronize()
+    if eng.st.no_fused == 0:                                    # the default plan won: the same fit, bit for bit
+        assert np.array_equal(eng.get_W(), ref[0]) and np.array_equal(eng.get_H(), ref[1])
+    np.testing.assert_allclose(eng.history()["loss"], ref[2], rtol=2e-7)
+    eng.st.no_fused = 0
+    del X
