@@ -275,9 +275,12 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     h_finalize_body(a.fin, fscratch);   // (fin.hstat_out = the statistics of this rank's record in its OWN mailbox)
     __syncthreads();
     const double* mine = reinterpret_cast<const double*>(record(x.rank, x.rank) + x.hstat_off);
+    // (every store into a mailbox is a system-scope write-through store: whatever memory type a peer's mapping has here,
+    //  the data is on its way to that rank's memory when the store is acknowledged, and `s_waitcnt vmcnt(0)` orders the flag)
     for (int i = threadIdx.x; i < x.world * ESPM_HS_STRIDE; i += 256) {
       const int r = i / ESPM_HS_STRIDE, j = i - r * ESPM_HS_STRIDE;
-      if (r != x.rank) reinterpret_cast<double*>(record(r, x.rank) + x.hstat_off)[j] = mine[j];
+      if (r != x.rank)
+        __hip_atomic_store(reinterpret_cast<double*>(record(r, x.rank) + x.hstat_off) + j, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (x.with_halo) {
       for (int d = -1; d <= 1; ++d) {   // the neighbours read these rows as their halo; this rank keeps a copy (record layout)
@@ -287,8 +290,9 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         float* bot = reinterpret_cast<float*>(record(r, x.rank) + x.bot_off);
         for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += 256) {
           const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
-          top[e] = x.halo_h[(size_t)kk * x.halo_ppad + j];
-          bot[e] = x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j];
+          __hip_atomic_store(top + e, x.halo_h[(size_t)kk * x.halo_ppad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(bot + e, x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }

@@ -38,12 +38,14 @@ struct XchgPostArgs {
 
 __global__ __launch_bounds__(256) void xchg_post_kernel(const XchgPostArgs a) {
   unsigned char* mb = a.dst[blockIdx.x];
-  const uint4* s = reinterpret_cast<const uint4*>(a.src);
-  uint4* d = reinterpret_cast<uint4*>(mb + a.slot_off);
-  const size_t n16 = a.record_bytes / 16;
-  for (size_t i = threadIdx.x; i < n16; i += 256) d[i] = s[i];
-  // the mailbox is uncached memory: a store is delivered once acknowledged; what is needed is ORDER (every thread's stores
-  // before the flag), not a system-scope fence, which would write back this XCD's whole L2
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(a.src);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(mb + a.slot_off);
+  const size_t n8 = a.record_bytes / 8;
+  // system-scope write-through stores: whatever memory type the peer's mapping has here, the data is on its way to that
+  // rank's memory when the store is acknowledged
+  for (size_t i = threadIdx.x; i < n8; i += 256) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // what is needed then is ORDER (every thread's stores before the flag), not a system-scope fence, which would write back
+  // this XCD's whole L2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
