@@ -23,6 +23,8 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   size_t bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
   args.cnt_lds_off = (int)bytes;   // the two unit counters
   bytes += 16;
+  args.meta_lds_off = (int)bytes;  // the block's list offsets
+  bytes += (size_t)(3 * (ESPM_ELL_PB / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
   if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
     args.h.cs_lds_off = (int)bytes;
     bytes += KP * sizeof(double);
@@ -46,7 +48,8 @@ size_t fused_ell_lds_bytes(int n_pad, int k) {
   const int tab_rows = n_pad > ESPM_ELL_PB ? n_pad : ESPM_ELL_PB;
   const int tabf = 4 + (k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4)));
   const int seg = k <= 5 ? 4 : (k == 6 ? 3 : 2);   // FusedGeom<K>::S
-  return (size_t)tab_rows * tabf * 4 + (size_t)seg * (k + 1) * ESPM_ELL_PB * 4 + 16 + KP * sizeof(double);
+  const int n_cg = (n_pad + 63) / 64;   // (>= the channel groups of any n with this n_pad)
+  return (size_t)tab_rows * tabf * 4 + (size_t)seg * (k + 1) * ESPM_ELL_PB * 4 + 16 + (size_t)(3 * (ESPM_ELL_PB / 64) + 2 * n_cg + 4) / 4 * 16 + KP * sizeof(double);
 }
 
 int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units) {

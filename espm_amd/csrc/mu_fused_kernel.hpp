@@ -33,6 +33,8 @@ struct FusedArgs {
   HStepArgs h;      // write_h = 1, ell_tp = 512; h_t unused
   WAccumArgs w;     // h_t unused
   int cnt_lds_off;  // byte offset of the two unit counters in LDS
+  int meta_lds_off; // byte offset of the block's list offsets in LDS: 16 x (first row, first general row, end) of the pixel-list
+                    // groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
 };
 
@@ -43,7 +45,10 @@ struct FusedGeom {
   static constexpr int PROWS = K + 1;   // K numerators + the KL part
   // first row of segment s of a group of `len` rows: the segments shrink (35 / 30 / 20 / 15 % of the rows), so that the
   // units handed out last are the short ones and the waves end close together
+  // A group of fewer than MIN_SPLIT rows (low doses) is ONE unit: starting a unit costs a chain of dependent loads.
+  static constexpr int MIN_SPLIT = 48;
   static __device__ __forceinline__ int seg_begin(int len, int s) {
+    if (len < MIN_SPLIT) return s == 0 ? 0 : len;
     constexpr int cut4[5] = {0, 35, 65, 85, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, 60, 100};
     const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
     return (int)((long)len * c / 100);
@@ -80,6 +85,14 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
   }
   for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
   if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
+  // the block's list offsets, once: a unit then starts from LDS instead of from two dependent scalar loads
+  int* meta = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.meta_lds_off);
+  if (threadIdx.x < 3 * NGRP) {
+    const int gi = threadIdx.x / 3, j = threadIdx.x - 3 * gi;
+    const bool tile_ok = blockIdx.x * PB + (gi >> 3) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
+    meta[threadIdx.x] = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
+  }
+  for (int i = threadIdx.x; i <= 2 * fa.w.n_cg; i += NT) meta[3 * NGRP + i] = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + i];
   __syncthreads();
   ESPM_PHASE_STAMP(1);
   const int lane = threadIdx.x & 63;
@@ -107,29 +120,31 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
     int lp = lane;   // place of the lane's pixel inside its tile
     if (blk0 + (gi >> 3) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
       lp = a.ell_pix[grp * 64 + lane];       // slot -> pixel of the window (lists ordered by length)
-      const int px = blk0 + (gi >> 3) * TP + lp;
-      float hk[K];
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
-      const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg, len = a.ell_off[2 * grp + 2] - beg;
+      const int beg = meta[3 * gi], mid = meta[3 * gi + 1] - beg, len = meta[3 * gi + 2] - beg;
       const int x0 = FusedGeom<K>::seg_begin(len, seg), x1 = FusedGeom<K>::seg_begin(len, seg + 1);
-      const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-      if (x0 < mid) {
-        ell_walk<K, UNR_H>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
-          const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
-          ell_axpy<K>(acc, g, r);
-          if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
-        });
-      }
-      if (x1 > mid) {
-        const int g0 = max(x0, mid);
-        ell_walk<K, UNR_H>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
-          const float y = ell_dot<K>(g, hk);
-          // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
-          const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-          ell_axpy<K>(acc, g, r);
-          if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-        });
+      if (x0 < x1) {
+        const int px = blk0 + (gi >> 3) * TP + lp;
+        float hk[K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
+        const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
+        if (x0 < mid) {
+          ell_walk<K, UNR_H>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
+            const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+            ell_axpy<K>(acc, g, r);
+            if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
+          });
+        }
+        if (x1 > mid) {
+          const int g0 = max(x0, mid);
+          ell_walk<K, UNR_H>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
+            const float y = ell_dot<K>(g, hk);
+            // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+            const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+            ell_axpy<K>(acc, g, r);
+            if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+          });
+        }
       }
     }
     float* dst = part + (size_t)seg * PROWS * PB + (gi >> 3) * TP + lp;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
       gw[kk] = gsrc[kk];
       acc[kk] = 0.f;
     }
-    const int32_t* off = w.ell_off + 2 * ((size_t)b * w.n_cg + cg);
+    const int* off = meta + 3 * NGRP + 2 * cg;
     const int beg = off[0], mid = off[1], end = off[2];
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
     ell_walk<K, UNR_W>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
