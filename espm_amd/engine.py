@@ -212,6 +212,11 @@ class MUEngine:
         else:
             st.nx, st.ny, st.grid_mode = 0, 0, 0
         self._check(self.lib.espm_mu_query(C.byref(st)))
+        # tests: the sparse store's full geometry (512-pixel H tiles, hence the fused kernel) on images far smaller than the
+        # ones espm_mu_query gives it to - ESPM_FORCE_ELL_TILE=512 (or tile_px=512)
+        force_tile = tile_px if tile_px is not None else (int(os.environ["ESPM_FORCE_ELL_TILE"]) if os.environ.get("ESPM_FORCE_ELL_TILE") else None)
+        if x_store == "ell" and force_tile in (64, 128, 256, 512):
+            st.tile_px = st.x_tile = int(force_tile)
         p_total = torch.tensor([p], dtype=torch.int64, device=dev)
         if group is not None:
             torch.distributed.all_reduce(p_total, group=group)
@@ -431,6 +436,7 @@ class MUEngine:
         st.cur, st.it = 0, 0
         self._pending_finalize = None
         self._pending_tail = False
+        self._accum_done = False
         self.hist.zero_()
         self.w[0].copy_(Wt)
         self.h[0][:, :self.p].copy_(Ht)
@@ -611,7 +617,7 @@ class MUEngine:
         if self.frobenius:
             return self._finish_iteration_frobenius()
         s = _stream()
-        if not (self._accum_done and getattr(self, "_pending_finalize", None) == (cur, slot)):
+        if not self._accum_done:   # (fused: the W accumulation of this H update rode in eval_current's launch, and h_t was not written)
             self._check(self.lib.espm_mu_w_accum(C.byref(st), s))
         self._accum_done = False
         ride = getattr(self, "_pending_finalize", None) == (cur, slot)   # the H-step's record reduction rides along
@@ -703,6 +709,7 @@ class MUEngine:
         if st.it + n_iter + 1 > self.hist_len:
             raise ValueError("history buffer exhausted: raise max_iter")
         self._flush_finalize()
+        self._accum_done = False   # (a pending fused H update is simply redone by the loop)
         if not self.sharded and not self.frobenius:
             self._check(self.lib.espm_mu_iterate(C.byref(st), int(n_iter), int(bool(final_loss)), _stream()))
         elif self.sharded and self.exchange.ctx is not None and not self.frobenius:

@@ -90,6 +90,31 @@ def test_c3_trajectory_against_the_sparse_oracle(c3):
     print("C3 five iterations, worst relative loss error: fused %.2e, two launches %.2e" % (worst[True], worst[False]))
 
 
+def test_c3_estimator_with_stop_rules_takes_the_same_steps(c3):
+    """The estimator's DEFAULT loop - a loss read back and the stop rules evaluated after every iteration, i.e. the
+    granular eval_current / finish_iteration sequence with the history read in between - on the fused kernel at the
+    headline size: the same iterates as the batch loop (which the sparse oracle checks above)."""
+    import contextlib
+    import io
+    from espm_amd.engine import MUEngine
+    from espm_amd.estimators import SmoothNMF
+    iters = 3
+    eng = MUEngine(c3["X"], K3, **c3["kw"])
+    eng.load_state(c3["W0"], c3["H0"])
+    eng.iterate(iters, final_loss=True)
+    torch.cuda.synchronize()
+    ref_W, ref_H, ref_loss = eng.get_W(), eng.get_H(), eng.history()["loss"][1:iters + 1]
+    del eng
+    Xh = c3["X"].T.contiguous().cpu().numpy()                              # (n, p) float32 on the host, as a user hands it over
+    est = SmoothNMF(n_components=K3, shape_2d=(NX3, NY3), lambda_L=1.0, simplex_H=True, simplex_W=False, max_iter=iters, verbose=0, tol=1e-9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit_transform(Xh, W=c3["W0"].astype(np.float32), H=c3["H0"].astype(np.float32))
+    assert est.n_iter_ == iters and est._engine.x_store == "ell"
+    np.testing.assert_allclose(est.losses_, ref_loss, rtol=1e-6)
+    np.testing.assert_allclose(est.H_, ref_H, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(est.W_, ref_W, rtol=1e-5, atol=1e-8)
+
+
 def test_c3_w_rows_in_fp64_on_64_channels(c3):
     """W step at the headline size (32 channel groups, 256 pixel blocks, the slab reduction with the update folded in):
     for 64 channels spread over the spectrum, A[c, :] = sum_j X[c, j] / (GW[c] . H'[:, j]) H'[:, j] and

@@ -79,12 +79,24 @@ def test_random_configuration_matches_oracle(seed):
     _run(_case(seed), seed)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_CASES", "36"))))
+def test_random_configuration_on_the_fused_kernel(seed, monkeypatch):
+    """The same draws with the sparse store at its full geometry (512-pixel tiles), i.e. through the fused H update +
+    W accumulation launch, which images of this size never get by themselves: every component count 1..8 (4, 3 and 2
+    segments per list group), dictionary G, mu, the Laplacian, fixed_H, simplex over H or W, empty channels and pixels."""
+    c = _case(seed)
+    if not c["counts"] or c["algo"] not in ("log_surrogate", "bmd"):
+        pytest.skip("the fused kernel serves the sparse store with the default H rule")
+    monkeypatch.setenv("ESPM_FORCE_ELL_TILE", "512")
+    _run(c, seed, expect_fused=True)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_WIDE_CASES", "20"))))
 def test_random_configuration_with_9_to_16_components_matches_oracle(seed):
     _run(_case(seed, wide=True), seed)
 
 
-def _run(c, seed):
+def _run(c, seed, expect_fused=False):
     from espm_amd.estimators import SmoothNMF
     iters = 6
     try:
@@ -103,6 +115,9 @@ def _run(c, seed):
                     verbose=0, **c["kw"], **c["extra"])
     with contextlib.redirect_stdout(io.StringIO()):
         GW = est.fit_transform(c["X"], W=c["W0"].copy(), H=c["H0"].copy())
+    if expect_fused and est._engine.x_store == "ell":
+        import ctypes
+        assert est._engine.lib.espm_mu_fused_applies(ctypes.byref(est._engine.st)) == 1
     tag = f"seed {seed}: {c['algo']} k={c['k']} G={'yes' if c['G'] is not None else 'no'} {c['kw']} {sorted(c['extra'])} store={est._engine.x_store}"
     # the reference's bisections stop at 1e-5 (global rule); the oracle uses the exact root only for the default solver
     loose = c["algo"] != "log_surrogate" and c["kw"]["simplex_H"]
