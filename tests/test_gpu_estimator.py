@@ -32,6 +32,15 @@ def SmoothNMF():
     return cls
 
 
+@pytest.fixture(params=["auto", "fused"])
+def geometry(request, monkeypatch):
+    """"fused": the sparse store at its full geometry (512-pixel tiles) also on these small images, so that the fits run
+    through the fused H update + W accumulation launch (and the granular loop around it) that only large images get."""
+    if request.param == "fused":
+        monkeypatch.setenv("ESPM_FORCE_ELL_TILE", "512")
+    return request.param
+
+
 def _check_traj(est, GW, g, pre):
     assert est.n_iter_ == int(g[f"{pre}_n_iter"]), pre
     np.testing.assert_allclose(est.losses_, g[f"{pre}_losses"], rtol=LOSS_RTOL, err_msg=pre)
@@ -54,7 +63,7 @@ def _check_traj(est, GW, g, pre):
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "cw"])
-def test_trajectories_golden(SmoothNMF, golden, name):
+def test_trajectories_golden(SmoothNMF, golden, name, geometry):
     """F6: scaled-down analogues of BASELINE configs 1, 2, 3, 5 (+ simplex_W), free running 50 iterations
     and with the default stop rules (n_iter_ must match the reference)."""
     g = golden("f6_trajectories")
@@ -96,7 +105,7 @@ def test_no_simplex_rescaling(SmoothNMF, golden):
     np.testing.assert_allclose(est.reconstruction_err_, g["nosimplex_recon"], rtol=LOSS_RTOL)
 
 
-def test_normalize_golden_and_scale_invariance(SmoothNMF, golden):
+def test_normalize_golden_and_scale_invariance(SmoothNMF, golden, geometry):
     """espm/tests/test_estimators.py:207-247 (normalize=True => results invariant under X -> X / fac)."""
     g = golden("f8_api")
     X, fac = g["norm_X"], float(g["norm_fac"])
@@ -127,7 +136,7 @@ def test_normalize_golden_and_scale_invariance(SmoothNMF, golden):
     assert ratio(H_plus, H) < 1e-4
 
 
-def test_fixed_matrices_respected(SmoothNMF):
+def test_fixed_matrices_respected(SmoothNMF, geometry):
     """espm/tests/test_estimators.py:155-166."""
     from espm_amd import synth
     prob = synth.make_problem(40, 10, 20, 2, N=80.0, seed=5, m=8)
@@ -173,7 +182,7 @@ def test_float32_input_and_pickle(SmoothNMF, golden):
         quiet(est.fit_transform, -X)  # base.py:528 "Negative values in data"
 
 
-def test_iteration_method_matches_oracle(SmoothNMF, golden):
+def test_iteration_method_matches_oracle(SmoothNMF, golden, geometry):
     g = golden("f6_trajectories")
     X, W0, H0 = g["c3_X"], g["c3_W0"], g["c3_H0"]
     shape = tuple(int(v) for v in g["c3_shape"])
@@ -194,7 +203,7 @@ def test_sklearn_check_estimator(SmoothNMF):
                                   epsilon_reg=1.0, hspy_comp=False))
 
 
-def test_physics_model_protocol(SmoothNMF):
+def test_physics_model_protocol(SmoothNMF, geometry):
     """G given as an object with NMF_update / NMF_simplex / NMF_initialize_W (espm/models/base.py:217-264):
     G is refreshed every 3rd iteration (base.py:388-392) and simplex_W acts on NMF_simplex() rows only."""
     from espm_amd import synth
@@ -290,7 +299,7 @@ def test_count_stores_match_oracle(store, n, nx, ny, k, m, counts, hot, kw):
 
 @pytest.mark.parametrize("kw", [dict(simplex_H=True, simplex_W=False, mu=0.3, lambda_L=2.0), dict(simplex_H=False, simplex_W=True)])
 @pytest.mark.parametrize("m", [None, 5])
-def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m):
+def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m, geometry):
     """Measured spectra have channels without a single count in the whole image.  The reference fills them with
     log_shift (base.py:519-528); the sparse store leaves that fill out of its lists (an O(1e-14) change) instead of
     falling back to a dense fp32 X.  Engine and estimator against the fp64 oracle, which fills like the reference."""
@@ -382,7 +391,7 @@ def test_nine_to_sixteen_components(k, store, m, kw):
 @pytest.mark.parametrize("kw", [dict(simplex_H=True, simplex_W=False, mu=0.2, lambda_L=1.5), dict(simplex_H=True, simplex_W=False),
                                 dict(simplex_H=False, simplex_W=True, lambda_L=0.5), dict(simplex_H=False, simplex_W=False)])
 @pytest.mark.parametrize("m", [None, 6])
-def test_pixels_without_counts_keep_the_sparse_store(SmoothNMF, kw, m):
+def test_pixels_without_counts_keep_the_sparse_store(SmoothNMF, kw, m, geometry):
     """Holes, vacuum and low doses leave pixels without a single count.  The reference fills them with log_shift in every
     channel (base.py:519-528) and, under simplex_H, that fill alone decides their column of H.  The sparse store keeps
     their lists empty and the H-step adds the fill's numerator from a small pass of its own (ell_fill_* in espm_mu.h).
@@ -545,7 +554,7 @@ def test_sparse_store_unit_rows_edge_cases(case):
     assert h["bad"].sum() == 0
 
 
-def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden):
+def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden, geometry):
     """linesearch=True (gamma_ adapts every iteration) and true_D / true_H tracking against the reference's own
     trajectories (fixture F9)."""
     g = golden("f9_linesearch_truth")
@@ -579,7 +588,7 @@ def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden):
             np.testing.assert_allclose(np.log10(got[huge]), np.log10(want[huge]), atol=1.0)
 
 
-def test_bregman_variant_golden(SmoothNMF, golden):
+def test_bregman_variant_golden(SmoothNMF, golden, geometry):
     """use_bregman=True in both step functions and algo="bmd" fits (with mu, lambda, linesearch) against the reference's
     outputs (fixture F10)."""
     from espm_amd.estimators.updates import multiplicative_step_h, multiplicative_step_w
@@ -665,7 +674,7 @@ def test_frobenius_fit_golden(SmoothNMF, golden):
                                    rtol=1e-5, err_msg=name)
 
 
-def test_physics_model_trajectories_golden(SmoothNMF, golden):
+def test_physics_model_trajectories_golden(SmoothNMF, golden, geometry):
     """Fits with a physics model whose G changes with W (fixture F16, generated from the reference with
     tests/physics_double.py mixed into its abstract PhysicalModel): G refreshed after every third iteration and the loss
     re-evaluated with it before the next stop test (base.py:388-392), simplex over the NMF_simplex() rows, the same
