@@ -96,11 +96,14 @@ SYMBOLS = {
     "espm_mu_shard_exchange_finish": (C.c_int, [_SP, _vp, C.c_uint32, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate_sharded": (C.c_int, [_SP, _vp, C.POINTER(C.c_uint32), C.c_int, C.c_int, _vp]),
     "espm_mu_linesearch_terms": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp]),
+    "espm_mu_linesearch_terms_sharded": (C.c_int, [_SP, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "espm_surrogate_terms": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "espm_dichotomy_simplex_acc": (C.c_int, [C.c_double, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "espm_dichotomy_simplex_pg": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp]),
     "espm_mu_l2_step_h": (C.c_int, [_SP, C.c_int, _vp, _vp, C.c_int, _vp]),
     "espm_mu_l2_step_w": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "espm_mu_l2_w_partials": (C.c_int, [_SP, _vp, _vp, C.c_int, _vp]),
+    "espm_mu_l2_w_finish": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp]),
     "espm_dichotomy_simplex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "espm_mu_laplacian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
 }

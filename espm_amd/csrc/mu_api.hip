@@ -555,7 +555,8 @@ int espm_surrogate_terms(const float* h_old, const float* h_new, int k, int p, i
   ESPM_REQUIRE(h_old && h_new && part && out && k >= 1 && k <= ESPM_KP && p >= 1 && ld >= p, "surrogate_terms: bad arguments");
   ESPM_REQUIRE(!grid_mode || (nx >= 1 && ny >= 1 && (int64_t)nx * ny == p), "surrogate_terms: grid %d x %d does not match p=%d", nx, ny, p);
   ESPM_REQUIRE(part_doubles >= (4 + ESPM_KP) * ((p + 511) / 512), "surrogate_terms: scratch of %d doubles is too small", part_doubles);
-  return launch_linesearch_terms(h_old, h_new, k, p, (int)ld, nx, ny, grid_mode, part, out, static_cast<hipStream_t>(stream));
+  return launch_linesearch_terms(h_old, h_new, k, p, (int)ld, nx, ny, grid_mode, nullptr, nullptr, nullptr, nullptr, part, out,
+                                 static_cast<hipStream_t>(stream));
 }
 
 int espm_dichotomy_simplex_acc(double a, const double* b, const double* minus_c, int k, int p, int b_cols, double log_shift,
@@ -600,22 +601,31 @@ int espm_mu_l2_step_h(const espm_mu_state* st, int src, float* work, double* scr
   return dispatch_h_step(a, st->x_dtype, st->tile_px, nblk_h(st), s);
 }
 
-int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float* work, double* scratch, int scratch_doubles,
-                      espm_stream_t stream) {
+int espm_mu_l2_w_partials(const espm_mu_state* st, float* work, double* scratch, int scratch_doubles, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   if (int rc = check_l2(st, work, scratch, scratch_doubles)) return rc;
-  ESPM_REQUIRE(src == 0 || src == 1, "src must be 0/1");
-  ESPM_REQUIRE(st->m == 0 || gtg, "l2 W step: G^T G (m, m) is needed when G is given");
-  ESPM_REQUIRE(!st->simplex_w, "l2 W step: no simplex over W in the Frobenius branch (updates.py:31-36)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* hh = work + ESPM_KP * ESPM_KP;
   if (int rc = launch_gram(st->h_t, st->p, st->k, scratch, scratch_doubles, hh, s)) return rc;      // H H^T
   WAccumArgs wa = make_w_args(st);
   wa.l2 = 1;
   if (int rc = dispatch_w_accum(wa, st->k, st->x_dtype, st->nblk_w, s)) return rc;                 // slabs of X H^T
-  if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, s)) return rc;
-  return launch_w_finish_l2(st->a, st->n, st->n_pad, st->m, st->k, st->m > 0 ? st->g : nullptr, gtg, hh, st->w[src], st->w[1 - src],
-                            st->fixed_w, st->log_shift, s);
+  return launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, nullptr, s);
+}
+
+int espm_mu_l2_w_finish(const espm_mu_state* st, int src, const float* gtg, const float* work, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(work && (src == 0 || src == 1), "l2 W finish: bad arguments");
+  ESPM_REQUIRE(st->m == 0 || gtg, "l2 W step: G^T G (m, m) is needed when G is given");
+  ESPM_REQUIRE(!st->simplex_w, "l2 W step: no simplex over W in the Frobenius branch (updates.py:31-36)");
+  return launch_w_finish_l2(st->a, st->n, st->n_pad, st->m, st->k, st->m > 0 ? st->g : nullptr, gtg, work + ESPM_KP * ESPM_KP, st->w[src],
+                            st->w[1 - src], st->fixed_w, st->log_shift, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float* work, double* scratch, int scratch_doubles,
+                      espm_stream_t stream) {
+  if (int rc = espm_mu_l2_w_partials(st, work, scratch, scratch_doubles, stream)) return rc;
+  return espm_mu_l2_w_finish(st, src, gtg, work, stream);
 }
 
 int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream) {
@@ -624,8 +634,20 @@ int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double
   ESPM_REQUIRE(!st->halo_top && !st->halo_bot && (st->p_total == 0 || st->p_total == st->p), "linesearch_terms: not built for a sharded image");
   // the H-step's record buffer is free between espm_mu_h_finalize and the next espm_mu_step_h: ESPM_HP_STRIDE rows of
   // ceil(p / tile_px) >= ceil(p / 512) doubles hold the 3 + KP rows of partials
-  return launch_linesearch_terms(st->h[hold], st->h[hnew], st->k, st->p, st->p_pad, st->nx, st->ny, st->grid_mode, st->hpart, out,
-                                 static_cast<hipStream_t>(stream));
+  return launch_linesearch_terms(st->h[hold], st->h[hnew], st->k, st->p, st->p_pad, st->nx, st->ny, st->grid_mode, nullptr, nullptr,
+                                 nullptr, nullptr, st->hpart, out, static_cast<hipStream_t>(stream));
+}
+
+int espm_mu_linesearch_terms_sharded(const espm_mu_state* st, int hold, int hnew, const float* old_halo_top, const float* old_halo_bot,
+                                     double* out, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(out && (hold == 0 || hold == 1) && hnew == 1 - hold, "linesearch_terms_sharded: bad arguments");
+  // the boundary rows travel in the records only when the Laplacian term is on (espm_mu_shard_record_bytes)
+  ESPM_REQUIRE(!st->grid_mode || st->lambda_l != 0.f, "linesearch_terms_sharded: lambda_L = 0 leaves the boundary rows out of the records");
+  ESPM_REQUIRE((old_halo_top == nullptr) == (st->halo_top == nullptr) && (old_halo_bot == nullptr) == (st->halo_bot == nullptr),
+               "linesearch_terms_sharded: the old H's boundary rows must be given where the new H has them");
+  return launch_linesearch_terms(st->h[hold], st->h[hnew], st->k, st->p, st->p_pad, st->nx, st->ny, st->grid_mode, old_halo_top,
+                                 old_halo_bot, st->halo_top, st->halo_bot, st->hpart, out, static_cast<hipStream_t>(stream));
 }
 
 size_t espm_mu_shard_record_bytes(const espm_mu_state* st) {

@@ -274,8 +274,12 @@ int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* o
 // leaves in hstat).  One thread per pixel, stencil
 // as in the H-step; workgroup partials (field-major, LS_FIELDS rows) then a one-workgroup sum in fixed order.
 constexpr int LS_FIELDS = 4 + KP;
+// Sharded image: the image rows above / below the local block come from the neighbours' boundary rows, (k, ny) each - of
+// the OLD H (old_top / old_bot) and of the new one (new_top / new_bot); null at the image edge and on one GPU.
 __global__ __launch_bounds__(256) void linesearch_terms_kernel(const float* __restrict__ h_old, const float* __restrict__ h_new,
                                                                int k, int p, int p_pad, int nx, int ny, int grid_mode,
+                                                               const float* __restrict__ old_top, const float* __restrict__ old_bot,
+                                                               const float* __restrict__ new_top, const float* __restrict__ new_bot,
                                                                double* __restrict__ part) {
   __shared__ double scratch[5 * LS_FIELDS];
   double v[LS_FIELDS];
@@ -286,8 +290,10 @@ __global__ __launch_bounds__(256) void linesearch_terms_kernel(const float* __re
       const float* ro = h_old + (size_t)kk * p_pad;
       const float* rn = h_new + (size_t)kk * p_pad;
       const float ho = ro[q], hn = rn[q];
-      const float lo = grid_mode ? stencil_hl(ro, nullptr, nullptr, q, nx, ny, ho) : ho;   // L = identity without a grid (base.py:289-291)
-      const float ln = grid_mode ? stencil_hl(rn, nullptr, nullptr, q, nx, ny, hn) : hn;
+      const size_t hk = (size_t)kk * ny;
+      const float lo = grid_mode ? stencil_hl(ro, old_top ? old_top + hk : nullptr, old_bot ? old_bot + hk : nullptr, q, nx, ny, ho)
+                                 : ho;   // L = identity without a grid (base.py:289-291)
+      const float ln = grid_mode ? stencil_hl(rn, new_top ? new_top + hk : nullptr, new_bot ? new_bot + hk : nullptr, q, nx, ny, hn) : hn;
       v[0] += (double)ho * (double)lo;
       v[1] += (double)lo * (double)hn;
       v[2] += (double)hn * (double)ln;
@@ -313,9 +319,11 @@ __global__ __launch_bounds__(256) void linesearch_sum_kernel(const double* __res
 }
 
 int launch_linesearch_terms(const float* h_old, const float* h_new, int k, int p, int p_pad, int nx, int ny, int grid_mode,
+                            const float* old_top, const float* old_bot, const float* new_top, const float* new_bot,
                             double* part, double* out, hipStream_t stream) {
   const int nblk = (p + 511) / 512;
-  hipLaunchKernelGGL(linesearch_terms_kernel, dim3(nblk), dim3(256), 0, stream, h_old, h_new, k, p, p_pad, nx, ny, grid_mode, part);
+  hipLaunchKernelGGL(linesearch_terms_kernel, dim3(nblk), dim3(256), 0, stream, h_old, h_new, k, p, p_pad, nx, ny, grid_mode, old_top,
+                     old_bot, new_top, new_bot, part);
   hipLaunchKernelGGL(linesearch_sum_kernel, dim3(1), dim3(256), 0, stream, part, nblk, out);
   return check_hip(hipGetLastError(), "linesearch_terms launch");
 }

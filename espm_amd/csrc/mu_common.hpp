@@ -785,6 +785,7 @@ int launch_dichotomy_acc(double a, const double* b, const double* c, int k, int 
 int launch_dichotomy_pg(const double* a, int k, int p, double eps, double tol, int maxit, double* nu_out, hipStream_t stream);
 int launch_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out, hipStream_t stream);
 int launch_linesearch_terms(const float* h_old, const float* h_new, int k, int p, int p_pad, int nx, int ny, int grid_mode,
+                            const float* old_top, const float* old_bot, const float* new_top, const float* new_bot,
                             double* part, double* out, hipStream_t stream);
 
 }  // namespace espm

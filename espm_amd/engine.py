@@ -143,8 +143,8 @@ class MUEngine:
         # quadratic-surrogate H step, Frobenius W step and loss; on the dense fp32 store
         self.frobenius = bool(frobenius)
         if self.frobenius:
-            if group is not None or float(xscale) != 1.0 or int(h_rule) != 1 or simplex_W:
-                raise NotImplementedError("the Frobenius fit is built for one GPU, xscale = 1 (hand over the scaled X), "
+            if float(xscale) != 1.0 or int(h_rule) != 1 or simplex_W:
+                raise NotImplementedError("the Frobenius fit is built for xscale = 1 (hand over the scaled X), "
                                           "h_rule = 1 and no simplex over W (updates.py:31-36 has none)")
             x_store = "f32"
         if h_variant:
@@ -529,6 +529,18 @@ class MUEngine:
         torch.distributed.all_reduce(hs[:self.V.HS_MAX], group=self.group)
         torch.distributed.all_reduce(hs[self.V.HS_MAX:], op=torch.distributed.ReduceOp.MAX, group=self.group)
 
+    def _gather_rows(self, vec):
+        """(world, len) tensor of every rank's ``vec``, in rank order (a host-sequenced collective: linesearch, read-back)."""
+        out = torch.empty((self.world,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        if torch.distributed.get_backend(self.group) == "gloo":
+            parts = [torch.empty_like(vec, device="cpu") for _ in range(self.world)]
+            torch.distributed.all_gather(parts, vec.cpu(), group=self.group)
+            for r, part in enumerate(parts):
+                out[r].copy_(part)
+        else:
+            torch.distributed.all_gather_into_tensor(out, vec.contiguous(), group=self.group)
+        return out
+
     def _set_halo_from_records(self):
         top, bot = self.exchange.halo_offsets()
         base = self.exchange.recv_ptr
@@ -592,8 +604,19 @@ class MUEngine:
         if self.m > 0 and getattr(self, "_gtg", None) is None:
             self._gtg = (self.g.double().t() @ self.g.double()).float().contiguous()
         s = _stream()
-        self._check(self.lib.espm_mu_l2_step_w(C.byref(st), cur, _ptr(self._gtg) if self.m > 0 else None, _ptr(work), _ptr(scratch),
-                                    scratch.numel(), s))
+        gtg = _ptr(self._gtg) if self.m > 0 else None
+        if self.sharded:
+            # the statistics of this rank's new H block become global, its boundary rows travel to the neighbours, and the two
+            # sums over the pixels the W step needs (X H^T, H H^T) are added over the ranks: the same W' on every rank
+            self._globalize_hstat(1 - cur)
+            if self.exchange.with_halo:
+                self._exchange_halo_only(1 - cur)
+            self._check(self.lib.espm_mu_l2_w_partials(C.byref(st), _ptr(work), _ptr(scratch), scratch.numel(), s))
+            torch.distributed.all_reduce(self.a, group=self.group)
+            torch.distributed.all_reduce(work[1], group=self.group)
+            self._check(self.lib.espm_mu_l2_w_finish(C.byref(st), cur, gtg, _ptr(work), s))
+        else:
+            self._check(self.lib.espm_mu_l2_step_w(C.byref(st), cur, gtg, _ptr(work), _ptr(scratch), scratch.numel(), s))
         self._check(self.lib.espm_mu_build_gw(C.byref(st), 1 - cur, s))
         wn, wo = self.w[1 - cur].double(), self.w[cur].double()
         self.hist[slot + 1, _lib.HI_REL_W] = ((wn - wo).abs() / (wn + self.rel_tol * wn.mean())).max()   # base.py:323
@@ -649,16 +672,31 @@ class MUEngine:
         H before the last update and H the current one, d = g(H, Ht) - 1/2 tr(H L H^T) (lambda_L = 1, as the reference
         calls it); gamma / 1.05 when d > 0, else gamma * 1.5.  Call after ``finish_iteration``; returns the new gamma
         (already in effect for the next H-step).  One host synchronisation."""
-        if self.sharded:
-            raise NotImplementedError("linesearch is not built for a sharded image")
         st = self.st
         if st.it < 1:
             raise ValueError("linesearch needs a completed iteration")
         self._flush_finalize()
         if getattr(self, "_ls_out", None) is None:
             self._ls_out = torch.zeros(4 + self.V.KP, dtype=torch.float64, device=self.device)
-        self._check(self.lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
-        t = self._ls_out.cpu().numpy()
+        if self.sharded:
+            # every rank: the terms of its block of image rows (the old H's boundary rows of the neighbours are still in the
+            # records of the exchange before the last one), summed over the ranks in rank order - the same d, hence the same
+            # gamma, on every rank
+            if st.grid_mode and self.lambda_L == 0.0:
+                raise NotImplementedError("linesearch of a sharded image with lambda_L = 0: the boundary rows of H are not exchanged")
+            top, bot = self.exchange.halo_offsets()
+            base = self.exchange.prev_recv_ptr
+            self._check(self.lib.espm_mu_linesearch_terms_sharded(C.byref(st), 1 - st.cur, st.cur,
+                                                                  C.c_void_p(base + top) if top is not None else None,
+                                                                  C.c_void_p(base + bot) if bot is not None else None,
+                                                                  _ptr(self._ls_out), _stream()))
+            parts = self._gather_rows(self._ls_out).cpu().numpy()
+            t = parts[0].copy()
+            for r in range(1, self.world):
+                t += parts[r]
+        else:
+            self._check(self.lib.espm_mu_linesearch_terms(C.byref(st), 1 - st.cur, st.cur, _ptr(self._ls_out), _stream()))
+            t = self._ls_out.cpu().numpy()
         if st.h_rule == 1:     # quadratic surrogate: sigma ||Ht - H||^2 (surrogates.py:6-58)
             t3 = float(t[3])
         else:                  # sigma sum_k max_j H_kj sum_j dgkl(Ht, H) (surrogates.py:65-114)
@@ -670,24 +708,45 @@ class MUEngine:
         return gamma
 
     # ---- linesearch of the projected gradient (espm/estimators/smooth_nmf.py:382-401, :438-447) -------------------------
-    def _loss_sum_of_slot(self, slot):
-        row = self.hist[slot].cpu().numpy()
+    def _loss_sum_of_slot(self, slot, local_stats=False):
+        """Un-averaged loss from a history row.  Sharded image: the sums over the pixels are added over the ranks; with
+        ``local_stats`` the row was evaluated from the statistics of this rank's H block alone (an H that has not been through
+        the exchange yet), so its sum-of-GWH term is a per-rank piece too."""
+        row = self.hist[slot]
+        if self.sharded:
+            cols = [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP] + ([_lib.HI_SUMY] if local_stats else [])
+            parts = self._gather_rows(row[cols].contiguous()).cpu().numpy()
+            tot = parts[0].copy()
+            for r in range(1, self.world):
+                tot += parts[r]
+            row = row.cpu().numpy().copy()
+            row[cols] = tot
+        else:
+            row = row.cpu().numpy()
         return float(row[_lib.HI_KLX] + row[_lib.HI_SUMY] - self.xscale * self.sum_x + row[_lib.HI_REG]
                      + 0.5 * self.lambda_L * row[_lib.HI_LAP])
+
+    def _pg_term(self, t, which):
+        """The quadratic term the H step (which = 0: a sum over the pixels, added over the ranks of a sharded image) or the W
+        step (1: W is replicated) of iteration t left in pg_q."""
+        if which == 0 and self.sharded:
+            parts = self._gather_rows(self.pg_q[t, 0:1].contiguous()).cpu().numpy()
+            return float(sum(float(v[0]) for v in parts))
+        return float(self.pg_q[t, which])
 
     def pg_linesearch_h(self, gamma_h):
         """After the H-step from state t (``eval_current(True)``), before the W-step: d = f(W, Ht) + <H - Ht, grad> +
         gamma ||H - Ht||^2 - f(W, H) with the losses not averaged; gamma_H / 1.05 when d > 0, else gamma_H * 1.5 (in effect
         from the next H-step).  Costs one loss-only pass over X (the loss of (W_t, H_{t+1})) and two host synchronisations."""
-        if self.sharded or self.pg_q is None:
-            raise NotImplementedError("the projected gradient's linesearch needs one GPU and an engine built with h_rule=2")
+        if self.pg_q is None:
+            raise NotImplementedError("the projected gradient's linesearch needs an engine built with h_rule=2")
         st = self.st
         t = st.it
         f_xt = float(self.history(upto=t, average=False)["loss"][t])   # (also reduces the H-step's records: pg_q[t][0])
         scratch = self.hist_len - 1
         self._check(self.lib.espm_mu_loss_only(C.byref(st), 1 - st.cur, scratch, _stream()))   # state (W_t, H_{t+1})
-        self._pg_f_mid = self._loss_sum_of_slot(scratch)
-        d = f_xt + float(self.pg_q[t, 0]) - self._pg_f_mid
+        self._pg_f_mid = self._loss_sum_of_slot(scratch, local_stats=True)   # (sharded: H_{t+1}'s statistics are still per rank)
+        d = f_xt + self._pg_term(t, 0) - self._pg_f_mid
         gamma_h = float(gamma_h) / 1.05 if d > 0 else float(gamma_h) * 1.5
         st.sigma_l = gamma_h
         return gamma_h
@@ -698,7 +757,7 @@ class MUEngine:
         st = self.st
         t = st.it
         f_x = float(self.history(upto=t, average=False)["loss"][t])
-        d = self._pg_f_mid + float(self.pg_q[t, 1]) - f_x
+        d = self._pg_f_mid + self._pg_term(t, 1) - f_x
         gamma_w = float(gamma_w) / 1.05 if d > 0 else float(gamma_w) * 1.5
         st.pg_gamma_w = gamma_w
         return gamma_w
@@ -798,7 +857,10 @@ class MUEngine:
         numel = float(self.n) * float(self.p_total) if average else 1.0
         kl = (h[:, _lib.HI_KLX] + h[:, _lib.HI_SUMY] - self.xscale * self.sum_x) / numel
         if self.frobenius:  # base.py:197-198
-            kl = 0.5 * self.frob[:upto + 1].cpu().numpy() / numel
+            frob = self.frob[:upto + 1].clone()
+            if self.sharded:
+                torch.distributed.all_reduce(frob, group=self.group)
+            kl = 0.5 * frob.cpu().numpy() / numel
         reg = h[:, _lib.HI_REG] / numel
         lap = 0.5 * self.lambda_L * h[:, _lib.HI_LAP] / numel
         return dict(loss=kl + reg + lap, kl=kl, reg=reg, lap=lap, rel_W=h[:, _lib.HI_REL_W],

@@ -35,6 +35,55 @@ def _is_physical_model(G):
     return G is not None and not isinstance(G, np.ndarray) and hasattr(G, "NMF_update")
 
 
+class _Shard:
+    """Pixel-row sharding of ONE fit over the ranks of a process group (espm_amd/sharding.py): every rank
+    runs the same script on the same X; its engine holds a contiguous block of image rows (X and H sharded, W / G replicated)
+    and the results are assembled on every rank."""
+
+    def __init__(self, group, shape_2d, p):
+        import torch.distributed as dist
+        from espm_amd.sharding import split_rows
+        self.group, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.src = dist.get_global_rank(group, 0)
+        if shape_2d is not None:
+            nx, ny = int(shape_2d[0]), int(shape_2d[1])
+            if nx * ny != p:
+                raise ValueError(f"shape_2d {shape_2d} does not match the {p} pixels of X")
+            blocks = [split_rows(nx, self.world, r) for r in range(self.world)]
+            self.counts = [rows * ny for _, rows in blocks]
+            row0, rows = blocks[self.rank]
+            self.sl, self.shape_2d = slice(row0 * ny, (row0 + rows) * ny), (rows, ny)
+        else:   # no image grid (L = identity, base.py:289-291): any contiguous split of the pixels
+            blocks = [split_rows(p, self.world, r) for r in range(self.world)]
+            self.counts = [rows for _, rows in blocks]
+            row0, rows = blocks[self.rank]
+            self.sl, self.shape_2d = slice(row0, row0 + rows), None
+
+    def cols(self, a):
+        """This rank's columns of an (.., p) array (None stays None)."""
+        return None if a is None else a[..., self.sl]
+
+    def broadcast(self, arrays, device):
+        """Rank 0's arrays on every rank (the initial W, H, G: bit-identical starts whatever the ranks' own init gave)."""
+        import torch
+        out = []
+        for a in arrays:
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            torch.distributed.broadcast(t, src=self.src, group=self.group)
+            out.append(t.cpu().numpy())
+        return out
+
+    def gather_cols(self, local):
+        """(k, p) numpy array from every rank's (k, p_local) device tensor, in rank order."""
+        import torch
+        width = max(self.counts)
+        mine = torch.zeros((local.shape[0], width), dtype=local.dtype, device=local.device)
+        mine[:, :local.shape[1]] = local
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        torch.distributed.all_gather(parts, mine, group=self.group)
+        return np.concatenate([part[:, :c].cpu().numpy() for part, c in zip(parts, self.counts)], axis=1)
+
+
 class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
     """Abstract NMF estimator, X (n, p) ~ G (n, m) W (m, k) H (k, p); parameters and attributes as in
     espm/estimators/base.py:68-152."""
@@ -79,9 +128,19 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
     def __getstate__(self):
         state = super().__getstate__()
         state = dict(state)
-        for key in ("_engine", "_truth_engine"):  # device buffers / ctypes pointers are not picklable
+        for key in ("_engine", "_truth_engine", "_shard_group", "_shard"):  # device buffers / ctypes pointers / process groups are not picklable
             state.pop(key, None)
         return state
+
+    # ---- one fit over the GPUs of a node ----------------------------------------------------------------
+    def shard(self, group):
+        """Run the fits of this estimator sharded by image rows over the ranks of ``group`` (a ``torch.distributed`` process
+        group with one GPU per rank; ``None`` switches it off).  Every rank calls ``fit`` / ``fit_transform`` with the same
+        arguments - the same script under ``torchrun`` - and gets the same results: W replicated (bit-identical across the
+        ranks), H and the returned arrays assembled from the ranks' blocks.  No reference analogue.
+        Returns self."""
+        self._shard_group = group
+        return self
 
     # ---- hooks implemented by the concrete estimator -------------------------------------------------
     @abstractmethod
@@ -95,8 +154,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False, shard=None):
+        """The device engine of a fit; with ``shard`` (a _Shard) X_fixed is the WHOLE image and the engine takes this rank's
+        block of it."""
         from espm_amd.engine import MUEngine
+        shape_2d, fixed_H, group = self.shape_2d, self.fixed_H, None
+        if shard is not None:
+            X_fixed = X_fixed[shard.sl] if layout == "pm" else X_fixed[:, shard.sl]
+            shape_2d, group = shard.shape_2d, shard.group
+            fixed_H = shard.cols(np.asarray(fixed_H)) if fixed_H is not None else None
+            filled_pixels = shard.cols(filled_pixels)
 
         rows = None
         if self.physics_model_ is not None and self.simplex_W:
@@ -111,11 +178,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 X_fixed, xscale = X_fixed * xscale, 1.0
         # (and the projected-gradient W step of a fit is called without fixed_W, smooth_nmf.py:430-437)
         fixed_W = None if getattr(self, "algo", None) == "projected_gradient" else self.fixed_W
-        return MUEngine(X_fixed, self.n_components, G=G, shape_2d=self.shape_2d, simplex_H=self.simplex_H,
-                        simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=self.fixed_H,
+        return MUEngine(X_fixed, self.n_components, G=G, shape_2d=shape_2d, simplex_H=self.simplex_H,
+                        simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
                         fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, layout=layout,
-                        autotune=autotune, **self._engine_kwargs())
+                        autotune=autotune, group=group, **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -132,7 +199,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         else:
             assert X.shape == (self.G_.shape[0], H.shape[1])
             eng = self._make_engine(np.asarray(X), 1.0, self._engine_G())
-        eng.load_state(W, H)
+        eng.load_state(W, self._local_H(eng, H))   # (the sharded engine of a fit: this rank's block of H; the loss is summed over the ranks)
         eng.eval_current(advance_h=False)
         h = eng.history(upto=0, average=average)
         kl, loss = float(h["kl"][0]), float(h["loss"][0])
@@ -151,7 +218,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         if eng is None:
             check_is_fitted(self, "X_")
             scale = getattr(self, "norm_factor_", 1.0) if self.normalize else 1.0
-            eng = self._engine = self._make_engine(self._X_fixed(), scale, self._engine_G())
+            eng = self._engine = self._make_engine(self._X_fixed(), scale, self._engine_G(), shard=getattr(self, "_shard", None))
         return eng
 
     def _X_fixed(self):
@@ -265,6 +332,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,
                                                           physics_model=self.physics_model_, X_device=X_init_dev)
         del X_init_dev
+        # one fit over several GPUs (shard()): this rank's block of image rows; every rank starts from rank 0's W, H, G
+        grp = getattr(self, "_shard_group", None)
+        shard = None
+        if grp is not None:
+            import torch
+            if torch.distributed.get_world_size(grp) > 1:
+                shard = _Shard(grp, self.shape_2d, int(self.X_.shape[1]))
+                dev = f"cuda:{torch.cuda.current_device()}"
+                self.G_, self.W_, self.H_ = shard.broadcast([self.G_, self.W_, self.H_], dev)
+        self._shard = shard
+        say = print if shard is None or shard.rank == 0 else (lambda *a, **k: None)   # (the reference's messages: once, not per rank)
         # L_ (base.py:286-291) is only an attribute here - the kernels apply the Laplacian as a stencil - and building the
         # sparse matrix of a 512 x 512 grid costs 0.07 s: it is built on first access (property L_ below)
         self._L_cache = None
@@ -274,10 +352,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
                                                 filled_channels=empty_ch if bool(empty_ch.any()) else None,
                                                 filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout,
-                                                autotune=Xd is not None and self.max_iter >= 100)   # (a long fit of a large image: time the launch plans once)
+                                                autotune=Xd is not None and self.max_iter >= 100,   # (a long fit of a large image: time the launch plans once)
+                                                shard=shard)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         del X_fixed, Xd, Xd_raw
-        eng.load_state(self.W_, self.H_)
+        eng.load_state(self.W_, self.H_ if shard is None else shard.cols(self.H_))
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]
         self.const_KL_ = (getattr(self, "_const_KL_dev", None) if Xv.size >= _DEVICE_PREP_MIN_SIZE else None)
         if self.const_KL_ is None:
@@ -294,8 +373,6 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         pg_ls = bool(getattr(self, "linesearch", False)) and getattr(self, "algo", None) == "projected_gradient"
         adapt = bool(getattr(self, "linesearch", False)) and not pg_ls
         sync_each = (not self.no_stop_criterion) or self.physics_model_ is not None or track or adapt or pg_ls or bool(self.l2)
-        if (track or adapt or pg_ls) and getattr(eng, "world", 1) > 1:
-            raise NotImplementedError("linesearch / ground-truth tracking are not built for a sharded image")
         eval_before = np.inf
         eval_init = None
         stop = False
@@ -340,24 +417,24 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 rel_W, rel_H = self.rel_[-1]
 
                 if self.n_iter_ >= self.max_iter:  # base.py:354-378
-                    print("exits because max_iteration was reached")
+                    say("exits because max_iteration was reached")
                     break
                 if not self.no_stop_criterion:
                     if max(rel_H, rel_W) < self.tol:
-                        print("exits because of relative change rel_A {} and rel_P {} < tol ".format(rel_H, rel_W))
+                        say("exits because of relative change rel_A {} and rel_P {} < tol ".format(rel_H, rel_W))
                         break
                     elif abs((eval_before - eval_after) / eval_init) < self.tol:
-                        print("exits because of relative change < tol: {}".format((eval_before - eval_after) / eval_init))
+                        say("exits because of relative change < tol: {}".format((eval_before - eval_after) / eval_init))
                         break
                     elif np.isnan(eval_after):
-                        print("exit because of the presence of NaN")
+                        say("exit because of the presence of NaN")
                         break
                     elif (eval_before - eval_after) < 0:
-                        print("exit because of negative decrease {}: {}, {}".format((eval_before - eval_after),
+                        say("exit because of negative decrease {}: {}, {}".format((eval_before - eval_after),
                                                                                      eval_before, eval_after))
                         break
                 if self.verbose > 0 and np.mod(self.n_iter_, self.eval_print) == 0:
-                    print(f"It {self.n_iter_} / {self.max_iter}: loss {eval_after:3e},  "
+                    say(f"It {self.n_iter_} / {self.max_iter}: loss {eval_after:3e},  "
                           f"{self.n_iter_ / (time.time() - algo_start + log_shift):0.3f} it/s")
                 if self.physics_model_ is not None and self.n_iter_ % 3 == 0:  # base.py:388-392
                     self.G_ = self.physics_model_.NMF_update(eng.get_W().astype(out_dtype))
@@ -370,12 +447,12 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             pass
 
         self.W_ = eng.get_W().astype(out_dtype)
-        self.H_ = eng.get_H().astype(out_dtype)
+        self.H_ = self._full_H(eng).astype(out_dtype)
         if not self.simplex_H and not self.simplex_W:
             self.W_, self.H_ = rescaled_DH(self.W_, self.H_)  # base.py:399-400
 
         algo_time = time.time() - algo_start
-        print(f"Stopped after {self.n_iter_} iterations in {algo_time // 60} minutes "
+        say(f"Stopped after {self.n_iter_} iterations in {algo_time // 60} minutes "
               f"and {np.round(algo_time) % 60} seconds.")
         if not self.simplex_H and not self.simplex_W:
             self.reconstruction_err_ = self.loss(self.W_, self.H_)
@@ -396,6 +473,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
 
     def _begin_fit(self):
         pass
+
+    def _local_H(self, eng, H):
+        """The block of H an engine holds: all of it, or this rank's image rows for the sharded engine of a fit."""
+        return self._shard.cols(np.asarray(H)) if getattr(eng, "world", 1) > 1 else H
+
+    def _full_H(self, eng):
+        """H of the whole image: the engine's, or the ranks' blocks of a sharded fit assembled on every rank."""
+        shard = getattr(self, "_shard", None)
+        if shard is None or getattr(eng, "world", 1) == 1:
+            return eng.get_H()
+        return shard.gather_cols(eng.h[eng.st.cur][:, :eng.p])
 
     def fit(self, X, y=None, **params):
         """Learn a NMF model for the data X (espm/estimators/base.py:422-441)."""
@@ -458,7 +546,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
 
     def _track_truth(self, eng):
         from espm_amd.measures import find_min_angle, find_min_MSE
-        W, H = eng.get_W().astype(np.float64), eng.get_H().astype(np.float64)
+        W, H = eng.get_W().astype(np.float64), self._full_H(eng).astype(np.float64)   # (sharded fit: every rank tracks the whole image)
         Wc, Hc = (W, H) if (self.simplex_H or self.simplex_W) else rescaled_DH(W, H)
         GW = self.G_ @ Wc
         self.angles_.append(find_min_angle(np.asarray(self.true_D).T, GW.T, unique=True))

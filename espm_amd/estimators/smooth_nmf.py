@@ -177,12 +177,12 @@ class SmoothNMF(NMFEstimator):
         if getattr(self, "gamma_", None) is None:
             self.gamma_ = sigmaL if self.gamma is None else deepcopy(self.gamma)
         eng = self._get_engine()
-        eng.load_state(W, H)
+        eng.load_state(W, self._local_H(eng, H))   # (sharded fit: this rank's block of image rows; the whole H comes back)
         eng.st.sigma_l = float(self._gamma_value())
         eng.iterate(1, final_loss=False)
         if self.linesearch:  # smooth_nmf.py:376-381
             self.gamma_ = eng.linesearch_step(self._gamma_value())
-        return eng.get_W().astype(W.dtype), eng.get_H().astype(H.dtype)
+        return eng.get_W().astype(W.dtype), self._full_H(eng).astype(H.dtype)
 
     def loss(self, W, H, average=True, X=None):
         """Regularised loss (espm/estimators/smooth_nmf.py:457-475)."""

@@ -89,13 +89,14 @@ class ShardExchange:
         self.lib, self._stream_fn = lib, stream_fn
         self.ctx = None          # espm_xchg* when the one-shot transport is up
         self.seq = C.c_uint32(0)
-        self.send = self.recv = None
+        self.send = None
+        self._recv2, self._gen = None, 0   # collective transport: two receive buffers in turn (the records before the last gather stay readable)
         mode = mode or os.environ.get("ESPM_XCHG", "p2p")
         if mode == "p2p" and lib is not None and torch.device(device).type == "cuda":
             self._open_p2p(device)
         if self.ctx is None:
             self.send = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=device)
-            self.recv = torch.zeros(self.world * self.layout.nbytes, dtype=torch.uint8, device=device)
+            self._recv2 = [torch.zeros(self.world * self.layout.nbytes, dtype=torch.uint8, device=device) for _ in range(2)]
 
     # ---- one-shot transport -------------------------------------------------------------------------------------------
     def _open_p2p(self, device):
@@ -143,9 +144,22 @@ class ShardExchange:
         return int(self.lib.espm_xchg_staging(self.ctx)) if self.ctx is not None else self.send.data_ptr()
 
     @property
+    def recv(self):
+        """Collective transport: the buffer the last ``gather`` filled."""
+        return self._recv2[self._gen & 1] if self._recv2 is not None else None
+
+    @property
     def recv_ptr(self):
         """The records of all ranks, in rank order, after ``gather``."""
         return int(self.lib.espm_xchg_records(self.ctx, self.seq.value & 1)) if self.ctx is not None else self.recv.data_ptr()
+
+    @property
+    def prev_recv_ptr(self):
+        """The records of the gather BEFORE the last one (both transports are double buffered): the neighbours' boundary rows of
+        the H that preceded the last update are still there (linesearch of a sharded image)."""
+        if self.ctx is not None:
+            return int(self.lib.espm_xchg_records(self.ctx, (self.seq.value - 1) & 1))
+        return self._recv2[(self._gen - 1) & 1].data_ptr()
 
     def gather(self):
         """All ranks' records, in rank order (stream-ordered on the current stream)."""
@@ -156,9 +170,11 @@ class ShardExchange:
             if rc:
                 raise RuntimeError(self.lib.espm_mu_last_error().decode())
         elif self._use_list:
+            self._gen += 1
             parts = list(self.recv.view(self.world, self.layout.nbytes).unbind(0))
             torch.distributed.all_gather(parts, self.send, group=self.group)
         else:
+            self._gen += 1
             torch.distributed.all_gather_into_tensor(self.recv, self.send, group=self.group)
 
     def lost_peers(self):

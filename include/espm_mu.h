@@ -434,6 +434,11 @@ int espm_dichotomy_simplex_pg(const double* a, int k, int p, double log_shift, d
 int espm_mu_l2_step_h(const espm_mu_state* st, int src, float* work, double* scratch, int scratch_doubles, espm_stream_t stream);
 int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float* work, double* scratch, int scratch_doubles,
                       espm_stream_t stream);
+/* The W step in two halves, for a sharded image: _partials leaves this rank's X H^T in st->a ((k, n_pad) fp32) and its
+ * H H^T in work[KP*KP ..] (KP x KP fp32) - both plain sums over the rank's pixels, which the caller adds over the ranks -
+ * and _finish forms W' from them.  espm_mu_l2_step_w is the two in a row. */
+int espm_mu_l2_w_partials(const espm_mu_state* st, float* work, double* scratch, int scratch_doubles, espm_stream_t stream);
+int espm_mu_l2_w_finish(const espm_mu_state* st, int src, const float* gtg, const float* work, espm_stream_t stream);
 
 /* Terms of the linesearch on the Laplacian surrogate (espm/estimators/surrogates.py:65-149, smooth_nmf.py:376-381)
  * between two H buffers, Ht = h[hold] (before the update) and H = h[hnew]: out (4 + ESPM_KP device doubles) =
@@ -443,6 +448,13 @@ int espm_mu_l2_step_w(const espm_mu_state* st, int src, const float* gtg, float*
  * when d > 0, else raises it by 1.5.  Uses st->hpart as scratch: call it between
  * espm_mu_h_finalize and the next espm_mu_step_h.  One GPU only. */
 int espm_mu_linesearch_terms(const espm_mu_state* st, int hold, int hnew, double* out, espm_stream_t stream);
+
+/* The same for a rank of a sharded image: the terms of its block of image rows (the caller sums the `out` of the ranks, in
+ * rank order).  The image rows above / below the block come from the neighbours' boundary rows: those of the new H from
+ * st->halo_top / halo_bot, those of the H before the update from old_halo_top / old_halo_bot ((k, ny) fp32 each - the
+ * previous exchange's records still hold them, the exchange being double buffered); null exactly where st's are. */
+int espm_mu_linesearch_terms_sharded(const espm_mu_state* st, int hold, int hnew, const float* old_halo_top, const float* old_halo_bot,
+                                     double* out, espm_stream_t stream);
 
 /* The same terms without a state (module-level surrogates, espm/estimators/surrogates.py): h_old, h_new (k, ld) fp32 with p
  * used columns, grid (nx, ny) when grid_mode != 0 else L = identity; part: scratch of (4 + KP) * ceil(p / 512) doubles. */

@@ -573,7 +573,10 @@ def test_linesearch_and_truth_tracking_golden(SmoothNMF, golden, geometry):
         np.testing.assert_allclose(est.losses_, g[f"{name}_losses"], rtol=LOSS_RTOL, err_msg=name)
         det = np.array(est.detailed_losses_, dtype=float)
         np.testing.assert_allclose(det[:, 3], g[f"{name}_detailed"][:, 3], rtol=1e-9, err_msg=name + " gamma")   # same decisions
-        np.testing.assert_allclose(det[:, :3], g[f"{name}_detailed"][:, :3], rtol=2e-5, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(det[:, :2], g[f"{name}_detailed"][:, :2], rtol=2e-5, atol=1e-12, err_msg=name)
+        # (the Laplacian term is a sum of differences of neighbours: with an unconstrained H - lsw - it is ~1e-2 of the loss and
+        # carries the fp32 rounding of H amplified by that ratio)
+        np.testing.assert_allclose(det[:, 2], g[f"{name}_detailed"][:, 2], rtol=1e-4, atol=1e-12, err_msg=name)
         np.testing.assert_allclose(est.H_, g[f"{name}_H"], rtol=5e-4, atol=5e-5, err_msg=name)
         np.testing.assert_allclose(GW, g[f"{name}_GW"], rtol=5e-4, atol=5e-4 * np.abs(g[f"{name}_GW"]).mean(), err_msg=name)
         if name in g["names_tm"]:
