@@ -29,8 +29,11 @@
  *   espm_mu_w_reduce_finish, espm_mu_shard_combine_finish, espm_mu_w_reduce_pack
  *                         <- (new) the W-step after the accumulation in one call / launch (updates.py:58-76 folded into
  *                            the slab or rank-record reduction when W' needs nothing global)
- *   espm_mu_linesearch_terms <- espm/estimators/surrogates.py:6-149 + smooth_nmf.py:376-381 (linesearch=True)
- *   espm_mu_l2_step_h / _w <- espm/estimators/updates.py:109-118, :31-36 (Frobenius branch, l2=True, direct calls)
+ *   espm_mu_linesearch_terms, espm_mu_linesearch_terms_sharded
+ *                         <- espm/estimators/surrogates.py:6-149 + smooth_nmf.py:376-381 (linesearch=True; a rank's rows)
+ *   espm_mu_l2_step_h / _w, espm_mu_l2_w_partials / _finish
+ *                         <- espm/estimators/updates.py:109-118, :31-36 (Frobenius branch, l2=True; the W step in two halves
+ *                            around the sum over the ranks of a sharded image)
  *   state fields breg_sr_* <- updates.py:40-48, :120-125 (Bregman variant, algo = "bmd")
  *   state field h_rule = 1 <- updates.py:263-315 + dicotomy.py:57-82 (multiplicative_step_hq, algo = "l2_surrogate")
  *   h_rule = 2, pg_gamma_w, pg_q <- updates.py:317-395 + dicotomy.py:84-108 (proj_grad_step_h / _w, algo = "projected_gradient")
