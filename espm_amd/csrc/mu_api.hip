@@ -33,7 +33,8 @@ static int roundup(int v, int m) { return (v + m - 1) / m * m; }
   F(colsum_g) F(w) F(gw_s) F(colsum_gw) F(gw_a) F(gw_p) F(h) F(h_t) F(mu) F(fixed_h) F(fixed_w) F(simplex_rows) \
   F(halo_top) F(halo_bot) F(hpart) F(hstat) F(a_slab) F(a) F(w_scratch) F(hist) F(hist_len) F(cur) F(it) F(ell_h) \
   F(ell_h_off) F(ell_klc) F(ell_w) F(ell_w_off) F(chan_perm) F(ell_cbits) F(n_cg) F(pix_perm) F(g_t) F(breg_sr_px) \
-  F(breg_sr_ch) F(h_rule) F(pg_gamma_w) F(pg_q) F(ell_fill_px) F(ell_fill_num) F(ell_fill_n) F(tail_mode) F(no_fused)
+  F(breg_sr_ch) F(h_rule) F(pg_gamma_w) F(pg_q) F(ell_fill_px) F(ell_fill_num) F(ell_fill_n) F(tail_mode) F(no_fused) \
+  F(ell_pb)
 
 // the caller's view of the state must be this library's (include/espm_mu.h, ESPM_MU_ABI_VERSION): checked before any field is read
 static int check_abi(const espm_mu_state* st) {
@@ -57,9 +58,10 @@ static int check_state(const espm_mu_state* st) {
     ESPM_REQUIRE(st->ell_h && st->ell_h_off && st->ell_klc && st->ell_w && st->ell_w_off && st->chan_perm && st->pix_perm,
                  "the sparse count store needs ell_h, ell_h_off, ell_klc, ell_w, ell_w_off, chan_perm and pix_perm");
     ESPM_REQUIRE((st->tile_px == 64 || st->tile_px == 128 || st->tile_px == 256 || st->tile_px == ESPM_ELL_TILE) &&
-                     st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
-                 "sparse count store: tile_px must be 64..%d, nblk_w ceil(p / %d), n_cg ceil(n / 64); call espm_mu_query",
-                 ESPM_ELL_TILE, ESPM_ELL_PB);
+                     st->ell_pb == 2 * st->tile_px && st->nblk_w == (st->p + st->ell_pb - 1) / st->ell_pb &&
+                     st->n_cg == (st->n + 63) / 64 && st->h_variant == 0,
+                 "sparse count store: tile_px must be 64..%d, ell_pb 2 tile_px, nblk_w ceil(p / ell_pb), n_cg ceil(n / 64); call espm_mu_query",
+                 ESPM_ELL_TILE);
   }
   ESPM_REQUIRE(st->ell_fill_n >= 0 && (st->ell_fill_n == 0 || (st->x_dtype == ESPM_X_ELL && st->ell_fill_px && st->ell_fill_num)),
                "ell_fill_n=%d needs the sparse store, ell_fill_px and ell_fill_num", st->ell_fill_n);
@@ -85,11 +87,14 @@ static int check_state(const espm_mu_state* st) {
 
 static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / st->tile_px; }
 
-// Both half-steps in one launch (mu_fused_kernel.hpp): sparse store at its full geometry (512-pixel H tiles, i.e. an image
-// that fills the chip), the default H rule, LDS for the table and the numerators of 1024 pixels.  One record per pixel BLOCK.
+// Both half-steps in one launch (mu_fused_kernel.hpp): sparse store, the default H rule, LDS for the table and the numerators
+// of a block of ell_pb pixels.  One record per pixel BLOCK.  Below blocks of ESPM_FUSED_MIN_PB pixels (images under 2^17
+// pixels, shards) one workgroup per CU leaves the CU idle through its serial phases and the two launches with two
+// workgroups per CU are as fast or faster (profiles/r02o_small_variants.log): fused there only on request (no_fused = 3).
 static bool fused_ok(const espm_mu_state* st) {
-  return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->tile_px == ESPM_ELL_TILE && st->h_rule == 0 && st->no_fused != 1 &&
-         fused_ell_lds_bytes(st->n_pad, st->k) <= ESPM_ELL_LDS_MAX;
+  return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->h_rule == 0 && st->no_fused != 1 &&
+         (st->ell_pb >= ESPM_FUSED_MIN_PB || st->no_fused == 3) &&
+         fused_ell_lds_bytes(st->n_pad, st->k, st->ell_pb) <= ESPM_ELL_LDS_MAX;
 }
 static HStepArgs fused_h_args(const espm_mu_state* st, int src) {
   HStepArgs a = make_h_args(st, src, 1);
@@ -143,13 +148,17 @@ int espm_mu_query(espm_mu_state* st) {
   st->n_cm = roundup(st->n, ESPM_NCM);
   st->h_variant = 0;
   st->n_cg = (st->n + 63) / 64;
+  st->ell_pb = 0;
   if (st->x_dtype == ESPM_X_ELL) {  // sparse count store: fixed decomposition (mu_ell_kernel.hpp)
     // H-step: 512 pixels per workgroup (8 waves, one 64-pixel list group each); smaller images split every group
     // over 2, 4 or 8 waves so that about two workgroups per CU remain
     st->tile_px = ESPM_ELL_TILE;
     while (st->tile_px > 64 && (st->p + st->tile_px - 1) / st->tile_px < 2 * cus) st->tile_px /= 2;
     st->x_tile = st->tile_px;
-    st->nblk_w = (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB;
+    // W accumulation: blocks of two H tiles (1024 pixels for an image that fills the chip; about one block per CU below that,
+    // so that one workgroup can own a block through both half-steps: mu_fused_kernel.hpp)
+    st->ell_pb = 2 * st->tile_px;
+    st->nblk_w = (st->p + st->ell_pb - 1) / st->ell_pb;
     st->ell_cbits = 1;
     while ((1 << st->ell_cbits) < st->n) ++st->ell_cbits;
     if (st->ell_cbits > 14) return set_error(ESPM_EUNSUPPORTED, "sparse count store: n=%d needs more than 14 index bits", st->n);
@@ -184,8 +193,8 @@ static int check_ell_geometry(const espm_mu_state* st) {
   if (int rc = check_abi(st)) return rc;
   ESPM_REQUIRE(st->x_dtype == ESPM_X_ELL && st->n >= 1 && st->p >= 1 && st->n_pad == roundup(st->n, ESPM_NPAD) &&
                    st->p_pad == roundup(st->p, ESPM_PPAD) && st->n_cg == (st->n + 63) / 64 &&
-                   st->nblk_w == (st->p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && st->ell_cbits >= 1 && st->ell_cbits <= 14 &&
-                   (1 << st->ell_cbits) >= st->n &&
+                   st->ell_pb == 2 * st->tile_px && st->nblk_w == (st->p + st->ell_pb - 1) / st->ell_pb && st->ell_cbits >= 1 &&
+                   st->ell_cbits <= 14 && (1 << st->ell_cbits) >= st->n &&
                    (st->tile_px == 64 || st->tile_px == 128 || st->tile_px == 256 || st->tile_px == ESPM_ELL_TILE),
                "sparse store builder: set x_dtype = ESPM_X_ELL and call espm_mu_query first");
   return ESPM_OK;
@@ -196,7 +205,7 @@ int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt
   if (int rc = check_ell_geometry(st)) return rc;
   ESPM_REQUIRE(x_pm_u8 && cnt_px && cnt_bc && ell_klc, "ell_count: NULL pointer");
   return launch_ell_count(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
-                          st->nblk_w, cnt_px, cnt_bc, ell_klc, static_cast<hipStream_t>(stream));
+                          st->nblk_w, st->ell_pb, cnt_px, cnt_bc, ell_klc, static_cast<hipStream_t>(stream));
 }
 
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
@@ -213,7 +222,7 @@ int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t
   if (int rc = check_ell_geometry(st)) return rc;
   ESPM_REQUIRE(x_pm_u8 && chan_perm && pix_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
   return launch_ell_fill(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
-                         st->nblk_w, st->tile_px, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w,
+                         st->nblk_w, st->tile_px, st->ell_pb, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w,
                          static_cast<hipStream_t>(stream));
 }
 

@@ -569,6 +569,12 @@ struct HFinalizeArgs {
   float xscale;
   double* pg_q;  // projected-gradient rule: where the sum of the records' PGQ field goes, else null
 };
+// index bits of a W-step entry of the sparse store: log2 of the pixels per block (64 .. 1024)
+__host__ __device__ inline int ell_pbits(int pb) {
+  int b = 6;
+  while ((1 << b) < pb) ++b;
+  return b;
+}
 struct WAccumArgs {
   const void* x_pm;
   const void* x_cm;  // tile-major X (the matrix-core kernel of the wide build streams this copy)
@@ -582,6 +588,7 @@ struct WAccumArgs {
   const int32_t* ell_off;
   const int32_t* chan_perm;
   int n_cg;
+  int pb, pbits;     // pixels per block (espm_mu_state.ell_pb) and its log2: index bits of an entry
   int l2;            // Frobenius branch: A = X H^T
 };
 struct WFinishArgs {
@@ -735,6 +742,8 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
   a.ell_off = st->ell_w_off;
   a.chan_perm = st->chan_perm;
   a.n_cg = st->n_cg;
+  a.pb = st->ell_pb > 0 ? st->ell_pb : ESPM_ELL_PB;
+  a.pbits = ell_pbits(a.pb);
   a.l2 = 0;
   return a;
 }
@@ -743,12 +752,12 @@ int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, h
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
 int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units = 0);
-size_t fused_ell_lds_bytes(int n_pad, int k);
-int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+size_t fused_ell_lds_bytes(int n_pad, int k, int pb);
+int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);
 int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
                     int32_t* chan_perm, int32_t* pix_perm, int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
-int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win,
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
                     uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);

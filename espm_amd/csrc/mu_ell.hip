@@ -89,15 +89,20 @@ static int launch_w_ell_k(const WAccumArgs& args, int nblk, hipStream_t stream) 
   int nw = csplit == 1 ? (mine + 1) / 2 : mine;
   if (nw > ESPM_ELL_WTHREADS / 64) nw = ESPM_ELL_WTHREADS / 64;
   if (nw < 1) nw = 1;
-  const size_t bytes = (size_t)ESPM_ELL_PB * EllTab<K>::FLOATS * sizeof(float);
-  if (int rc = allow_lds(w_accum_ell_kernel<K, UNR>, bytes, "w_accum (ell)")) return rc;
-  hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR>), dim3(nblk, csplit), dim3(64 * nw), bytes, stream, args);
+  const size_t bytes = (size_t)args.pb * EllTab<K>::FLOATS * sizeof(float);
+  if (args.pb == ESPM_ELL_PB) {
+    if (int rc = allow_lds(w_accum_ell_kernel<K, UNR, true>, bytes, "w_accum (ell)")) return rc;
+    hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR, true>), dim3(nblk, csplit), dim3(64 * nw), bytes, stream, args);
+  } else {
+    hipLaunchKernelGGL((w_accum_ell_kernel<K, UNR, false>), dim3(nblk, csplit), dim3(64 * nw), bytes, stream, args);
+  }
   return check_hip(hipGetLastError(), "w_accum (ell) launch");
 }
 
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell && args.ell_off && args.chan_perm && args.n_cg >= 1, "w_accum: the sparse store needs ell_w, ell_w_off, chan_perm");
-  ESPM_REQUIRE(nblk == (args.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB, "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, ESPM_ELL_PB);
+  ESPM_REQUIRE(args.pb >= 128 && args.pb <= ESPM_ELL_PB && (args.pb & (args.pb - 1)) == 0 && nblk == (args.p + args.pb - 1) / args.pb,
+               "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, args.pb);
   switch (k) {
 #define ESPM_X(KK) case KK: return launch_w_ell_k<KK>(args, nblk, stream);
     ESPM_K_CASES(ESPM_X)

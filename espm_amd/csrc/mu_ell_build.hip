@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
 
 // lane = channel: walks the pixels of one block
 __global__ __launch_bounds__(256) void ell_count_w_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int ncol,
-                                                          int xmax, int32_t* __restrict__ cnt_bc) {
+                                                          int xmax, int pb, int32_t* __restrict__ cnt_bc) {
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= ncol) return;
   int cnt = 0, ones = 0;
   if (c < n) {
-    const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
+    const int q0 = b * pb, q1 = min(p, q0 + pb);
     for (int q = q0; q < q1; ++q) {
       const int x = x_pm[(size_t)q * n_pad + c];
       if (x) cnt += ell_reps(x, xmax);
@@ -254,18 +254,18 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
 }
 
 // lane = channel slot (a wave = one channel group of one pixel block)
-__global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg,
+__global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg, int pb, int pbits,
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
                                                         uint32_t* __restrict__ ell_w) {
   __shared__ uint16_t s_b[(16 + 16 + 17) * 64];
   const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
   const int c = chan_perm[((size_t)b * n_cg + cg) * 64 + lane];
   if (c < 0) return;
-  constexpr int xmax = (1 << (16 - ESPM_ELL_PBITS)) - 1;
+  const int xmax = (1 << (16 - pbits)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_w);
   const size_t row0 = (size_t)w_off[2 * ((size_t)b * n_cg + cg)], row1 = (size_t)w_off[2 * ((size_t)b * n_cg + cg) + 1];
   const int units = 2 * (int)(row1 - row0), slots = units / 16;
-  const int q0 = b * ESPM_ELL_PB, q1 = min(p, q0 + ESPM_ELL_PB);
+  const int q0 = b * pb, q1 = min(p, q0 + pb);
   EllBuckets bk{s_b, s_b + 16 * 64, s_b + 32 * 64, 64, lane};
   int holes = 0;
   if (units) {
@@ -286,20 +286,20 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
     }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;
-      ell_put(base16, row1, j++, lane, ((uint32_t)v << ESPM_ELL_PBITS) | (uint32_t)(q - q0));
+      ell_put(base16, row1, j++, lane, ((uint32_t)v << pbits) | (uint32_t)(q - q0));
       x -= v;
     }
   }
 }
 
-int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk,
+int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
-  const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ESPM_ELL_PBITS)) - 1;
+  const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ell_pbits(pb))) - 1;
   // a unit entry holds index << 4 in 16 bits
   hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
                      n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc);
   hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p,
-                     n_cg * 64, xmax_w, cnt_bc);
+                     n_cg * 64, xmax_w, pb, cnt_bc);
   return check_hip(hipGetLastError(), "ell_count launch");
 }
 
@@ -318,12 +318,12 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
   return check_hip(hipGetLastError(), "ell_plan launch");
 }
 
-int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win,
+int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
                     uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream) {
   hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
                      pix_perm, h_off, ell_h);
-  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, n_cg), dim3(64), 0, stream, x_pm, n_pad, p, n_cg, chan_perm, w_off, ell_w);
+  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, n_cg), dim3(64), 0, stream, x_pm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
   return check_hip(hipGetLastError(), "ell_fill launch");
 }
 

@@ -144,8 +144,10 @@ __device__ __forceinline__ void ell_axpy(float (&acc)[K], const float (&g)[K], f
 // dword, consecutive dwords are 64 apart.  UNR dwords are requested one batch ahead of their use and the
 // 2 UNR table gathers of a batch are issued together.  get(dword, half, g) gathers the table row of entry
 // `half` of the dword into g and returns the entry's count; body(count, g) consumes one entry.
-template <int K, int UNR, typename Get, typename Body>
+template <int K, int UNR, int PF = 1, typename Get, typename Body>
 __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body) {
+  // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
+  // that has a SIMD almost to itself needs the memory latency covered by its own requests)
   auto batch = [&](const uint32_t (&e)[UNR]) {
     float g[2 * UNR][K], x[2 * UNR];
 #pragma unroll
@@ -158,16 +160,25 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
   };
   int j = 0;
   if (len >= UNR) {
-    uint32_t e[UNR], en[UNR];
+    uint32_t q[PF][UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) e[u] = row[(size_t)u * 64];
+    for (int d = 0; d < PF; ++d) {
+      const int jd = min(d * UNR, len - UNR);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) q[d][u] = row[(size_t)(jd + u) * 64];
+    }
     for (; j + UNR <= len; j += UNR) {
-      const int jn = min(j + UNR, len - UNR);  // the last batch re-requests itself (no branch, no overrun)
+      uint32_t e[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) en[u] = row[(size_t)(jn + u) * 64];
+      for (int u = 0; u < UNR; ++u) e[u] = q[0][u];
+#pragma unroll
+      for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) q[d][u] = q[d + 1][u];
+      const int jn = min(j + PF * UNR, len - UNR);  // the last batches re-request the last rows (no branch, no overrun)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) q[PF - 1][u] = row[(size_t)(jn + u) * 64];
       batch(e);
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) e[u] = en[u];
     }
   }
   for (; j < len; ++j) {
@@ -309,14 +320,16 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_ker
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------
-// Workgroup (b, y) = pixel block b (ESPM_ELL_PB = 1024 pixels) x the channel groups cg = y, y + csplit, ...
-// (csplit = gridDim.y; 1 at the headline size, more for small images so that the grid covers the chip).
+// Workgroup (b, y) = pixel block b (a.pb pixels: ESPM_ELL_PB = 1024 at the full geometry - FULL, a compile-time constant
+// there - 128 .. 512 for smaller images) x the channel groups cg = y, y + csplit, ...
+// (csplit = gridDim.y; 1 at the headline size, more when the blocks alone do not cover the chip).
 // A wave handles 64 channels (one per lane) at a time.  Channel groups are in order of decreasing total
 // count: with nw waves, wave w takes the workgroup's groups w, 2 nw - 1 - w, 2 nw + w, ... so the waves carry
 // about the same number of entries.  updates.py:38-39, :53, :59.
-template <int K, int UNR>
+template <int K, int UNR, bool FULL>
 __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WAccumArgs a) {
-  constexpr int PB = ESPM_ELL_PB;
+  const int PB = FULL ? ESPM_ELL_PB : a.pb;
+  const int PBITS = FULL ? ESPM_ELL_PBITS : a.pbits;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;  // [PB] columns of H
   ell_table_at_lds_zero(tab);
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void w_accum_ell_kernel(const WA
     ell_walk<K, UNR>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     });
-    ell_walk<K, UNR>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, ESPM_ELL_PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk<K, UNR>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });

@@ -14,8 +14,9 @@ namespace espm {
 template <int K>
 static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream) {
   FusedArgs args = args_in;
-  const int tab_rows = args.h.n_pad > ESPM_ELL_PB ? args.h.n_pad : ESPM_ELL_PB;
-  size_t part = (size_t)FusedGeom<K>::S * FusedGeom<K>::PROWS * ESPM_ELL_PB * sizeof(float);
+  const int pb = args.w.pb;
+  const int tab_rows = args.h.n_pad > pb ? args.h.n_pad : pb;
+  size_t part = (size_t)(pb == ESPM_ELL_PB ? FusedGeom<K>::S : ESPM_ELL_PB / pb) * FusedGeom<K>::PROWS * pb * sizeof(float);
   const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
   if (red > part) part = red;
@@ -24,38 +25,51 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   args.cnt_lds_off = (int)bytes;   // the two unit counters
   bytes += 16;
   args.meta_lds_off = (int)bytes;  // the block's list offsets
-  bytes += (size_t)(3 * (ESPM_ELL_PB / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
+  bytes += (size_t)(3 * (pb / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
+  args.perm_lds_off = (int)bytes;  // below the full geometry: the block's pix_perm and chan_perm
+  if (pb != ESPM_ELL_PB) bytes += (size_t)(pb + 64 * args.w.n_cg) * sizeof(int);
   if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
     args.h.cs_lds_off = (int)bytes;
     bytes += KP * sizeof(double);
   }
   if (bytes > ESPM_ELL_LDS_MAX) return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
-  auto go = [&](auto kern) -> int {
+  auto go = [&](auto kern, int threads) -> int {
     if (bytes > 64 * 1024)
       if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
                              "fused half-steps"))
         return rc;
-    hipLaunchKernelGGL(kern, dim3(nblk + (args.h.tail_on ? 1 : 0)), dim3(ESPM_ELL_WTHREADS), bytes, stream, args);
+    hipLaunchKernelGGL(kern, dim3(nblk + (args.h.tail_on ? 1 : 0)), dim3(threads), bytes, stream, args);
     return check_hip(hipGetLastError(), "fused half-steps launch");
   };
-  return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W>)
-                             : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W>);
+  if (pb == ESPM_ELL_PB)   // the full geometry: 16 waves, sizes known at compile time
+    return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true>, ESPM_ELL_WTHREADS)
+                               : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true>, ESPM_ELL_WTHREADS);
+  return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS)
+                             : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS);
 }
 #endif
 
 // LDS the fused kernel needs for (n_pad, k): the caller decides with it whether the fused path applies
-size_t fused_ell_lds_bytes(int n_pad, int k) {
-  const int tab_rows = n_pad > ESPM_ELL_PB ? n_pad : ESPM_ELL_PB;
+size_t fused_ell_lds_bytes(int n_pad, int k, int pb) {
+  if (pb < 128 || pb > ESPM_ELL_PB || (pb & (pb - 1))) return (size_t)-1;
+  const int tab_rows = n_pad > pb ? n_pad : pb;
   const int tabf = 4 + (k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4)));
-  const int seg = k <= 5 ? 4 : (k == 6 ? 3 : 2);   // FusedGeom<K>::S
+  const int seg = pb == ESPM_ELL_PB ? (k <= 5 ? 4 : (k == 6 ? 3 : 2)) : ESPM_ELL_PB / pb;   // FusedGeom<K>::S | 1024 / pb
   const int n_cg = (n_pad + 63) / 64;   // (>= the channel groups of any n with this n_pad)
-  return (size_t)tab_rows * tabf * 4 + (size_t)seg * (k + 1) * ESPM_ELL_PB * 4 + 16 + (size_t)(3 * (ESPM_ELL_PB / 64) + 2 * n_cg + 4) / 4 * 16 + KP * sizeof(double);
+  size_t part = (size_t)seg * (k + 1) * pb * 4;
+  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * k) * sizeof(double);
+  const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
+  if (red > part) part = red;
+  if (tail_scratch > part) part = tail_scratch;
+  return (size_t)tab_rows * tabf * 4 + part + 16 + (size_t)(3 * (pb / 64) + 2 * n_cg + 4) / 4 * 16 + KP * sizeof(double) +
+         (pb != ESPM_ELL_PB ? (size_t)(pb + 64 * n_cg) * sizeof(int) : 0);
 }
 
 int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units) {
   ESPM_REQUIRE(h.ell && h.ell_off && h.ell_klc && h.ell_pix && w.ell && w.ell_off && w.chan_perm, "fused half-steps: the sparse store's lists are missing");
-  ESPM_REQUIRE(h.ell_tp == ESPM_ELL_TILE && h.h_rule == 0 && h.write_h && !h.l2_m, "fused half-steps: 512-pixel tiles, the default H rule, write_h");
-  ESPM_REQUIRE(nblk == (h.p + ESPM_ELL_PB - 1) / ESPM_ELL_PB && w.n_cg >= 1, "fused half-steps: nblk_w=%d must be ceil(p / %d)", nblk, ESPM_ELL_PB);
+  ESPM_REQUIRE(w.pb >= 128 && w.pb <= ESPM_ELL_PB && (w.pb & (w.pb - 1)) == 0 && 2 * h.ell_tp == w.pb && h.h_rule == 0 && h.write_h && !h.l2_m,
+               "fused half-steps: blocks of two H tiles (tile_px=%d, ell_pb=%d), the default H rule, write_h", h.ell_tp, w.pb);
+  ESPM_REQUIRE(nblk == (h.p + w.pb - 1) / w.pb && w.n_cg >= 1, "fused half-steps: nblk_w=%d must be ceil(p / %d)", nblk, w.pb);
   FusedArgs fa;
   fa.h = h;
   fa.w = w;

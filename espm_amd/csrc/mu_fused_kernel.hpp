@@ -1,4 +1,4 @@
-// One launch for both half-steps of an iteration on the sparse count store (x_dtype = ESPM_X_ELL, 512-pixel H tiles).
+// One launch for both half-steps of an iteration on the sparse count store (x_dtype = ESPM_X_ELL).
 //
 // The W accumulation of a pixel block needs the new H of THAT block only (updates.py:38-39, :53-59: R = X / (GW H') and
 // R H'^T are sums over pixels), so the workgroup that has just updated the 1024 pixels of a block can go on and walk the
@@ -6,7 +6,10 @@
 // What IS global - the row sums of H' in the denominator of W', the sum of the slabs - stays in the reduction launch
 // that follows (w_reduce_update_kernel / w_reduce_kernel, mu_w_step.hip).
 //
-//   workgroup = 16 waves = one block of ESPM_ELL_PB = 1024 pixels = two H tiles of 512 pixels (16 pixel-list groups)
+//   workgroup = 16 waves = one block of ESPM_ELL_PB = 1024 pixels = two H tiles of 512 pixels (16 pixel-list groups);
+//   images that do not fill the chip with such blocks (and the shards of a sharded image) have blocks of ell_pb = 128 .. 512
+//   pixels = two H tiles of 64 .. 256, about one per compute unit, and a workgroup of 8 waves (NT = 512; the block
+//   size is then a run-time value)
 //   1. GW table -> LDS (address 0), as in h_step_ell_kernel
 //   2. H walk, DYNAMIC: the rows of every list group are cut into S segments; the 16 S (group, segment) units are handed
 //      out through a counter in LDS, so a wave that is done takes the next unit.  A unit's partial numerators (and its
@@ -27,18 +30,27 @@
 #pragma once
 #include "mu_ell_kernel.hpp"
 
+// the fused kernel below the full geometry (blocks of 128 .. 512 pixels): threads of a workgroup, list batches in flight
+#ifndef ESPM_FUSED_SMALL_THREADS
+#define ESPM_FUSED_SMALL_THREADS 1024
+#endif
+#ifndef ESPM_FUSED_SMALL_PREFETCH
+#define ESPM_FUSED_SMALL_PREFETCH 1
+#endif
+
 namespace espm {
 
 struct FusedArgs {
-  HStepArgs h;      // write_h = 1, ell_tp = 512; h_t unused
+  HStepArgs h;      // write_h = 1, ell_tp = w.pb / 2; h_t unused
   WAccumArgs w;     // h_t unused
   int cnt_lds_off;  // byte offset of the two unit counters in LDS
-  int meta_lds_off; // byte offset of the block's list offsets in LDS: 16 x (first row, first general row, end) of the pixel-list
-                    // groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
+  int meta_lds_off; // byte offset of the block's list offsets in LDS: pb / 64 x (first row, first general row, end) of the
+                    // pixel-list groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
+  int perm_lds_off; // below the full geometry: byte offset of the block's copy of pix_perm (pb ints) and chan_perm (64 n_cg ints) in LDS
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
 };
 
-// segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of 1024 floats each)
+// segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of pb floats each)
 template <int K>
 struct FusedGeom {
   static constexpr int S = K <= 5 ? 4 : (K == 6 ? 3 : 2);
@@ -53,16 +65,26 @@ struct FusedGeom {
     const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
     return (int)((long)len * c / 100);
   }
+  // below the full geometry: `segs` equal segments
+  static __device__ __forceinline__ int seg_begin_even(int len, int s, int segs) {
+    if (len < MIN_SPLIT) return s == 0 ? 0 : len;
+    return (int)((long)len * s / segs);
+  }
 };
 
-template <int K, bool LOSS, int UNR_H, int UNR_W>
-__global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const FusedArgs fa) {
-  constexpr int NT = ESPM_ELL_WTHREADS;       // 1024 threads
-  constexpr int TP = ESPM_ELL_TILE;           // 512 pixels per H tile
-  constexpr int PB = ESPM_ELL_PB;             // 1024 pixels per workgroup
-  static_assert(PB == 2 * TP && NT == PB, "a workgroup is two H tiles and one thread per pixel");
-  constexpr int S = FusedGeom<K>::S, PROWS = FusedGeom<K>::PROWS;
-  constexpr int NGRP = PB / 64;               // 16 pixel-list groups
+template <int K, bool LOSS, int UNR_H, int UNR_W, int NT, bool FULL>   // FULL: the full geometry, block and tile sizes are constants
+__global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
+  static_assert(!FULL || NT == ESPM_ELL_WTHREADS, "full geometry: 1024 threads");
+  static_assert(ESPM_ELL_PB == 2 * ESPM_ELL_TILE && ESPM_ELL_WTHREADS == ESPM_ELL_PB, "full geometry: a workgroup is two H tiles, one thread per pixel");
+  const int PB = FULL ? ESPM_ELL_PB : fa.w.pb;     // pixels per workgroup
+  const int PBITS = FULL ? ESPM_ELL_PBITS : fa.w.pbits;
+  const int TP = PB / 2;                           // pixels per H tile
+  const int GPT_SHIFT = PBITS - 7;                 // log2(list groups per tile)
+  constexpr int PROWS = FusedGeom<K>::PROWS;
+  // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
+  const int S = FULL ? FusedGeom<K>::S : ESPM_ELL_PB / PB;
+  constexpr int PF = FULL ? 1 : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
+  const int NGRP = PB / 64;                        // pixel-list groups of the block
   const HStepArgs& a = fa.h;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tab = smem;   // [n_pad] rows of GW, later [PB] rows of H'
@@ -72,27 +94,37 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
   float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
   int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk
   if (a.tail_on && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
-    w_tail_body<10>(a.tail, reinterpret_cast<double*>(smem));
+    w_tail_body<(10 * ESPM_ELL_WTHREADS) / NT>(a.tail, reinterpret_cast<double*>(smem));
     return;
   }
   double* cs_lds = a.cs_parts ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + a.cs_lds_off) : nullptr;
-  if (cs_lds && (int)(threadIdx.x >> 6) < K) {      // wave kk: column sum kk of G W' from the W update's partials
-    const int kk = threadIdx.x >> 6;
-    double v = 0.0;
-    for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
+  if (cs_lds) {      // wave w: column sums w, w + NT / 64, ... of G W' from the W update's partials
+    for (int kk = threadIdx.x >> 6; kk < K; kk += NT / 64) {
+      double v = 0.0;
+      for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
+      v = wave_sum(v);
+      if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
+    }
   }
   for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
   if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
   // the block's list offsets, once: a unit then starts from LDS instead of from two dependent scalar loads
   int* meta = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.meta_lds_off);
-  if (threadIdx.x < 3 * NGRP) {
+  if ((int)threadIdx.x < 3 * NGRP) {
     const int gi = threadIdx.x / 3, j = threadIdx.x - 3 * gi;
-    const bool tile_ok = blockIdx.x * PB + (gi >> 3) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
+    const bool tile_ok = blockIdx.x * PB + (gi >> GPT_SHIFT) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
     meta[threadIdx.x] = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
   }
   for (int i = threadIdx.x; i <= 2 * fa.w.n_cg; i += NT) meta[3 * NGRP + i] = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + i];
+  // Below the full geometry a wave has a SIMD almost to itself and a unit is short: what a unit needs before its first
+  // list row - the slot -> pixel map, the block's channel order - is fetched once by the workgroup, so that a unit starts
+  // with ONE round trip to memory (its H column or GW rows and its first list rows together) instead of a chain of three.
+  int* lpix = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.perm_lds_off);
+  int* lchan = lpix + PB;
+  if constexpr (!FULL) {
+    for (int i = threadIdx.x; i < PB; i += NT) lpix[i] = a.ell_pix[(size_t)blockIdx.x * PB + i];
+    for (int i = threadIdx.x; i < 64 * fa.w.n_cg; i += NT) lchan[i] = fa.w.chan_perm[(size_t)blockIdx.x * fa.w.n_cg * 64 + i];
+  }
   __syncthreads();
   ESPM_PHASE_STAMP(1);
   const int lane = threadIdx.x & 63;
@@ -111,25 +143,26 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
 
   // ---- H walk: units u = segment * 16 + group (segment-major: every group is started early) ----
   for (int u = next_unit(0); u < NGRP * S; u = next_unit(0)) {
-    const int seg = u / NGRP, gi = u - seg * NGRP;     // group gi of the block: tile gi >> 3, its group gi & 7
+    const int seg = u / NGRP, gi = u - seg * NGRP;     // group gi of the block: tile gi >> GPT_SHIFT
     const int grp = blk0 / 64 + gi;
     float acc[K];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) acc[kk] = 0.f;
     float kl = 0.f;
     int lp = lane;   // place of the lane's pixel inside its tile
-    if (blk0 + (gi >> 3) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
-      lp = a.ell_pix[grp * 64 + lane];       // slot -> pixel of the window (lists ordered by length)
+    if (blk0 + (gi >> GPT_SHIFT) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
+      lp = FULL ? a.ell_pix[grp * 64 + lane] : lpix[gi * 64 + lane];   // slot -> pixel of the window (lists ordered by length)
       const int beg = meta[3 * gi], mid = meta[3 * gi + 1] - beg, len = meta[3 * gi + 2] - beg;
-      const int x0 = FusedGeom<K>::seg_begin(len, seg), x1 = FusedGeom<K>::seg_begin(len, seg + 1);
+      const int x0 = FULL ? FusedGeom<K>::seg_begin(len, seg) : FusedGeom<K>::seg_begin_even(len, seg, S);
+      const int x1 = FULL ? FusedGeom<K>::seg_begin(len, seg + 1) : FusedGeom<K>::seg_begin_even(len, seg + 1, S);
       if (x0 < x1) {
-        const int px = blk0 + (gi >> 3) * TP + lp;
+        const int px = blk0 + (gi >> GPT_SHIFT) * TP + lp;
         float hk[K];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
         if (x0 < mid) {
-          ell_walk<K, UNR_H>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
+          ell_walk<K, UNR_H, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
             const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
             ell_axpy<K>(acc, g, r);
             if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
@@ -137,7 +170,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
         }
         if (x1 > mid) {
           const int g0 = max(x0, mid);
-          ell_walk<K, UNR_H>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
+          ell_walk<K, UNR_H, PF>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
             const float y = ell_dot<K>(g, hk);
             // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
             const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
@@ -147,14 +180,14 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
         }
       }
     }
-    float* dst = part + (size_t)seg * PROWS * PB + (gi >> 3) * TP + lp;
+    float* dst = part + (size_t)seg * PROWS * PB + (gi >> GPT_SHIFT) * TP + lp;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) dst[(size_t)kk * PB] = acc[kk];
     dst[(size_t)K * PB] = kl;
   }
   ESPM_PHASE_STAMP(2);   // wave 0 found no unit left
   ESPM_WAVE_STAMP(8);
-  // per-pixel epilogue over the 1024 pixels of the block; H' rows go into the LDS table of the W walk (rows of the
+  // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
   h_epilogue<K, true, 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true);
 
@@ -163,7 +196,7 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
   const WAccumArgs& w = fa.w;
   const int b = blockIdx.x;
   for (int cg = next_unit(1); cg < w.n_cg; cg = next_unit(1)) {
-    const int c = w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane];
+    const int c = FULL ? w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane] : lchan[cg * 64 + lane];
     const float* gsrc = w.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
 #pragma unroll
@@ -174,10 +207,10 @@ __global__ __launch_bounds__(ESPM_ELL_WTHREADS) void mu_fused_ell_kernel(const F
     const int* off = meta + 3 * NGRP + 2 * cg;
     const int beg = off[0], mid = off[1], end = off[2];
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk<K, UNR_W>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     });
-    ell_walk<K, UNR_W>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, ESPM_ELL_PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });

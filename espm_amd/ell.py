@@ -122,7 +122,8 @@ def build(Xpm, p_pad, cbits, tile_px=512, chunk=16384):
     entries_w, rows_h, rows_w, unit_rows_h, unit_rows_w."""
     dev = Xpm.device
     p, n = Xpm.shape
-    PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
+    PB = 2 * tile_px                      # pixels per block of the W accumulation (espm_mu_state.ell_pb): two H tiles
+    PBITS = PB.bit_length() - 1
     xmax_h = (1 << (16 - cbits)) - 1
     xmax_w = (1 << (16 - PBITS)) - 1
     n_cg = (n + 63) // 64

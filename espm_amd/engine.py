@@ -217,6 +217,8 @@ class MUEngine:
         force_tile = tile_px if tile_px is not None else (int(os.environ["ESPM_FORCE_ELL_TILE"]) if os.environ.get("ESPM_FORCE_ELL_TILE") else None)
         if x_store == "ell" and force_tile in (64, 128, 256, 512):
             st.tile_px = st.x_tile = int(force_tile)
+            st.ell_pb = 2 * st.tile_px        # (a block of the W accumulation is two H tiles, include/espm_mu.h)
+            st.nblk_w = (p + st.ell_pb - 1) // st.ell_pb
         p_total = torch.tensor([p], dtype=torch.int64, device=dev)
         if group is not None:
             torch.distributed.all_reduce(p_total, group=group)
@@ -360,7 +362,9 @@ class MUEngine:
         st.cur, st.it = 0, 0
         # both half-steps of an iteration in one launch where the library's fused kernel applies (sparse store at 512-pixel
         # tiles, default H rule: include/espm_mu.h, no_fused); `fused=False` keeps the two launches (A/B, tests)
-        st.no_fused = 2 if fused == "static" else (0 if fused else 1)
+        if os.environ.get("ESPM_FUSED"):   # tests: "always" runs the fused launch on small blocks too, "0" never
+            fused = {"0": False, "1": True}.get(os.environ["ESPM_FUSED"], os.environ["ESPM_FUSED"])
+        st.no_fused = {"static": 2, "always": 3}.get(fused, 0 if fused else 1)   # ("always": also blocks below ESPM_FUSED_MIN_PB pixels)
         self._accum_done = False
         # autotune: at the first load_state the launch plans that apply to this problem are timed on the ingested image and
         # the fastest is kept (see autotune_plan)

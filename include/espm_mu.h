@@ -94,11 +94,12 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_PPAD 512      /* p_pad is a multiple of this */
 #define ESPM_NPAD 8        /* n_pad is a multiple of this */
 #define ESPM_ELL_TILE 512  /* sparse store: pixels per H-step workgroup (8 lists of 64 pixels)               */
-#define ESPM_ELL_PB 1024   /* sparse store: pixels per block of the W accumulation                          */
-#define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB): index bits of a W-step entry                               */
+#define ESPM_ELL_PB 1024   /* sparse store at its full geometry: pixels per block of the W accumulation (state field ell_pb) */
+#define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB)                                                             */
 #define ESPM_ELL_UNIT_ROWS 8 /* sparse store: the unit rows of a list group are a multiple of this (16 entries: one per bank quad) */
 #define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
+#define ESPM_FUSED_MIN_PB 512 /* sparse store: smallest W block (ell_pb) for which the fused launch is the default   */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
@@ -138,7 +139,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
  * point that takes a state checks st->struct_size == sizeof(espm_mu_state) and st->abi_version == ESPM_MU_ABI_VERSION
  * first and fails with ESPM_EINVAL otherwise: a binding whose copy of the layout has drifted is refused instead of
  * having its pointers misread.  A binding can also compare its layout field by field with espm_mu_state_layout(). */
-#define ESPM_MU_ABI_VERSION 2
+#define ESPM_MU_ABI_VERSION 3
 
 typedef struct espm_mu_state {
   uint32_t struct_size;   /* sizeof(espm_mu_state) as the CALLER sees it                  */
@@ -204,10 +205,10 @@ typedef struct espm_mu_state {
    *           window starting at pixel w0 is pixel w0 + pix_perm[w0 + s], and the 64 lists of a wave are 64
    *           consecutive slots, so they have about the same length (little padding).  Rows
    *           [ell_h_off[2 g], ell_h_off[2 g + 2]) belong to slots 64 g .. 64 g + 63.
-   *   W-step: one list per (block of ESPM_ELL_PB pixels, channel); inside block b the 64 lists of a wave are
+   *   W-step: one list per (block of ell_pb = 2 tile_px pixels, channel); inside block b the 64 lists of a wave are
    *           the channels chan_perm[b][64 cg .. 64 cg + 63] (the block's channels by decreasing list length,
-   *           -1 = none); entry = count << ESPM_ELL_PBITS | pixel - block start; rows
-   *           [ell_w_off[2 i], ell_w_off[2 i + 2]) with i = b * n_cg + cg.  nblk_w = ceil(p / ESPM_ELL_PB).
+   *           -1 = none); entry = count << log2(ell_pb) | pixel - block start; rows
+   *           [ell_w_off[2 i], ell_w_off[2 i + 2]) with i = b * n_cg + cg.  nblk_w = ceil(p / ell_pb).
    *   UNIT rows: most non-zero entries of a count image are ones.  The first rows [off[2 i], off[2 i + 1]) of
    *           a group hold only entries with count 1, in EVERY lane and position (no padding), stored without a
    *           count as index << 4 (the byte offset of a 16-byte table row): u = min over the 64 lists of their
@@ -262,12 +263,16 @@ typedef struct espm_mu_state {
    * itself; the caller sets the bit for that one call, or flushes with espm_mu_w_update_tail.  espm_mu_iterate does all
    * this internally and ignores the field. */
   int32_t tail_mode;
-  /* Sparse store at its full geometry (tile_px = ESPM_ELL_TILE: an image that fills the chip), default H rule:
-   * espm_mu_iterate and espm_mu_step_hw run both half-steps of an iteration in ONE launch - the workgroup that has
-   * updated the 1024 pixels of a block goes straight on with that block's part of R H^T, which needs no other pixel's
-   * new H (updates.py:38-39, :53-59); h_t is then not written.  no_fused = 1 keeps the two launches (A/B, tests); 2 runs the
-   * fused kernel with a fixed assignment of its work units to waves instead of the dynamic one (A/B only). */
+  /* Sparse store, default H rule: espm_mu_iterate and espm_mu_step_hw run both half-steps of an iteration in ONE launch -
+   * the workgroup that has updated the ell_pb pixels of a block (two H tiles) goes straight on with that block's part of
+   * R H^T, which needs no other pixel's new H (updates.py:38-39, :53-59); h_t is then not written.  no_fused = 1 keeps the
+   * two launches (A/B, tests); 2 runs the fused kernel with a fixed assignment of its work units to waves instead of the
+   * dynamic one (A/B only). */
   int32_t no_fused;
+  /* Sparse store: pixels per block of the W accumulation = 2 tile_px (espm_mu_query): ESPM_ELL_PB = 1024 for an image that
+   * fills the chip with 512-pixel H tiles, 128 .. 512 for smaller images and shards, so that there is about one block per
+   * compute unit and one workgroup can own the block through both half-steps. */
+  int32_t ell_pb;
 } espm_mu_state;
 
 const char* espm_mu_version(void);

@@ -31,7 +31,8 @@ def _decode_group(X_rows, words, off, i, bits, row_of_lane):
 
 
 def decode(store, p, n, p_pad, cbits, tile_px):
-    PB, PBITS = _lib.ELL_PB, _lib.ELL_PBITS
+    PB = 2 * tile_px                  # espm_mu_state.ell_pb: a block of the W accumulation is two H tiles
+    PBITS = PB.bit_length() - 1
     eh = store["ell_h"].numpy().astype(np.int64) & 0xFFFFFFFF
     off = store["ell_h_off"].numpy()
     assert off.shape == (2 * (p_pad // 64) + 1,)

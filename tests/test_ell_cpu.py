@@ -35,11 +35,13 @@ def test_lists_decode_to_x(n, p, rate, big, tile_px):
     assert (ref > 0).any() == bool((X > xmax).any())
     # channels of every block in order of decreasing list length, every channel exactly once
     perm = store["chan_perm"].numpy()
-    xmax_w = (1 << (16 - _lib.ELL_PBITS)) - 1
+    pb = 2 * tile_px                                  # a block of the W lists is two H tiles (espm_mu_state.ell_pb)
+    xmax_w = (1 << (16 - (pb.bit_length() - 1))) - 1
+    assert store["nblk_w"] == (p + pb - 1) // pb
     for b in range(store["nblk_w"]):
         row = perm[b][perm[b] >= 0]
         assert sorted(row.tolist()) == list(range(n))
-        ent_c = np.ceil(X[b * _lib.ELL_PB:(b + 1) * _lib.ELL_PB] / xmax_w).sum(axis=0)
+        ent_c = np.ceil(X[b * pb:(b + 1) * pb] / xmax_w).sum(axis=0)
         assert (np.diff(ent_c[row]) <= 0).all()
     # pixels of every window in order of decreasing list length; lists padded to the longest of their 64 slots only
     ent = np.ceil(X / xmax).sum(axis=1)

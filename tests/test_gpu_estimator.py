@@ -7,6 +7,7 @@ Tolerance (stated for fp32 device arithmetic against the fp64 reference): losses
 dicotomy_tol = 1e-5 only), W 2e-4 relative to its scale.
 """
 import contextlib
+import ctypes as C
 import io
 import json
 import pickle
@@ -32,12 +33,15 @@ def SmoothNMF():
     return cls
 
 
-@pytest.fixture(params=["auto", "fused"])
+@pytest.fixture(params=["auto", "fused", "fused_small"])
 def geometry(request, monkeypatch):
-    """"fused": the sparse store at its full geometry (512-pixel tiles) also on these small images, so that the fits run
-    through the fused H update + W accumulation launch (and the granular loop around it) that only large images get."""
+    """"fused": the sparse store at its full geometry (512-pixel tiles, 1024-pixel blocks) also on these small images, so that
+    the fits run through the fused H update + W accumulation launch (and the granular loop around it) that only large images
+    get; "fused_small": the fused launch on the small images' own geometry (blocks of 128 pixels: the run-time-sized variant)."""
     if request.param == "fused":
         monkeypatch.setenv("ESPM_FORCE_ELL_TILE", "512")
+    if request.param == "fused_small":
+        monkeypatch.setenv("ESPM_FUSED", "always")
     return request.param
 
 
@@ -806,10 +810,12 @@ def test_sparse_store_at_its_lds_limit():
         assert h["bad"].sum() == 0
 
 
+@pytest.mark.parametrize("fused", ["always", False])
 @pytest.mark.parametrize("nx,ny,tile", [(300, 300, 128), (400, 401, 256), (250, 180, 64)])
-def test_sparse_store_mid_size_tiles(nx, ny, tile):
-    """Images between 256 x 256 and 512 x 512 pixels run the sparse H-step with 128- and 256-pixel windows (two or four waves
-    share a list group), several W blocks and pixels past the last full window: whole iterations against the oracle."""
+def test_sparse_store_mid_size_tiles(nx, ny, tile, fused):
+    """Images between 256 x 256 and 512 x 512 pixels run the sparse store with 128- and 256-pixel H windows and W blocks of two
+    windows, pixels past the last full window included - as one fused launch per block (8 waves) or as the two kernels (two
+    or four waves share a list group): whole iterations against the oracle."""
     import torch
     from espm_amd import synth
     from espm_amd.engine import MUEngine
@@ -820,8 +826,9 @@ def test_sparse_store_mid_size_tiles(nx, ny, tile):
     X[:, 1000:1003] = 0                       # a few pixels without counts
     W0, H0 = synth.random_init(n, k, nx * ny, seed=nx, scale=0.2)
     kw = dict(shape_2d=(nx, ny), lambda_L=0.7, mu=0.05, simplex_H=True, simplex_W=False)
-    eng = MUEngine(X, k, max_iter=4, tol=0, **kw)
-    assert eng.x_store == "ell" and eng.st.tile_px == tile and eng.st.nblk_w == -(-nx * ny // 1024)
+    eng = MUEngine(X, k, max_iter=4, tol=0, fused=fused, **kw)
+    assert eng.x_store == "ell" and eng.st.tile_px == tile and eng.st.ell_pb == 2 * tile and eng.st.nblk_w == -(-nx * ny // (2 * tile))
+    assert bool(eng.lib.espm_mu_fused_applies(C.byref(eng.st))) == bool(fused)
     eng.load_state(W0, H0)
     eng.iterate(4, final_loss=True)
     torch.cuda.synchronize()

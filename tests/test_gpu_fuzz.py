@@ -79,15 +79,20 @@ def test_random_configuration_matches_oracle(seed):
     _run(_case(seed), seed)
 
 
+@pytest.mark.parametrize("blocks", ["full", "small"])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_CASES", "36"))))
-def test_random_configuration_on_the_fused_kernel(seed, monkeypatch):
-    """The same draws with the sparse store at its full geometry (512-pixel tiles), i.e. through the fused H update +
-    W accumulation launch, which images of this size never get by themselves: every component count 1..8 (4, 3 and 2
-    segments per list group), dictionary G, mu, the Laplacian, fixed_H, simplex over H or W, empty channels and pixels."""
+def test_random_configuration_on_the_fused_kernel(seed, blocks, monkeypatch):
+    """The same draws through the fused H update + W accumulation launch, which images of this size never get by themselves:
+    "full" - the sparse store at its full geometry (512-pixel tiles, 1024-pixel blocks: sizes known at compile time), "small" -
+    the images' own 128-pixel blocks (the variant with run-time sizes); every component count 1..8 (4, 3 and 2 segments per
+    list group), dictionary G, mu, the Laplacian, fixed_H, simplex over H or W, empty channels and pixels."""
     c = _case(seed)
     if not c["counts"] or c["algo"] not in ("log_surrogate", "bmd"):
         pytest.skip("the fused kernel serves the sparse store with the default H rule")
-    monkeypatch.setenv("ESPM_FORCE_ELL_TILE", "512")
+    if blocks == "full":
+        monkeypatch.setenv("ESPM_FORCE_ELL_TILE", "512")
+    else:
+        monkeypatch.setenv("ESPM_FUSED", "always")
     _run(c, seed, expect_fused=True)
 
 

@@ -294,7 +294,10 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
     for which in (0, 1):
         (s_hip, rows), (s_torch, _) = spread["hip"][which], spread["torch"][which]
         if rows >= 64:  # conflict-free gathers: most read groups of the C builder's unit rows, few of an index-ordered list
-            assert s_hip > 0.6 and s_hip > 3 * s_torch, (which, s_hip, s_torch)
+            # (W lists of a small image: a channel has a few dozen entries in a block of 2 tile_px pixels, so its 16 index
+            # buckets are unevenly filled and the placement has to fill holes - better than index order is all it can be)
+            floor = 0.6 if (which == 0 or eng.st.ell_pb == 1024) else 0.15
+            assert s_hip > floor and s_hip > 3 * s_torch, (which, s_hip, s_torch)
 
 
 @pytest.mark.parametrize("n,nx,ny,k,fix", [(70, 9, 13, 6, True), (2048, 16, 32, 5, False), (333, 7, 19, 3, True)])

@@ -18,14 +18,14 @@ import torch  # noqa: E402
 from espm_amd import _lib, synth  # noqa: E402
 from espm_amd.engine import MUEngine  # noqa: E402
 
-N_CH, NX, NY, K = 2048, 512, 512, int(os.environ.get("K", "5"))
+N_CH, NX, NY, K = 2048, int(os.environ.get("ROWS", "512")), 512, int(os.environ.get("K", "5"))   # (ROWS < 512: the smaller block geometries)
 dev = torch.device("cuda", 0)
-prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0)
-X = synth.sample_torch(prob, dev, seed=1000)
-W0, H0 = synth.random_init(N_CH, K, NX * NY, seed=0, scale=500.0 / N_CH)
+prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0, row0=0, nx_total=512)
+X = synth.sample_torch(prob, dev, seed=1000, row0=0)
+W0, H0 = synth.random_init(N_CH, K, 512 * 512, seed=0, scale=500.0 / N_CH)
 eng = MUEngine(X, K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=600, device=dev)
 del X
-eng.load_state(W0, H0)
+eng.load_state(W0, H0[:, :NX * NY])
 eng.iterate(300, final_loss=False)
 torch.cuda.synchronize()
 nblk = eng.st.nblk_w
@@ -56,7 +56,8 @@ ell = eng.ell
 off = ell["ell_h_off"].cpu().numpy()
 rows = off[2::2] - off[0:-1:2]
 unit = off[1::2] - off[0:-1:2]
-g = rows.reshape(-1, 8)
-u = unit.reshape(-1, 8)
-print("H list groups of a 512-pixel window, rows (mean over windows):        " + " ".join(f"{v:6.1f}" for v in g.mean(axis=0)))
+gpt = max(eng.st.tile_px // 64, 1)
+g = rows.reshape(-1, gpt)
+u = unit.reshape(-1, gpt)
+print("H list groups of a window, rows (mean over windows):        " + " ".join(f"{v:6.1f}" for v in g.mean(axis=0)))
 print("                                   of which unit rows:                " + " ".join(f"{v:6.1f}" for v in u.mean(axis=0)))
