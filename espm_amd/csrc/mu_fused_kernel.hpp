@@ -37,6 +37,9 @@
 #ifndef ESPM_FUSED_SMALL_PREFETCH
 #define ESPM_FUSED_SMALL_PREFETCH 1
 #endif
+#ifndef ESPM_FUSED_FULL_PREFETCH
+#define ESPM_FUSED_FULL_PREFETCH 1
+#endif
 
 namespace espm {
 
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   constexpr int PROWS = FusedGeom<K>::PROWS;
   // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
   const int S = FULL ? FusedGeom<K>::S : ESPM_ELL_PB / PB;
-  constexpr int PF = FULL ? 1 : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
+  constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
   const HStepArgs& a = fa.h;
   extern __shared__ __attribute__((aligned(16))) float smem[];
