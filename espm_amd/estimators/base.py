@@ -35,6 +35,67 @@ def _is_physical_model(G):
     return G is not None and not isinstance(G, np.ndarray) and hasattr(G, "NMF_update")
 
 
+class _HostCopy:
+    """``X_`` of a large fit in the making.  The reference keeps its own copy of the data (remove_zeros_lines copies,
+    base.py:519-528; normalize scales it, base.py:264-267): at 2048 x 512^2 fp32 those host passes are 0.2-0.4 s of a fit whose
+    200 iterations take 0.03 s.  They run on a worker thread (numpy releases the GIL) while the device ingests the image and
+    iterates; the fit joins it at its end.  Until then this object stands in for the array: shape and dtype are known at once,
+    anything else (``__array__``, ``.T``, indexing ...) waits for the copy."""
+
+    def __init__(self, src, layout):
+        import threading
+        self.shape, self.dtype, self.size, self.ndim = src.shape, src.dtype, src.size, src.ndim
+        self._src, self._layout = src, layout
+        self._params = None            # (pixel mask, channel mask, fill, scale), set by finish()
+        self._go, self._out, self._err = threading.Event(), None, None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            # a straight copy of the memory as it lies (for a pixel-major input: its transposed view), not a strided gather
+            out = self._src.copy() if self._layout == "cm" else self._src.T.copy().T
+            self._src = None
+            self._go.wait()
+            if self._params is None:   # cancelled
+                return
+            zp, zc, fill, scale = self._params
+            if zp is not None:
+                out[:, zp] = fill
+                out[zc, :] = fill
+            if scale is not None:
+                np.multiply(out, scale, out=out)
+            self._out = out
+        except BaseException as e:  # noqa: BLE001 - re-raised by result()
+            self._err = e
+
+    def finish(self, zp=None, zc=None, fill=None, scale=None):
+        """What the device scans found: empty pixels / channels to fill (base.py:519-528), the normalisation factor."""
+        self._params = (zp, zc, fill, scale)
+        self._go.set()
+
+    def cancel(self):
+        self._go.set()
+
+    def result(self):
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.result()
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+    def __getattr__(self, name):   # (only reached for what the stand-in does not have: .T, .sum, ...)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.result(), name)
+
+    def __getitem__(self, key):
+        return self.result()[key]
+
+
 class _Shard:
     """Pixel-row sharding of ONE fit over the ranks of a process group (espm_amd/sharding.py): every rank
     runs the same script on the same X; its engine holds a contiguous block of image rows (X and H sharded, W / G replicated)
@@ -231,7 +292,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
     def fit_transform(self, X, y=None, W=None, H=None):
         """Learn X ~ G W H and return G W (or H.T with ``hspy_comp``), espm/estimators/base.py:209-420."""
         # base.py:243-247.  For a large array that will be uploaded anyway the finiteness scan of validate_data (a full
-        # host pass: 0.18 s of a 0.43 s fit at 2048 x 512^2 fp32) moves to the device copy below; everything else
+        # host pass: 0.18 s at 2048 x 512^2 fp32) moves to the device copy below; everything else
         # (dtype, shape, n_features_in_, feature names) is still scikit-learn's.
         big = False
         try:
@@ -269,6 +330,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         # is the logical (n, p) view of the device copy either way.
         Xd = Xd_raw = None
         dev_layout = "cm"
+        lazy = None    # the estimator's own host copy X_ of a large X, made on a worker thread (_HostCopy)
         if Xv.size >= _DEVICE_PREP_MIN_SIZE:
             import torch
             if torch.cuda.is_available():
@@ -278,10 +340,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     host, dev_layout = Xv.T, "pm"
                 else:
                     host = np.ascontiguousarray(Xv)
-                Xd_raw = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
-                Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
-                if big and not bool(torch.isfinite(Xd).all()):   # the scan validate_data was told to skip, same message
-                    raise ValueError(f"Input X contains {'NaN' if bool(torch.isnan(Xd).any()) else 'infinity'}.")
+                lazy = _HostCopy(Xv, dev_layout)
+                try:
+                    Xd_raw = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
+                    Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
+                    if big and not bool(torch.isfinite(Xd).all()):   # the scan validate_data was told to skip, same message
+                        raise ValueError(f"Input X contains {'NaN' if bool(torch.isnan(Xd).any()) else 'infinity'}.")
+                    if bool((Xd < 0).any()):
+                        raise ValueError("Negative values in data")
+                except BaseException:
+                    lazy.cancel()
+                    raise
         if big and Xd is None:   # (no device after all: scikit-learn's own check)
             from sklearn.utils import assert_all_finite
             assert_all_finite(Xv, input_name="X")
@@ -293,26 +362,26 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             mean_x = None
             empty_ch, empty_px = Xv.sum(axis=1) == 0, Xv.sum(axis=0) == 0
         else:
-            if bool((Xd < 0).any()):
-                raise ValueError("Negative values in data")
             zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
             empty_ch, empty_px = zc, zp
-            # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies): a straight copy of the
-            # memory as it lies (for a pixel-major input: its transposed view), not a strided gather
-            X_fixed = Xv.copy() if dev_layout == "cm" else Xv.T.copy().T
-            if bool(zp.any()) or bool(zc.any()):
-                X_fixed[:, zp.cpu().numpy()] = self.log_shift
-                X_fixed[zc.cpu().numpy(), :] = self.log_shift
+            fill = bool(zp.any()) or bool(zc.any())
+            if fill:
                 Xd[:, zp] = self.log_shift
                 Xd[zc, :] = self.log_shift
             mean_x = float(Xd.mean(dtype=torch.float64))
+            # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies): the worker thread that is
+            # copying it now fills the empty lines and applies the normalisation
+            X_fixed = lazy
         if self.normalize:
             self.norm_factor_ = (normalization_factor(X_fixed, self.n_components) if mean_x is None
                                  else self.n_components / (mean_x * X_fixed.shape[0]))
-            self.X_ = self.norm_factor_ * X_fixed
             xscale = float(self.norm_factor_)
+        if lazy is not None:
+            lazy.finish(zp.cpu().numpy() if fill else None, zc.cpu().numpy() if fill else None, self.log_shift,
+                        self.norm_factor_ if self.normalize else None)
+            self.X_ = lazy
         else:
-            self.X_ = X_fixed
+            self.X_ = self.norm_factor_ * X_fixed if self.normalize else X_fixed
         X_init_dev = None
         if Xd is not None:
             X_init_dev = Xd * xscale if self.normalize else Xd
@@ -446,6 +515,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         except KeyboardInterrupt:
             pass
 
+        if lazy is not None:   # the host copy that was made meanwhile
+            self.X_ = lazy.result()
         self.W_ = eng.get_W().astype(out_dtype)
         self.H_ = self._full_H(eng).astype(out_dtype)
         if not self.simplex_H and not self.simplex_W:
