@@ -164,7 +164,7 @@ class Variant:
 
 _narrow = Variant(lib, KP, 1, MAX_K)
 _wide = None
-WIDE_LIB_PATH = os.path.join(_HERE, "lib", "libespm_mu_wide.so")
+WIDE_LIB_PATH = os.environ.get("ESPM_MU_WIDE_LIB", os.path.join(_HERE, "lib", "libespm_mu_wide.so"))
 
 
 def variant(k) -> Variant:

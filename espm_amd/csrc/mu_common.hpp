@@ -347,9 +347,16 @@ __device__ __forceinline__ void w_tail_body(const WTailArgs& a, double* scratch)
 #pragma unroll
   for (int u = 0; u < HELD; ++u)
     if (tid + u * nt < mk) rel = fmaxf(rel, fabsf(wn[u] - wo[u]) / (wn[u] + shift));
-  for (int i = tid + HELD * nt; i < mk; i += nt) {
-    const float x = a.w_new[i], y = a.w_old[i];
-    rel = fmaxf(rel, fabsf(x - y) / (x + shift));
+  for (int i0 = tid + HELD * nt; i0 < mk; i0 += 8 * nt) {   // (beyond the held entries: eight loads of each array in flight per trip)
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * nt;
+      x[u] = i < mk ? a.w_new[i] : 1.f;
+      y[u] = i < mk ? a.w_old[i] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rel = fmaxf(rel, fabsf(x[u] - y[u]) / (x[u] + shift));
   }
   double r1[1] = {(double)rel};
   block_reduce<1, 0>(r1, scratch);
@@ -517,6 +524,8 @@ __device__ __forceinline__ float stencil_hl(const float* hrow, const float* halo
 // kernel-side argument blocks and launchers (mu_h_step.hip, mu_w_step.hip, mu_aux.hip)
 struct HStepArgs {
   const void* x_cm;
+  const void* x_pm;  // pixel-major copy (p, n_pad): the matrix-core H-step of the wide build streams this one
+  int mfma;          // matrix-core kernels allowed (espm_mu_state.no_fused == 0)
   const float* gw_s;
   const double* colsum_gw;
   const float* h_in;
@@ -672,6 +681,8 @@ __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* 
 inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {
   HStepArgs a;
   a.x_cm = st->x_cm;
+  a.x_pm = st->x_pm;
+  a.mfma = st->no_fused == 0;   // (no_fused != 0: the vector-ALU kernels, for A/B)
   a.gw_s = st->gw_s;
   a.colsum_gw = st->colsum_gw;
   a.h_in = st->h[src];

@@ -12,6 +12,12 @@
 //   - log regulariser and Laplacian quadratic form of the input state (measures.py:543-548, :574-577)
 //   - row sums / row maxima of H' (updates.py:60, :139 of the NEXT half steps)
 #include "mu_h_kernel.hpp"
+#include "mu_h_mfma_kernel.hpp"
+
+// both contractions of the dense H-step on the matrix cores from this many components on (the wide build)
+#ifndef ESPM_H_MFMA_MIN_K
+#define ESPM_H_MFMA_MIN_K 13   // measured at the headline image, 8-bit store (profiles/r02o_wide_h_mfma_ab.log): k = 12 665 vs 651 us per iteration, k = 13 671 vs 686, k = 16 687 vs 759
+#endif
 
 // This file holds most of the library's kernel instantiations (component count x store x tile x rule); the build may
 // compile it ESPM_H_PARTS (<= 4) times, part ESPM_H_PART instantiating every ESPM_H_PARTS-th component count, so that
@@ -44,6 +50,19 @@ static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
   else
     hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   return check_hip(hipGetLastError(), "h_step launch");
+}
+
+template <int K, typename XT, int TILE>
+static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
+  constexpr int STEPS = ESPM_H_MFMA_STEPS, PASSES = TILE / (16 * STEPS);   // pixel steps of 16 per pass, passes per tile
+  const size_t lds = (size_t)4 * K * 16 * STEPS * PASSES * sizeof(float);
+  const size_t lds_min = (size_t)(4 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t bytes = lds > lds_min ? lds : lds_min;
+  if (args.compute_loss)
+    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), dim3(nblk), dim3(256), bytes, stream, args);
+  else
+    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, false>), dim3(nblk), dim3(256), bytes, stream, args);
+  return check_hip(hipGetLastError(), "h_step (mfma) launch");
 }
 
 template <int K, int PX, int NW, int U, int NBUF>
@@ -82,6 +101,13 @@ static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nbl
     if (tile_px == 256) return launch_h_l2<K, 4, 4, 8, 0>(args, nblk, stream);
     if (tile_px == 128) return launch_h_l2<K, 2, 8, 8, 2>(args, nblk, stream);
     return set_error(ESPM_EINVAL, "h_step (l2): tile_px %d not available", tile_px);
+  }
+  if constexpr (K >= ESPM_H_MFMA_MIN_K) {   // matrix cores (mu_h_mfma_kernel.hpp): the pixel-major copy of X, tiles of 16 pixel steps
+    if (args.mfma && args.x_pm && (tile_px == 256 || tile_px == 128)) {
+      if (x_dtype == ESPM_X_U8) return tile_px == 256 ? launch_h_mfma<K, uint8_t, 256>(args, nblk, stream) : launch_h_mfma<K, uint8_t, 128>(args, nblk, stream);
+      if (x_dtype == ESPM_X_BF16) return tile_px == 256 ? launch_h_mfma<K, bf16_t, 256>(args, nblk, stream) : launch_h_mfma<K, bf16_t, 128>(args, nblk, stream);
+      return tile_px == 256 ? launch_h_mfma<K, float, 256>(args, nblk, stream) : launch_h_mfma<K, float, 128>(args, nblk, stream);
+    }
   }
   if (x_dtype == ESPM_X_U8) {
     if (tile_px == 256) return launch_h<K, uint8_t, 4, 4, 8, 0>(args, nblk, stream);

@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
           mf_f4 y = mf_mma3(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float yi = y[i];
+            // The first reader of a matrix-core result must be an instruction the compiler knows: it owes the wait states
+            // between v_mfma and a vector read of its result, cannot see into the asm below and places none for it (found in
+            // mu_h_mfma_kernel.hpp, where the same pattern gave non-finite numerators with two waves per SIMD).
+            float yi = fmaxf(y[i], 1e-37f);
             asm volatile("v_rcp_f32 %0, %0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard)
             r[i] = x[i] * yi;
           }

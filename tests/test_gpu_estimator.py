@@ -348,6 +348,11 @@ def test_empty_channels_keep_the_sparse_store(SmoothNMF, kw, m, geometry):
     (11, "bf16", 14, dict(lambda_L=0.0, simplex_H=False, simplex_W=True)),
     (16, "f32", None, dict(lambda_L=0.3, simplex_H=True, simplex_W=False, fixed=True)),
     (10, "u8", None, dict(lambda_L=0.0, simplex_H=False, simplex_W=False)),
+    # from 13 components on the dense H-step runs on the matrix cores too (mu_h_mfma_kernel.hpp; n_pad = 152 is neither a
+    # multiple of 16 nor of 64: the guarded loads and the partial last channel tile); "valu": the vector kernels at that k
+    (13, "u8", None, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),
+    (14, "bf16", 9, dict(lambda_L=0.4, mu=0.05, simplex_H=True, simplex_W=False)),
+    (16, "u8", None, dict(lambda_L=1.0, simplex_H=False, simplex_W=True, valu=True)),
     # the sparse count store with 12- and 16-float table rows (round 2)
     (9, "ell", None, dict(lambda_L=0.7, mu=0.02, simplex_H=True, simplex_W=False)),
     (12, "ell", 20, dict(lambda_L=0.5, mu=0.05, simplex_H=True, simplex_W=False)),
@@ -373,9 +378,11 @@ def test_nine_to_sixteen_components(k, store, m, kw):
     if kw.pop("fixed", False):
         fixed_H = -np.ones((k, nx * ny))
         fixed_H[k - 1, ::3] = 0.05
+    fused = not kw.pop("valu", False)
     ref = oc.fit(X, k, G=prob["G"], W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), exact_root=True, no_stop_criterion=True,
                  max_iter=6, tol=0, fixed_H=fixed_H, **kw)
-    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=6, tol=0, fixed_H=fixed_H, x_store="auto" if store == "f32" else store, **kw)
+    eng = MUEngine(X, k, G=prob["G"], shape_2d=(nx, ny), max_iter=6, tol=0, fixed_H=fixed_H, x_store="auto" if store == "f32" else store,
+                   fused=fused, **kw)
     assert eng.x_store == store and eng.V.KP == 16
     eng.load_state(W0, H0)
     eng.iterate(6, final_loss=True)
