@@ -230,3 +230,35 @@ def test_launch_plan_autotune_restores_the_state(big):
     np.testing.assert_allclose(eng.history()["loss"], ref[2], rtol=2e-7)
     eng.st.no_fused = 0
     del X
+
+
+@pytest.mark.parametrize("store,tile", [("u8", 256), ("bf16", 128)])
+def test_matrix_core_kernels_of_the_wide_build_at_full_size(store, tile):
+    """16 components on a dense store at the headline image: both contractions of the H-step and of the W accumulation on
+    the matrix cores (bf16 hi/lo splits, mu_h_mfma_kernel.hpp / mu_w_mfma_kernel.hpp) against the vector kernels of the same
+    build from the same state - fp32-grade agreement after three iterations, identical losses to 1e-6, bit-reproducible
+    from run to run (the kernels read matrix-core results through inline asm: a missing wait state shows here)."""
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    k = 16
+    prob = synth.make_problem(N, NX, NY, k, N=500.0, seed=3)
+    X = synth.sample_torch(prob, "cuda", seed=1003)
+    W0, H0 = synth.random_init(N, k, NX * NY, seed=3, scale=500.0 / N)
+    kw = dict(layout="pm", shape_2d=(NX, NY), lambda_L=1.0, mu=0.05, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4,
+              x_store=store, tile_px=tile)
+    out = {}
+    for name, fused in (("mfma", True), ("mfma_again", True), ("valu", False)):
+        eng = MUEngine(X, k, fused=fused, **kw)
+        assert eng.x_store == store and eng.V.KP == 16 and eng.st.tile_px == tile
+        eng.load_state(W0, H0)
+        eng.iterate(3, final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        assert h["bad"].sum() == 0
+        out[name] = (eng.h[eng.st.cur][:, :eng.p].clone(), eng.w[eng.st.cur].clone(), h["loss"])
+        del eng
+    assert torch.equal(out["mfma"][0], out["mfma_again"][0]) and torch.equal(out["mfma"][1], out["mfma_again"][1])
+    np.testing.assert_allclose(out["mfma"][2], out["valu"][2], rtol=1e-6)
+    dh = (out["mfma"][0] - out["valu"][0]).abs().max().item()
+    dw = ((out["mfma"][1] - out["valu"][1]).abs() / (out["valu"][1].abs() + 1e-6 * out["valu"][1].abs().mean())).max().item()
+    assert dh < 2e-5 and dw < 2e-4, (dh, dw)
