@@ -19,7 +19,10 @@
 // entries come from two accumulator tiles (the accumulator reads place them in one register pair).
 #pragma once
 // (retired from the product in round 1; kept as a record - it needs the product headers of that
-//  time plus the helpers below, which moved here from mu_common.hpp when the variant was retired)
+//  time plus the helpers below, which moved here from mu_common.hpp when the variant was retired.  Round 2's matrix-core
+//  H-step for 13..16 components is espm_amd/csrc/mu_h_mfma_kernel.hpp; the instability this variant was retired for was
+//  very likely the one found and fixed there: an inline-asm reciprocal as the FIRST reader of a v_mfma result gets no
+//  wait states from the compiler.)
 #include <type_traits>
 
 #include "mu_h_kernel.hpp"
