@@ -421,7 +421,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
                                                 filled_channels=empty_ch if bool(empty_ch.any()) else None,
                                                 filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout,
-                                                autotune=Xd is not None and self.max_iter >= 100,   # (a long fit of a large image: time the launch plans once)
+                                                # (timing the launch plans costs ~30 ms of device time and gains a few per cent
+                                                #  per iteration: it pays for itself only in very long fits of large images)
+                                                autotune=Xd is not None and self.max_iter >= 5000,
                                                 shard=shard)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         del X_fixed, Xd, Xd_raw

@@ -1,9 +1,6 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02o; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O
 cd $R
-python tools/analysis/default_args_iter.py 2>&1 | grep -v amdgpu.ids | tail -4
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ksd -- python3 $R/tools/analysis/default_args_iter.py > /dev/null 2>&1
-for f in $O/ksd/*/*_kernel_stats.csv; do (head -1 $f; grep "espm::" $f) > $O/ks_default_args_kernel_stats.csv; done
-rm -rf $O/ksd
-cut -d, -f1-7 $O/ks_default_args_kernel_stats.csv | head -8 | cut -c1-220
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('20/5', round(d['value']), d['config']['launch_plan'])"; done
+python bench.py --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('default', round(d['value']), d.get('steady_state',{}).get('value'))"
+timeout -k 10 300 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k autotune 2>&1 | tail -1
