@@ -362,13 +362,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             mean_x = None
             empty_ch, empty_px = Xv.sum(axis=1) == 0, Xv.sum(axis=0) == 0
         else:
-            zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
-            empty_ch, empty_px = zc, zp
-            fill = bool(zp.any()) or bool(zc.any())
-            if fill:
-                Xd[:, zp] = self.log_shift
-                Xd[zc, :] = self.log_shift
-            mean_x = float(Xd.mean(dtype=torch.float64))
+            try:
+                zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
+                empty_ch, empty_px = zc, zp
+                fill = bool(zp.any()) or bool(zc.any())
+                if fill:
+                    Xd[:, zp] = self.log_shift
+                    Xd[zc, :] = self.log_shift
+                mean_x = float(Xd.mean(dtype=torch.float64))
+            except BaseException:   # (the worker must not wait for a finish() that will not come)
+                lazy.cancel()
+                raise
             # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies): the worker thread that is
             # copying it now fills the empty lines and applies the normalisation
             X_fixed = lazy
