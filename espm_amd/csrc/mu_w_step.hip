@@ -447,6 +447,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* s_w = dyn;
   float* s_gta = dyn + MK;
+  ESPM_PHASE_STAMP(0);
 
   float wn[WF_ROWS][KA];
 #pragma unroll
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       }
       __syncthreads();
     }
+    ESPM_PHASE_STAMP(1);   // (instrumented build, tools/analysis/w_finish_clock.py) G^T A done
     float rs[KA];
 #pragma unroll
     for (int kk = 0; kk < KA; ++kk) rs[kk] = kk < k ? (float)a.hstat[ESPM_HS_ROWSUM + kk] : 0.f;
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         }
       }
     }
+    ESPM_PHASE_STAMP(10);   // loads, numerators, denominators
     if (a.simplex_w) {
       // Multipliers of the simplex over W, all components at once.  The reference bisects the bracket [a, b] of every
       // column with a GLOBAL stop rule (dicotomy.py:146-171): all columns stop at the first sweep t in which every column's
@@ -646,6 +649,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         s_flag[tid] = o_done ? 1 : 0;
       }
       __syncthreads();
+      ESPM_PHASE_STAMP(2);   // numerators, denominators, bracket
       int evals = 0;
       // per-wave partial sums of f_kk and f_kk' at delta = s_x[kk] into bis[evals & 1]; ends with a barrier
       auto evaluate = [&]() {
@@ -733,6 +737,10 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         const double cell = fmin(floor(uu * scale), scale - 1.0);
         return ldexp(2.0 * cell + 1.0, -t);
       };
+      ESPM_PHASE_STAMP(3);   // roots found
+#ifdef ESPM_PHASE_CLOCK
+      if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[8] = (unsigned long long)evals;
+#endif
       // the sweeps are independent given the roots: lane l of wave 0 looks at sweeps l + 1 and l + 65 (dicotomy.py:152: at
       // most maxit = 100 sweeps after the first midpoint); two bit masks - "certainly stops here", "within 1 % of tol"
       if (wave == 0) {
@@ -775,6 +783,10 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       if (owner) s_mid[tid] = solve ? s_ad[tid] + s_width[tid] * mid_frac(s_u[tid], t_stop) : s_dstar[tid];   // delta = nu + d* (no multiplier: nu = 0)
       __syncthreads();
     }
+    ESPM_PHASE_STAMP(4);   // the sweep the reference stops at
+#ifdef ESPM_PHASE_CLOCK
+    if (a.simplex_w && threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[9] = 1000ull;   // (marks a simplex call)
+#endif
     // W' = max(num / (den + nu), eps), fixed entries (updates.py:70-76); rel_W (base.py:323)
     double sum_l = 0.0;
 #pragma unroll
@@ -845,6 +857,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     __syncthreads();
   }
 
+  ESPM_PHASE_STAMP(5);   // W', rel_W
   // GW = G W' (updates.py:107 of the next half step), stored / xscale with a positive floor
   double cs[KA];
 #pragma unroll
@@ -906,6 +919,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   block_reduce<KA, KA>(cs, scratch);
   if (tid == 0)
     for (int kk = 0; kk < espm::KP; ++kk) a.colsum_gw[kk] = kk < KA ? cs[kk] : 0.0;
+  ESPM_PHASE_STAMP(6);   // rows of G W', column sums
 }
 
 __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs a) {
@@ -1287,3 +1301,11 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
 }
 
 }  // namespace espm
+
+#ifdef ESPM_PHASE_CLOCK
+// debug build only (tools/analysis/w_finish_clock.py): where this file's kernels write their phase stamps
+extern "C" int espm_debug_phase_buffer_w(void* dev_ptr) {
+  unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+  return espm::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm::espm_phase_buf), &p, sizeof(p)), "phase buffer (w)");
+}
+#endif
