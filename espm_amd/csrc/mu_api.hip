@@ -265,7 +265,9 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   a.simplex_w = st->simplex_w;
   a.update_w = update_w;
   a.log_shift = st->log_shift;
-  a.tol = st->dicotomy_tol;
+  // (the reference's W step has no tolerance argument: it calls dichotomy_simplex with the module constant,
+  //  updates.py:61-68 / conf.py - only the H step takes the estimator's dicotomy_tol)
+  a.tol = ESPM_W_DICOTOMY_TOL;
   a.rel_tol = st->rel_tol;
   a.xscale = st->xscale;
   a.gw_floor = st->gw_floor;

@@ -103,6 +103,9 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
+#define ESPM_W_DICOTOMY_TOL 1e-5f /* tolerance of the simplex multiplier of the W update: espm/conf.py dicotomy_tol, which the
+                                     reference's multiplicative_step_w always uses (updates.py:61-68); the state's
+                                     dicotomy_tol is the H update's (the estimator's argument, smooth_nmf.py) */
 #define ESPM_TAIL_DEFER 1  /* espm_mu_state.tail_mode bits */
 #define ESPM_TAIL_RIDE 2
 

@@ -847,3 +847,21 @@ def test_sparse_store_mid_size_tiles(nx, ny, tile, fused):
     np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.get_W(), ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
     assert h["bad"].sum() == 0
+
+
+def test_w_simplex_tolerance_is_the_module_constant(SmoothNMF, golden):
+    """The reference's W step calls dichotomy_simplex with conf.dicotomy_tol whatever the estimator's dicotomy_tol is
+    (updates.py:61-68: multiplicative_step_w has no such argument; only the H step takes it): a looser dicotomy_tol must not
+    change a fit that has a simplex over W only."""
+    g = golden("f6_trajectories")
+    X, W0, H0 = g["cw_X"], g["cw_W0"], g["cw_H0"]
+    shape = tuple(int(v) for v in g["cw_shape"])
+    c = json.loads(str(g["configs"]))["cw"]
+    fits = []
+    for tol in (1e-5, 1e-2):
+        est = SmoothNMF(n_components=c["k"], shape_2d=shape, verbose=0, tol=0, no_stop_criterion=True, max_iter=20, dicotomy_tol=tol, **c["kw"])
+        quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        fits.append((est.W_.copy(), est.H_.copy(), np.array(est.losses_)))
+    assert c["kw"].get("simplex_W") and not c["kw"].get("simplex_H")
+    np.testing.assert_array_equal(fits[0][0], fits[1][0])
+    np.testing.assert_array_equal(fits[0][2], fits[1][2])
