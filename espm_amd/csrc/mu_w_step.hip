@@ -448,6 +448,9 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   float* s_w = dyn;
   float* s_gta = dyn + MK;
   ESPM_PHASE_STAMP(0);
+#ifdef ESPM_PHASE_CLOCK
+  if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[20] = (unsigned long long)clock64();   // shader clock ticks (against the 100 MHz stamps)
+#endif
 
   float wn[WF_ROWS][KA];
 #pragma unroll
@@ -920,6 +923,9 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   if (tid == 0)
     for (int kk = 0; kk < espm::KP; ++kk) a.colsum_gw[kk] = kk < KA ? cs[kk] : 0.0;
   ESPM_PHASE_STAMP(6);   // rows of G W', column sums
+#ifdef ESPM_PHASE_CLOCK
+  if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[21] = (unsigned long long)clock64();
+#endif
 }
 
 __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs a) {

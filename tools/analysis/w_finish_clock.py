@@ -43,4 +43,5 @@ for i, nm in enumerate(names):
     print(f"  {nm:28s} mean {d[:, i].mean():6.2f}  min {d[:, i].min():6.2f}  max {d[:, i].max():6.2f} us")
 fine = (t[:, [10, 2]] - t[:, [1, 10]]) * 0.01
 print("  inside 'num / den / bracket': loads + num / den %.2f | six reductions over the 16 waves + owner set-up %.2f us" % tuple(fine.mean(axis=0)))
+print(f"  shader clock during the kernel: {((t[:, 21] - t[:, 20]) / ((t[:, 6] - t[:, 0]) * 0.01)).mean():.0f} ticks per us")
 print(f"  total {((t[:, 6] - t[:, 0]) * 0.01).mean():6.2f} us; evaluations of f in the root finder: {t[:, 8].mean():.1f}")
