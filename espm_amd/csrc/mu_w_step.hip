@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
 }
 
 constexpr int WF_THREADS = 1024;
+constexpr int WF_HALF_MAX_K = 6;   // component counts up to which the register-resident W finish also exists with 512 threads
 
 // ---- Slab (or rank-record) reduction with the W update folded in: G = identity, no simplex_W -------------------
 // When W' needs nothing global beyond the row sums of the new H (updates.py:58-60, :70-76 with G = I and no
@@ -430,11 +431,17 @@ __device__ __forceinline__ double rcp_f64(double x) {
   return r;
 }
 
-template <int KK, int WF_ROWS>
-__global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinishArgs a) {
+// NT threads: 1024 (16 waves, 128 registers each) or 512 (8 waves, 256 registers): the thread count that spills less wins -
+// with G = identity and the simplex over W the 16-wave version kept 80 of its values in scratch memory and took 49 us, the
+// 8-wave one takes 37 (tools/analysis/w_finish_clock.py); with a dictionary G the loops over its rows want the 16 waves.
+// WF_ROWS rows of W per thread (its state stays in registers through the phases); CROWS channels per thread in the phase that
+// forms G^T A with thread = channel (a dictionary G has few rows - W state for ONE row per thread - and many channels: sizing
+// the W state by the channels spilled 245 registers at 8 components).
+template <int KK, int WF_ROWS, int NT, int CROWS = WF_ROWS>
+__global__ __launch_bounds__(NT) void w_finish_fast_kernel(const WFinishArgs a) {
   constexpr int KA = KK;  // per-thread arrays are sized by the real component count (k == KK)
-  __shared__ double scratch[(WF_THREADS / 64 + 1) * KP];
-  __shared__ double bis[2][(WF_THREADS / 64) * 2 * KA];   // per-wave partial sums (f, f') of the root finder, two alternating buffers
+  __shared__ double scratch[(NT / 64 + 1) * KP];
+  __shared__ double bis[2][(NT / 64) * 2 * KA];   // per-wave partial sums (f, f') of the root finder, two alternating buffers
   __shared__ double s_lo[KA], s_hi[KA], s_mid[KA], s_dstar[KA], s_sum[KA];
   __shared__ double s_x[KA], s_root[KA], s_fder[KA], s_ad[KA], s_width[KA], s_u[KA];
   __shared__ int s_flag[KA];
@@ -463,11 +470,11 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       // G^T A with the association G^T (R H^T), updates.py:58-59, with every thread busy: thread = channel
       // (its k entries of A in registers), G^T rows read coalesced, the products of a wave summed across its lanes
       // and the per-wave partials by the workgroup.  s_part lives behind s_gta.
-      float* s_part = s_gta + MK;  // [WF_THREADS / 64][MK]
-      float av[WF_ROWS][KA];
+      float* s_part = s_gta + MK;  // [NT / 64][MK]
+      float av[CROWS][KA];
 #pragma unroll
-      for (int r = 0; r < WF_ROWS; ++r) {
-        const int c = tid + r * WF_THREADS;
+      for (int r = 0; r < CROWS; ++r) {
+        const int c = tid + r * NT;
 #pragma unroll
         for (int kk = 0; kk < KA; ++kk) av[r][kk] = (kk < k && c < a.n) ? load_a(a, kk, c) : 0.f;
       }
@@ -476,13 +483,13 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       // takes 32 cross-lane moves instead of 6 x 32 (the moves, on one CU, are what bounds this phase).
       constexpr int MB = 4, KB8 = 8;
       for (int m0 = 0; m0 < a.m; m0 += MB) {
-        float gv[MB][WF_ROWS];
+        float gv[MB][CROWS];
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
           const int mm = m0 + b < a.m ? m0 + b : a.m - 1;
 #pragma unroll
-          for (int r = 0; r < WF_ROWS; ++r) {
-            const int c = tid + r * WF_THREADS;
+          for (int r = 0; r < CROWS; ++r) {
+            const int c = tid + r * NT;
             gv[b][r] = c < a.n ? a.g_t[(size_t)mm * a.n_pad + c] : 0.f;
           }
         }
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
             float t = 0.f;
             if (kk < KA) {
 #pragma unroll
-              for (int r = 0; r < WF_ROWS; ++r) t = fmaf(gv[b][r], av[r][kk < KA ? kk : 0], t);
+              for (int r = 0; r < CROWS; ++r) t = fmaf(gv[b][r], av[r][kk < KA ? kk : 0], t);
             }
             v[b * KB8 + kk] = t;
           }
@@ -508,14 +515,14 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         if (!(lane & 1) && m0 + b < a.m && kk < k) s_part[wave * MK + (m0 + b) * k + kk] = total;
       }
       __syncthreads();
-      for (int o = tid; o < MK; o += WF_THREADS) {
+      for (int o = tid; o < MK; o += NT) {
         float t = 0.f;
-        for (int w = 0; w < WF_THREADS / 64; ++w) t += s_part[w * MK + o];
+        for (int w = 0; w < NT / 64; ++w) t += s_part[w * MK + o];
         s_gta[o] = t;
       }
       __syncthreads();
     } else if (a.g) {  // no transposed copy: one wave per (mm, kk), G read with a stride of m
-      for (int o = wave; o < MK; o += WF_THREADS / 64) {
+      for (int o = wave; o < MK; o += NT / 64) {
         const int mm = o / k, kk = o - mm * k;
         float sacc = 0.f;
         for (int c = lane; c < a.n; c += 64) sacc = fmaf(a.g[(size_t)c * a.m + mm], load_a(a, kk, c), sacc);
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     bool in_set[WF_ROWS];
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
-      const int mm = tid + r * WF_THREADS;
+      const int mm = tid + r * NT;
       in_set[r] = false;
 #pragma unroll
       for (int kk = 0; kk < KA; ++kk) { wo[r][kk] = 0.f; nv[r][kk] = 0.f; dv[r][kk] = 1.f; pgrad[r][kk] = 0.f; }
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       // barriers per evaluation): per-thread copies of the state of all components cost more registers than a wave has.
       double cnt_l = 0.0;
 #pragma unroll
-      for (int r = 0; r < WF_ROWS; ++r) cnt_l += (tid + r * WF_THREADS < M && in_set[r]) ? 1.0 : 0.0;
+      for (int r = 0; r < WF_ROWS; ++r) cnt_l += (tid + r * NT < M && in_set[r]) ? 1.0 : 0.0;
       const double rows = block_sum1(cnt_l, scratch);
       {  // per column: max(num/2 - den), max num, max(-den) (dicotomy.py:29-49); max(-den | num > 0), sum num
         double b1[KA], b2[KA], b3[KA];
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         for (int kk = 0; kk < KA; ++kk) { b1[kk] = -INFINITY; b2[kk] = 0.0; b3[kk] = -INFINITY; }
 #pragma unroll
         for (int r = 0; r < WF_ROWS; ++r) {
-          if (tid + r * WF_THREADS < M && in_set[r]) {
+          if (tid + r * NT < M && in_set[r]) {
 #pragma unroll
             for (int kk = 0; kk < KA; ++kk) {
               if (kk < k) {
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
         for (int kk = 0; kk < KA; ++kk) { b4[kk] = -INFINITY; b5[kk] = 0.0; }
 #pragma unroll
         for (int r = 0; r < WF_ROWS; ++r) {
-          if (tid + r * WF_THREADS < M && in_set[r]) {
+          if (tid + r * NT < M && in_set[r]) {
 #pragma unroll
             for (int kk = 0; kk < KA; ++kk) {
               if (kk < k && nv[r][kk] > 0.f) {
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
           }
       }
       __syncthreads();
-      constexpr int NWV = WF_THREADS / 64;
+      constexpr int NWV = NT / 64;
       const double tol = (double)a.tol;
       // owner state (threads kk < k); a column without a positive numerator has no multiplier (dicotomy.py:19)
       const bool owner = tid < k;
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
             const double at = s_x[kk] - s_dstar[kk];   // (delta + den - d*: den - d* >= 0 is exact in fp64 for fp32 inputs of one scale)
 #pragma unroll
             for (int r = 0; r < WF_ROWS; ++r) {
-              if (tid + r * WF_THREADS < M && in_set[r]) {
+              if (tid + r * NT < M && in_set[r]) {
                 const double inv = rcp_f64(at + (double)dv[r][kk]);
                 const double t = nv[r][kk] > 0.f ? (double)nv[r][kk] * inv : 0.0;
                 if (t > (double)a.log_shift) {
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     double sum_l = 0.0;
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
-      const int mm = tid + r * WF_THREADS;
+      const int mm = tid + r * NT;
       if (mm < M) {
 #pragma unroll
         for (int kk = 0; kk < KA; ++kk) {
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
     double rel_l = 0.0;
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
-      if (tid + r * WF_THREADS < M) {
+      if (tid + r * NT < M) {
 #pragma unroll
         for (int kk = 0; kk < KA; ++kk)
           if (kk < k)
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
       double q_l = 0.0;
 #pragma unroll
       for (int r = 0; r < WF_ROWS; ++r) {
-        if (tid + r * WF_THREADS < M) {
+        if (tid + r * NT < M) {
 #pragma unroll
           for (int kk = 0; kk < KA; ++kk)
             if (kk < k) {
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   } else {
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
-      const int mm = tid + r * WF_THREADS;
+      const int mm = tid + r * NT;
       if (mm < M) {
 #pragma unroll
         for (int kk = 0; kk < KA; ++kk) {
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   };
   const int n_rows = a.n_pad;
   if (a.g) {
-    for (int c = tid; c < n_rows; c += WF_THREADS) {
+    for (int c = tid; c < n_rows; c += NT) {
       float row[KA];
 #pragma unroll
       for (int kk = 0; kk < KA; ++kk) row[kk] = 0.f;
@@ -915,7 +922,7 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_fast_kernel(const WFinish
   } else {  // G = identity: row c of G W' is row c of W', already in this thread's registers
 #pragma unroll
     for (int r = 0; r < WF_ROWS; ++r) {
-      const int c = tid + r * WF_THREADS;
+      const int c = tid + r * NT;
       if (c < n_rows) emit_row(c, wn[r]);
     }
   }
@@ -1277,25 +1284,41 @@ int launch_w_update_tail(const WTailArgs& t, hipStream_t stream) {
   return check_hip(hipGetLastError(), "w_update_tail launch");
 }
 
-template <int KK>
-static void launch_fast(const WFinishArgs& args, int rows, size_t lds, hipStream_t stream) {
+template <int KK, int NT>
+static void launch_fast(const WFinishArgs& args, int rows, int crows, size_t lds, hipStream_t stream) {
+  if (crows > rows && rows <= 1) {   // dictionary G with at most NT rows: W state of one row per thread, 2 or 4 channels per thread for G^T A
+    if (crows <= 2)
+      hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1, NT, 2>), dim3(1), dim3(NT), lds, stream, args);
+    else
+      hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1, NT, 4>), dim3(1), dim3(NT), lds, stream, args);
+    return;
+  }
+  if (crows > rows) rows = crows;
   if (rows <= 1)
-    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1>), dim3(1), dim3(WF_THREADS), lds, stream, args);
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1, NT>), dim3(1), dim3(NT), lds, stream, args);
   else if (rows <= 2)
-    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 2>), dim3(1), dim3(WF_THREADS), lds, stream, args);
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 2, NT>), dim3(1), dim3(NT), lds, stream, args);
   else
-    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 4>), dim3(1), dim3(WF_THREADS), lds, stream, args);
+    hipLaunchKernelGGL((w_finish_fast_kernel<KK, 4, NT>), dim3(1), dim3(NT), lds, stream, args);
 }
 
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int M = args.m > 0 ? args.m : args.n;
   const long mk = (long)M * args.k;
   const int span = M > args.n_cm ? M : args.n_cm;
-  const int rows = (span + WF_THREADS - 1) / WF_THREADS;
-  if (rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
+  // G = identity, up to 6 components, up to 2048 rows: 8 waves with 256 registers each (49 -> 37 us with the simplex over W
+  // at the headline size); a dictionary G keeps the 16 waves (its loops over the rows of G want them: C5 141 vs 151 us)
+  const int nt = (!args.g && args.k <= WF_HALF_MAX_K && span <= 4 * 512) ? 512 : WF_THREADS;
+  const int crows = (span + nt - 1) / nt;               // channels (or, with G = identity, rows of W) per thread
+  const int rows = args.g ? (M + nt - 1) / nt : crows;   // rows of W per thread
+  if (crows <= 4 && rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
     const size_t lds = args.g ? (size_t)mk * sizeof(float) * (2 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0)) : 0;
     switch (args.k) {
-#define ESPM_X(KK) case KK: launch_fast<KK>(args, rows, lds, stream); break;
+#define ESPM_X(KK)                                                              \
+  case KK:                                                                      \
+    if (nt == 512) launch_fast<KK, (KK <= WF_HALF_MAX_K ? 512 : WF_THREADS)>(args, rows, crows, lds, stream); \
+    else launch_fast<KK, WF_THREADS>(args, rows, crows, lds, stream);                  \
+    break;
       ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
       default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
