@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
 }
 
 constexpr int WF_THREADS = 1024;
+#ifndef ESPM_WF_FEW_THREADS
+#define ESPM_WF_FEW_THREADS 512
+#endif
+constexpr int WF_FEW_THREADS = ESPM_WF_FEW_THREADS;   // threads of the register-resident W finish for G = identity, k <= WF_HALF_MAX_K (A/B: 256)
 constexpr int WF_HALF_MAX_K = 6;   // component counts up to which the register-resident W finish also exists with 512 threads
 
 // ---- Slab (or rank-record) reduction with the W update folded in: G = identity, no simplex_W -------------------
@@ -1294,6 +1298,12 @@ static void launch_fast(const WFinishArgs& args, int rows, int crows, size_t lds
     return;
   }
   if (crows > rows) rows = crows;
+  if constexpr (NT == 256) {   // (4 waves: 8 rows per thread at 2048 channels)
+    if (rows > 4) {
+      hipLaunchKernelGGL((w_finish_fast_kernel<KK, 8, NT>), dim3(1), dim3(NT), lds, stream, args);
+      return;
+    }
+  }
   if (rows <= 1)
     hipLaunchKernelGGL((w_finish_fast_kernel<KK, 1, NT>), dim3(1), dim3(NT), lds, stream, args);
   else if (rows <= 2)
@@ -1308,15 +1318,15 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int span = M > args.n_cm ? M : args.n_cm;
   // G = identity, up to 6 components, up to 2048 rows: 8 waves with 256 registers each (49 -> 37 us with the simplex over W
   // at the headline size); a dictionary G keeps the 16 waves (its loops over the rows of G want them: C5 141 vs 151 us)
-  const int nt = (!args.g && args.k <= WF_HALF_MAX_K && span <= 4 * 512) ? 512 : WF_THREADS;
+  const int nt = (!args.g && args.k <= WF_HALF_MAX_K && span <= 4 * 512) ? WF_FEW_THREADS : WF_THREADS;
   const int crows = (span + nt - 1) / nt;               // channels (or, with G = identity, rows of W) per thread
   const int rows = args.g ? (M + nt - 1) / nt : crows;   // rows of W per thread
-  if (crows <= 4 && rows <= 4 && (!args.g || mk <= WF_GTA_MAX)) {
+  if (crows <= (nt == 256 ? 8 : 4) && rows <= (nt == 256 ? 8 : 4) && (!args.g || mk <= WF_GTA_MAX)) {
     const size_t lds = args.g ? (size_t)mk * sizeof(float) * (2 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0)) : 0;
     switch (args.k) {
 #define ESPM_X(KK)                                                              \
   case KK:                                                                      \
-    if (nt == 512) launch_fast<KK, (KK <= WF_HALF_MAX_K ? 512 : WF_THREADS)>(args, rows, crows, lds, stream); \
+    if (nt == WF_FEW_THREADS) launch_fast<KK, (KK <= WF_HALF_MAX_K ? WF_FEW_THREADS : WF_THREADS)>(args, rows, crows, lds, stream); \
     else launch_fast<KK, WF_THREADS>(args, rows, crows, lds, stream);                  \
     break;
       ESPM_K_CASES(ESPM_X)

@@ -1,8 +1,7 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O
+R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1 || (tail -40 $O/pytest.log | cut -c1-300; exit 1)
-tail -1 $O/pytest.log
-python tools/analysis/default_args_iter.py 2>&1 | grep "us/iteration" > $O/default_args_iter.log; cat $O/default_args_iter.log
-ROWS=128 python tools/analysis/c5_iter.py 2>&1 | tail -1
-python bench.py --no-cpu --no-extras 2>/dev/null | tail -1 | cut -c1-200
+for i in 1 2; do
+ESPM_MU_LIB=$R/tools/analysis/libespm_mu_wf256.so python tools/analysis/default_args_iter.py 2>&1 | grep "reference default" | sed 's/^/256: /'
+python tools/analysis/default_args_iter.py 2>&1 | grep "reference default" | sed 's/^/512: /'
+done
