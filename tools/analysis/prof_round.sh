@@ -8,12 +8,12 @@ mkdir -p $O
 cd $R && python bench.py > $O/bench_default.log 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench_20_5.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu --no-extras > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu --no-extras --no-autotune > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu --no-extras --no-autotune --steps 20 --warmup 5 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --no-cpu --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq1 -- python3 $R/bench.py --no-cpu --no-extras --no-autotune --steps 20 --warmup 5 > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --no-cpu --no-extras --no-autotune --steps 20 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_c5 -- python3 $R/tools/analysis/c5_iter.py > $O/c5_iter.log 2>&1
 K="12" rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_wide -- python3 $R/tools/analysis/wide_iter.py > $O/wide_iter.log 2>&1
 cd $R
