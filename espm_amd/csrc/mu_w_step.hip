@@ -79,7 +79,10 @@ constexpr int WF_THREADS = 1024;
 #define ESPM_WF_FEW_THREADS 512
 #endif
 constexpr int WF_FEW_THREADS = ESPM_WF_FEW_THREADS;   // threads of the register-resident W finish for G = identity, k <= WF_HALF_MAX_K (A/B: 256)
-constexpr int WF_HALF_MAX_K = 6;   // component counts up to which the register-resident W finish also exists with 512 threads
+#ifndef ESPM_WF_HALF_MAX_K
+#define ESPM_WF_HALF_MAX_K 8
+#endif
+constexpr int WF_HALF_MAX_K = ESPM_WF_HALF_MAX_K;   // component counts up to which the register-resident W finish also exists with 512 threads
 
 // ---- Slab (or rank-record) reduction with the W update folded in: G = identity, no simplex_W -------------------
 // When W' needs nothing global beyond the row sums of the new H (updates.py:58-60, :70-76 with G = I and no
@@ -1316,8 +1319,9 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int M = args.m > 0 ? args.m : args.n;
   const long mk = (long)M * args.k;
   const int span = M > args.n_cm ? M : args.n_cm;
-  // G = identity, up to 6 components, up to 2048 rows: 8 waves with 256 registers each (49 -> 37 us with the simplex over W
-  // at the headline size); a dictionary G keeps the 16 waves (its loops over the rows of G want them: C5 141 vs 151 us)
+  // G = identity, up to 8 components (the narrow build), up to 2048 rows: 8 waves with 256 registers each (with the simplex
+  // over W at the headline size 49 -> 37 us at k = 5, iteration 278 -> 248 us at k = 8); a dictionary G keeps the 16 waves
+  // (its loops over the rows of G want them: C5 141 vs 151 us)
   const int nt = (!args.g && args.k <= WF_HALF_MAX_K && span <= 4 * 512) ? WF_FEW_THREADS : WF_THREADS;
   const int crows = (span + nt - 1) / nt;               // channels (or, with G = identity, rows of W) per thread
   const int rows = args.g ? (M + nt - 1) / nt : crows;   // rows of W per thread

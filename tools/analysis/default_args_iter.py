@@ -9,7 +9,7 @@ from espm_amd.engine import MUEngine
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-n, nx, ny, k = 2048, 512, 512, 5
+n, nx, ny, k = 2048, 512, 512, int(os.environ.get("K", "5"))
 prob = synth.make_problem(n, nx, ny, k, N=500.0, seed=0)
 X = synth.sample_torch(prob, dev, seed=1000)
 W0, H0 = synth.random_init(n, k, nx * ny, seed=0, scale=500.0 / n)
