@@ -1,7 +1,11 @@
+# scratch script of the last verification run of round 2 (GPU box): full GPU suite, smoke, bench at the driver's protocol and by default
 set -e
-R=$GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02q; mkdir -p $O
 cd $R
-for k in 7 8; do
-ESPM_MU_LIB=$R/tools/analysis/libespm_mu_wfk8.so K=$k python tools/analysis/default_args_iter.py 2>&1 | grep "reference default" | sed "s/^/k=$k 512 threads: /"
-K=$k python tools/analysis/default_args_iter.py 2>&1 | grep "reference default" | sed "s/^/k=$k 1024 threads: /"
-done
+timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1 || (tail -40 $O/pytest.log | cut -c1-300; exit 1)
+tail -1 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 20 --warmup 5 > $O/bench_20_5.log 2>&1
+tail -1 $O/bench_20_5.log | cut -c1-260
+python bench.py > $O/bench_default.log 2>&1
+tail -1 $O/bench_default.log | cut -c1-260
