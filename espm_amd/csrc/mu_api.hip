@@ -236,6 +236,19 @@ int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {
 static bool w_update_is_local(const espm_mu_state* st) {
   return st->m == 0 && !st->simplex_w && st->n >= 64 && st->w_scratch != nullptr;
 }
+// The simplex over W with G = identity and every row in the simplex: the multipliers follow from per-component sums over the
+// channels, so the update runs as two many-workgroup launches (slab reduction + those sums, then w_simplex_update_kernel)
+// instead of the reduction and ONE workgroup that finds the multipliers (mu_w_step.hip).  Its tail is the local update's.
+static bool w_simplex_split(const espm_mu_state* st) {
+  return st->m == 0 && st->simplex_w && !st->simplex_rows && !st->breg_sr_ch && !(st->pg_gamma_w > 0.f) && st->n >= 64 &&
+         st->w_scratch != nullptr && st->n_pad % 32 == 0 && st->no_fused != 1;
+}
+// where the partials of the bracket live: behind the tail's three arrays of k * nbk doubles in w_scratch (2 n k floats)
+static double* simplex_bparts(const espm_mu_state* st) {
+  return reinterpret_cast<double*>(st->w_scratch) + 3 * (size_t)st->k * ((st->n_pad + 31) / 32);
+}
+// the two launches: st->a_slab -> st->a and the partials; then W', G W' and the tail's partials
+static int w_simplex_reduce_update(const espm_mu_state* st, int src, int slot, const HFinalizeArgs* fin, WTailArgs* defer_tail, hipStream_t s);
 
 static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int slot, int update_w) {
   WFinishArgs a;
@@ -274,6 +287,14 @@ static WFinishArgs finish_args(const espm_mu_state* st, int src, int hsrc, int s
   return a;
 }
 
+static int w_simplex_reduce_update(const espm_mu_state* st, int src, int slot, const HFinalizeArgs* fin, WTailArgs* defer_tail, hipStream_t s) {
+  if (st->log_shift > 0.f && (double)st->n * (double)st->log_shift >= 1.0)
+    return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
+  double* bparts = simplex_bparts(st);
+  if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, fin, s, st->w[src], bparts, st->n, st->k, st->n_pad)) return rc;
+  return launch_w_simplex_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a, bparts, (double)ESPM_W_DICOTOMY_TOL, s, defer_tail);
+}
+
 int espm_mu_build_gw(const espm_mu_state* st, int which, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(which == 0 || which == 1, "which must be 0/1");
@@ -286,7 +307,7 @@ int espm_mu_step_h(const espm_mu_state* st, int src, int write_h, espm_stream_t 
   if (st->x_dtype == ESPM_X_ELL) {
     HStepArgs a = make_h_args(st, src, write_h);
     if (st->tail_mode & ESPM_TAIL_RIDE) {  // the tail of the W update that produced this state rides along (include/espm_mu.h)
-      ESPM_REQUIRE(st->it >= 1 && w_update_is_local(st), "tail_mode: no local W update produced state %d", st->it);
+      ESPM_REQUIRE(st->it >= 1 && (w_update_is_local(st) || w_simplex_split(st)), "tail_mode: no local W update produced state %d", st->it);
       a.tail = make_w_tail_args(finish_args(st, 1 - src, src, st->it, 1));
       a.cs_parts = a.tail.parts;
       a.cs_nbk = a.tail.nbk;
@@ -360,7 +381,7 @@ int espm_mu_step_hw(const espm_mu_state* st, int src, espm_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   HStepArgs a = fused_h_args(st, src);
   if (st->tail_mode & ESPM_TAIL_RIDE) {  // the tail of the W update that produced this state rides along (include/espm_mu.h)
-    ESPM_REQUIRE(st->it >= 1 && w_update_is_local(st), "tail_mode: no local W update produced state %d", st->it);
+    ESPM_REQUIRE(st->it >= 1 && (w_update_is_local(st) || w_simplex_split(st)), "tail_mode: no local W update produced state %d", st->it);
     a.tail = make_w_tail_args(finish_args(st, 1 - src, src, st->it, 1));
     a.cs_parts = a.tail.parts;
     a.cs_nbk = a.tail.nbk;
@@ -411,6 +432,8 @@ int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with
                                   0, nullptr, with_finalize ? &fin : nullptr, s,   // (no riding finalize: hstat[1-src] is already reduced)
                                   (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
   }
+  if (w_simplex_split(st))
+    return w_simplex_reduce_update(st, src, slot, with_finalize ? &fin : nullptr, (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr, s);
   if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, with_finalize ? &fin : nullptr, s)) return rc;
   return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
 }
@@ -437,7 +460,7 @@ int espm_mu_w_update_is_local(const espm_mu_state* st) {
 
 int espm_mu_w_update_tail(const espm_mu_state* st, int src, int slot, espm_stream_t stream) {
   if (int rc = check_state(st)) return rc;
-  ESPM_REQUIRE((src == 0 || src == 1) && slot >= 0 && slot + 1 < st->hist_len && w_update_is_local(st), "w_update_tail: bad arguments");
+  ESPM_REQUIRE((src == 0 || src == 1) && slot >= 0 && slot + 1 < st->hist_len && (w_update_is_local(st) || w_simplex_split(st)), "w_update_tail: bad arguments");
   return launch_w_update_tail(make_w_tail_args(finish_args(st, src, 1 - src, slot + 1, 1)), static_cast<hipStream_t>(stream));
 }
 
@@ -449,7 +472,8 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
   // Sparse store with a local W update: the tail of the W update (column sums of G W', rel_W: one small workgroup, 8 us as
   // a launch of its own) rides in the NEXT H-step's launch as an extra workgroup; that H-step sums the partial column sums
   // itself, and the slab reduction that follows finds colsum_gw written.  The last tail is a launch of its own.
-  const bool defer = st->x_dtype == ESPM_X_ELL && w_update_is_local(st) && !(st->pg_q && st->pg_gamma_w > 0.f);
+  const bool split = w_simplex_split(st);   // (the simplex over W with G = identity: two launches after the accumulation, same tail)
+  const bool defer = st->x_dtype == ESPM_X_ELL && (w_update_is_local(st) || split) && !(st->pg_q && st->pg_gamma_w > 0.f);
   // Both half-steps in one launch where the fused kernel applies (mu_fused_kernel.hpp): 2 launches per iteration instead of 3.
   const bool fused = fused_ok(st);
   bool pending = false;
@@ -475,9 +499,12 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
         if ((rc = espm_mu_w_accum(st, stream))) return rc;
       }
       const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
-      if ((rc = launch_w_reduce_update(finish_args(st, cur, 1 - cur, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
-                                       st->nblk_w, st->a, st->hpart, nblk_h(st), nullptr, 0, nullptr, &fin, s, &tail)))
+      if (split) {
+        if ((rc = w_simplex_reduce_update(st, cur, slot, &fin, &tail, s))) return rc;
+      } else if ((rc = launch_w_reduce_update(finish_args(st, cur, 1 - cur, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float),
+                                              st->nblk_w, st->a, st->hpart, nblk_h(st), nullptr, 0, nullptr, &fin, s, &tail))) {
         return rc;
+      }
       pending = true;
     } else {
       if ((rc = espm_mu_step_hw(st, cur, stream))) return rc;   // (one launch where the fused kernel applies, else H-step + W accumulation)

@@ -776,7 +776,8 @@ int launch_ell_fill_num(const float* gw_s, const float* h_in, const int32_t* fil
                         float* fill_num, hipStream_t stream);
 int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipStream_t stream);
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
-                    hipStream_t stream);
+                    hipStream_t stream, const float* bw_old = nullptr, double* bparts = nullptr, int n = 0, int k = 0, int n_pad = 0);
+int launch_w_simplex_update(const WFinishArgs& f, float* a_inout, const double* bparts, double tol, hipStream_t stream, WTailArgs* defer_tail);
 int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HFinalizeArgs& fin_to_record,
                          const float* h_new, int nx, int ny, int p_pad, int with_halo, void* rec, hipStream_t stream);
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream);

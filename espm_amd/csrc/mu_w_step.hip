@@ -35,6 +35,12 @@ struct WReduceArgs {
   float* halo_top;
   float* halo_bot;
   int halo_k, halo_nx, halo_ny, halo_ppad;
+  // simplex over W with G = identity (w_simplex_update_kernel): the workgroup also leaves, for its 32 entries of component
+  // kk = entry / n_pad (n_pad a multiple of 32), what the bracket and the root of that component's multiplier need -
+  // sum, maximum and count of the positive numerators W A (dicotomy.py:29-49) - in bparts[3 * workgroup ..]; else null
+  const float* bw_old;
+  double* bparts;
+  int bn, bk, bn_pad;
 };
 
 __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
@@ -66,11 +72,30 @@ __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
   }
   s_part[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (grp == 0 && e < a.total) {
+  if (grp == 0) {   // (32 lanes: half of wave 0)
     float t = 0.f;
+    if (e < a.total) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += s_part[g][col];
-    a.out[e] = t;
+      for (int g = 0; g < 8; ++g) t += s_part[g][col];
+      a.out[e] = t;
+    }
+    if (a.bparts) {
+      const int kk = e / a.bn_pad, c = e - kk * a.bn_pad;
+      const float num = (e < a.total && c < a.bn) ? a.bw_old[(size_t)c * a.bk + kk] * t : 0.f;   // updates.py:59 (G = identity)
+      double sum = num > 0.f ? (double)num : 0.0, cnt = num > 0.f ? 1.0 : 0.0;
+      float mx = fmaxf(num, 0.f);
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {   // (fixed order: the same partials run to run)
+        sum += __shfl_xor(sum, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      }
+      if (col == 0) {
+        a.bparts[3 * (size_t)blockIdx.x] = sum;
+        a.bparts[3 * (size_t)blockIdx.x + 1] = (double)mx;
+        a.bparts[3 * (size_t)blockIdx.x + 2] = cnt;
+      }
+    }
   }
 }
 
@@ -235,6 +260,114 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     }
     w_update_entries(a, kk, c, e, owns, t, rs, nwg);
   }
+}
+
+// ---- W update under the simplex over W, G = identity, all rows in the simplex: many workgroups instead of one ----------------
+// With G = identity every denominator of a column of W is the same number (rowsum of H', updates.py:60), so the multiplier's
+// function is f(delta) = S / delta + n0 eps - 1 in delta = nu + rowsum, with S the sum of the positive numerators and n0 the
+// rows without one: what the reference's bisection (dicotomy.py:111-173, global stop rule) does to it follows from S, the
+// largest numerator and the counts alone.  w_reduce_kernel leaves those per 32 channels (WReduceArgs::bparts); here EVERY
+// workgroup (component kk, 32 channels - the geometry of w_reduce_update_kernel) adds the partials of all components in a
+// fixed order, walks the same decisions as w_finish_fast_kernel - bracket, root, the sweep the reference stops at (estimate
+// from the linearisation, the exact f where that is within 1 % of the tolerance), the midpoint of that sweep - and updates
+// its 32 entries with delta in the place of the row sum.  37 us of one workgroup become 8 us of 320.
+// (A positive numerator below eps delta counts as itself, not as eps: at most n eps = 2e-11 of f.)
+struct WSimplexArgs {
+  WUpdateArgs u;             // the update of the entries and what it leaves for the tail (src / hpart unused: A is read from u.a_out)
+  const double* bparts;      // [k * nbk][3]
+  const double* hstat;       // statistics of the new H (row sums)
+  double rows;               // rows of W (all of them in the simplex)
+  double tol;
+};
+
+__global__ __launch_bounds__(64) void w_simplex_update_kernel(const WSimplexArgs x) {
+  const WUpdateArgs& a = x.u;
+  const int nwg = a.k * a.nbk;
+  const int kk = blockIdx.x / a.nbk, j = blockIdx.x - kk * a.nbk;
+  const int lane = threadIdx.x;
+  // the entries first: their loads fly while the multipliers are worked out
+  const int c = 32 * j + (lane & 31);
+  const int e = kk * a.n_pad + c;
+  const bool owns = lane < 32 && c < a.n_pad;
+  const float t_e = owns ? a.a_out[e] : 0.f;
+  double ssum[KP], smax[KP], spos[KP], rs[KP];
+#pragma unroll
+  for (int q = 0; q < KP; ++q) {
+    ssum[q] = 0.0; smax[q] = 0.0; spos[q] = 0.0; rs[q] = 1.0;
+    if (q < a.k) {
+      double s1 = 0.0, s3 = 0.0, s2 = 0.0;
+      for (int b = lane; b < a.nbk; b += 64) {
+        const double* p = x.bparts + 3 * ((size_t)q * a.nbk + b);
+        s1 += p[0];
+        s2 = fmax(s2, p[1]);
+        s3 += p[2];
+      }
+      ssum[q] = wave_sum(s1);
+      smax[q] = wave_max(s2);
+      spos[q] = wave_sum(s3);
+      rs[q] = x.hstat[ESPM_HS_ROWSUM + q];
+    }
+  }
+  // per component (every lane the same arithmetic): bracket [ad, ad + width] in delta, root, slope, place of the root
+  const double eps = (double)a.log_shift;
+  double root[KP], fder[KP], ad[KP], width[KP], uu[KP], cst[KP];
+  bool solve[KP];
+#pragma unroll
+  for (int q = 0; q < KP; ++q) {
+    solve[q] = q < a.k && ssum[q] > 0.0 && ssum[q] < INFINITY;
+    const double den = (double)(float)rs[q];                 // dv = colsum(G) * (float) rowsum = the fp32 row sum
+    const double lo = smax[q] / 2 - den;                     // a, dicotomy.py:29-43
+    const double hi = x.rows * smax[q] / 0.5 - den;          // b, dicotomy.py:49
+    cst[q] = (x.rows - spos[q]) * eps;                       // the rows without a positive numerator: eps each
+    ad[q] = lo + den;
+    width[q] = hi - lo;
+    // Newton from delta = S: f(S) = cst; the finish accepts |f| <= 1e-11, else converges to S / (1 - cst)
+    root[q] = solve[q] ? (fabs(cst[q]) <= 1e-11 ? ssum[q] : ssum[q] / (1.0 - cst[q])) : 1.0;
+    fder[q] = solve[q] ? -ssum[q] / (root[q] * root[q]) : 0.0;
+    uu[q] = solve[q] ? fmin(fmax((root[q] - ad[q]) / width[q], 0.0), 1.0) : 0.5;
+  }
+  auto mid_frac = [](double u1, int t) {
+    const double scale = ldexp(1.0, t - 1);
+    const double cell = fmin(floor(u1 * scale), scale - 1.0);
+    return ldexp(2.0 * cell + 1.0, -t);
+  };
+  // the sweep the reference stops at: lane l looks at sweeps l + 1 and l + 65 (at most 101)
+  unsigned long long mc[2], mb[2];
+  for (int hf = 0; hf < 2; ++hf) {
+    const int t = 1 + lane + 64 * hf;
+    double est = 0.0;
+#pragma unroll
+    for (int q = 0; q < KP; ++q)
+      if (q < a.k) est = fmax(est, fabs(fder[q] * ((ad[q] + width[q] * mid_frac(uu[q], t)) - root[q])));
+    const bool certain = t <= 101 && (est <= 0.99 * x.tol || t == 101);
+    const bool band = t <= 101 && !certain && est <= 1.01 * x.tol;
+    mc[hf] = __ballot(certain);
+    mb[hf] = __ballot(band);
+  }
+  int t_stop = 101;
+  for (;;) {   // (uniform)
+    const unsigned long long w0 = mc[0] | mb[0], w1 = mc[1] | mb[1];
+    if (!w0 && !w1) break;
+    const int hf = w0 ? 0 : 1;
+    const int bit = __ffsll((long long)(hf ? w1 : w0)) - 1;
+    const int t = 1 + bit + 64 * hf;
+    if ((mc[hf] >> bit) & 1ull) { t_stop = t; break; }
+    double worst = 0.0;
+#pragma unroll
+    for (int q = 0; q < KP; ++q)
+      if (q < a.k && fder[q] != 0.0) {
+        const double d = ad[q] + width[q] * mid_frac(uu[q], t);
+        worst = fmax(worst, fabs(ssum[q] / d + cst[q] - 1.0));
+      }
+    if (worst <= x.tol) { t_stop = t; break; }
+    mb[hf] &= ~(1ull << bit);
+  }
+  // delta of this workgroup's component: den + nu = (den - d*) + delta = delta (no multiplier without a positive numerator)
+  double delta = rs[0];
+#pragma unroll
+  for (int q = 0; q < KP; ++q)
+    if (q == kk) delta = solve[q] ? ad[q] + width[q] * mid_frac(uu[q], t_stop) : (double)(float)rs[q];
+  w_update_entries(a, kk, c, e, owns, t_e, delta, nwg);
 }
 
 // ---- Slab reduction, record exchange and W update of a SHARDED image in ONE launch (espm_mu_shard_exchange_finish) ----------
@@ -1127,8 +1260,13 @@ int dispatch_w_accum(const WAccumArgs& args, int k, int x_dtype, int nblk, hipSt
 }
 
 int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HFinalizeArgs* fused_finalize,
-                    hipStream_t stream) {
+                    hipStream_t stream, const float* bw_old, double* bparts, int n, int k, int n_pad) {
   WReduceArgs a;
+  a.bw_old = bw_old;
+  a.bparts = bparts;
+  a.bn = n;
+  a.bk = k;
+  a.bn_pad = n_pad;
   a.slab = slab;
   a.out = out;
   a.nblk = nblk;
@@ -1164,6 +1302,9 @@ int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HF
   a.halo_nx = nx;
   a.halo_ny = ny;
   a.halo_ppad = p_pad;
+  a.bw_old = nullptr;
+  a.bparts = nullptr;
+  a.bn = a.bk = a.bn_pad = 0;
   hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + 1), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce_pack launch");
 }
@@ -1221,6 +1362,48 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   else
     hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
   return check_hip(hipGetLastError(), "w_reduce_update launch");
+}
+
+int launch_w_simplex_update(const WFinishArgs& f, float* a_inout, const double* bparts, double tol, hipStream_t stream, WTailArgs* defer_tail) {
+  WSimplexArgs x;
+  WUpdateArgs& a = x.u;
+  a.src = nullptr;
+  a.src_stride = 0;
+  a.nsrc = 0;
+  a.n = f.n;
+  a.n_pad = f.n_pad;
+  a.k = f.k;
+  a.nbk = (f.n_pad + 31) / 32;
+  a.a_out = a_inout;
+  a.hpart = nullptr;
+  a.hstat_rs = nullptr;
+  a.nblk_h = 0;
+  a.rec_hstat_off = 0;
+  a.hstat_out = nullptr;
+  a.w_old = f.w_old;
+  a.w_new = f.w_new;
+  a.fixed_w = f.fixed_w;
+  a.breg_sr = nullptr;
+  a.pg_gamma_w = 0.f;
+  a.pg_track = 0;
+  a.gw_s = f.gw_s;
+  a.parts = reinterpret_cast<double*>(f.scratch);
+  a.log_shift = f.log_shift;
+  a.gw_floor = f.gw_floor;
+  a.xscale = f.xscale;
+  a.fuse_finalize = 0;
+  x.bparts = bparts;
+  x.hstat = f.hstat;
+  x.rows = (double)f.n;
+  x.tol = tol;
+  hipLaunchKernelGGL(w_simplex_update_kernel, dim3(a.k * a.nbk), dim3(64), 0, stream, x);
+  if (int rc = check_hip(hipGetLastError(), "w_simplex_update launch")) return rc;
+  const WTailArgs t = make_w_tail_args(f);
+  if (defer_tail)
+    *defer_tail = t;
+  else
+    hipLaunchKernelGGL(w_update_tail_kernel, dim3(1), dim3(WT_THREADS), 0, stream, t);
+  return check_hip(hipGetLastError(), "w_simplex_update tail launch");
 }
 
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,

@@ -353,7 +353,11 @@ int espm_mu_w_finish(const espm_mu_state* st, int src, int hsrc, int slot, espm_
  * riding in its launch when with_finalize != 0) and the W update w[src] -> w[1-src] with the row sums of the new H
  * h[1-src]; rel_W goes to history slot + 1.  When W' needs nothing global (G = identity, no simplex_W, n >= 64) the
  * reduction workgroups finish their own entries of W and a one-workgroup tail forms colsum(GW') and rel_W (w_scratch
- * holds the partials); otherwise this is espm_mu_w_reduce[_finalize] + espm_mu_w_finish. */
+ * holds the partials).  With the simplex over W, G = identity, every row in the simplex (no simplex_rows), the default
+ * multiplicative rule and n_pad a multiple of 32, the multipliers follow from per-component sums over the channels
+ * (dicotomy.py:111-173 applied to f(delta) = S / delta + n0 eps - 1): the reduction also leaves those sums per 32 channels
+ * and a second many-workgroup launch finds the multipliers and updates W (same tail; no_fused = 1 keeps the one-workgroup
+ * finish for A/B).  Otherwise this is espm_mu_w_reduce[_finalize] + espm_mu_w_finish. */
 int espm_mu_w_reduce_finish(const espm_mu_state* st, int src, int slot, int with_finalize, espm_stream_t stream);
 
 /* n_iter full iterations on one GPU, no host synchronisation; updates st->cur / st->it.

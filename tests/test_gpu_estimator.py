@@ -865,3 +865,47 @@ def test_w_simplex_tolerance_is_the_module_constant(SmoothNMF, golden):
     assert c["kw"].get("simplex_W") and not c["kw"].get("simplex_H")
     np.testing.assert_array_equal(fits[0][0], fits[1][0])
     np.testing.assert_array_equal(fits[0][2], fits[1][2])
+
+
+@pytest.mark.parametrize("n,nx,ny,k,kw", [
+    (96, 14, 17, 3, dict(simplex_H=False, simplex_W=True)),
+    (160, 9, 21, 5, dict(simplex_H=False, simplex_W=True, lambda_L=0.5, mu=0.1)),
+    (2048, 8, 12, 8, dict(simplex_H=False, simplex_W=True, lambda_L=1.0)),   # (449 channels without a count at this dose)
+    (64, 20, 20, 1, dict(simplex_H=False, simplex_W=True)),
+])
+def test_simplex_over_w_as_many_workgroups(n, nx, ny, k, kw):
+    """With G = identity and every row in the simplex the multipliers of the W update follow from per-component sums over
+    the channels: two many-workgroup launches (w_reduce_kernel's partials + w_simplex_update_kernel) instead of one
+    workgroup that searches them.  Against the oracle (the reference's global-stop bisection) and against the one-workgroup
+    finish of the same build (fused=False), including empty channels (numerators of zero) and a fixed entry of W."""
+    import torch
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine
+    prob = synth.make_problem(n, nx, ny, k, N=60.0, seed=n + k)
+    X = synth.sample_numpy(prob, seed=n + k)
+    X[5] = 0                      # a channel without counts: its numerators are zero, it takes eps
+    X[0, X.sum(axis=0) == 0] = 1.0
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=n + k, scale=0.2)
+    W0 /= W0.sum(axis=0, keepdims=True)
+    fixed_W = -np.ones((n, k))
+    fixed_W[3, 0] = 0.01
+    ref = oc.fit(X, k, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), no_stop_criterion=True, max_iter=8, tol=0, fixed_W=fixed_W, **kw)
+    out = {}
+    for name, fused in (("split", True), ("one_workgroup", False)):
+        eng = MUEngine(X, k, shape_2d=(nx, ny), max_iter=8, tol=0, fixed_W=fixed_W, fused=fused, **kw)
+        assert eng.st.n_pad % 32 == 0
+        eng.load_state(W0, H0)
+        eng.iterate(8, final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        assert h["bad"].sum() == 0
+        out[name] = (eng.get_W(), eng.get_H(), h["loss"], h["rel_W"])
+    W, H, loss, rel_w = out["split"]
+    np.testing.assert_allclose(loss[1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(W, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
+    np.testing.assert_allclose(H, ref["H"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(W.sum(axis=0) - W[3, 0] + 0.0, ref["W"].sum(axis=0) - ref["W"][3, 0], rtol=1e-4)
+    # the same multipliers as the one-workgroup finish: the same sweep, the same midpoint
+    np.testing.assert_allclose(W, out["one_workgroup"][0], rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(loss, out["one_workgroup"][2], rtol=1e-7)
+    np.testing.assert_allclose(rel_w[1:], out["one_workgroup"][3][1:], rtol=1e-4, atol=1e-9)
