@@ -449,6 +449,16 @@ int espm_mu_shard_combine_finish(const espm_mu_state* st, const void* records, i
                                   nullptr, 0, nullptr, (size_t)st->k * st->n_pad * sizeof(float), st->hstat[1 - src], nullptr,
                                   static_cast<hipStream_t>(stream), (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
   }
+  if (w_simplex_split(st)) {   // the simplex over W with G = identity: the sum over the ranks leaves the bracket's sums, many workgroups update
+    if (st->log_shift > 0.f && (double)st->n * (double)st->log_shift >= 1.0)
+      return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
+    double* bparts = simplex_bparts(st);
+    if (int rc = launch_shard_combine(records, world, espm_mu_shard_record_bytes(st), st->k * st->n_pad, st->a, st->hstat[1 - src],
+                                      static_cast<hipStream_t>(stream), st->w[src], bparts, st->n, st->k, st->n_pad))
+      return rc;
+    return launch_w_simplex_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a, bparts, (double)ESPM_W_DICOTOMY_TOL,
+                                   static_cast<hipStream_t>(stream), (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
+  }
   if (int rc = espm_mu_shard_combine(st, records, world, 1 - src, stream)) return rc;
   return espm_mu_w_finish(st, src, 1 - src, slot + 1, stream);
 }

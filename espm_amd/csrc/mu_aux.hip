@@ -354,14 +354,38 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict
 }
 
 // Fixed-order sum over ranks (bit-identical on every rank), global row sums / maxima.
+// With bparts (the simplex over W with G = identity, mu_w_step.hip: w_simplex_update_kernel; n_pad a multiple of 32): every
+// half wave also leaves sum, maximum and count of the positive numerators W A of its 32 entries in bparts[3 * (entry / 32) ..],
+// as w_reduce_kernel does for one GPU.
 __global__ __launch_bounds__(256) void shard_combine_kernel(const unsigned char* __restrict__ recs, int world,
                                                             size_t stride, int na, float* __restrict__ a_out,
-                                                            double* __restrict__ hstat_out) {
+                                                            double* __restrict__ hstat_out, const float* __restrict__ bw_old,
+                                                            double* __restrict__ bparts, int bn, int bk, int bn_pad) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-  for (int e = tid; e < na; e += nt) {
+  for (int e0 = tid & ~31; e0 < na; e0 += nt) {   // (whole half waves enter every trip)
+    const int e = e0 + (tid & 31);
     float s = 0.f;
-    for (int r = 0; r < world; ++r) s += reinterpret_cast<const float*>(recs + r * stride)[e];
-    a_out[e] = s;
+    if (e < na) {
+      for (int r = 0; r < world; ++r) s += reinterpret_cast<const float*>(recs + r * stride)[e];
+      a_out[e] = s;
+    }
+    if (bparts) {
+      const int kk = e / bn_pad, c = e - kk * bn_pad;
+      const float num = (e < na && c < bn) ? bw_old[(size_t)c * bk + kk] * s : 0.f;
+      double sum = num > 0.f ? (double)num : 0.0, cnt = num > 0.f ? 1.0 : 0.0;
+      float mx = fmaxf(num, 0.f);
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      }
+      if ((tid & 31) == 0) {
+        bparts[3 * (size_t)(e0 / 32)] = sum;
+        bparts[3 * (size_t)(e0 / 32) + 1] = (double)mx;
+        bparts[3 * (size_t)(e0 / 32) + 2] = cnt;
+      }
+    }
   }
   for (int e = tid; e < ESPM_HS_STRIDE; e += nt) {
     double s = 0.0;
@@ -383,11 +407,11 @@ int launch_shard_pack(const float* a, const double* hstat, const float* h_new, i
 }
 
 int launch_shard_combine(const void* recs, int world, size_t stride, int na, float* a_out, double* hstat_out,
-                         hipStream_t stream) {
+                         hipStream_t stream, const float* bw_old, double* bparts, int n, int k, int n_pad) {
   int blocks = (na + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(shard_combine_kernel, dim3(blocks), dim3(256), 0, stream,
-                     static_cast<const unsigned char*>(recs), world, stride, na, a_out, hstat_out);
+                     static_cast<const unsigned char*>(recs), world, stride, na, a_out, hstat_out, bw_old, bparts, n, k, n_pad);
   return check_hip(hipGetLastError(), "shard_combine launch");
 }
 

@@ -800,7 +800,7 @@ int launch_dichotomy(const double* num, const double* den, int k, int p, int den
 int launch_shard_pack(const float* a, const double* hstat, const float* h_new, int k, int n_pad, int nx, int ny,
                       int p_pad, int with_halo, void* rec, hipStream_t stream);
 int launch_shard_combine(const void* recs, int world, size_t stride, int na, float* a_out, double* hstat_out,
-                         hipStream_t stream);
+                         hipStream_t stream, const float* bw_old = nullptr, double* bparts = nullptr, int n = 0, int k = 0, int n_pad = 0);
 int launch_dichotomy_acc(double a, const double* b, const double* c, int k, int p, int b_cols, double eps, double tol, int maxit,
                          double* nu_out, int32_t* status, hipStream_t stream);
 int launch_dichotomy_pg(const double* a, int k, int p, double eps, double tol, int maxit, double* nu_out, hipStream_t stream);

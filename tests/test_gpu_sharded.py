@@ -17,28 +17,35 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-N, NX, NY, K, ITERS = 200, 24, 40, 5, 12
-KW = dict(lambda_L=1.0, mu=0.1, simplex_H=True, simplex_W=False, tol=0.0)
+NX, NY, K, ITERS = 24, 40, 5, 12
+# "h": the headline's constraints; "w": the reference's default ones - the simplex over W, whose multipliers come from sums over
+# the channels that the sum over the ranks' records leaves (224 channels: a multiple of 32, the many-workgroup update applies)
+CASES = {"h": (200, dict(lambda_L=1.0, mu=0.1, simplex_H=True, simplex_W=False, tol=0.0)),
+         "w": (224, dict(lambda_L=0.5, mu=0.05, simplex_H=False, simplex_W=True, tol=0.0))}
 
 
-def _data():
+def _data(case):
     from espm_amd import synth
-    prob = synth.make_problem(N, NX, NY, K, N=40.0, seed=2)
+    n = CASES[case][0]
+    prob = synth.make_problem(n, NX, NY, K, N=40.0, seed=2)
     X = synth.sample_numpy(prob, seed=2)
     X[7] = 0                       # a channel without counts in the whole image, pixels without counts in two shards
     X[:, [3, NY + 1, (NX - 1) * NY + 5]] = 0
-    W0, H0 = synth.random_init(N, K, NX * NY, seed=2, scale=0.5)
+    W0, H0 = synth.random_init(n, K, NX * NY, seed=2, scale=0.5)
+    if case == "w":
+        W0 /= W0.sum(axis=0, keepdims=True)
     return X, W0, H0
 
 
-def _worker(rank, world, port, out, transport, granular):
+def _worker(rank, world, port, out, transport, granular, case):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESPM_XCHG=transport)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from espm_amd import sharding
         from espm_amd.engine import MUEngine
         torch.cuda.set_device(0)
-        X, W0, H0 = _data()
+        X, W0, H0 = _data(case)
+        KW = CASES[case][1]
         row0, rows = sharding.split_rows(NX, world, rank)
         sl = slice(row0 * NY, (row0 + rows) * NY)
         eng = MUEngine(X[:, sl], K, shape_2d=(rows, NY), max_iter=ITERS, group=dist.group.WORLD, device="cuda:0", **KW)
@@ -64,21 +71,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,transport,granular", [(2, "p2p", False), (3, "p2p", False), (3, "p2p", True), (2, "collective", False),
-                                                      (3, "collective", True)])
-def test_sharded_engine_matches_single_gpu(world, transport, granular):
+@pytest.mark.parametrize("world,transport,granular,case", [(2, "p2p", False, "h"), (3, "p2p", False, "h"), (3, "p2p", True, "h"),
+                                                           (2, "collective", False, "h"), (3, "collective", True, "h"),
+                                                           (2, "p2p", False, "w"), (3, "collective", True, "w")])
+def test_sharded_engine_matches_single_gpu(world, transport, granular, case):
     from espm_amd.engine import MUEngine
     from oracle import mu_oracle as oc
-    X, W0, H0 = _data()
+    X, W0, H0 = _data(case)
+    KW = CASES[case][1]
     eng = MUEngine(X, K, shape_2d=(NX, NY), max_iter=ITERS, device="cuda:0", **KW)
     assert eng.x_store == "ell" and eng.st.ell_fill_n == 3    # the sparse store, with its pass for the pixels without counts
+    assert case == "h" or eng.st.n_pad % 32 == 0
     eng.load_state(W0, H0)
     eng.iterate(ITERS, final_loss=True)
     torch.cuda.synchronize()
     ref_W, ref_H, ref = eng.get_W(), eng.get_H(), eng.history()
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out, transport, granular), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, transport, granular, case), nprocs=world, join=True)
         res = dict(out)
     assert all(res[r][5] == transport and res[r][6] == 0 for r in range(world)), [(res[r][5], res[r][6]) for r in range(world)]
     for r in range(1, world):
