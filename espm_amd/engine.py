@@ -455,12 +455,12 @@ class MUEngine:
 
     PLANS = {0: "fused, units handed out dynamically", 2: "fused, fixed unit assignment", 1: "H-step and W accumulation as two launches"}
 
-    def autotune_plan(self, iters=24, warm=4):
+    def autotune_plan(self, iters=48, warm=4):
         """Times the launch plans of the iteration that apply to this problem - the fused kernel with dynamic or fixed
         assignment of its work units, the two-launch path (include/espm_mu.h: no_fused) - on the ingested image from the
         loaded state, keeps the fastest and restores the state.  Which plan wins depends on the component count (the fused
         kernel has fewer segments per list group from k = 6 on), the dose and the image size; at the headline problem the
-        dynamic fused plan does.  ~(3 plans) x (warm + iters) iterations of device time, once per fit.  One GPU only."""
+        dynamic fused plan does.  ~(2 + 3) x iters iterations of device time, once per fit.  One GPU only."""
         st = self.st
         if self.sharded or self.frobenius or self.ell is None:
             return None
@@ -469,6 +469,7 @@ class MUEngine:
         if not bool(self.lib.espm_mu_fused_applies(C.byref(st))):
             st.no_fused = keep
             return None
+        iters = int(os.environ.get("ESPM_AUTOTUNE_ITERS", iters))
         iters = min(iters, self.hist_len - st.it - 2 - warm)
         if iters < 4:   # (a fit of a few iterations: nothing to gain)
             st.no_fused = keep
@@ -477,19 +478,33 @@ class MUEngine:
                    self.w_scratch, self.hpart]
         saved = [t.clone() for t in tensors]
         state = (st.cur, st.it)
-        timings = {}
-        for plan in self.PLANS:
-            st.no_fused = plan
-            self._check(self.lib.espm_mu_iterate(C.byref(st), warm, 0, _stream()))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self._check(self.lib.espm_mu_iterate(C.byref(st), iters, 0, _stream()))
-            e1.record()
-            e1.synchronize()
-            timings[plan] = e0.elapsed_time(e1) * 1e3 / iters
+
+        def restore():
             for t, sv in zip(tensors, saved):
                 t.copy_(sv)
             st.cur, st.it = state
+        # The device clocks ramp for ~20 ms after the memory-bound ingest, and the ramp is worth more than
+        # the plans differ by: timed one after the other, the plan that goes first loses (on some boxes of the pool the default
+        # lost to the two-launch plan that way and the loop then ran 5 % slower).  So: a run-in first, then the plans in
+        # interleaved rounds - every plan gets an early, a middle and a late slice.
+        rounds = 3
+        per = max(iters // rounds, 2)
+        st.no_fused = 0
+        self._check(self.lib.espm_mu_iterate(C.byref(st), min(2 * iters, self.hist_len - st.it - 2), 0, _stream()))
+        restore()
+        total = {plan: 0.0 for plan in self.PLANS}
+        for _ in range(rounds):
+            for plan in self.PLANS:
+                st.no_fused = plan
+                self._check(self.lib.espm_mu_iterate(C.byref(st), min(warm, 2), 0, _stream()))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._check(self.lib.espm_mu_iterate(C.byref(st), per, 0, _stream()))
+                e1.record()
+                e1.synchronize()
+                total[plan] += e0.elapsed_time(e1) * 1e3
+                restore()
+        timings = {plan: total[plan] / (rounds * per) for plan in self.PLANS}
         best = min(timings, key=timings.get)
         # the plans are timed inside the clock ramp that follows the ingest, a few per cent of noise included: another plan
         # has to beat the default (fused, dynamic units: the steady-state winner wherever it applies) by 3 % to replace it

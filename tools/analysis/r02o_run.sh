@@ -1,8 +1,6 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02q; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02r; mkdir -p $O
 cd $R
-timeout -k 10 300 python tools/analysis/w_finish_clock_c5.py 2>&1 | grep -v amdgpu
-ROWS=128 python tools/analysis/c5_iter.py 2>&1 | tail -1
-python tools/analysis/c5_iter.py 2>&1 | tail -1
-timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1 || (tail -60 $O/pytest.log | cut -c1-300; exit 1)
-tail -1 $O/pytest.log
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-cpu --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('20/5:', round(d['value']), d['config']['launch_plan'][:14], d['config']['launch_plan_timings_us'])"; done
+python bench.py --no-cpu 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('default:', round(d['value']), d.get('steady_state',{}).get('value'))"
+timeout -k 10 600 python -m pytest tests/test_gpu_fullsize.py -m gpu -q 2>&1 | tail -1
