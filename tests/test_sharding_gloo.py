@@ -164,3 +164,45 @@ def test_split_rows():
     assert [sharding.split_rows(10, 3, r) for r in range(3)] == [(0, 3), (3, 3), (6, 4)]
     with pytest.raises(ValueError):
         sharding.split_rows(2, 4, 0)
+
+
+def _shard_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from espm_amd.estimators.base import _Shard
+        rng = np.random.default_rng(5)            # the same arrays on every rank, rank 0's made distinguishable below
+        H = rng.random((K, NX * NY))
+        W = rng.random((N, K)) + rank             # what a rank's own initialisation would give
+        sh = _Shard(dist.group.WORLD, (NX, NY), NX * NY)
+        row0, rows = sharding.split_rows(NX, world, rank)
+        assert (sh.sl.start, sh.sl.stop) == (row0 * NY, (row0 + rows) * NY) and sh.shape_2d == (rows, NY) and sum(sh.counts) == NX * NY
+        Wb, Hb = sh.broadcast([W, H], "cpu")                     # rank 0's arrays everywhere
+        mine = torch.from_numpy(sh.cols(H)).contiguous()         # this rank's columns ...
+        full = sh.gather_cols(mine)                              # ... assembled on every rank
+        flat = _Shard(dist.group.WORLD, None, NX * NY)           # no image grid: a contiguous split of the pixels
+        out[rank] = (Wb, Hb, full, sh.cols(None) is None, (flat.sl.start, flat.sl.stop), flat.shape_2d, flat.counts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_estimator_shard_helper_under_gloo(world):
+    """The host side of ``est.shard(group)`` (espm_amd/estimators/base.py::_Shard) without a GPU: every rank's block of image
+    rows, rank 0's initial arrays on every rank, the ranks' blocks of H assembled in rank order."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_shard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    rng = np.random.default_rng(5)
+    H = rng.random((K, NX * NY))
+    W0 = rng.random((N, K))
+    stops = []
+    for r in range(world):
+        Wb, Hb, full, none_ok, flat_sl, flat_shape, flat_counts = res[r]
+        np.testing.assert_array_equal(Wb, W0)                    # rank 0's W (the others had + rank)
+        np.testing.assert_array_equal(Hb, H)
+        np.testing.assert_array_equal(full, H)
+        assert none_ok and flat_shape is None and sum(flat_counts) == NX * NY
+        stops.append(flat_sl)
+    assert stops[0][0] == 0 and stops[-1][1] == NX * NY and all(a[1] == b[0] for a, b in zip(stops[:-1], stops[1:]))
