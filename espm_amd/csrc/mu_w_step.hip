@@ -592,8 +592,9 @@ __global__ __launch_bounds__(NT) void w_finish_fast_kernel(const WFinishArgs a) 
   const int k = a.k;
   const int MK = M * k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int SW = (KA + 3) / 4 * 4;   // stride of a row of W' in LDS: whole 16-byte quads (the rows of G W' read them as float4)
   float* s_w = dyn;
-  float* s_gta = dyn + MK;
+  float* s_gta = dyn + (size_t)M * SW;
   ESPM_PHASE_STAMP(0);
 #ifdef ESPM_PHASE_CLOCK
   if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[20] = (unsigned long long)clock64();   // shader clock ticks (against the 100 MHz stamps)
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(NT) void w_finish_fast_kernel(const WFinishArgs a) 
             }
             wn[r][kk] = v;
             a.w_new[mm * k + kk] = v;
-            if (a.g) s_w[mm * k + kk] = v;
+            if (a.g) s_w[mm * SW + kk] = v;
             sum_l += (double)v;
           }
         }
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(NT) void w_finish_fast_kernel(const WFinishArgs a) 
         for (int kk = 0; kk < KA; ++kk) {
           if (kk < k) {
             wn[r][kk] = a.w_new[mm * k + kk];
-            if (a.g) s_w[mm * k + kk] = wn[r][kk];
+            if (a.g) s_w[mm * SW + kk] = wn[r][kk];
           }
         }
       }
@@ -1050,9 +1051,16 @@ __global__ __launch_bounds__(NT) void w_finish_fast_kernel(const WFinishArgs a) 
 #pragma unroll
           for (int b = 0; b < MB; ++b) {
             if (m0 + b < a.m) {
+              // a row of W' as aligned 16-byte reads (one 4-byte read per multiply-add was 16 us of this kernel's 36 at C5)
+              const float4* wr = reinterpret_cast<const float4*>(s_w + (size_t)(m0 + b) * SW);
 #pragma unroll
-              for (int kk = 0; kk < KA; ++kk)
-                if (kk < k) row[kk] = fmaf(gv[b], s_w[(m0 + b) * k + kk], row[kk]);
+              for (int q4 = 0; q4 < SW / 4; ++q4) {
+                const float4 w4 = wr[q4];
+                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (4 * q4 + i < KA) row[4 * q4 + i] = fmaf(gv[b], wv[i], row[4 * q4 + i]);
+              }
             }
           }
         }
@@ -1508,8 +1516,10 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int nt = (!args.g && args.k <= WF_HALF_MAX_K && span <= 4 * 512) ? WF_FEW_THREADS : WF_THREADS;
   const int crows = (span + nt - 1) / nt;               // channels (or, with G = identity, rows of W) per thread
   const int rows = args.g ? (M + nt - 1) / nt : crows;   // rows of W per thread
-  if (crows <= (nt == 256 ? 8 : 4) && rows <= (nt == 256 ? 8 : 4) && (!args.g || mk <= WF_GTA_MAX)) {
-    const size_t lds = args.g ? (size_t)mk * sizeof(float) * (2 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0)) : 0;
+  // G given: [M][k rounded up to 4] new W, [M k] G^T A, and the per-wave partials of the all-threads G^T A (within the 64 KB a
+  // kernel gets without asking)
+  const size_t lds = args.g ? ((size_t)M * ((args.k + 3) / 4 * 4) + (size_t)mk * (1 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0))) * sizeof(float) : 0;
+  if (crows <= (nt == 256 ? 8 : 4) && rows <= (nt == 256 ? 8 : 4) && (!args.g || (mk <= WF_GTA_MAX && lds <= 64 * 1024))) {
     switch (args.k) {
 #define ESPM_X(KK)                                                              \
   case KK:                                                                      \

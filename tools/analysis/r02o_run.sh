@@ -1,7 +1,7 @@
-# scratch script of the last verification run of round 2 (GPU box): bench logs with the final code
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02r; mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.log 2>&1
-python bench.py --steps 20 --warmup 5 > $O/bench_20_5.log 2>&1
-tail -1 $O/bench_default.log | cut -c1-160; tail -1 $O/bench_20_5.log | cut -c1-160
+timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1 || (tail -60 $O/pytest.log | cut -c1-300; exit 1)
+tail -1 $O/pytest.log
+ROWS=128 python tools/analysis/c5_iter.py 2>&1 | tail -1
+python tools/analysis/c5_iter.py 2>&1 | tail -1
