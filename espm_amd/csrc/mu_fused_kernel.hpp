@@ -37,6 +37,10 @@
 #ifndef ESPM_FUSED_SMALL_PREFETCH
 #define ESPM_FUSED_SMALL_PREFETCH 1
 #endif
+// first segment of a list group split in two (k = 7, 8), per cent of its rows
+#ifndef ESPM_FUSED_CUT2
+#define ESPM_FUSED_CUT2 60
+#endif
 #ifndef ESPM_FUSED_FULL_PREFETCH
 #define ESPM_FUSED_FULL_PREFETCH 1
 #endif
@@ -64,7 +68,7 @@ struct FusedGeom {
   static constexpr int MIN_SPLIT = 48;
   static __device__ __forceinline__ int seg_begin(int len, int s) {
     if (len < MIN_SPLIT) return s == 0 ? 0 : len;
-    constexpr int cut4[5] = {0, 35, 65, 85, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, 60, 100};
+    constexpr int cut4[5] = {0, 35, 65, 85, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, ESPM_FUSED_CUT2, 100};
     const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
     return (int)((long)len * c / 100);
   }

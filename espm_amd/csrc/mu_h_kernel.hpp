@@ -107,6 +107,25 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     h_epilogue_load<K>(a, tile0 + (int)threadIdx.x, stencil, in);
     loaded = true;
   }
+  // likewise ahead of the barrier: what every pixel needs of the state's global statistics (scalar loads the compiler may
+  // not move across a barrier itself) and the pixel's loss constant / fill mark
+  const bool want_klc = kl_rows || a.fill_num;
+  float klc_first = 0.f;
+  bool klc_loaded = false;
+  if (want_klc && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {
+    klc_first = a.ell_klc[tile0 + (int)threadIdx.x];
+    klc_loaded = true;
+  }
+  float rel_shift = 0.f;
+  if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
+    double tot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) tot += a.hstat_in[ESPM_HS_ROWSUM + kk];
+    rel_shift = (float)((double)a.rel_tol * tot * a.inv_count);
+  }
+  float mhv[K];   // GLOBAL max over pixels of every row of H, updates.py:139
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) mhv[kk] = (RULE == 0 && a.lambda_l != 0.f) ? (float)a.hstat_in[ESPM_HS_MAX + kk] : 0.f;
   __syncthreads();
   ESPM_PHASE_STAMP(3);
 
@@ -121,13 +140,6 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     }
   };
   const float ls = a.lambda_l * a.sigma_l;
-  float rel_shift = 0.f;
-  if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
-    double tot = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) tot += a.hstat_in[ESPM_HS_ROWSUM + kk];
-    rel_shift = (float)((double)a.rel_tol * tot * a.inv_count);
-  }
   for (int jj = threadIdx.x; jj < TP; jj += (int)blockDim.x) {
     const int q = tile0 + jj;
     if (q >= a.p) {
@@ -136,10 +148,12 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     }
     if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
     loaded = false;
+    const float klc = klc_loaded ? klc_first : (want_klc ? a.ell_klc[q] : 0.f);
+    klc_loaded = false;
     float hin[K], nv[K], dv[K];
     const int prows = kl_rows ? K + 1 : K;   // rows of TP floats per partial
     if (kl_rows) {
-      float s = fmaxf(a.ell_klc[q], 0.f);   // (negative: the mark of a pixel without counts, no constant)
+      float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
       for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + K) * TP + jj];
       red[ESPM_HP_KL] += s;
     }
@@ -152,7 +166,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
     }
     if (a.fill_num) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
-      const float mark = a.ell_klc[q];
+      const float mark = klc;
       if (mark < 0.f) {
         const int idx = (int)(-mark) - 1;
 #pragma unroll
@@ -208,7 +222,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         hlv[kk] = hl;
         red[ESPM_HP_LAP] += hin[kk] * hl;             // measures.py:574-577
         if constexpr (RULE == 0) {
-          const float mh = (float)a.hstat_in[ESPM_HS_MAX + kk];   // GLOBAL max over pixels, updates.py:139
+          const float mh = mhv[kk];
           nv[kk] += ls * mh;                                      // updates.py:140
           dv[kk] += ls * mh + a.lambda_l * hl;                    // updates.py:141
         }
