@@ -626,7 +626,7 @@ struct WFinishArgs {
 
 // ---- reduction of the H-step's per-workgroup records (one workgroup of 256 threads) ---------------
 __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* scratch) {
-  // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and 4 blocks
+  // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and U blocks
   // per thread are in flight at once.  Few waves on purpose: the cross-lane part costs per wave.
   constexpr int NV = ESPM_HP_NSCALAR + 2 * KP;   // [0..3] scalar sums, [4..4+KP) row sums | [4+KP] RELH, then maxima
   constexpr int V_RELH = 4 + KP, V_MAX = 5 + KP;
@@ -634,16 +634,19 @@ __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* 
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = 0.0;
   const size_t nb = a.nblk;
-  for (int b0 = threadIdx.x; b0 < a.nblk; b0 += 4 * 256) {
-    double t[4][ESPM_HP_RELH + 1];
+  // (the wide build's records have 37 fields: 4 of them in flight are 296 registers on top of the 74 of the sums, which took
+  //  every kernel this body rides in - the slab reductions - to one wave per SIMD; the order of the sums does not depend on U)
+  constexpr int U = KP > 8 ? 1 : 4;
+  for (int b0 = threadIdx.x; b0 < a.nblk; b0 += U * 256) {
+    double t[U][ESPM_HP_RELH + 1];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int b = b0 + u * 256;
 #pragma unroll
       for (int i = 0; i <= ESPM_HP_RELH; ++i) t[u][i] = b < a.nblk ? a.hpart[i * nb + b] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < 4 + KP; ++i) v[i] += t[u][i];
       v[V_RELH] = fmax(v[V_RELH], t[u][ESPM_HP_RELH]);
