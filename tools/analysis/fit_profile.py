@@ -24,3 +24,6 @@ for rep in range(2):
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
 print(s.getvalue()[:6000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).print_callers("sum|reduce|method .to.|method .cpu.")
+print(s.getvalue()[:5000])
