@@ -225,3 +225,24 @@ def test_synthetic_generator_is_sharding_consistent():
     np.testing.assert_allclose(full["phases"].sum(axis=1), 1.0, rtol=1e-12)
     X = synth.sample_numpy(full, seed=0)
     assert X.shape == (32, 48) and (X >= 0).all() and X.sum() > 0
+
+
+def test_lu_normaliser_of_the_device_init_equals_scipy():
+    """espm_amd/init_device.py::_lu_pl (the power iterations' normaliser of scikit-learn's randomized SVD, which the reference
+    initialises through: espm/estimators/updates.py:179) against scipy.linalg.lu(A, permute_l=True)[0] - tall, square and
+    wide matrices, both precisions, and identical rows (pixels with the same few counts), which tie for a pivot."""
+    import scipy.linalg as sl
+    import torch
+    from espm_amd.init_device import _lu_pl
+
+    rs = np.random.RandomState(3)
+    for shape in [(5000, 15), (257, 13), (15, 15), (12, 15), (40, 3)]:
+        for dt, tol in ((np.float64, 5e-14), (np.float32, 5e-6)):
+            A = rs.normal(size=shape).astype(dt)
+            ref = sl.lu(A, permute_l=True)[0]
+            got = _lu_pl(torch.from_numpy(A)).numpy()
+            assert got.shape == ref.shape and got.dtype == ref.dtype
+            np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+    A = rs.normal(size=(600, 15))
+    A[100] = A[7] = A[431] = 50.0 * A[3]     # three identical rows, the largest of every column
+    np.testing.assert_allclose(_lu_pl(torch.from_numpy(A)).numpy(), sl.lu(A, permute_l=True)[0], rtol=0, atol=5e-14)
