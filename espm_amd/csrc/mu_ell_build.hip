@@ -16,6 +16,28 @@ namespace espm {
 
 __device__ __forceinline__ int ell_reps(int x, int xmax) { return (x + xmax - 1) / xmax; }
 
+// The non-zero counts of one pixel's row of the (p, n_pad) 8-bit matrix in channel order: f(channel, count).  The row is
+// read 8 bytes at a time (rows start on 8 bytes and end on them: n_pad is a multiple of ESPM_NPAD = 8); byte by byte, with
+// every lane on a row of its own, the builder spent its time on cache lines it had already evicted (count + fill of the
+// pixel lists: 13 ms at the headline size, 96 ms at C5).
+template <typename F>
+__device__ __forceinline__ void ell_for_each_count(const uint8_t* __restrict__ row, int n, F f) {
+  static_assert(ESPM_NPAD % 8 == 0, "8-byte row reads");
+  for (int c0 = 0; c0 < n; c0 += 8) {
+    const uint2 v = *reinterpret_cast<const uint2*>(row + c0);
+    const uint32_t w[2] = {v.x, v.y};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      if (w[d] == 0) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = (int)((w[d] >> (8 * i)) & 255u), c = c0 + 4 * d + i;
+        if (x != 0 && c < n) f(c, x);
+      }
+    }
+  }
+}
+
 // lane = pixel: walks the pixel's row of the (p, n_pad) 8-bit matrix
 __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
                                                           int xmax, int unit_ok, int32_t* __restrict__ cnt_px,
@@ -27,9 +49,7 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
   if (q < p) {
     const uint8_t* row = x_pm + (size_t)q * n_pad;
     const double lxm = (double)xmax * log2((double)xmax);
-    for (int c = 0; c < n; ++c) {
-      const int x = row[c];
-      if (x == 0) continue;
+    ell_for_each_count(row, n, [&](int, int x) {
       const int r = ell_reps(x, xmax);
       cnt += r;
       ones += x == 1;
@@ -37,7 +57,7 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
         const int rest = x - (r - 1) * xmax;
         corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
       }
-    }
+    });
   }
   cnt_px[q] = cnt;
   cnt_px[p_pad + q] = unit_ok ? ones : 0;
@@ -129,6 +149,44 @@ __device__ __forceinline__ long long ell_group_rows(int m, int u, int& unit) {
   return (long long)unit + (m - 2 * unit + 1) / 2;
 }
 
+// (longest list, fewest unit elements) of every list group, one wave per group: H groups [0, ngrp), then the W groups
+// (block, channel group); left in the offset arrays themselves (h_off[2 g], h_off[2 g + 1]), which ell_offsets_kernel then
+// turns into offsets in place.  (Inside the scan, with one thread per few groups and 64 dependent loads each, this took
+// 3 ms of the headline's build and 16 ms of C5's.)
+__global__ __launch_bounds__(256) void ell_group_extent_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc,
+                                                               int n_cg, int nblk, int ngrp, int win,
+                                                               const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ pix_perm,
+                                                               int32_t* __restrict__ h_off, int32_t* __restrict__ w_off) {
+  const int lane = threadIdx.x & 63;
+  const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ncol = n_cg * 64, p_pad = ngrp * 64;
+  if (g >= (long long)ngrp + (long long)nblk * n_cg) return;   // (whole waves)
+  int m, u;
+  int32_t* out;
+  if (g < ngrp) {
+    const int w0 = ((int)g * 64) / win * win;
+    const int q = w0 + pix_perm[g * 64 + lane];
+    m = cnt_px[q];
+    u = cnt_px[p_pad + q];
+    out = h_off + 2 * g;
+  } else {
+    const long long i = g - ngrp;
+    const int b = (int)(i / n_cg);
+    const int c = chan_perm[i * 64 + lane];
+    m = c >= 0 ? cnt_bc[(size_t)b * ncol + c] : 0;
+    u = c >= 0 ? cnt_bc[((size_t)nblk + b) * ncol + c] : 0;
+    out = w_off + 2 * i;
+  }
+  for (int o = 32; o; o >>= 1) {
+    m = max(m, __shfl_xor(m, o));
+    u = min(u, __shfl_xor(u, o));
+  }
+  if (lane == 0) {
+    out[0] = m;
+    out[1] = u;
+  }
+}
+
 __global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc,
                                                            int n_cg, int nblk, int ngrp, int win,
                                                            const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ pix_perm,
@@ -136,32 +194,10 @@ __global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __rest
                                                            long long* __restrict__ rows) {
   __shared__ long long s_sums[1024];
   const int ncol = n_cg * 64, p_pad = ngrp * 64;
-  // H lists of slot group g
-  block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g, int& unit) {
-    const int w0 = (g * 64) / win * win;
-    int m = 0, u = 0x7fffffff;
-    for (int l = 0; l < 64; ++l) {
-      const int q = w0 + pix_perm[g * 64 + l];
-      m = max(m, cnt_px[q]);
-      u = min(u, cnt_px[p_pad + q]);
-    }
-    return ell_group_rows(m, u, unit);
-  });
-  // W lists of (block, channel group)
-  block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i, int& unit) {
-    const int b = i / n_cg;
-    int m = 0, u = 0x7fffffff;
-    for (int l = 0; l < 64; ++l) {
-      const int c = chan_perm[(size_t)i * 64 + l];
-      if (c >= 0) {
-        m = max(m, cnt_bc[(size_t)b * ncol + c]);
-        u = min(u, cnt_bc[((size_t)nblk + b) * ncol + c]);
-      } else {
-        u = 0;
-      }
-    }
-    return ell_group_rows(m, u, unit);
-  });
+  // H lists of slot group g, then the W lists of (block, channel group): extents from ell_group_extent_kernel, replaced by
+  // the offsets (a thread reads an entry before it overwrites it)
+  block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g, int& unit) { return ell_group_rows(h_off[2 * g], h_off[2 * g + 1], unit); });
+  block_scan_rows(nblk * n_cg, w_off, &rows[1], s_sums, [&](int i, int& unit) { return ell_group_rows(w_off[2 * i], w_off[2 * i + 1], unit); });
 }
 
 // Placement of a list's ones in its unit rows so that the table gathers of a wave spread over the LDS banks.
@@ -231,18 +267,18 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
   int holes = 0;
   if (units) {
     b.clear();
-    for (int c = 0; c < n; ++c)
-      if (row[c] == 1) b.count(c);
+    ell_for_each_count(row, n, [&](int c, int x) {
+      if (x == 1) b.count(c);
+    });
     holes = b.plan(slots);
   }
   int j = 0, overflow = 0;
-  for (int c = 0; c < n; ++c) {
-    int x = row[c];
+  ell_for_each_count(row, n, [&](int c, int x) {
     if (x == 1 && units) {
       const int pos = b.place(c, lane, slots, holes, overflow);
       if (pos >= 0) {
         ell_put(base16, row0, pos, lane, (uint32_t)c << 4);
-        continue;
+        return;
       }
     }
     while (x > 0) {
@@ -250,7 +286,7 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
       ell_put(base16, row1, j++, lane, ((uint32_t)v << cbits) | (uint32_t)c);
       x -= v;
     }
-  }
+  });
 }
 
 // lane = channel slot (a wave = one channel group of one pixel block)
@@ -268,28 +304,40 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
   const int q0 = b * pb, q1 = min(p, q0 + pb);
   EllBuckets bk{s_b, s_b + 16 * 64, s_b + 32 * 64, 64, lane};
   int holes = 0;
+  // the channel's counts over the block's pixels, 16 loads in flight at a time (one by one, each waited for, this kernel
+  // was the longest of the build: the lanes' bytes of a pixel lie all over its row)
+  auto for_each_count = [&](auto f) {
+    for (int qb = q0; qb < q1; qb += 16) {
+      int x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = qb + u < q1 ? (int)x_pm[(size_t)(qb + u) * n_pad + c] : 0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (x[u] != 0) f(qb + u - q0, x[u]);
+    }
+  };
   if (units) {
     bk.clear();
-    for (int q = q0; q < q1; ++q)
-      if (x_pm[(size_t)q * n_pad + c] == 1) bk.count(q - q0);
+    for_each_count([&](int i, int x) {
+      if (x == 1) bk.count(i);
+    });
     holes = bk.plan(slots);
   }
   int j = 0, overflow = 0;
-  for (int q = q0; q < q1; ++q) {
-    int x = x_pm[(size_t)q * n_pad + c];
+  for_each_count([&](int i, int x) {
     if (x == 1 && units) {
-      const int pos = bk.place(q - q0, lane, slots, holes, overflow);
+      const int pos = bk.place(i, lane, slots, holes, overflow);
       if (pos >= 0) {
-        ell_put(base16, row0, pos, lane, (uint32_t)(q - q0) << 4);
-        continue;
+        ell_put(base16, row0, pos, lane, (uint32_t)i << 4);
+        return;
       }
     }
     while (x > 0) {
       const int v = x > xmax ? xmax : x;
-      ell_put(base16, row1, j++, lane, ((uint32_t)v << pbits) | (uint32_t)(q - q0));
+      ell_put(base16, row1, j++, lane, ((uint32_t)v << pbits) | (uint32_t)i);
       x -= v;
     }
-  }
+  });
 }
 
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
@@ -313,6 +361,9 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
   }
   hipLaunchKernelGGL(ell_order_kernel, dim3(nblk + p_pad / win), dim3(1024), lds, stream, cnt_px, cnt_bc, n, n_cg, nblk, win,
                      chan_perm, pix_perm);
+  const long long groups = (long long)(p_pad / 64) + (long long)nblk * n_cg;
+  hipLaunchKernelGGL(ell_group_extent_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, cnt_px, cnt_bc, n_cg, nblk,
+                     p_pad / 64, win, chan_perm, pix_perm, h_off, w_off);
   hipLaunchKernelGGL(ell_offsets_kernel, dim3(1), dim3(1024), 0, stream, cnt_px, cnt_bc, n_cg, nblk, p_pad / 64, win, chan_perm,
                      pix_perm, h_off, w_off, rows);
   return check_hip(hipGetLastError(), "ell_plan launch");
