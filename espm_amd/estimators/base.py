@@ -9,6 +9,7 @@ Stop rules, attribute names, printed messages and return conventions follow the 
 """
 from __future__ import annotations
 
+import os
 import time
 from abc import ABC, abstractmethod
 
@@ -38,50 +39,104 @@ def _is_physical_model(G):
 class _HostCopy:
     """``X_`` of a large fit in the making.  The reference keeps its own copy of the data (remove_zeros_lines copies,
     base.py:519-528; normalize scales it, base.py:264-267): at 2048 x 512^2 fp32 those host passes are 0.2-0.4 s of a fit whose
-    200 iterations take 0.03 s.  They run on a worker thread (numpy releases the GIL) while the device ingests the image and
-    iterates; the fit joins it at its end.  Until then this object stands in for the array: shape and dtype are known at once,
-    anything else (``__array__``, ``.T``, indexing ...) waits for the copy."""
+    200 iterations take 0.03 s.  They run on worker threads (numpy releases the GIL) while the device initialises and
+    iterates; the fit joins them at its end.  Until then this object stands in for the array: shape and dtype are known at once,
+    anything else (``__array__``, ``.T``, indexing ...) waits for the copy.
+
+    ``finish`` hands over what the device scans found, ``start`` lets the copy run - ONE pass over row blocks on a few threads:
+    copy, scale, fill - once the fit is in its iteration loop: overlapping the upload it competed with it for the host's memory
+    bandwidth (upload 47 -> 140 ms, copy 160 -> 340 ms), overlapping the initialisation or the engine set-up its page faults
+    stalled those (50 -> 220 ms)."""
+
+    THREADS = 4
+
+    class _State:   # what the worker holds (not the stand-in itself: a stand-in nobody references any more lets its worker go)
+        __slots__ = ("src", "layout", "params", "go", "out", "err")
 
     def __init__(self, src, layout):
         import threading
         self.shape, self.dtype, self.size, self.ndim = src.shape, src.dtype, src.size, src.ndim
-        self._src, self._layout = src, layout
-        self._params = None            # (pixel mask, channel mask, fill, scale), set by finish()
-        self._go, self._out, self._err = threading.Event(), None, None
-        self._thread = threading.Thread(target=self._run, daemon=True)
+        st = self._st = _HostCopy._State()
+        st.src, st.layout = src, layout
+        st.params = None            # (pixel mask, channel mask, fill, scale), set by finish()
+        st.go, st.out, st.err = threading.Event(), None, None
+        self._thread = threading.Thread(target=_HostCopy._run, args=(st,), daemon=True)
         self._thread.start()
 
-    def _run(self):
+    def __del__(self):
+        st = self.__dict__.get("_st")
+        if st is not None and not st.go.is_set():   # never started (a fit that raised before its loop): nothing to copy for
+            st.params = None
+            st.go.set()
+
+    @staticmethod
+    def _run(st):
+        import threading
         try:
-            # a straight copy of the memory as it lies (for a pixel-major input: its transposed view), not a strided gather
-            out = self._src.copy() if self._layout == "cm" else self._src.T.copy().T
-            self._src = None
-            self._go.wait()
-            if self._params is None:   # cancelled
+            st.go.wait()
+            if st.params is None:   # cancelled
+                st.src = None
                 return
-            zp, zc, fill, scale = self._params
+            zp, zc, fill, scale = st.params
+            # the memory as it lies (for a pixel-major input: its transposed view), not a strided gather
+            src = st.src if st.layout == "cm" else st.src.T
+            st.src = None
+            base = np.empty(src.shape, dtype=src.dtype)
+            row_mask, col_mask = (zc, zp) if st.layout == "cm" else (zp, zc)   # masks over the rows / columns of `base`
+            # an empty line holds fill, then everything is scaled (base.py:519-528, :264-267): fill * scale in the array's precision
+            filled = None
             if zp is not None:
-                out[:, zp] = fill
-                out[zc, :] = fill
-            if scale is not None:
-                np.multiply(out, scale, out=out)
-            self._out = out
+                filled = np.full(1, fill, dtype=src.dtype)
+                if scale is not None:
+                    np.multiply(filled, scale, out=filled)
+            errs = []
+
+            def block(a, b):
+                try:
+                    if scale is not None:
+                        np.multiply(src[a:b], scale, out=base[a:b])
+                    else:
+                        np.copyto(base[a:b], src[a:b])
+                    if filled is not None:
+                        base[a:b][:, col_mask] = filled[0]
+                        base[a:b][row_mask[a:b]] = filled[0]
+                except BaseException as e:  # noqa: BLE001
+                    errs.append(e)
+
+            nt = max(1, min(_HostCopy.THREADS, src.shape[0]))
+            edges = np.linspace(0, src.shape[0], nt + 1).astype(int)
+            helpers = [threading.Thread(target=block, args=(int(edges[i]), int(edges[i + 1])), daemon=True) for i in range(1, nt)]
+            for t in helpers:
+                t.start()
+            block(int(edges[0]), int(edges[1]))
+            for t in helpers:
+                t.join()
+            if errs:
+                raise errs[0]
+            st.out = base if st.layout == "cm" else base.T
         except BaseException as e:  # noqa: BLE001 - re-raised by result()
-            self._err = e
+            st.err = e
 
     def finish(self, zp=None, zc=None, fill=None, scale=None):
         """What the device scans found: empty pixels / channels to fill (base.py:519-528), the normalisation factor."""
-        self._params = (zp, zc, fill, scale)
-        self._go.set()
+        self._st.params = (zp, zc, fill, scale)
+
+    def start(self):
+        """Lets the copy run: called when the fit enters its iteration loop (the main thread then sits in one C call per chunk
+        of iterations; started earlier, the copy's page faults and memory traffic stalled whatever host phase it overlapped -
+        upload, initialisation, set-up - by 100 ms at a time)."""
+        self._st.go.set()
 
     def cancel(self):
-        self._go.set()
+        self._st.params = None
+        self._st.go.set()
 
     def result(self):
+        self._st.go.set()   # (asked for before the loop - e.g. a least-squares initialisation reads X_ - or never started)
         self._thread.join()
-        if self._err is not None:
-            raise self._err
-        return self._out
+        if self._st.err is not None:
+            raise self._st.err
+        return self._st.out
 
     def __array__(self, dtype=None, copy=None):
         out = self.result()
@@ -451,6 +506,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         eval_before = np.inf
         eval_init = None
         stop = False
+        if lazy is not None:
+            lazy.start()
         try:
             eng.eval_current(advance_h=True)  # loss of the initial state rides on the first H-step
             while not stop:
