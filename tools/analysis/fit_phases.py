@@ -29,7 +29,11 @@ base.NMFEstimator._make_engine = timed("engine set-up (pack, sparse store build,
 MUEngine.iterate = timed("iterate", MUEngine.iterate)
 MUEngine.history = timed("history read-back", MUEngine.history)
 MUEngine.get_W = timed("get_W", MUEngine.get_W)
-base._HostCopy.result = timed("join of the host copy X_", base._HostCopy.result)
+if os.environ.get("NOCOPY") == "1":   # experiment: the fit without the estimator's host copy X_ (is the copy what unsettles the phases?)
+    base._HostCopy.start = lambda self: None
+    base._HostCopy.result = lambda self: None
+else:
+    base._HostCopy.result = timed("join of the host copy X_", base._HostCopy.result)
 _to = torch.Tensor.to
 
 
