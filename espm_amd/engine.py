@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -77,6 +78,14 @@ class MUEngine:
         self.V = _lib.variant(k)          # the build with the kernels for k components (1..8, or 9..16 on the dense stores)
         self.lib, self._check = self.V.lib, self.V.check
 
+        _t_dbg = [time.perf_counter()] if os.environ.get("ESPM_ENGINE_TIMING") else None
+
+        def _tick(name):   # ESPM_ENGINE_TIMING=1: device-synchronised time of the set-up steps (tools/analysis)
+            if _t_dbg is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                print(f"[engine set-up] {name}: {1e3 * (now - _t_dbg[0]):.1f} ms", flush=True)
+                _t_dbg[0] = now
         # ---- X to the device, zero lines, storage type ------------------------------------------
         Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
         if Xd.dtype not in (torch.float32, torch.float64):
@@ -127,6 +136,7 @@ class MUEngine:
         if group is not None:
             torch.distributed.all_reduce(self.sum_x, group=group)
         self.sum_x = float(self.sum_x)
+        _tick("sign check, empty lines, sum of X")
         self.bregman = bool(bregman)
         if self.bregman:
             # Bregman variant (updates.py:40-48, :120-125): sums of X over the channels (per pixel) and over the pixels
@@ -175,8 +185,10 @@ class MUEngine:
             if unfilled:
                 set_empty(0)
             is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
-            exact = (Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16
-            code = 2 if bool(is_count) else (1 if bool(exact) else 0)
+            if bool(is_count):
+                code = 2
+            else:   # (the bf16 round trip is two more passes over X and two temporaries of its size: only when it decides)
+                code = 1 if bool((Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16) else 0
             if code == 2:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
@@ -185,6 +197,7 @@ class MUEngine:
                 if fits and (x_store == "ell" or sparse):
                     code = 3
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
+            _tick("storage type (integer counts, bf16-exact, density)")
             if group is not None:
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
             if unfilled and int(flag.item()) != 3:
@@ -234,6 +247,7 @@ class MUEngine:
                 self.ell = _ell.build(Xd if layout == "pm" else Xd.t(), st.p_pad, st.ell_cbits, st.tile_px)
             else:
                 self.ell = self._build_ell(Xd.contiguous(), layout)
+                _tick("sparse store build")
             assert self.ell["n_cg"] == st.n_cg and self.ell["nblk_w"] == st.nblk_w
             # pixels without counts: marked in the per-pixel loss constants, their fill's numerator has its own small pass
             if empty_px is not None and bool(empty_px.any()):
@@ -307,6 +321,7 @@ class MUEngine:
         nblk_h = (self.p + st.tile_px - 1) // st.tile_px
         self.hpart = torch.zeros((nblk_h, self.V.HP_STRIDE), **f64)
         self.hstat = [torch.zeros(self.V.HS_STRIDE, **f64) for _ in range(2)]
+        _tick("rest up to the state buffers")
         self.a_slab = torch.zeros((st.nblk_w, k, st.n_pad), **f32)
         self.a = torch.zeros((k, st.n_pad), **f32)
         self.w_scratch = torch.zeros((2, self.M, k), **f32)
