@@ -86,6 +86,7 @@ class MUEngine:
                 now = time.perf_counter()
                 print(f"[engine set-up] {name}: {1e3 * (now - _t_dbg[0]):.1f} ms", flush=True)
                 _t_dbg[0] = now
+
         # ---- X to the device, zero lines, storage type ------------------------------------------
         Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
         if Xd.dtype not in (torch.float32, torch.float64):
