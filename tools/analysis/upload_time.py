@@ -33,7 +33,38 @@ def staged():
     return out
 
 
-for name, fn in (("torch .to() from pageable memory", plain), ("64 MB pinned double buffer", staged), ("torch .to() from pageable memory", plain)):
+NB = 4
+pin4 = [torch.empty((CH, X.shape[1]), dtype=torch.float32).pin_memory() for _ in range(NB)]
+pin4_np = [p.numpy() for p in pin4]
+ev4 = [torch.cuda.Event() for _ in range(NB)]
+
+
+def staged_threads(nthreads=2):
+    # `nthreads` host threads fill the pinned buffers (numpy releases the GIL), each thread owns the buffers j = t mod nthreads
+    import threading
+    out = torch.empty(X.shape, dtype=torch.float32, device=dev)
+    chunks = list(range(0, X.shape[0], CH))
+    streams = [torch.cuda.Stream() for _ in range(nthreads)]
+
+    def work(t):
+        with torch.cuda.stream(streams[t]):
+            for i in range(t, len(chunks), nthreads):
+                j = (i // nthreads % (NB // nthreads)) * nthreads + t
+                ev4[j].synchronize()
+                a = chunks[i]
+                b = min(a + CH, X.shape[0])
+                np.copyto(pin4_np[j][:b - a], X[a:b])
+                out[a:b].copy_(pin4[j][:b - a], non_blocking=True)
+                ev4[j].record(streams[t])
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    return out
+
+
+for name, fn in (("torch .to() from pageable memory", plain), ("64 MB pinned double buffer", staged), ("pinned buffers filled by 2 threads", staged_threads),
+                 ("torch .to() from pageable memory", plain)):
     ts = []
     for _ in range(7):
         torch.cuda.synchronize()
@@ -41,5 +72,7 @@ for name, fn in (("torch .to() from pageable memory", plain), ("64 MB pinned dou
         y = fn()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
+        if ts[-1:] and len(ts) == 1:
+            assert bool((y.cpu() == torch.from_numpy(X)).all()), name
         del y
     print(f"{name:36s}: " + " ".join(f"{1e3 * t:6.1f}" for t in ts) + " ms")
