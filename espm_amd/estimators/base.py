@@ -444,9 +444,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         X_init_dev = None
         if Xd is not None:
             X_init_dev = Xd * xscale if self.normalize else Xd
-            xs = X_init_dev.to(torch.float64) if X_init_dev.dtype != torch.float64 else X_init_dev
-            self._const_KL_dev = float((xs * torch.log(xs.clamp_min(self.log_shift))).sum() - xs.sum())
-            del xs
+            # const_KL_ = sum(X log X - X) in fp64 (base.py:200-201), in row chunks of 64 M entries: in one piece its fp64 copy
+            # and the three temporaries of the expression were 17 GB next to a 2 GB image
+            rows_of = X_init_dev if X_init_dev.is_contiguous() else X_init_dev.t()   # (the orientation the memory lies in)
+            step = max(1, (64 << 20) // max(1, int(rows_of.shape[1])))
+            total = torch.zeros((), dtype=torch.float64, device=rows_of.device)
+            for a in range(0, int(rows_of.shape[0]), step):
+                xs = rows_of[a:a + step].to(torch.float64)
+                total += (xs * torch.log(xs.clamp_min(self.log_shift))).sum() - xs.sum()
+            self._const_KL_dev = float(total)
+            del xs, rows_of
 
         if _is_physical_model(self.G):
             self.physics_model_ = self.G
