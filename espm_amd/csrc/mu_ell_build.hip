@@ -187,13 +187,9 @@ __global__ __launch_bounds__(256) void ell_group_extent_kernel(const int32_t* __
   }
 }
 
-__global__ __launch_bounds__(1024) void ell_offsets_kernel(const int32_t* __restrict__ cnt_px, const int32_t* __restrict__ cnt_bc,
-                                                           int n_cg, int nblk, int ngrp, int win,
-                                                           const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ pix_perm,
-                                                           int32_t* __restrict__ h_off, int32_t* __restrict__ w_off,
-                                                           long long* __restrict__ rows) {
+__global__ __launch_bounds__(1024) void ell_offsets_kernel(int n_cg, int nblk, int ngrp, int32_t* __restrict__ h_off,
+                                                           int32_t* __restrict__ w_off, long long* __restrict__ rows) {
   __shared__ long long s_sums[1024];
-  const int ncol = n_cg * 64, p_pad = ngrp * 64;
   // H lists of slot group g, then the W lists of (block, channel group): extents from ell_group_extent_kernel, replaced by
   // the offsets (a thread reads an entry before it overwrites it)
   block_scan_rows(ngrp, h_off, &rows[0], s_sums, [&](int g, int& unit) { return ell_group_rows(h_off[2 * g], h_off[2 * g + 1], unit); });
@@ -364,8 +360,7 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
   const long long groups = (long long)(p_pad / 64) + (long long)nblk * n_cg;
   hipLaunchKernelGGL(ell_group_extent_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, cnt_px, cnt_bc, n_cg, nblk,
                      p_pad / 64, win, chan_perm, pix_perm, h_off, w_off);
-  hipLaunchKernelGGL(ell_offsets_kernel, dim3(1), dim3(1024), 0, stream, cnt_px, cnt_bc, n_cg, nblk, p_pad / 64, win, chan_perm,
-                     pix_perm, h_off, w_off, rows);
+  hipLaunchKernelGGL(ell_offsets_kernel, dim3(1), dim3(1024), 0, stream, n_cg, nblk, p_pad / 64, h_off, w_off, rows);
   return check_hip(hipGetLastError(), "ell_plan launch");
 }
 
