@@ -286,11 +286,18 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
 }
 
 // lane = channel slot (a wave = one channel group of one pixel block)
-__global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg, int pb, int pbits,
+// (ESPM_ELL_FILLW_WAVES channel groups of one block per workgroup: the waves read the same pixel rows at about the same
+//  time, and a lane's byte drags in the cache line around it - with a group per workgroup every row was fetched 32 times)
+#ifndef ESPM_ELL_FILLW_WAVES
+#define ESPM_ELL_FILLW_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg, int pb, int pbits,
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
                                                         uint32_t* __restrict__ ell_w) {
-  __shared__ uint16_t s_b[(16 + 16 + 17) * 64];
-  const int b = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
+  constexpr int NT = 64 * ESPM_ELL_FILLW_WAVES;
+  __shared__ uint16_t s_b[(16 + 16 + 17) * NT];
+  const int b = blockIdx.x, cg = blockIdx.y * ESPM_ELL_FILLW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cg >= n_cg) return;   // (whole waves; no barrier below)
   const int c = chan_perm[((size_t)b * n_cg + cg) * 64 + lane];
   if (c < 0) return;
   const int xmax = (1 << (16 - pbits)) - 1;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(64) void ell_fill_w_kernel(const uint8_t* __restric
   const size_t row0 = (size_t)w_off[2 * ((size_t)b * n_cg + cg)], row1 = (size_t)w_off[2 * ((size_t)b * n_cg + cg) + 1];
   const int units = 2 * (int)(row1 - row0), slots = units / 16;
   const int q0 = b * pb, q1 = min(p, q0 + pb);
-  EllBuckets bk{s_b, s_b + 16 * 64, s_b + 32 * 64, 64, lane};
+  EllBuckets bk{s_b, s_b + 16 * NT, s_b + 32 * NT, NT, (int)threadIdx.x};
   int holes = 0;
   // the channel's counts over the block's pixels, 16 loads in flight at a time (one by one, each waited for, this kernel
   // was the longest of the build: the lanes' bytes of a pixel lie all over its row)
@@ -369,7 +376,7 @@ int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int
                     uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream) {
   hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
                      pix_perm, h_off, ell_h);
-  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, n_cg), dim3(64), 0, stream, x_pm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
+  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, stream, x_pm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
   return check_hip(hipGetLastError(), "ell_fill launch");
 }
 
