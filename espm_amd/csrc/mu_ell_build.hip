@@ -16,25 +16,44 @@ namespace espm {
 
 __device__ __forceinline__ int ell_reps(int x, int xmax) { return (x + xmax - 1) / xmax; }
 
-// The non-zero counts of one pixel's row of the (p, n_pad) 8-bit matrix in channel order: f(channel, count).  The row is
-// read 8 bytes at a time (rows start on 8 bytes and end on them: n_pad is a multiple of ESPM_NPAD = 8); byte by byte, with
-// every lane on a row of its own, the builder spent its time on cache lines it had already evicted (count + fill of the
-// pixel lists: 13 ms at the headline size, 96 ms at C5).
+// The non-zero counts of the 256 pixel rows of a workgroup (thread t: row q_mine of the (p, n_pad) 8-bit matrix, -1 for none),
+// each in channel order: f(channel, count).  The rows are staged through LDS in chunks of 128 channels: the workgroup fetches
+// the chunk of all its rows with consecutive threads on consecutive 8 bytes of a row (rows start and end on 8 bytes: n_pad is a
+// multiple of ESPM_NPAD = 8), then every thread walks its own 128 bytes.  Byte by byte and thread by thread, straight from
+// memory, the builder spent its time on cache lines it had already evicted (pixel-list count + fill: 13 ms of the build at the
+// headline size, 96 ms at C5; now 3.5 and 12.8).
+// tile: 256 rows of 33 words (the odd stride keeps the 64 lanes of a wave on distinct banks), s_q: 256 ints.  Every thread
+// of the workgroup must call it (barriers).
 template <typename F>
-__device__ __forceinline__ void ell_for_each_count(const uint8_t* __restrict__ row, int n, F f) {
+__device__ __forceinline__ void ell_block_for_each_count(const uint8_t* __restrict__ x_pm, int n, int n_pad, int q_mine,
+                                                         uint32_t* tile, int* s_q, F f) {
   static_assert(ESPM_NPAD % 8 == 0, "8-byte row reads");
-  for (int c0 = 0; c0 < n; c0 += 8) {
-    const uint2 v = *reinterpret_cast<const uint2*>(row + c0);
-    const uint32_t w[2] = {v.x, v.y};
+  const int t = threadIdx.x;
+  s_q[t] = q_mine;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 128) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      if (w[d] == 0) continue;
+    for (int i = 0; i < 16; ++i) {
+      const int id = i * 256 + t, r = id >> 4, c8 = id & 15;
+      const int q = s_q[r], c = c0 + 8 * c8;
+      uint2 v = make_uint2(0u, 0u);
+      if (q >= 0 && c < n_pad) v = *reinterpret_cast<const uint2*>(x_pm + (size_t)q * n_pad + c);
+      tile[r * 33 + 2 * c8] = v.x;
+      tile[r * 33 + 2 * c8 + 1] = v.y;
+    }
+    __syncthreads();
+    if (q_mine >= 0) {
+      for (int w = 0; w < 32; ++w) {
+        const uint32_t word = tile[t * 33 + w];
+        if (word == 0) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = (int)((w[d] >> (8 * i)) & 255u), c = c0 + 4 * d + i;
-        if (x != 0 && c < n) f(c, x);
+        for (int i = 0; i < 4; ++i) {
+          const int x = (int)((word >> (8 * i)) & 255u), c = c0 + 4 * w + i;
+          if (x != 0 && c < n) f(c, x);
+        }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -42,23 +61,22 @@ __device__ __forceinline__ void ell_for_each_count(const uint8_t* __restrict__ r
 __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
                                                           int xmax, int unit_ok, int32_t* __restrict__ cnt_px,
                                                           float* __restrict__ klc) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= p_pad) return;
+  __shared__ uint32_t s_tile[256 * 33];
+  __shared__ int s_q[256];
+  const int q = blockIdx.x * 256 + threadIdx.x;   // (p_pad is a multiple of 256: every thread has a slot)
   int cnt = 0, ones = 0;
   double corr = 0.0;
-  if (q < p) {
-    const uint8_t* row = x_pm + (size_t)q * n_pad;
-    const double lxm = (double)xmax * log2((double)xmax);
-    ell_for_each_count(row, n, [&](int, int x) {
-      const int r = ell_reps(x, xmax);
-      cnt += r;
-      ones += x == 1;
-      if (r > 1) {  // x log2 x - sum over its entries of x_i log2 x_i
-        const int rest = x - (r - 1) * xmax;
-        corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
-      }
-    });
-  }
+  const double lxm = (double)xmax * log2((double)xmax);
+  ell_block_for_each_count(x_pm, n, n_pad, q < p ? q : -1, s_tile, s_q, [&](int, int x) {
+    const int r = ell_reps(x, xmax);
+    cnt += r;
+    ones += x == 1;
+    if (r > 1) {  // x log2 x - sum over its entries of x_i log2 x_i
+      const int rest = x - (r - 1) * xmax;
+      corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
+    }
+  });
+  if (q >= p_pad) return;
   cnt_px[q] = cnt;
   cnt_px[p_pad + q] = unit_ok ? ones : 0;
   klc[q] = (float)corr;
@@ -249,27 +267,32 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
                                                          int cbits, int win, const int32_t* __restrict__ pix_perm,
                                                          const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
   __shared__ uint16_t s_b[(16 + 16 + 17) * 256];
+  __shared__ uint32_t s_tile[256 * 33];
+  __shared__ int s_q[256];
   const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= p_pad) return;
-  const int q = slot / win * win + pix_perm[slot];
-  if (q >= p) return;
+  int q = -1;   // (a slot beyond p_pad, a pixel beyond p: no list, but the thread still helps to stage the rows)
+  if (slot < p_pad) {
+    q = slot / win * win + pix_perm[slot];
+    if (q >= p) q = -1;
+  }
   const int xmax = (1 << (16 - cbits)) - 1;
   uint16_t* base16 = reinterpret_cast<uint16_t*>(ell_h);
-  const size_t row0 = (size_t)h_off[2 * (slot >> 6)], row1 = (size_t)h_off[2 * (slot >> 6) + 1];
+  size_t row0 = 0, row1 = 0;
+  if (q >= 0) {
+    row0 = (size_t)h_off[2 * (slot >> 6)];
+    row1 = (size_t)h_off[2 * (slot >> 6) + 1];
+  }
   const int units = 2 * (int)(row1 - row0), slots = units / 16;
   const int lane = slot & 63;
-  const uint8_t* row = x_pm + (size_t)q * n_pad;
   EllBuckets b{s_b, s_b + 16 * 256, s_b + 32 * 256, 256, (int)threadIdx.x};
   int holes = 0;
-  if (units) {
-    b.clear();
-    ell_for_each_count(row, n, [&](int c, int x) {
-      if (x == 1) b.count(c);
-    });
-    holes = b.plan(slots);
-  }
+  b.clear();
+  ell_block_for_each_count(x_pm, n, n_pad, q, s_tile, s_q, [&](int c, int x) {
+    if (x == 1 && units) b.count(c);
+  });
+  if (units) holes = b.plan(slots);
   int j = 0, overflow = 0;
-  ell_for_each_count(row, n, [&](int c, int x) {
+  ell_block_for_each_count(x_pm, n, n_pad, q, s_tile, s_q, [&](int c, int x) {
     if (x == 1 && units) {
       const int pos = b.place(c, lane, slots, holes, overflow);
       if (pos >= 0) {
