@@ -9,4 +9,4 @@ package without that library fails loudly.
 """
 from . import _lib  # noqa: F401  (loads libespm_mu.so or raises)
 
-__version__ = "0.1.0"
+from ._version import __version__  # noqa: E402,F401

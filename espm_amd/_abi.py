@@ -10,7 +10,11 @@ import ctypes as C
 import os
 import re
 
-HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "espm_mu.h")
+# The repository's include/espm_mu.h (the one hand-kept copy); an installed package carries a copy of it next to the library
+# (espm_amd/include/espm_mu.h, placed there by __graft_entry__.build() and listed in pyproject.toml's package-data).
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO_HEADER = os.path.join(os.path.dirname(_HERE), "include", "espm_mu.h")
+HEADER = _REPO_HEADER if os.path.exists(_REPO_HEADER) else os.path.join(_HERE, "include", "espm_mu.h")
 
 _SCALARS = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "float": C.c_float,
             "double": C.c_double, "int": C.c_int, "size_t": C.c_size_t}

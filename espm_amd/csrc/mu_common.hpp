@@ -791,6 +791,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
                            const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream, WTailArgs* defer_tail = nullptr);
 int launch_w_update_tail(const WTailArgs& t, hipStream_t stream);
+int w_exchange_resident_workgroups();   // workgroups of the one-launch exchange kernel the device holds at once (its grid must fit)
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const struct ::espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny,
                              int p_pad, int with_halo, hipStream_t stream, WTailArgs* defer_tail);

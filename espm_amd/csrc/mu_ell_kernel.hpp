@@ -116,9 +116,20 @@ struct EllTab {
 
 // y = sum_k g[k] h[k] and acc[k] += g[k] r with component PAIRS in fp32x2 registers (v_pk_fma_f32: the float4
 // of a gathered row already sits in two aligned register pairs), an odd last component as a scalar FMA.
+// ESPM_ELL_DOT_PLAIN: y as a chain of K scalar FMAs instead of K / 2 packed ones + the horizontal add (by the issue costs of
+// tools/ubench/valu_rate.hip 12.5 against 14.4 cycles at k = 5).  Measured: no gain (147.9 against 146.9 us per iteration at
+// the headline, profiles/r03a_variant_ab_512.log) - off.
+#ifndef ESPM_ELL_DOT_PLAIN
+#define ESPM_ELL_DOT_PLAIN 0
+#endif
 template <int K>
 __device__ __forceinline__ float ell_dot(const float (&g)[K], const float (&h)[K]) {
-  if constexpr (K == 1) {
+  if constexpr (ESPM_ELL_DOT_PLAIN) {
+    float y = g[0] * h[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) y = fmaf(g[i], h[i], y);
+    return y;
+  } else if constexpr (K == 1) {
     return g[0] * h[0];
   } else {
     f2 s = f2{g[0], g[1]} * f2{h[0], h[1]};
@@ -144,8 +155,14 @@ __device__ __forceinline__ void ell_axpy(float (&acc)[K], const float (&g)[K], f
 // dword, consecutive dwords are 64 apart.  UNR dwords are requested one batch ahead of their use and the
 // 2 UNR table gathers of a batch are issued together.  get(dword, half, g) gathers the table row of entry
 // `half` of the dword into g and returns the entry's count; body(count, g) consumes one entry.
-template <int K, int UNR, int PF = 1, typename Get, typename Body>
-__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body) {
+// flush(redo): called after every batch of 2 UNR entries (and after every dword of the remainder); redo(alt) walks the
+// entries of that batch once more with the body `alt` (the logarithm of a product of ratios falls back on it, ell_h_rows).
+struct EllNoFlush {
+  template <typename Redo>
+  __device__ __forceinline__ void operator()(Redo) const {}
+};
+template <int K, int UNR, int PF = 1, typename Get, typename Body, typename Flush = EllNoFlush>
+__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
   auto batch = [&](const uint32_t (&e)[UNR]) {
@@ -157,6 +174,15 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
     }
 #pragma unroll
     for (int u = 0; u < 2 * UNR; ++u) body(x[u], g[u]);
+    flush([&](auto alt) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        float g0[K], g1[K];
+        const float x0 = get(e[u], 0, g0), x1 = get(e[u], 1, g1);
+        alt(x0, g0);
+        alt(x1, g1);
+      }
+    });
   };
   int j = 0;
   if (len >= UNR) {
@@ -187,6 +213,12 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
     const float x0 = get(v, 0, g0), x1 = get(v, 1, g1);
     body(x0, g0);
     body(x1, g1);
+    flush([&](auto alt) {
+      float a0[K], a1[K];
+      const float y0 = get(v, 0, a0), y1 = get(v, 1, a1);
+      alt(y0, a0);
+      alt(y1, a1);
+    });
   }
 }
 // general entries: count << idx_bits | index
@@ -212,6 +244,60 @@ struct EllGetUnit {
     return 1.f;
   }
 };
+
+// The H walk over rows [x0, x1) of a list group whose first `mid` rows are unit rows: num += GW^T (X / (GW H)) of the lane's
+// pixel (updates.py:127-128 at the non-zero entries) and, with LOSS, kl += sum x log2(x / y).
+// ESPM_ELL_KLPROD: the unit rows' part of the loss, sum log2(1 / y), as ONE logarithm per batch of 2 UNR entries - of the
+// product of their ratios (v_log_f32 costs 8 cycles of the vector pipe and the add 2.5, the multiply 2.5).  The product of
+// eight ratios can leave the normal range where the single ratios do not (y < ~2e-5 throughout a batch): if ANY lane of the
+// wave finds its product not a positive normal number, the wave takes the batch's logarithms entry by entry (the rows are
+// gathered once more; wave-uniform branch, not taken on data a fit sees after its first iterations).  The grouping follows the
+// rows of the list, not the wave that walks them: the loss stays bit-reproducible.
+// Measured at the headline (tools/analysis/variant_ab.py, profiles/r03a_variant_ab_512.log): 146-150 -> 142-148 us per iteration,
+// losses equal to 4e-9 relative, W and H bit for bit.
+#ifndef ESPM_ELL_KLPROD
+#define ESPM_ELL_KLPROD 1
+#endif
+template <int K, bool LOSS, int UNR, int PF>
+__device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1, int mid, const float* tab, int n_pad, int ell_bits,
+                                           const float (&hk)[K], float (&acc)[K], float& kl) {
+  if (x0 < mid) {
+    if constexpr (LOSS && ESPM_ELL_KLPROD) {
+      float prod = 1.f;
+      ell_walk<K, UNR, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
+        [&](float, const float (&g)[K]) {
+          const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+          ell_axpy<K>(acc, g, r);
+          prod *= r;
+        },
+        [&](auto redo) {
+          const bool ok = __builtin_amdgcn_classf(prod, 0x100);   // a positive normal number
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+            redo([&](float, const float (&g)[K]) { kl += __builtin_amdgcn_logf(__builtin_amdgcn_rcpf(ell_dot<K>(g, hk))); });
+          } else {
+            kl += __builtin_amdgcn_logf(prod);
+          }
+          prod = 1.f;
+        });
+    } else {
+      ell_walk<K, UNR, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
+        const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
+        ell_axpy<K>(acc, g, r);
+        if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
+      });
+    }
+  }
+  if (x1 > mid) {
+    const int g0 = max(x0, mid);
+    ell_walk<K, UNR, PF>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
+      const float y = ell_dot<K>(g, hk);
+      // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
+      const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
+      ell_axpy<K>(acc, g, r);
+      if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
+    });
+  }
+}
 
 // ---- H-step --------------------------------------------------------------------------------------
 // One workgroup = 8 waves = TP = 512 / nsplit pixels.  updates.py:127-132 restricted to the non-zero entries of X;
@@ -274,23 +360,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_ker
     // rows [0, mid) of the group: unit entries, [mid, len): general entries
     const int beg = a.ell_off[2 * grp], mid = a.ell_off[2 * grp + 1] - beg;
     const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-    if (x0 < mid) {
-      ell_walk<K, UNR>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
-        const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
-        ell_axpy<K>(acc, g, r);
-        if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
-      });
-    }
-    if (x1 > mid) {
-      const int g0 = max(x0, mid);
-      ell_walk<K, UNR>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
-        const float y = ell_dot<K>(g, hk);
-        // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
-        const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-        ell_axpy<K>(acc, g, r);
-        if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-      });
-    }
+    ell_h_rows<K, LOSS, UNR, 1>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) part[((size_t)slot * K + kk) * TP + lp] = acc[kk];
     if (LOSS && slot == 0) kl += fmaxf(a.ell_klc[px], 0.f);   // (negative: the mark of a pixel without counts, no constant)

@@ -8,6 +8,14 @@
 #define ESPM_ELL_UNR_W 4
 #endif
 
+// the full geometry: the block's permutations in LDS (mu_fused_kernel.hpp) when they fit next to the tables.  Measured: no
+// gain at the headline (150.1 against 146.9-150.2 us per iteration, profiles/r03a_variant_ab_512.log: with four waves per SIMD
+// a unit's start - 4 of them per wave and walk - is covered by the other waves) - off.
+#ifndef ESPM_FUSED_FULL_PERM_LDS
+#define ESPM_FUSED_FULL_PERM_LDS 0
+#endif
+#define ESPM_FUSED_LDS_LIMIT (160 * 1024)   // a workgroup's LDS on gfx950
+
 namespace espm {
 
 #if ESPM_MIN_K <= 8
@@ -27,12 +35,16 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   args.meta_lds_off = (int)bytes;  // the block's list offsets
   bytes += (size_t)(3 * (pb / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
   args.perm_lds_off = (int)bytes;  // below the full geometry: the block's pix_perm and chan_perm
-  if (pb != ESPM_ELL_PB) bytes += (size_t)(pb + 64 * args.w.n_cg) * sizeof(int);
+  const size_t perm_bytes = (size_t)(pb + 64 * args.w.n_cg) * sizeof(int);
+  // (the full geometry: the copies are an extra where the workgroup's 160 KB still hold them)
+  args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
+  if (args.perm_lds) bytes += perm_bytes;
   if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
     args.h.cs_lds_off = (int)bytes;
     bytes += KP * sizeof(double);
   }
-  if (bytes > ESPM_ELL_LDS_MAX) return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
+  if (bytes > (args.perm_lds && pb == ESPM_ELL_PB ? ESPM_FUSED_LDS_LIMIT : ESPM_ELL_LDS_MAX))
+    return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
   auto go = [&](auto kern, int threads) -> int {
     if (bytes > 64 * 1024)
       if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),

@@ -55,6 +55,7 @@ struct FusedArgs {
                     // pixel-list groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
   int perm_lds_off; // below the full geometry: byte offset of the block's copy of pix_perm (pb ints) and chan_perm (64 n_cg ints) in LDS
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
+  int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
 };
 
 // segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of pb floats each)
@@ -123,12 +124,14 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     meta[threadIdx.x] = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
   }
   for (int i = threadIdx.x; i <= 2 * fa.w.n_cg; i += NT) meta[3 * NGRP + i] = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + i];
-  // Below the full geometry a wave has a SIMD almost to itself and a unit is short: what a unit needs before its first
-  // list row - the slot -> pixel map, the block's channel order - is fetched once by the workgroup, so that a unit starts
-  // with ONE round trip to memory (its H column or GW rows and its first list rows together) instead of a chain of three.
+  // What a unit needs before its first list row - the slot -> pixel map, the block's channel order - is fetched once by the
+  // workgroup (below the full geometry always; at the full geometry where the 4 (PB + 64 n_cg) bytes fit, ESPM_FUSED_FULL_PERM_LDS),
+  // so that a unit starts with ONE round trip to memory (its H column or GW rows and its first list rows together) instead
+  // of a chain of three.
   int* lpix = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.perm_lds_off);
   int* lchan = lpix + PB;
-  if constexpr (!FULL) {
+  const bool perm_lds = !FULL || fa.perm_lds;   // (uniform)
+  if (perm_lds) {
     for (int i = threadIdx.x; i < PB; i += NT) lpix[i] = a.ell_pix[(size_t)blockIdx.x * PB + i];
     for (int i = threadIdx.x; i < 64 * fa.w.n_cg; i += NT) lchan[i] = fa.w.chan_perm[(size_t)blockIdx.x * fa.w.n_cg * 64 + i];
   }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     float kl = 0.f;
     int lp = lane;   // place of the lane's pixel inside its tile
     if (blk0 + (gi >> GPT_SHIFT) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
-      lp = FULL ? a.ell_pix[grp * 64 + lane] : lpix[gi * 64 + lane];   // slot -> pixel of the window (lists ordered by length)
+      lp = perm_lds ? lpix[gi * 64 + lane] : a.ell_pix[grp * 64 + lane];   // slot -> pixel of the window (lists ordered by length)
       const int beg = meta[3 * gi], mid = meta[3 * gi + 1] - beg, len = meta[3 * gi + 2] - beg;
       const int x0 = FULL ? FusedGeom<K>::seg_begin(len, seg) : FusedGeom<K>::seg_begin_even(len, seg, S);
       const int x1 = FULL ? FusedGeom<K>::seg_begin(len, seg + 1) : FusedGeom<K>::seg_begin_even(len, seg + 1, S);
@@ -168,23 +171,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-        if (x0 < mid) {
-          ell_walk<K, UNR_H, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(a.n_pad), [&](float, const float (&g)[K]) {
-            const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
-            ell_axpy<K>(acc, g, r);
-            if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
-          });
-        }
-        if (x1 > mid) {
-          const int g0 = max(x0, mid);
-          ell_walk<K, UNR_H, PF>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, a.n_pad, a.ell_bits), [&](float x, const float (&g)[K]) {
-            const float y = ell_dot<K>(g, hk);
-            // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
-            const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);
-            ell_axpy<K>(acc, g, r);
-            if constexpr (LOSS) kl = fmaf(x, __builtin_amdgcn_logf(r), kl);
-          });
-        }
+        ell_h_rows<K, LOSS, UNR_H, PF>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
       }
     }
     float* dst = part + (size_t)seg * PROWS * PB + (gi >> GPT_SHIFT) * TP + lp;
@@ -203,7 +190,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const WAccumArgs& w = fa.w;
   const int b = blockIdx.x;
   for (int cg = next_unit(1); cg < w.n_cg; cg = next_unit(1)) {
-    const int c = FULL ? w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane] : lchan[cg * 64 + lane];
+    const int c = perm_lds ? lchan[cg * 64 + lane] : w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane];
     const float* gsrc = w.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
 #pragma unroll

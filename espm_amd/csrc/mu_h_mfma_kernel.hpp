@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
             // The first reader of a matrix-core result must be an instruction the compiler knows (it owes the wait states
             // between v_mfma and a vector read of its result; it cannot see into the asm below and places none for it).
             float yi = fmaxf(y[i], 1e-37f);
-            asm volatile("v_rcp_f32 %0, %0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard)
+            asm volatile("v_rcp_f32 %0, %0\n\ts_nop 0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard); s_nop: the wait state a vector instruction that reads a transcendental result needs - the compiler's hazard recognizer does not see into the asm
             // (+1e-37 with the loss: keeps log2(R) finite where X = 0, as in the vector kernels)
             r[i] = LOSS ? fmaf(x[i], yi, 1e-37f) : x[i] * yi;
             if constexpr (LOSS) {
               float lg = r[i];
-              asm volatile("v_log_f32 %0, %0" : "+v"(lg));   // in place, like the reciprocal
+              asm volatile("v_log_f32 %0, %0\n\ts_nop 0" : "+v"(lg));   // in place, like the reciprocal (and with its wait state)
               kl = fmaf(x[i], lg, kl);
             }
           }

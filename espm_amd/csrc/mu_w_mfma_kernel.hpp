@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
             // between v_mfma and a vector read of its result, cannot see into the asm below and places none for it (found in
             // mu_h_mfma_kernel.hpp, where the same pattern gave non-finite numerators with two waves per SIMD).
             float yi = fmaxf(y[i], 1e-37f);
-            asm volatile("v_rcp_f32 %0, %0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard)
+            asm volatile("v_rcp_f32 %0, %0\n\ts_nop 0" : "+v"(yi));   // in place: the transcendental unit reads its source late (the matrix-core hazard); s_nop: the wait state a vector instruction that reads a transcendental result needs - the compiler's hazard recognizer does not see into the asm
             r[i] = x[i] * yi;
           }
         }

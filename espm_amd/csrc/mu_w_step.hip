@@ -146,7 +146,7 @@ struct WUpdateArgs {
 
 // The update of the 32 entries of W (component kk, channels c of the lanes that own one) from their summed A and the row
 // sum rs of the new H, by wave 0 of a reduction workgroup; the per-workgroup partials of what is global go to a.parts.
-__device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, int c, int e, bool owns, float t, double rs, int nwg) {
+__device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, int c, int e, bool owns, float t, double rs, int nwg, int wg) {   // wg: index of the reduction workgroup (its slot of the partials)
   double cs = 0.0, sw = 0.0, qw = 0.0;
   if (owns) {
     a.a_out[e] = t;
@@ -180,9 +180,9 @@ __device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, i
   sw = wave_sum(sw);
   if (a.pg_track) qw = wave_sum(qw);
   if (threadIdx.x == 0) {
-    a.parts[blockIdx.x] = cs;
-    a.parts[nwg + blockIdx.x] = sw;
-    if (a.pg_track) a.parts[2 * nwg + blockIdx.x] = qw;
+    a.parts[wg] = cs;
+    a.parts[nwg + wg] = sw;
+    if (a.pg_track) a.parts[2 * nwg + wg] = qw;
   }
 }
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += s_part[g][col];
     }
-    w_update_entries(a, kk, c, e, owns, t, rs, nwg);
+    w_update_entries(a, kk, c, e, owns, t, rs, nwg, blockIdx.x);
   }
 }
 
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64) void w_simplex_update_kernel(const WSimplexArgs
 #pragma unroll
   for (int q = 0; q < KP; ++q)
     if (q == kk) delta = solve[q] ? ad[q] + width[q] * mid_frac(uu[q], t_stop) : (double)(float)rs[q];
-  w_update_entries(a, kk, c, e, owns, t_e, delta, nwg);
+  w_update_entries(a, kk, c, e, owns, t_e, delta, nwg, blockIdx.x);
 }
 
 // ---- Slab reduction, record exchange and W update of a SHARDED image in ONE launch (espm_mu_shard_exchange_finish) ----------
@@ -412,7 +412,10 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   auto flag = [&](int dst, int src_rank, int idx) {
     return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + idx) * sizeof(unsigned int));
   };
-  if ((int)blockIdx.x >= nwg) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
+  // The extra workgroup is workgroup 0 of the grid: every reduction workgroup waits for ITS flag (of every rank) after posting
+  // its own piece, so it must not be the one workgroup a grid larger than the device holds at once leaves undispatched
+  // (workgroups start in index order; launch_w_exchange_update checks the residency and takes the four-launch path otherwise).
+  if (blockIdx.x == 0) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
     h_finalize_body(a.fin, fscratch);   // (fin.hstat_out = the statistics of this rank's record in its OWN mailbox)
     __syncthreads();
     const double* mine = reinterpret_cast<const double*>(record(x.rank, x.rank) + x.hstat_off);
@@ -444,7 +447,8 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  const int kk = blockIdx.x / a.nbk, j = blockIdx.x - kk * a.nbk;
+  const int wg = (int)blockIdx.x - 1;   // reduction workgroup (component kk, 32 channels)
+  const int kk = wg / a.nbk, j = wg - kk * a.nbk;
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = 32 * j + col;
   const int e = kk * a.n_pad + c;
@@ -481,10 +485,10 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         __hip_atomic_store(reinterpret_cast<float*>(record(r, x.rank)) + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's pieces are delivered before its flags are issued (order, not a cache flush)
-    if (lane < x.world) __hip_atomic_store(flag(lane, x.rank, blockIdx.x), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane < x.world) __hip_atomic_store(flag(lane, x.rank, wg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lane < x.world) {
       unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
-      xchg_wait_flag(flag(x.rank, lane, blockIdx.x), x.seq, x.max_ticks, err);
+      xchg_wait_flag(flag(x.rank, lane, wg), x.seq, x.max_ticks, err);
       xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
     }
     // (every lane's polls are done when the wave goes on: one program counter; the loads below bypass the caches)
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       rs += __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + ESPM_HS_ROWSUM + kk, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (blockIdx.x == 0 && lane < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
+    if (wg == 0 && lane < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
       double g = 0.0;
       for (int r = 0; r < x.world; ++r) {
         const double v2 = __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + lane, __ATOMIC_RELAXED,
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       }
       a.hstat_out[lane] = g;
     }
-    w_update_entries(a, kk, c, e, owns, tt, rs, nwg);
+    w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg);
   }
 }
 
@@ -1414,6 +1418,27 @@ int launch_w_simplex_update(const WFinishArgs& f, float* a_inout, const double* 
   return check_hip(hipGetLastError(), "w_simplex_update tail launch");
 }
 
+// Workgroups of w_exchange_update_kernel the device holds at once.  Its workgroups wait for each other (pieces of every rank,
+// the extra workgroup's flag), so the whole grid has to be resident: the occupancy query, capped by what the hardware admits
+// for 256-thread workgroups (MI355X_MICROARCH.md: min(API, 8, floor(800 / (ceil(sgpr / 16) 16 + 16))) per CU - the API answers
+// one high for 81..112 SGPRs), with one workgroup per CU of margin.
+int w_exchange_resident_workgroups() {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  int dev = 0, cus = 0, per_cu = 0;
+  hipFuncAttributes fa;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(w_exchange_update_kernel), 256, 0) != hipSuccess ||
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(w_exchange_update_kernel)) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached = 0;
+  }
+  if (per_cu > 8) per_cu = 8;
+  per_cu -= 1;   // margin: the occupancy answer is one high for some register counts, and other kernels' workgroups may still be draining
+  if (per_cu < 1) per_cu = 1;
+  return cached = per_cu * cus;
+}
+
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny, int p_pad,
                              int with_halo, hipStream_t stream, WTailArgs* defer_tail) {
@@ -1468,6 +1493,8 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.halo_ny = ny;
   x.halo_ppad = p_pad;
   a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
+  if (nwg + 1 > w_exchange_resident_workgroups())   // (espm_mu_shard_exchange_finish takes the four-launch path before it gets here)
+    return set_error(ESPM_EUNSUPPORTED, "exchange: %d workgroups that wait for each other, the device holds %d at once", nwg + 1, w_exchange_resident_workgroups());
   hipLaunchKernelGGL(w_exchange_update_kernel, dim3(nwg + 1), dim3(256), 0, stream, x);
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)

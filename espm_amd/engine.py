@@ -553,14 +553,33 @@ class MUEngine:
         torch.distributed.all_reduce(lost, op=torch.distributed.ReduceOp.MAX, group=self.group)
         return int(lost.item())
 
+    def settle_exchange(self, iters=3):
+        """Sharded engine on the one-shot transport: ``iters`` iterations from the loaded state with the real kernels (the
+        in-launch, piece-wise exchange of espm_mu_shard_exchange_finish, not only the start-up self-test's post / wait), then
+        the health check - jointly, on every rank - and, if a bounded wait gave up anywhere, the collective transport on every
+        rank.  Returns the transport in effect.  The state has moved: the caller loads it again.  (A transport that stalls
+        only later still raises from ``history``; this catches the configurations in which it never works - ranks sharing a
+        device with whole-CU workgroups, a node without peer mapping.)"""
+        if not self.sharded or self.exchange.ctx is None or self.frobenius:
+            return self.exchange.transport if self.sharded else None
+        n = max(0, min(int(iters), self.hist_len - self.st.it - 2))
+        if n:
+            self.iterate(n, final_loss=False)
+        torch.cuda.synchronize()
+        if self.exchange_health() > 0:
+            self.use_collective_exchange()
+        return self.exchange.transport
+
     def use_collective_exchange(self):
         """Replaces the one-shot exchange by the collective transport on every rank (call it on all of them); the state has to
         be loaded again afterwards."""
         from .sharding import ShardExchange
         torch.cuda.synchronize()
+        tested = self.exchange.selftest_result
         self.exchange.close()
         self.exchange = ShardExchange(self.group, self.k, self.st.n_pad, self.st.ny, bool(self.st.grid_mode and self.lambda_L != 0.0),
                                       self.device, lib=self.lib, stream_fn=_stream, mode="collective")
+        self.exchange.selftest_result = dict(tested or {}, transport="collective", fell_back_from="p2p")
 
     # ---- sharded helpers ---------------------------------------------------------------------------
     def _globalize_hstat(self, which):

@@ -494,6 +494,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         del X_fixed, Xd, Xd_raw
         eng.load_state(self.W_, self.H_ if shard is None else shard.cols(self.H_))
+        if shard is not None and getattr(eng, "sharded", False) and eng.exchange.ctx is not None:
+            # the one-shot record exchange is rehearsed with the fit's own kernels before the loop depends on it; every rank
+            # moves to the collective transport together if a wait gave up (MUEngine.settle_exchange), then the state again
+            eng.settle_exchange()
+            eng.load_state(self.W_, shard.cols(self.H_))
         self.GWH_numel_ = self.G_.shape[0] * self.H_.shape[1]
         self.const_KL_ = (getattr(self, "_const_KL_dev", None) if Xv.size >= _DEVICE_PREP_MIN_SIZE else None)
         if self.const_KL_ is None:
@@ -584,9 +589,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     eval_before = eval_after
         except KeyboardInterrupt:
             pass
-
-        if lazy is not None:   # the host copy that was made meanwhile
-            self.X_ = lazy.result()
+        finally:
+            if lazy is not None:   # the host copy that was made meanwhile - also when the loop raised: X_ must not stay a stand-in
+                self.X_ = lazy.result()   # (holding a thread and an event: not picklable)
         self.W_ = eng.get_W().astype(out_dtype)
         self.H_ = self._full_H(eng).astype(out_dtype)
         if not self.simplex_H and not self.simplex_W:

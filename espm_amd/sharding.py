@@ -74,8 +74,9 @@ class ShardExchange:
     * ``p2p`` (default on GPUs): the library's one-shot exchange (``espm_xchg_*``, csrc/mu_xchg.hip) - every rank writes its
       record into every peer's mailbox over the direct links and raises a flag; no host-side collective, no host
       synchronisation, and ``espm_mu_iterate_sharded`` runs whole batches of iterations on it.  The mailboxes are mapped
-      through hipIpc; the 64-byte handles travel once through the process group.  A start-up hand-shake (one exchange of a
-      known pattern) decides - jointly - whether the transport works; if not, every rank falls back to
+      through hipIpc; the 64-byte handles travel once through the process group.  A start-up self-test (``selftest``: 64
+      exchanges of checksummed patterns, ESPM_XCHG_SELFTEST) decides - jointly - whether the transport works; if not, every
+      rank falls back to
     * ``collective``: ``torch.distributed.all_gather_into_tensor`` (RCCL over xGMI on the GPU box, gloo in the CPU tests).
     """
 
@@ -90,6 +91,7 @@ class ShardExchange:
         self.ctx = None          # espm_xchg* when the one-shot transport is up
         self.seq = C.c_uint32(0)
         self.send = None
+        self.selftest_result = None   # what the start-up self-test of the one-shot transport measured (selftest)
         self._recv2, self._gen = None, 0   # collective transport: two receive buffers in turn (the records before the last gather stay readable)
         mode = mode or os.environ.get("ESPM_XCHG", "p2p")
         if mode == "p2p" and lib is not None and torch.device(device).type == "cuda":
@@ -111,20 +113,14 @@ class ShardExchange:
         if ok:
             blob = b"".join(g[1] for g in gathered)
             ok = lib.espm_xchg_connect(ctx, C.create_string_buffer(blob, len(blob))) == 0
-        if ok:   # hand-shake: one exchange of a pattern every rank can check
-            stage = _as_tensor(lib.espm_xchg_staging(ctx), nb, device)
-            stage.fill_(self.rank + 1)
-            torch.cuda.synchronize()
-            s = self._stream_fn()
-            self.seq.value += 1
-            ok = lib.espm_xchg_post(ctx, self.seq, s) == 0 and lib.espm_xchg_wait(ctx, self.seq, s) == 0
-            torch.cuda.synchronize()
-            if ok:
-                recs = _as_tensor(lib.espm_xchg_records(ctx, self.seq.value & 1), nb * self.world, device).view(self.world, nb)
-                lost = C.c_uint32(0)
-                lib.espm_xchg_timeouts(ctx, C.byref(lost))
-                ok = lost.value == 0 and all(bool((recs[r] == r + 1).all()) for r in range(self.world))
-            stage.zero_()
+        if ok:   # self-test: exchanges of patterns every rank can check word by word (selftest below), timed
+            self.ctx = ctx
+            try:
+                self.selftest_result = self.selftest(int(os.environ.get("ESPM_XCHG_SELFTEST", "64")), device=device)
+                ok = self.selftest_result["lost"] == 0 and self.selftest_result["corrupt"] == 0
+            except Exception:
+                ok = False
+            self.ctx = None
         flags = [None] * self.world
         torch.distributed.all_gather_object(flags, bool(ok), group=self.group)
         if all(flags):
@@ -133,6 +129,53 @@ class ShardExchange:
             if ctx:
                 lib.espm_xchg_destroy(ctx)
             self.seq.value = 0
+            self.selftest_result = dict(self.selftest_result or {}, transport="collective", fell_back_from="p2p")
+
+    def selftest(self, n=1000, device=None):
+        """``n`` exchanges of records filled with a pattern that depends on the sending rank AND the sequence number, every byte
+        of every received record compared with what its sender must have written, each exchange timed with HIP events on the
+        launch stream (post + wait: what a rank pays between having its record and having everybody's).  What this is for: the
+        one-shot transport orders its write-through stores and the flag with ``s_waitcnt vmcnt(0)``, not with a system-scope
+        fence (csrc/mu_xchg.hip), and the peers' mailboxes are mapped through hipIpc - neither can be validated on a box with
+        one GPU, so every start on real peers is a test: a record that arrives after its flag shows up as ``corrupt`` (the
+        pattern of the PREVIOUS use of the slot, two sequence numbers back), a flag that never arrives as ``lost``.
+        One GPU (a group of one rank, or ranks sharing a device): the same kernels and flags, no link crossed.
+        Returns dict(transport, n, p50_us, p99_us, max_us, lost, corrupt)."""
+        if self.ctx is None:
+            return dict(transport="collective", n=0, p50_us=None, p99_us=None, max_us=None, lost=0, corrupt=0)
+        lib, nb = self.lib, self.layout.nbytes
+        device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        stage = _as_tensor(lib.espm_xchg_staging(self.ctx), nb, device)
+        keep = stage.clone()
+        bad = torch.zeros((), dtype=torch.int64, device=device)
+        ranks = torch.arange(self.world, device=device, dtype=torch.int32).view(self.world, 1)
+        views = [_as_tensor(lib.espm_xchg_records(self.ctx, par), nb * self.world, device).view(self.world, nb) for par in (0, 1)]
+        lost0 = self.lost_peers()
+        events = []
+        s = self._stream_fn()
+        for i in range(int(n)):
+            if i in (1, 16) or (i and i % 256 == 0):   # a transport that does not deliver costs a 2 s bounded wait per exchange: stop early
+                torch.cuda.synchronize()
+                if self.lost_peers() - lost0 > 0 or int(bad.item()) > 0:
+                    break
+            self.seq.value += 1
+            q = int(self.seq.value)
+            stage.fill_((self.rank * 37 + q * 11 + 1) & 255)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.espm_xchg_post(self.ctx, self.seq, s) or lib.espm_xchg_wait(self.ctx, self.seq, s)
+            e1.record()
+            if rc:
+                raise RuntimeError(lib.espm_mu_last_error().decode())
+            events.append((e0, e1))
+            expect = ((ranks * 37 + (q * 11 + 1)) & 255).to(torch.uint8)
+            bad += (views[q & 1] != expect).sum()
+        torch.cuda.synchronize()
+        stage.copy_(keep)
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in events)
+        pick = (lambda f: us[min(len(us) - 1, int(f * len(us)))]) if us else (lambda f: None)
+        return dict(transport="p2p", n=len(events), p50_us=pick(0.5), p99_us=pick(0.99), max_us=us[-1] if us else None,
+                    lost=self.lost_peers() - lost0, corrupt=int(bad.item()))
 
     @property
     def transport(self):

@@ -9,7 +9,8 @@ path, so an empty stand-in package is put on sys.path from a temp dir (outside t
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
 
 Only DATA is stored: inputs and the reference's outputs.  Each archive also records the
-library versions used.  Fixture families follow SURVEY.md section 8(c): F1..F8; F9 covers the options of section 8(f) rank 4 that
+library versions used.  Fixture families follow SURVEY.md section 8(c): F1..F8; F17: the hyperspy calling convention on a
+(96 x 96, 512) cube; F9 covers the options of section 8(f) rank 4 that
 are built (linesearch, true_D / true_H tracking).
 """
 import contextlib
@@ -709,7 +710,46 @@ def f16():
     save("f16_physics_model", **out)
 
 
+# ------------------------------------------------------------------ F17: the hyperspy calling convention at a size where the
+# (pixels, channels) input goes to the device as it lies (espm/estimators/base.py:243-247, :412-420,
+# espm/datasets/eds_spim.py:597-604: decomposition(algorithm=est) hands fit_transform the (p, n) matrix)
+def f17():
+    rng = np.random.default_rng(1717)
+    n, nx, ny, k = 512, 96, 96, 3
+    p = nx * ny
+    # spectra: a few Gaussian lines per phase on a weak continuum; maps: smooth, on the simplex; ~60 counts per pixel
+    ch = np.arange(n)[:, None]
+    D = np.zeros((n, k))
+    for j in range(k):
+        for _ in range(4):
+            D[:, j] += rng.random() * np.exp(-0.5 * ((ch[:, 0] - rng.integers(20, n - 20)) / (2.0 + 4.0 * rng.random())) ** 2)
+        D[:, j] += 0.002 * np.exp(-ch[:, 0] / 200.0)
+    D /= D.sum(axis=0, keepdims=True)
+    yy, xx = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny), indexing="ij")
+    maps = np.stack([1.2 + np.cos(3.1 * xx + 0.4) * np.cos(2.3 * yy), 1.2 + np.sin(4.0 * yy + 0.3), 1.2 + np.cos(5.0 * (xx - yy))])
+    maps = (maps / maps.sum(axis=0, keepdims=True)).reshape(k, p)
+    X = rng.poisson(60.0 * D @ maps).astype(np.float64)                   # (n, p)
+    assert X.max() <= 255 and (X.sum(axis=0) > 0).all()
+    Xp = np.ascontiguousarray(X.T)                                           # (p, n): what hyperspy hands over
+    W0 = rng.random((n, k)) * 60.0 / n + 1e-3
+    H0 = rng.random((k, p)) + 0.1
+    H0 /= H0.sum(axis=0, keepdims=True)
+    out = dict(X_u8=Xp.astype(np.uint8), W0=W0, H0=H0, shape=np.array([nx, ny]))
+    for tag, kw, iters in (("free", dict(tol=0, no_stop_criterion=True), 30), ("stop", dict(tol=6e-4), 200)):
+        est = SmoothNMF(n_components=k, hspy_comp=True, shape_2d=(nx, ny), simplex_H=True, simplex_W=False, lambda_L=1.0, verbose=0,
+                        max_iter=iters, **kw)
+        ret = quiet(est.fit_transform, Xp.copy(), W=W0.copy(), H=H0.copy())
+        assert ret.shape == (p, k) and est.components_.shape == (k, n)
+        out[f"{tag}_loadings"], out[f"{tag}_components"] = ret, est.components_
+        out[f"{tag}_W"], out[f"{tag}_H"] = est.W_, est.H_
+        out[f"{tag}_losses"], out[f"{tag}_rel"] = np.array(est.losses_), np.array(est.rel_)
+        out[f"{tag}_detailed"] = np.array(est.detailed_losses_, dtype=float)
+        out[f"{tag}_n_iter"] = np.array(est.n_iter_)
+        print(f"f17 {tag}: n_iter {est.n_iter_}, loss {est.losses_[0]:.6g} -> {est.losses_[-1]:.6g}")
+    save("f17_hyperspy_ingest", **out)
+
+
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -106,3 +106,43 @@ def test_decomposition_end_to_end_matches_a_direct_fit():
     np.testing.assert_allclose(est2.H_, ref.H_, rtol=1e-2, atol=3e-3)   # (the device NNDSVD multiplies X in the other stride order: rounding-level differences in W0, H0)
     assert np.all(np.diff(est2.losses_) < 0)
     del torch
+
+
+@pytest.mark.gpu
+def test_pixel_major_ingest_against_the_reference_fixture():
+    """Fixture F17 (tests/golden/make_golden.py::f17): the REFERENCE's SmoothNMF(hspy_comp=True) on the (pixels, channels)
+    matrix of a 96 x 96 x 512 cube (espm/estimators/base.py:243-247, :412-420; eds_spim.py:597-604).  Here the same cube goes
+    through hyperspy's calling convention - SpectrumImage.decomposition -> fit_transform((p, n)) - at a size where the matrix
+    is uploaded as it lies (pixel-major ingest) and everything the reference returns or leaves on the estimator is compared
+    with what the reference produced: loadings, components_, W_, H_, losses_, rel_, n_iter_."""
+    from espm_amd import hyperspy_adapter as ha
+    from espm_amd.estimators import SmoothNMF
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "f17_hyperspy_ingest.npz")))
+    nx, ny = (int(v) for v in g["shape"])
+    Xp = g["X_u8"].astype(np.float64)                                        # (p, n), as hyperspy unfolds the cube
+    p, n = Xp.shape
+    k = g["W0"].shape[1]
+    cube = Xp.reshape(nx, ny, n)
+
+    class Seeded(SmoothNMF):                                                 # hyperspy passes only the data: fix the initial state
+        def fit_transform(self, Xq, y=None, W=None, H=None):
+            assert Xq.shape == (p, n) and np.shares_memory(Xq, cube)         # the cube's own memory, not a transposed copy
+            return super().fit_transform(Xq, W=g["W0"].copy(), H=g["H0"].copy())
+
+    for tag, kw, iters in (("free", dict(tol=0, no_stop_criterion=True), 30), ("stop", dict(tol=6e-4), 200)):
+        est = Seeded(n_components=k, hspy_comp=True, simplex_H=True, simplex_W=False, lambda_L=1.0, verbose=0, max_iter=iters, **kw)
+        s = ha.SpectrumImage(cube)
+        lr = quiet(ha.decompose, s, est)                                     # shape_2d comes from the signal
+        assert est._ingest_layout == "pm" and est.shape_2d == (nx, ny)
+        assert est._engine.x_store == "ell"                                  # count data: the sparse store
+        assert est.n_iter_ == int(g[f"{tag}_n_iter"]), (tag, est.n_iter_)
+        np.testing.assert_allclose(est.losses_, g[f"{tag}_losses"], rtol=1e-5)          # (measured ~1e-7)
+        np.testing.assert_allclose(lr.loadings, g[f"{tag}_loadings"], rtol=0, atol=5e-5)
+        scale = np.abs(g[f"{tag}_components"]).max()
+        np.testing.assert_allclose(lr.factors.T, g[f"{tag}_components"], rtol=0, atol=2e-4 * scale)
+        np.testing.assert_allclose(est.components_, g[f"{tag}_components"], rtol=0, atol=2e-4 * scale)
+        np.testing.assert_allclose(est.H_, g[f"{tag}_H"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(est.W_, g[f"{tag}_W"], rtol=0, atol=2e-4 * np.abs(g[f"{tag}_W"]).max())
+        np.testing.assert_allclose(np.array(est.rel_), g[f"{tag}_rel"], rtol=2e-3, atol=1e-6)
+        assert lr.loadings.shape == (p, k) and lr.factors.shape == (n, k) and lr.decomposition_algorithm is est
+        np.testing.assert_array_equal(est.X_.shape, (n, p))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""A/B of builds of the narrow library in ONE process, on one device, interleaved: same image, same state.
+
+    python tools/analysis/variant_ab.py base=espm_amd/lib/libespm_mu.so klprod=tools/analysis/libespm_mu_klprod.so ...
+
+env: ROWS (image rows of the 512-wide headline image: 512 = the headline, 64 = an eighth), K, COUNTS, FUSED (engine's `fused`),
+ITERS (per timing slice), REPS.  Every build runs 6 iterations from the same state first: losses, W, H against the first build."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from espm_amd import _lib, synth  # noqa: E402
+from espm_amd.engine import MUEngine  # noqa: E402
+
+ROWS, K = int(os.environ.get("ROWS", "512")), int(os.environ.get("K", "5"))
+COUNTS = float(os.environ.get("COUNTS", "500"))
+ITERS, REPS = int(os.environ.get("ITERS", "300")), int(os.environ.get("REPS", "4"))
+fused = {"0": False, "1": True}.get(os.environ.get("FUSED", "1"), os.environ.get("FUSED", "1"))
+dev = torch.device("cuda", 0)
+prob = synth.make_problem(2048, ROWS, 512, K, N=COUNTS, seed=0, row0=0, nx_total=512)
+X = synth.sample_torch(prob, dev, seed=1000, row0=0)
+W0, H0 = synth.random_init(2048, K, 512 * 512, seed=0, scale=COUNTS / 2048)
+H0 = H0[:, :ROWS * 512]
+kw = dict(layout="pm", shape_2d=(ROWS, 512), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=ITERS * (REPS + 1) + 20, device=dev, fused=fused)
+engs, ref = {}, None
+for spec in sys.argv[1:]:
+    name, path = spec.split("=", 1)
+    handle = _lib._load(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
+    _lib._narrow = _lib.Variant(handle, _lib.KP, 1, _lib.MAX_K)
+    eng = MUEngine(X, K, **kw)
+    eng.load_state(W0, H0)
+    eng.iterate(6, final_loss=True)
+    torch.cuda.synchronize()
+    out = (eng.get_W(), eng.get_H(), eng.history()["loss"])
+    if ref is None:
+        ref = out
+        print(f"{name:10s}: losses {out[2]}")
+    else:
+        dl = np.max(np.abs(out[2] - ref[2]) / np.abs(ref[2]))
+        print(f"{name:10s}: max rel dloss {dl:.2e}  max|dW|/max W {np.abs(out[0] - ref[0]).max() / ref[0].max():.2e}  max|dH| {np.abs(out[1] - ref[1]).max():.2e}")
+        assert dl < 2e-6
+    eng.load_state(W0, H0)
+    eng.iterate(6, final_loss=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.get_W(), out[0]) and np.array_equal(eng.history()["loss"], out[2]), f"{name}: not reproducible run to run"
+    engs[name] = eng
+del X
+best = {n: 1e9 for n in engs}
+for rep in range(REPS + 1):      # (the first round is the run-in)
+    for name, eng in engs.items():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.iterate(ITERS, final_loss=False)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / ITERS * 1e6
+        if rep:
+            best[name] = min(best[name], us)
+        print(f"rep {rep} {name:10s}: {us:7.1f} us / iteration", flush=True)
+print("best: " + "  ".join(f"{n} {v:.1f}" for n, v in best.items()))
