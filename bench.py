@@ -22,8 +22,15 @@ Prints ONE JSON line on rank 0.  Beside the contract's fields:
                 entries of this dose; the dense rates do not)
   steady_state  300 further iterations timed the same way: the first tens of milliseconds after an idle phase run
                 8-15 % slower (clocks), which a 20-step timed region sits inside
-  cpu_baseline  the numpy oracle (reference-faithful op sequence) on the host cores, on a crop of the SAME image
+  cpu_baseline  the numpy oracle (reference-faithful op sequence) on the host cores: ONE iteration at the full size when the
+                host has the memory for its dense fp64 temporaries (~30 GB), and 8 iterations on a 64-row crop of the
+                SAME image scaled by 64/512 beside it (`crop`); BLAS thread pool from threadpoolctl in `threadpools`
   loss_parity_rel  final loss of the HIP path against the oracle's on that crop, same W0 / H0
+  product_default  the same loop on an engine built the way SmoothNMF.fit builds it (no launch-plan timing at set-up)
+  c5            BASELINE configuration 5 on ONE GPU (1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05): iteration time and
+                its fused kernel against its own algorithmic bytes
+  per_rank      (N > 1) every rank's launch times from HIP events: the local half-steps, and the W step with the record
+                exchange in it (where a rank waits for its peers); `record_exchange`: the start-up self-test of the transport
 """
 import argparse
 import json
@@ -45,7 +52,7 @@ VALU_F32_PEAK = 157.3e12
 CROP_ROWS, CROP_ITERS = 64, 8
 
 
-def cpu_baseline_and_parity(X_crop_pm, device):
+def cpu_baseline_and_parity(X_crop_pm, device, skip_full=None):
     """Oracle (numpy fp64, the reference's op sequence incl. the dense identity G and (G^T R) H^T) on the first CROP_ROWS
     image rows of the benchmark's own X, and the HIP path on the same crop from the same W0 / H0.
 
@@ -66,9 +73,11 @@ def cpu_baseline_and_parity(X_crop_pm, device):
     dt = time.perf_counter() - t0
     its_crop = r["n_iter"] / dt
     threads = os.cpu_count()
+    pools = None
     try:
         from threadpoolctl import threadpool_info
-        for info in threadpool_info():
+        pools = [{k: info.get(k) for k in ("user_api", "internal_api", "num_threads", "version", "threading_layer")} for info in threadpool_info()]
+        for info in pools:
             if info.get("user_api") == "blas":
                 threads = info.get("num_threads", threads)
     except Exception:
@@ -83,11 +92,27 @@ def cpu_baseline_and_parity(X_crop_pm, device):
                   worst_rel_over_trajectory=float(np.max(np.abs(ours[1:] - r["losses"]) / np.abs(r["losses"]))),
                   max_abs_dH=float(np.abs(eng.get_H() - r["H"]).max()),
                   sample=f"{CROP_ITERS} iterations on the first {CROP_ROWS} image rows of the benchmark's X, same W0 / H0; x_store {eng.x_store}")
-    base = dict(value=its_crop * CROP_ROWS / NX, unit="it/s", cores=int(threads), kind="port",
-                sample=f"numpy fp64 oracle (reference op sequence), {CROP_ITERS} iterations on the first {CROP_ROWS} of {NX} image rows of the "
-                       f"benchmark's own X ({p_crop} px x {N_CH} ch, {dt:.1f} s), scaled by {CROP_ROWS}/{NX}; a crop because the faithful loop "
-                       f"needs ~25 GB of dense fp64 temporaries and ~{dt / CROP_ITERS * NX / CROP_ROWS:.0f} s per full-size iteration")
+    crop = dict(value=its_crop * CROP_ROWS / NX, unit="it/s",
+                sample=f"{CROP_ITERS} iterations on the first {CROP_ROWS} of {NX} image rows of the benchmark's own X ({p_crop} px x {N_CH} ch, "
+                       f"{dt:.1f} s), scaled by {CROP_ROWS}/{NX}")
+    base = dict(value=crop["value"], unit="it/s", cores=int(threads), kind="port",
+                sample="numpy fp64 oracle (reference op sequence: dense identity G, three n x k x p products, global-stop bisection), "
+                       + crop["sample"] + "; no full-size iteration: " + (skip_full or "not attempted"),
+                crop=crop, threadpools=pools)
     return base, parity
+
+
+def cpu_full_size_iteration(X_dev):
+    """the reference-faithful loop AT THE FULL SIZE - one iteration (H update, W update, the loss of the new state:
+    what `value` counts per step), timed by the oracle around its loop; the initial loss and the final re-evaluation the fit
+    also makes are outside that clock.  Needs ~30 GB of host memory for the dense (n, p) fp64 temporaries."""
+    from oracle import mu_oracle as oc
+    from espm_amd import synth
+    X = X_dev.cpu().numpy().T.astype(np.float64)                        # (n, p) C-order, like the reference's input
+    W0, H0 = synth.random_init(N_CH, K, NX * NY, seed=0, scale=COUNTS / N_CH)
+    r = oc.fit(X, K, W=W0, H=H0, lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(NX, NY), tol=0, no_stop_criterion=True,
+               max_iter=1, time_iterations=True)
+    return dict(value=1.0 / r["seconds"], unit="it/s", seconds_per_iteration=r["seconds"], iterations=1, loss=float(r["losses"][-1]))
 
 
 def main():
@@ -96,6 +121,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity leg")
+    ap.add_argument("--no-cpu-full", action="store_true", help="CPU baseline from the 64-row crop only (skip the ~25 s full-size iteration)")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense-store and steady-state legs (profiling runs)")
     ap.add_argument("--lambda-l", type=float, default=LAMBDA_L)
     ap.add_argument("--x-store", default="auto", choices=["auto", "ell", "u8", "bf16", "f32"])
@@ -139,12 +165,14 @@ def main():
     W0, H0_full = synth.random_init(N_CH, K, NX * NY, seed=0, scale=COUNTS / N_CH)
     H0 = H0_full[:, row0 * NY:(row0 + rows) * NY]
     del H0_full
+    if world > 1:   # the start-up self-test of the one-shot record exchange (espm_amd/sharding.py) at full length: reported below
+        os.environ.setdefault("ESPM_XCHG_SELFTEST", "1000")
     total_iters = args.warmup + args.steps
     W0d, H0d = torch.from_numpy(W0).to(device, torch.float32), torch.from_numpy(H0).to(device, torch.float32)
     X = synth.sample_torch(prob, device, seed=1000, row0=row0)            # (p_local, n) f32 counts
     X_crop = X[:CROP_ROWS * NY].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
     eng = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=total_iters + 400, group=group, device=device, x_store=args.x_store, fused=not args.no_fused,
+                   tol=0.0, max_iter=total_iters + 600, group=group, device=device, x_store=args.x_store, fused=not args.no_fused,
                    autotune=not (args.no_fused or args.no_autotune))
     # (W0 / H0 go up before the engine is built and load_state takes device tensors: nothing crosses the host here)
     eng.load_state(W0d, H0d)
@@ -192,6 +220,17 @@ def main():
         n_ss = 300
         steady = dict(steps=n_ss, value=n_ss / timed(n_ss), unit="it/s",
                       note="300 further iterations, same bracket: the device clocks have ramped by then")
+
+    # ---- N > 1: every rank's launch times (HIP events on the launch stream), so that a scaling curve can be read: the local
+    # half-steps against the W step that holds the record exchange - a rank that waits for a slower peer shows it there ----
+    per_rank = None
+    if world > 1:
+        hs, ws = eng.timed_iterations(40)
+        mine = dict(rank=rank, rows=rows, half_steps_us=float(np.median(hs)), w_step_with_exchange_us=float(np.median(ws)),
+                    w_step_with_exchange_p90_us=float(np.percentile(ws, 90)), lost_peers=int(eng.exchange.lost_peers()),
+                    exchange_selftest=eng.exchange.selftest_result)
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
 
     # ---- loss sanity + per-kernel timing with HIP events on the launch stream (rank-local) --------
     eng.eval_current(advance_h=False)
@@ -285,7 +324,49 @@ def main():
             dense[name + "_its"] = 100 / (time.perf_counter() - t0)
             del e2
         dense["note"] = "dense 8-bit / bf16 stores, 100 iterations after 20 warm-up, same image and state"
-    del X
+
+    # ---- the engine as SmoothNMF.fit builds it (espm_amd/estimators/base.py: no launch-plan timing below 5000 iterations) ----
+    product_default = None
+    if world == 1 and not args.no_extras and eng.x_store == "ell" and not (args.no_fused or args.no_autotune):
+        e3 = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
+                      tol=0.0, max_iter=total_iters + 10, device=device, x_store=args.x_store)
+        e3.load_state(W0d, H0d)
+        e3.iterate(args.warmup, final_loss=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e3.iterate(args.steps, final_loss=False)
+        torch.cuda.synchronize()
+        product_default = dict(value=args.steps / (time.perf_counter() - t0), unit="it/s", steps=args.steps, warmup=args.warmup,
+                               note="autotune off: the engine of SmoothNMF.fit for max_iter < 5000")
+        del e3
+
+    # ---- BASELINE configuration 5 on one GPU: 1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05, lambda = 1, simplex_H ----
+    c5 = None
+    if world == 1 and not args.no_extras and args.x_store == "auto":
+        n5, nx5, ny5, k5, m5 = 1980, 1024, 1024, 8, 17
+        prob5 = synth.make_problem(n5, nx5, ny5, k5, N=COUNTS, seed=0, m=m5)
+        X5 = synth.sample_torch(prob5, device, seed=3000)
+        W5, H5 = synth.random_init(m5, k5, nx5 * ny5, seed=0, scale=COUNTS / n5)
+        e5 = MUEngine(X5, k5, layout="pm", G=prob5["G"], shape_2d=(nx5, ny5), lambda_L=1.0, mu=0.05, simplex_H=True, simplex_W=False,
+                      tol=0.0, max_iter=200, device=device)
+        del X5
+        e5.load_state(W5, H5)
+        e5.iterate(30, final_loss=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e5.iterate(100, final_loss=False)
+        torch.cuda.synchronize()
+        it5 = (time.perf_counter() - t0) / 100
+        c5 = dict(workload="1980ch x (1024x1024)px, k=8, G 1980x17 fixed, mu=0.05, lambda_L=1, simplex_H, X stored %s" % e5.x_store,
+                  us_per_iteration=it5 * 1e6, value=1.0 / it5, unit="it/s", n_gpus=1)
+        if e5.x_store == "ell" and bool(e5.lib.espm_mu_fused_applies(C.byref(e5.st))):
+            t5 = time_kernel(lambda: _lib.check(e5.lib.espm_mu_step_hw(C.byref(e5.st), e5.st.cur, s)))
+            b5 = 2 * float(e5.ell["nnz"]) + 2 * k5 * nx5 * ny5 * 4
+            c5["roofline"] = dict(bound="hbm", kernel="mu_fused_ell_kernel<8, loss>", launch_ms=t5 * 1e3, bytes_per_launch=b5,
+                                  achieved=b5 / t5 / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=b5 / t5 / HBM_PEAK,
+                                  frac_lists_twice=(2 * (e5.ell["entries_h"] + e5.ell["entries_w"]) + 2 * k5 * nx5 * ny5 * 4 + nx5 * ny5 * 4) / t5 / HBM_PEAK,
+                                  nnz_frac=float(e5.ell["nnz"]) / (float(n5) * nx5 * ny5))
+        del e5
 
     out = None
     if rank == 0:
@@ -297,7 +378,9 @@ def main():
             "config": {"workload": "2048ch x (512x512)px, k=5, SmoothNMF simplex_H + Laplacian lambda=%g, "
                                    "X stored %s, W/H fp32" % (args.lambda_l, eng.x_store),
                        "n": N_CH, "shape_2d": [NX, NY], "k": K, "lambda_L": args.lambda_l, "simplex_H": True,
-                       "parallelism": f"pixel-row shard x{world}" if world > 1 else "single GPU", "record_exchange": transport,
+                       "parallelism": f"pixel-row shard x{world}" if world > 1 else "single GPU",
+                       "record_exchange": (dict(eng.exchange.selftest_result or {}, transport=transport) if world > 1 else None),
+                       "autotune": bool(eng.plan_timings is not None), "per_rank": per_rank,
                        "loss_every_iteration": True, "launches_per_iteration": 2 if fused else 3,
                        "launch_plan": getattr(eng, "plan", None), "launch_plan_timings_us": eng.plan_timings,
                        "nnz_frac": nnz_frac, "counts_per_pixel": COUNTS},
@@ -308,11 +391,37 @@ def main():
             out["steady_state"] = steady
         if dense:
             out["dense_store"] = dense
+        if product_default:
+            out["product_default"] = product_default
+        if c5:
+            out["c5"] = c5
         if X_crop is not None:
-            out["cpu_baseline"], parity = cpu_baseline_and_parity(X_crop, device)
+            # a full-size faithful iteration where the host can hold it (checked, not assumed)
+            full, skip = None, None
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available / 2 ** 30
+                if avail < 45:
+                    skip = f"{avail:.0f} GiB of host memory available, ~30 GiB of dense fp64 temporaries + copies needed"
+            except Exception as e:   # noqa: BLE001
+                skip = f"psutil: {e}"
+            if skip is None and not args.no_cpu_full:
+                try:
+                    full = cpu_full_size_iteration(X)
+                except MemoryError:
+                    skip = "MemoryError"
+            elif args.no_cpu_full:
+                skip = "--no-cpu-full"
+            out["cpu_baseline"], parity = cpu_baseline_and_parity(X_crop, device, skip_full=skip)
+            if full:
+                cb = out["cpu_baseline"]
+                cb["value"], cb["full_size"] = full["value"], full
+                cb["sample"] = (f"numpy fp64 oracle (reference op sequence: dense identity G, three n x k x p products, global-stop bisection), ONE iteration "
+                                f"at the full size ({N_CH} ch x {NX * NY} px, {full['seconds_per_iteration']:.1f} s); beside it `crop`: {cb['crop']['sample']}")
             out["loss_parity_rel"] = parity["rel"]
             out["loss_parity"] = parity
         print(json.dumps(out), flush=True)
+    del X
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

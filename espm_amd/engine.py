@@ -840,6 +840,57 @@ class MUEngine:
             if final_loss:
                 self.eval_current(False)
 
+    def timed_iterations(self, n_iter):
+        """``n_iter`` iterations with HIP events between the launches, for diagnosis (bench.py prints the per-rank figures of a
+        multi-GPU run): returns (half_steps_us, w_step_us), two float arrays of length n_iter.  ``half_steps``: the launch(es)
+        that update this rank's H block and accumulate its R H'^T - local work only; ``w_step``: what follows up to the new W -
+        slab reduction, the record exchange (this is where a rank WAITS for its peers) and the W update.  The same entry
+        points, in the same order, as ``iterate`` (for the one-shot transport the two launches espm_mu_iterate_sharded
+        enqueues per iteration), sequenced from Python; the events cost ~2 us per iteration."""
+        st = self.st
+        n_iter = int(n_iter)
+        if st.it + n_iter + 1 > self.hist_len:
+            raise ValueError("history buffer exhausted: raise max_iter")
+        if self.frobenius:
+            raise NotImplementedError("timed_iterations: not for the Frobenius fit")
+        self._flush_finalize()
+        self._accum_done = False
+        s = _stream()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_iter)]
+        oneshot = self.sharded and self.exchange.ctx is not None
+        if oneshot:
+            defer = self.ell is not None and self.pg_q is None and bool(self.lib.espm_mu_w_update_is_local(C.byref(st)))
+            pending = False
+            for e0, e1, e2 in ev:
+                cur, slot = st.cur, st.it
+                st.tail_mode = _lib.TAIL_RIDE if pending else 0
+                e0.record()
+                try:
+                    self._check(self.lib.espm_mu_step_hw(C.byref(st), cur, s))
+                finally:
+                    st.tail_mode = 0
+                e1.record()
+                self.exchange.seq.value += 1
+                st.tail_mode = _lib.TAIL_DEFER if defer else 0
+                try:
+                    self._check(self.lib.espm_mu_shard_exchange_finish(C.byref(st), self.exchange.ctx, self.exchange.seq, cur, slot, s))
+                finally:
+                    st.tail_mode = 0
+                e2.record()
+                pending = defer
+                self._set_halo_from_records()
+                st.cur, st.it = 1 - cur, slot + 1
+            self._pending_tail = pending
+        else:
+            for e0, e1, e2 in ev:
+                e0.record()
+                self.eval_current(True)
+                e1.record()
+                self.finish_iteration()
+                e2.record()
+        torch.cuda.synchronize()
+        return (np.array([a.elapsed_time(b) * 1e3 for a, b, _ in ev]), np.array([b.elapsed_time(c) * 1e3 for _, b, c in ev]))
+
     # ---- single half steps for the module-level functions ----------------------------------------------
     def _l2_buffers(self):
         if getattr(self, "_l2_work", None) is None:
