@@ -536,9 +536,7 @@ int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_
   ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
   ESPM_REQUIRE(x->record_bytes == espm_mu_shard_record_bytes(st), "shard_exchange_finish: the exchange was created for records of %zu bytes, the state packs %zu",
                x->record_bytes, espm_mu_shard_record_bytes(st));
-  // W' needs a global finish (G given, simplex over W), or the one-launch kernel's grid (k n_pad / 32 + 1 workgroups that wait
-  // for each other) is larger than the device holds at once: the four steps
-  if (!w_update_is_local(st) || st->no_fused == 1 || st->k * ((st->n_pad + 31) / 32) + 1 > w_exchange_resident_workgroups()) {
+  if (!w_update_is_local(st) || st->no_fused == 1) {   // W' needs a global finish (G given, simplex over W): the four steps
     if (int rc = espm_mu_w_reduce_pack(st, src, slot, x->staging, stream)) return rc;
     if (int rc = espm_xchg_post(x, seq, stream)) return rc;
     if (int rc = espm_xchg_wait(x, seq, stream)) return rc;

@@ -30,7 +30,7 @@ constexpr int WAVE = 64;
 // the product's build).  Thread 0 of a workgroup writes the 100 MHz wall clock into slot `id` of its 8 slots.
 #ifdef ESPM_PHASE_CLOCK
 static __device__ unsigned long long* espm_phase_buf = nullptr;
-#define ESPM_PHASE_SLOTS 40   // 8 workgroup stamps, then one per wave (16) for the end of the H walk and of the W walk
+#define ESPM_PHASE_SLOTS 56   // 8 workgroup stamps, one per wave (16) for the end of the H walk and of the W walk, 16 more inside the phases (40..)
 #define ESPM_PHASE_STAMP(id)                                                                                                 \
   do {                                                                                                                       \
     if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[(size_t)blockIdx.x * ESPM_PHASE_SLOTS + (id)] = wall_clock64();   \
@@ -268,6 +268,36 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
 // `scratch` ((blockDim.x / 64) * NV doubles), then thread i < NV combines value i over the waves in wave order
 // (deterministic, fp64) and hands it to emit(i, value) - no gathering thread, no second and third barrier.  The other
 // threads leave after the barrier; `scratch` must not be reused before the next barrier of the caller.
+// The same in two halves for a caller that has a barrier of its own between them: `block_reduce_f32_wave` (every wave, BEFORE the
+// barrier: its sums / maxima into scratch that nothing else uses meanwhile), `block_reduce_f32_finish` (after it: thread i < NV adds
+// the waves' values of item i in wave order - the same value as block_reduce_f32 - and emits it; no further barrier).
+template <int NV, int NSUM>
+__device__ __forceinline__ void block_reduce_f32_wave(const float (&v)[NV], double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = (double)r[i];
+  }
+}
+template <int NV, int NSUM, typename Emit>
+__device__ __forceinline__ void block_reduce_f32_finish(const double* scratch, Emit emit) {
+  const int nw = blockDim.x >> 6;
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    double o[16];   // (all reads requested together: as a loop over a run-time wave count every read waited for the one before)
+#pragma unroll
+    for (int w = 0; w < 16; ++w) o[w] = w < nw ? scratch[w * NV + i] : 0.0;
+    double acc = o[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w)
+      if (w < nw) acc = (i < NSUM) ? acc + o[w] : (o[w] > acc ? o[w] : acc);
+    emit(i, acc);
+  }
+}
+
 template <int NV, int NSUM, typename Emit>
 __device__ __forceinline__ void block_reduce_f32(const float (&v)[NV], double* scratch, Emit emit) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -559,7 +589,7 @@ struct HStepArgs {
   const float* fill_num;  // sparse store: numerators of the pixels that hold nothing but the fill (k, fill_n), else null
   int fill_n;
   // espm_mu_iterate, sparse store, local W update: the tail of the previous W update rides in this launch as one extra
-  // workgroup (tail_on), and the workgroups sum the partial column sums of G W' themselves (cs_parts: (k, cs_nbk) doubles,
+  // workgroup (tail_on = 1; 2: no extra workgroup - the launch's own workgroups share the tail, mu_fused_kernel.hpp), and the workgroups sum the partial column sums of G W' themselves (cs_parts: (k, cs_nbk) doubles,
   // into k doubles of LDS at byte offset cs_lds_off) instead of waiting for colsum_gw
   const double* cs_parts;
   int cs_nbk, cs_lds_off, tail_on;
@@ -628,28 +658,31 @@ struct WFinishArgs {
 __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* scratch) {
   // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and U blocks
   // per thread are in flight at once.  Few waves on purpose: the cross-lane part costs per wave.
-  constexpr int NV = ESPM_HP_NSCALAR + 2 * KP;   // [0..3] scalar sums, [4..4+KP) row sums | [4+KP] RELH, then maxima
-  constexpr int V_RELH = 4 + KP, V_MAX = 5 + KP;
+  constexpr int NV = ESPM_HP_NSCALAR + 2 * KP + 1;   // [0..3] scalar sums, [4..4+KP) row sums | [4+KP] RELH, then maxima, RELW
+  constexpr int V_RELH = 4 + KP, V_MAX = 5 + KP, V_RELW = 5 + 2 * KP;
   double v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = 0.0;
+  v[V_RELW] = -1.0;   // (-1: the launch carried no W update's tail; a record's share of rel_W is >= 0)
   const size_t nb = a.nblk;
   // (the wide build's records have 37 fields: 4 of them in flight are 296 registers on top of the 74 of the sums, which took
   //  every kernel this body rides in - the slab reductions - to one wave per SIMD; the order of the sums does not depend on U)
   constexpr int U = KP > 8 ? 1 : 4;
   for (int b0 = threadIdx.x; b0 < a.nblk; b0 += U * 256) {
-    double t[U][ESPM_HP_RELH + 1];
+    double t[U][ESPM_HP_RELH + 1], tw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int b = b0 + u * 256;
 #pragma unroll
       for (int i = 0; i <= ESPM_HP_RELH; ++i) t[u][i] = b < a.nblk ? a.hpart[i * nb + b] : 0.0;
+      tw[u] = b < a.nblk ? a.hpart[(size_t)ESPM_HP_RELW * nb + b] : -1.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < 4 + KP; ++i) v[i] += t[u][i];
       v[V_RELH] = fmax(v[V_RELH], t[u][ESPM_HP_RELH]);
+      v[V_RELW] = fmax(v[V_RELW], tw[u]);
 #pragma unroll
       for (int i = 0; i < KP; ++i) v[V_MAX + i] = fmax(v[V_MAX + i], t[u][ESPM_HP_MAX + i]);
     }
@@ -670,6 +703,7 @@ __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* 
     a.hist_slot[ESPM_HI_SUMY] = sumy;
     a.hist_slot[ESPM_HI_BAD] = v[ESPM_HP_BAD];
     if (a.have_prev) a.hist_slot[ESPM_HI_REL_H] = v[V_RELH];
+    if (v[V_RELW] >= 0.0) a.hist_slot[ESPM_HI_REL_W] = v[V_RELW];   // rel_W of the update that produced this state, where the H-step's workgroups formed it (mu_fused_kernel.hpp)
     if (a.hstat_out) {
       for (int kk = 0; kk < KP; ++kk) {
         a.hstat_out[ESPM_HS_ROWSUM + kk] = v[ESPM_HP_ROWSUM + kk];
@@ -791,7 +825,6 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
                            const double* hpart, int nblk_h, const double* hstat_rs, size_t rec_hstat_off, double* hstat_out,
                            const HFinalizeArgs* fused_finalize, hipStream_t stream, WTailArgs* defer_tail = nullptr);
 int launch_w_update_tail(const WTailArgs& t, hipStream_t stream);
-int w_exchange_resident_workgroups();   // workgroups of the one-launch exchange kernel the device holds at once (its grid must fit)
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const struct ::espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny,
                              int p_pad, int with_halo, hipStream_t stream, WTailArgs* defer_tail);

@@ -21,7 +21,7 @@ static int allow_lds(KernelT kern, size_t bytes, const char* what) {
 template <int K>
 static int launch_h_ell_k(const HStepArgs& args_in, int nblk, hipStream_t stream) {
   constexpr int UNR = K > 8 ? 2 : ESPM_ELL_UNR_H;   // (a batch holds 2 UNR gathered rows of K floats)
-  const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t red = (size_t)(ESPM_ELL_TILE / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   // [nsplit][K][tile_px]: K * 512 floats whatever the split; two such sets when the groups of a 512-pixel window are walked in pairs
   size_t part = (size_t)K * ESPM_ELL_TILE * sizeof(float) * ((K <= ESPM_ELL_PAIR_MAX_K && args_in.ell_tp == ESPM_ELL_TILE) ? 2 : 1);
   if (red > part) part = red;

@@ -161,7 +161,20 @@ struct EllNoFlush {
   template <typename Redo>
   __device__ __forceinline__ void operator()(Redo) const {}
 };
-template <int K, int UNR, int PF = 1, typename Get, typename Body, typename Flush = EllNoFlush>
+// PRIO > 0: before every batch the wave sets its issue priority to min(3, dwords left / PRIO).  The waves of a SIMD are served
+// oldest first: where every wave walks ONE unit of about equal length (the fused kernel below its full
+// geometry) the youngest wave of a SIMD ends long after the oldest, and the SIMD runs one wave deep meanwhile; with the
+// priority following the work that is left, whoever is behind is served first.
+template <int PRIO>
+__device__ __forceinline__ void ell_walk_prio(int left) {
+  if constexpr (PRIO > 0) {
+    if (left > 3 * PRIO) __builtin_amdgcn_s_setprio(3);
+    else if (left > 2 * PRIO) __builtin_amdgcn_s_setprio(2);
+    else if (left > PRIO) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+}
+template <int K, int UNR, int PF = 1, int PRIO = 0, typename Get, typename Body, typename Flush = EllNoFlush>
 __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
@@ -194,6 +207,7 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
       for (int u = 0; u < UNR; ++u) q[d][u] = row[(size_t)(jd + u) * 64];
     }
     for (; j + UNR <= len; j += UNR) {
+      ell_walk_prio<PRIO>(len - j);
       uint32_t e[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) e[u] = q[0][u];
@@ -258,13 +272,13 @@ struct EllGetUnit {
 #ifndef ESPM_ELL_KLPROD
 #define ESPM_ELL_KLPROD 1
 #endif
-template <int K, bool LOSS, int UNR, int PF>
+template <int K, bool LOSS, int UNR, int PF, int PRIO = 0>
 __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1, int mid, const float* tab, int n_pad, int ell_bits,
                                            const float (&hk)[K], float (&acc)[K], float& kl) {
   if (x0 < mid) {
     if constexpr (LOSS && ESPM_ELL_KLPROD) {
       float prod = 1.f;
-      ell_walk<K, UNR, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
+      ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
         [&](float, const float (&g)[K]) {
           const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
           ell_axpy<K>(acc, g, r);
@@ -280,7 +294,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
           prod = 1.f;
         });
     } else {
-      ell_walk<K, UNR, PF>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
+      ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
         const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
         ell_axpy<K>(acc, g, r);
         if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
@@ -289,7 +303,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
   }
   if (x1 > mid) {
     const int g0 = max(x0, mid);
-    ell_walk<K, UNR, PF>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
+    ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
       const float y = ell_dot<K>(g, hk);
       // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
       const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);

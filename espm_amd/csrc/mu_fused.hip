@@ -25,7 +25,7 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   const int pb = args.w.pb;
   const int tab_rows = args.h.n_pad > pb ? args.h.n_pad : pb;
   size_t part = (size_t)(pb == ESPM_ELL_PB ? FusedGeom<K>::S : ESPM_ELL_PB / pb) * FusedGeom<K>::PROWS * pb * sizeof(float);
-  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
   if (red > part) part = red;
   if (tail_scratch > part) part = tail_scratch;
@@ -39,18 +39,27 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   // (the full geometry: the copies are an extra where the workgroup's 160 KB still hold them)
   args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
   if (args.perm_lds) bytes += perm_bytes;
-  if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
-    args.h.cs_lds_off = (int)bytes;
-    bytes += KP * sizeof(double);
+  args.red_lds_off = -1;
+  if (ESPM_FUSED_RED_ONE_BARRIER && bytes + (ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double) + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
+    bytes = (bytes + 7) / 8 * 8;
+    args.red_lds_off = (int)bytes;
+    bytes += (size_t)(ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   }
-  if (bytes > (args.perm_lds && pb == ESPM_ELL_PB ? ESPM_FUSED_LDS_LIMIT : ESPM_ELL_LDS_MAX))
+  if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators (and, for the shared tail, the sums of W')
+    args.h.cs_lds_off = (int)bytes;
+    bytes += 2 * KP * sizeof(double);
+  }
+  // the tail of the previous W update is shared by the launch's own workgroups (mu_fused_kernel.hpp) unless it carries the
+  // projected gradient's quadratic term, which only the extra workgroup sums
+  if (args.h.tail_on && !args.h.tail.pg_q) args.h.tail_on = 2;
+  if (bytes > ((args.perm_lds && pb == ESPM_ELL_PB) || args.red_lds_off >= 0 ? ESPM_FUSED_LDS_LIMIT : ESPM_ELL_LDS_MAX))
     return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
   auto go = [&](auto kern, int threads) -> int {
     if (bytes > 64 * 1024)
       if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
                              "fused half-steps"))
         return rc;
-    hipLaunchKernelGGL(kern, dim3(nblk + (args.h.tail_on ? 1 : 0)), dim3(threads), bytes, stream, args);
+    hipLaunchKernelGGL(kern, dim3(nblk + (args.h.tail_on == 1 ? 1 : 0)), dim3(threads), bytes, stream, args);
     return check_hip(hipGetLastError(), "fused half-steps launch");
   };
   if (pb == ESPM_ELL_PB)   // the full geometry: 16 waves, sizes known at compile time
@@ -69,11 +78,11 @@ size_t fused_ell_lds_bytes(int n_pad, int k, int pb) {
   const int seg = pb == ESPM_ELL_PB ? (k <= 5 ? 4 : (k == 6 ? 3 : 2)) : ESPM_ELL_PB / pb;   // FusedGeom<K>::S | 1024 / pb
   const int n_cg = (n_pad + 63) / 64;   // (>= the channel groups of any n with this n_pad)
   size_t part = (size_t)seg * (k + 1) * pb * 4;
-  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * k) * sizeof(double);
+  const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * k + 1) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
   if (red > part) part = red;
   if (tail_scratch > part) part = tail_scratch;
-  return (size_t)tab_rows * tabf * 4 + part + 16 + (size_t)(3 * (pb / 64) + 2 * n_cg + 4) / 4 * 16 + KP * sizeof(double) +
+  return (size_t)tab_rows * tabf * 4 + part + 16 + (size_t)(3 * (pb / 64) + 2 * n_cg + 4) / 4 * 16 + 2 * KP * sizeof(double) +
          (pb != ESPM_ELL_PB ? (size_t)(pb + 64 * n_cg) * sizeof(int) : 0);
 }
 

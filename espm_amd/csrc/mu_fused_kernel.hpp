@@ -44,6 +44,20 @@
 #ifndef ESPM_FUSED_FULL_PREFETCH
 #define ESPM_FUSED_FULL_PREFETCH 1
 #endif
+// Round 3, measured together (tools/analysis/variant_ab.py, profiles/r03b_variant_ab_*.log; same results bit for bit): a 64-row shard
+// of the headline image 46.3 -> 43.5 us per iteration with the fused launch, a 128-row one 57.2 -> 54.4, the headline 147.4 -> 145.9.
+// the record reduction with ONE barrier (h_epilogue, red_scratch)
+#ifndef ESPM_FUSED_RED_ONE_BARRIER
+#define ESPM_FUSED_RED_ONE_BARRIER 1
+#endif
+// below the full geometry: a wave's issue priority follows the rows it still has to walk, in steps of this many dwords (0: off)
+#ifndef ESPM_FUSED_SMALL_PRIO
+#define ESPM_FUSED_SMALL_PRIO 8
+#endif
+// the prologue's global loads issued together (the kernel's comment at its prologue)
+#ifndef ESPM_FUSED_PROLOGUE_BATCH
+#define ESPM_FUSED_PROLOGUE_BATCH 1
+#endif
 
 namespace espm {
 
@@ -55,6 +69,7 @@ struct FusedArgs {
                     // pixel-list groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
   int perm_lds_off; // below the full geometry: byte offset of the block's copy of pix_perm (pb ints) and chan_perm (64 n_cg ints) in LDS
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
+  int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
 };
 
@@ -92,6 +107,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
   const int S = FULL ? FusedGeom<K>::S : ESPM_ELL_PB / PB;
   constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
+  constexpr int PRIO = FULL ? 0 : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
   const HStepArgs& a = fa.h;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -101,42 +117,144 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const int tab_rows = a.n_pad > PB ? a.n_pad : PB;
   float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
   int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk
-  if (a.tail_on && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
+  if (a.tail_on == 1 && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
     w_tail_body<(10 * ESPM_ELL_WTHREADS) / NT>(a.tail, reinterpret_cast<double*>(smem));
+    ESPM_PHASE_STAMP(7);   // (instrumented build: when the extra workgroup got a CU - stamp 0 - and when it was done)
     return;
   }
   double* cs_lds = a.cs_parts ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + a.cs_lds_off) : nullptr;
-  if (cs_lds) {      // wave w: column sums w, w + NT / 64, ... of G W' from the W update's partials
-    for (int kk = threadIdx.x >> 6; kk < K; kk += NT / 64) {
-      double v = 0.0;
-      for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
-      v = wave_sum(v);
-      if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
-    }
-  }
-  for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
-  if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
-  // the block's list offsets, once: a unit then starts from LDS instead of from two dependent scalar loads
   int* meta = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.meta_lds_off);
-  if ((int)threadIdx.x < 3 * NGRP) {
-    const int gi = threadIdx.x / 3, j = threadIdx.x - 3 * gi;
-    const bool tile_ok = blockIdx.x * PB + (gi >> GPT_SHIFT) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
-    meta[threadIdx.x] = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
-  }
-  for (int i = threadIdx.x; i <= 2 * fa.w.n_cg; i += NT) meta[3 * NGRP + i] = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + i];
-  // What a unit needs before its first list row - the slot -> pixel map, the block's channel order - is fetched once by the
-  // workgroup (below the full geometry always; at the full geometry where the 4 (PB + 64 n_cg) bytes fit, ESPM_FUSED_FULL_PERM_LDS),
-  // so that a unit starts with ONE round trip to memory (its H column or GW rows and its first list rows together) instead
-  // of a chain of three.
   int* lpix = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.perm_lds_off);
   int* lchan = lpix + PB;
   const bool perm_lds = !FULL || fa.perm_lds;   // (uniform)
-  if (perm_lds) {
-    for (int i = threadIdx.x; i < PB; i += NT) lpix[i] = a.ell_pix[(size_t)blockIdx.x * PB + i];
-    for (int i = threadIdx.x; i < 64 * fa.w.n_cg; i += NT) lchan[i] = fa.w.chan_perm[(size_t)blockIdx.x * fa.w.n_cg * 64 + i];
+  // ---- prologue: GW table, the block's list offsets and permutations, the column sums of G W' -> LDS.
+  // ESPM_FUSED_PROLOGUE_BATCH: every global load of the prologue is issued before the first result is consumed.  As loops
+  // with run-time trip counts (the round-2 form, kept below) each of the five pieces waited for its own loads: five serial
+  // round trips to memory, 3.2 us of a workgroup's 127 at the headline and 4.1 of 34 on a 64-row shard.
+  // The tail of the W update that produced the input state (tail_on = 2): no extra workgroup - at one workgroup per CU it starts when
+  // the first regular one exits and the launch ends with it, 5.5 us after everybody else on a 64-row shard
+  // (profiles/r03c_phase_clock_64rows.log).  Instead every workgroup sums the partials it needs anyway (column sums of G W'; with
+  // them the sums of W' for its mean), takes the entries of W', W with index in its slice [rw_lo, rw_hi) and leaves its share of
+  // rel_W (base.py:323) in its record (ESPM_HP_RELW: the reduction of the records writes the history); workgroup 0 writes colsum_gw.
+  const bool spread = a.tail_on == 2 && cs_lds;   // (uniform)
+  constexpr int RW = 2;                           // entries of W a thread holds across the prologue
+  const int rw_n = a.tail.n * a.tail.k, rw_per = (rw_n + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int rw_lo = min(rw_n, (int)blockIdx.x * rw_per), rw_hi = min(rw_n, rw_lo + rw_per);
+  const bool rw_staged = rw_per <= RW * NT;
+  float rwn[RW], rwo[RW];
+#pragma unroll
+  for (int u = 0; u < RW; ++u) rwn[u] = rwo[u] = 1.f;
+  bool staged = false;
+  if constexpr (ESPM_FUSED_PROLOGUE_BATCH) {
+    constexpr int TR = 4, PC = 4;   // table rows / permutation entries a thread stages
+    const int n_perm = perm_lds ? PB + 64 * fa.w.n_cg : 0, n_woff = 2 * fa.w.n_cg + 1;
+    staged = a.n_pad <= TR * NT && n_perm <= PC * NT && n_woff <= NT && a.cs_nbk <= 64 && 2 * K <= NT / 64;   // (uniform)
+    if (staged) {
+      float4 tlo[TR], thi[TR];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int r = threadIdx.x + i * NT;
+        const float* src = a.gw_s + (size_t)min(r, a.n_pad - 1) * KP;
+        tlo[i] = *reinterpret_cast<const float4*>(src);
+        thi[i] = K > 4 ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      int pv[PC];
+#pragma unroll
+      for (int i = 0; i < PC; ++i) {
+        const int j = threadIdx.x + i * NT;
+        pv[i] = 0;
+        if (j < n_perm) pv[i] = j < PB ? a.ell_pix[(size_t)blockIdx.x * PB + j] : fa.w.chan_perm[(size_t)blockIdx.x * fa.w.n_cg * 64 + (j - PB)];
+      }
+      int mh = 0, mw = 0;
+      if ((int)threadIdx.x < 3 * NGRP) {
+        const int gi = threadIdx.x / 3, j = threadIdx.x - 3 * gi;
+        const bool tile_ok = blockIdx.x * PB + (gi >> GPT_SHIFT) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
+        mh = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
+      }
+      if ((int)threadIdx.x < n_woff) mw = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + threadIdx.x];
+      double csv = 0.0;
+      const int cw = threadIdx.x >> 6;   // wave w: column sum w of G W' from the W update's partials; wave K + w (shared tail): sum of W'[:, w]
+      if (cs_lds && cw < K && (int)(threadIdx.x & 63) < a.cs_nbk) csv = a.cs_parts[(size_t)cw * a.cs_nbk + (threadIdx.x & 63)];
+      if (spread && cw >= K && cw < 2 * K && (int)(threadIdx.x & 63) < a.cs_nbk)
+        csv = a.cs_parts[(size_t)K * a.cs_nbk + (size_t)(cw - K) * a.cs_nbk + (threadIdx.x & 63)];
+      if (spread && rw_staged) {
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+          const int i = rw_lo + (int)threadIdx.x + u * NT;
+          rwn[u] = i < rw_hi ? a.tail.w_new[i] : 1.f;
+          rwo[u] = i < rw_hi ? a.tail.w_old[i] : 1.f;
+        }
+      }
+      // ---- consume
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const int r = threadIdx.x + i * NT;
+        if (r < a.n_pad) lds_table_put<K>(tab, a.n_pad, r, tlo[i], thi[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < PC; ++i) {
+        const int j = threadIdx.x + i * NT;
+        if (j < n_perm) lpix[j] = pv[i];   // (lchan = lpix + PB: one array)
+      }
+      if ((int)threadIdx.x < 3 * NGRP) meta[threadIdx.x] = mh;
+      if ((int)threadIdx.x < n_woff) meta[3 * NGRP + threadIdx.x] = mw;
+      if (cs_lds && cw < (spread ? 2 * K : K)) {
+        csv = wave_sum(csv);
+        if ((threadIdx.x & 63) == 0) (cw < K ? cs_lds : cs_lds + KP - K)[cw] = csv;   // (sums of W' behind the KP column sums)
+      }
+      if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
+    }
+  }
+  if (!staged) {
+    if (cs_lds) {      // wave w: column sums w, w + NT / 64, ... of G W' from the W update's partials (shared tail: then the sums of W' as well)
+      for (int kk = threadIdx.x >> 6; kk < (spread ? 2 * K : K); kk += NT / 64) {
+        double v = 0.0;
+        for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];   // (row K + w of the partials: W'[:, w])
+        v = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) (kk < K ? cs_lds : cs_lds + KP - K)[kk] = v;
+      }
+    }
+    for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
+    if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
+    // the block's list offsets, once: a unit then starts from LDS instead of from two dependent scalar loads
+    if ((int)threadIdx.x < 3 * NGRP) {
+      const int gi = threadIdx.x / 3, j = threadIdx.x - 3 * gi;
+      const bool tile_ok = blockIdx.x * PB + (gi >> GPT_SHIFT) * TP < a.p_pad;   // (an odd number of tiles: the last block has one)
+      meta[threadIdx.x] = tile_ok ? a.ell_off[2 * (blockIdx.x * NGRP + gi) + j] : 0;
+    }
+    for (int i = threadIdx.x; i <= 2 * fa.w.n_cg; i += NT) meta[3 * NGRP + i] = fa.w.ell_off[(size_t)2 * blockIdx.x * fa.w.n_cg + i];
+    // What a unit needs before its first list row - the slot -> pixel map, the block's channel order - is fetched once by the
+    // workgroup (below the full geometry always; at the full geometry where the 4 (PB + 64 n_cg) bytes fit, ESPM_FUSED_FULL_PERM_LDS),
+    // so that a unit starts with ONE round trip to memory (its H column or GW rows and its first list rows together) instead
+    // of a chain of three.
+    if (perm_lds) {
+      for (int i = threadIdx.x; i < PB; i += NT) lpix[i] = a.ell_pix[(size_t)blockIdx.x * PB + i];
+      for (int i = threadIdx.x; i < 64 * fa.w.n_cg; i += NT) lchan[i] = fa.w.chan_perm[(size_t)blockIdx.x * fa.w.n_cg * 64 + i];
+    }
   }
   __syncthreads();
   ESPM_PHASE_STAMP(1);
+  float relw = -1.f;
+  if (spread) {
+    if (blockIdx.x == 0 && threadIdx.x < KP) a.tail.colsum_gw[threadIdx.x] = (int)threadIdx.x < K ? cs_lds[threadIdx.x] : 0.0;
+    if (a.tail.hist_slot) {
+      double sw = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) sw += cs_lds[KP + kk];
+      const float shift = (float)((double)a.tail.rel_tol * (sw / (double)rw_n));   // tol * mean(W'), base.py:323
+      relw = 0.f;
+      if (rw_staged && staged) {
+#pragma unroll
+        for (int u = 0; u < RW; ++u)
+          if (rw_lo + (int)threadIdx.x + u * NT < rw_hi) relw = fmaxf(relw, fabsf(rwn[u] - rwo[u]) / (rwn[u] + shift));
+      } else {
+        for (int i = rw_lo + (int)threadIdx.x; i < rw_hi; i += NT) {
+          const float x = a.tail.w_new[i], y = a.tail.w_old[i];
+          relw = fmaxf(relw, fabsf(x - y) / (x + shift));
+        }
+      }
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int blk0 = blockIdx.x * PB;
   int own_next[2] = {(int)(threadIdx.x >> 6), (int)(threadIdx.x >> 6)};
@@ -171,7 +289,8 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-        ell_h_rows<K, LOSS, UNR_H, PF>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
+        ell_h_rows<K, LOSS, UNR_H, PF, PRIO>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
+        if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
     float* dst = part + (size_t)seg * PROWS * PB + (gi >> GPT_SHIFT) * TP + lp;
@@ -183,7 +302,9 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true);
+  h_epilogue<K, true, 0, FULL ? FusedGeom<K>::S : 8>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
+                                                     fa.red_lds_off >= 0 ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr,
+                                                     relw);
 
   ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
@@ -201,13 +322,14 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     const int* off = meta + 3 * NGRP + 2 * cg;
     const int beg = off[0], mid = off[1], end = off[2];
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk<K, UNR_W, PF>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     });
-    ell_walk<K, UNR_W, PF>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (c >= 0) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) w.a_slab[((size_t)b * K + kk) * w.n_pad + c] = acc[kk];

@@ -88,17 +88,23 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // kl_rows (fused half-steps): every partial carries K + 1 rows of TP floats, the last being the pixel's part of
 // sum X log2(X / Y) (summed per pixel in slot order: the loss does not depend on which wave walked which slot); kl_lane
 // is then unused and the per-pixel loss constant ell_klc is added here.
-template <int K, bool EARLY = true, int RULE = 0>
+// MAXP > 0: at most MAXP partials - their LDS reads are then requested together (as a loop over the run-time count every read
+// waited for the one before: 2.1 us of a 64-row shard's 33 with 8 partials of 6 rows); the sum keeps the slot order.
+// relw_lane: this lane's share of rel_W of the W update that produced the input state (record field ESPM_HP_RELW), -1: none.
+template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
-                                           float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false) {
-  constexpr int NRED = ESPM_HP_NSCALAR + 2 * K;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima
+                                           float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false,
+                                           double* red_scratch = nullptr,   // fused half-steps: scratch of its own for the waves' sums -> ONE barrier after the per-pixel work
+                                           float relw_lane = -1.f) {
+  constexpr int NRED = ESPM_HP_NSCALAR + 2 * K + 1;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima + RELW
   float red[NRED];   // per-thread partials in fp32 (one or two pixels per thread); fp64 from the wave results on (block_reduce_f32)
 #pragma unroll
   for (int i = 0; i < NRED; ++i) red[i] = 0.f;
   // layout inside red[]: [0..3] KL, REG, LAP, BAD (sums), [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima
-  constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K;
+  constexpr int R_ROWSUM = 4, R_RELH = 4 + K, R_MAX = 5 + K, R_RELW = 5 + 2 * K;
   red[ESPM_HP_KL] = kl_lane;
+  red[R_RELW] = relw_lane;
   double pg_q = 0.0;   // rule 2: <H' - H, grad> + gamma ||H' - H||^2 of this thread's pixels (the linesearch's quadratic bound)
   const bool stencil = a.lambda_l != 0.f && a.grid_mode;
   HEpiIn<K> in;
@@ -152,19 +158,45 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     klc_loaded = false;
     float hin[K], nv[K], dv[K];
     const int prows = kl_rows ? K + 1 : K;   // rows of TP floats per partial
-    if (kl_rows) {
-      float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
-      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + K) * TP + jj];
-      red[ESPM_HP_KL] += s;
-    }
+    if constexpr (MAXP > 0) {
+      float pv[MAXP][K + 1];
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      float s = 0.f;
-      for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + kk) * TP + jj];
-      hin[kk] = in.hin[kk];
-      nv[kk] = s * a.xscale;
-      dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
+      for (int w = 0; w < MAXP; ++w)
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = (w < nparts && (kk < K || kl_rows)) ? smem[((size_t)w * prows + kk) * TP + jj] : 0.f;
+      if (kl_rows) {
+        float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
+#pragma unroll
+        for (int w = 0; w < MAXP; ++w)
+          if (w < nparts) s += pv[w][K];
+        red[ESPM_HP_KL] += s;
+      }
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MAXP; ++w)
+          if (w < nparts) s += pv[w][kk];
+        hin[kk] = in.hin[kk];
+        nv[kk] = s * a.xscale;
+        dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
+      }
+    } else {
+      if (kl_rows) {
+        float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
+        for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + K) * TP + jj];
+        red[ESPM_HP_KL] += s;
+      }
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float s = 0.f;
+        for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + kk) * TP + jj];
+        hin[kk] = in.hin[kk];
+        nv[kk] = s * a.xscale;
+        dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
+      }
     }
+    ESPM_PHASE_STAMP(40);   // (instrumented build) partial numerators summed
     if (a.fill_num) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
       const float mark = klc;
       if (mark < 0.f) {
@@ -309,6 +341,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       emit_ht(q, jj, ht);
       continue;
     }
+    ESPM_PHASE_STAMP(41);   // regularisers, stencil (the pixel's loads have arrived)
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
     if (a.simplex_h) {
@@ -317,6 +350,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
     }
+    ESPM_PHASE_STAMP(42);   // simplex multiplier found
     float ht[KP];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
@@ -337,22 +371,33 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
 
   ESPM_PHASE_STAMP(4);
-  __syncthreads();  // smem is reused as reduction scratch
   // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced; thread i of the
   // workgroup finishes and writes value i itself
   const size_t nb = a.rec_nb ? (size_t)a.rec_nb : gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
   double* out = a.hpart + (a.rec_nb ? 2 * blockIdx.x : blockIdx.x);
-  block_reduce_f32<NRED, R_RELH>(red, reinterpret_cast<double*>(smem), [&](int i, double v) {
+  auto emit = [&](int i, double v) {
     // red[]: [0..3] KL, REG, LAP, BAD, [4..4+K) row sums, [4+K] RELH, [5+K..5+2K) maxima -> record fields
-    const int field = i < R_RELH ? i : (i == R_RELH ? ESPM_HP_RELH : ESPM_HP_MAX + (i - R_MAX));
+    const int field = i < R_RELH ? i : (i == R_RELH ? ESPM_HP_RELH : (i == R_RELW ? ESPM_HP_RELW : ESPM_HP_MAX + (i - R_MAX)));
     out[(size_t)field * nb] = v;
-  });
+  };
+  if (red_scratch && RULE != 2) {
+    // a wave reduces its own values as soon as its pixels are done (while slower waves are still at theirs) into scratch nobody
+    // else touches; the one barrier that follows is also the one the W walk needs (H' table complete); 15 threads then add the
+    // waves' values and store the record while everybody else is already walking
+    block_reduce_f32_wave<NRED, R_RELH>(red, red_scratch);
+    __syncthreads();
+    block_reduce_f32_finish<NRED, R_RELH>(red_scratch, emit);
+  } else {
+    __syncthreads();  // smem is reused as reduction scratch
+    block_reduce_f32<NRED, R_RELH>(red, reinterpret_cast<double*>(smem), emit);
+  }
   if (threadIdx.x >= 64 && threadIdx.x < 64 + 2 * (KP - K)) {   // the unused component slots of the record: zeros (second wave: off the reducing lanes' path)
     const int j = threadIdx.x - 64;
     out[(size_t)((j < KP - K ? ESPM_HP_ROWSUM + K + j : ESPM_HP_MAX + K + (j - (KP - K)))) * nb] = 0.0;
   }
   if (a.rec_nb && 2 * blockIdx.x + 1 < nb && threadIdx.x >= 128 && threadIdx.x <= 128 + ESPM_HP_RELH)   // the slot of the block's second tile: sums + 0, maxima of non-negative values with 0
     out[(size_t)(threadIdx.x - 128) * nb + 1] = 0.0;
+  if (a.rec_nb && 2 * blockIdx.x + 1 < nb && threadIdx.x == 192) out[(size_t)ESPM_HP_RELW * nb + 1] = -1.0;   // (and "no share of rel_W")
   if constexpr (RULE == 2) {
     __syncthreads();
     double one[1] = {pg_q};

@@ -34,7 +34,7 @@ namespace espm {
 #if ESPM_H_PART == 0
 // ---- reduction of the per-workgroup records (one workgroup) ---------------------------------
 __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) {
-  __shared__ double scratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ double scratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
   h_finalize_body(a, scratch);
 }
 #endif
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) 
 template <int K, typename XT, int PX, int NW, int U, int NBUF>
 static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
-  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
   if (args.compute_loss)
     hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
@@ -56,7 +56,7 @@ template <int K, typename XT, int TILE>
 static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
   constexpr int STEPS = ESPM_H_MFMA_STEPS, PASSES = TILE / (16 * STEPS);   // pixel steps of 16 per pass, passes per tile
   const size_t lds = (size_t)4 * K * 16 * STEPS * PASSES * sizeof(float);
-  const size_t lds_min = (size_t)(4 + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t lds_min = (size_t)(4 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
   if (args.compute_loss)
     hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), dim3(nblk), dim3(256), bytes, stream, args);
@@ -68,7 +68,7 @@ static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
 template <int K, int PX, int NW, int U, int NBUF>
 static int launch_h_l2(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
-  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, true>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min,
                      stream, args);
   return check_hip(hipGetLastError(), "h_step (l2) launch");
@@ -77,7 +77,7 @@ static int launch_h_l2(const HStepArgs& args, int nblk, hipStream_t stream) {
 template <int K, int PX, int NW, int U, int NBUF, int RULE>
 static int launch_h_rule(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
-  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
   if (args.compute_loss)
     hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);

@@ -43,10 +43,29 @@ __device__ __forceinline__ void mf_split(const float (&v)[4], mf_s4& hi, mf_s4& 
   hi = __builtin_bit_cast(mf_s4, mf_u2{h0, h1});
   lo = __builtin_bit_cast(mf_s4, mf_u2{l0, l1});
 }
+// c += (ah + al) . (bh + bl) over the 16 slots of the contraction.
+// ESPM_MFMA_K32 (gfx950's own shape): v_mfma_f32_16x16x32_bf16 contracts over 32 slots in the cycles the CDNA3-era 16x16x16 form
+// takes for 16, and the hi / lo split supplies exactly two 16-slot halves: with the A operand [ah | al] (the two halves side by
+// side in one 8-element operand - slot i of either half is the same component, so the order inside the 32 does not matter as
+// long as both operands agree) one instruction against [bl | bl] gives ah bl + al bl and one against [bh | bh] gives
+// ah bh + al bh: the three products of the 16-wide form (and the fourth, lo lo, for free) in TWO matrix instructions instead of
+// three.  What it costs is the duplicated operand: four registers instead of two, filled by two moves where the half is not
+// already held twice.
+typedef short mf_s8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
+#ifndef ESPM_MFMA_K32
+#define ESPM_MFMA_K32 1
+#endif
 __device__ __forceinline__ mf_f4 mf_mma3(const mf_s4 ah, const mf_s4 al, const mf_s4 bh, const mf_s4 bl, mf_f4 c) {
+#if ESPM_MFMA_K32
+  const mf_b8 a = __builtin_bit_cast(mf_b8, __builtin_shufflevector(ah, al, 0, 1, 2, 3, 4, 5, 6, 7));
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(mf_b8, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 4, 5, 6, 7)), c, 0, 0, 0);   // small terms first
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(mf_b8, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 4, 5, 6, 7)), c, 0, 0, 0);
+#else
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);   // small terms first
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+#endif
 }
 
 // 16 consecutive pixels of one channel row of the tile-major X; quad(s) = the 4 pixels of step s as floats

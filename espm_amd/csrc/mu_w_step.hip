@@ -9,6 +9,9 @@
 //   w_finish: numerator / denominator, optional simplex over the columns of W with the reference's
 //             global-stop bisection (dicotomy.py:111-173), clamp, fixed_W, then GW = G W for the
 //             next half step, its column sums, and rel_W (base.py:323).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "mu_w_kernel.hpp"
 #include "mu_w_mfma_kernel.hpp"
 #include "mu_xchg.hpp"
@@ -44,7 +47,7 @@ struct WReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
-  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
   __shared__ float s_part[8][32];
   if ((int)blockIdx.x >= a.nred_blocks) {  // the extra workgroup
     if (a.halo_top) {
@@ -187,7 +190,7 @@ __device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, i
 }
 
 __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs a) {
-  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
   __shared__ float s_part[8][32];
   __shared__ double s_rsw[4];
   const int nwg = a.k * a.nbk;
@@ -385,7 +388,7 @@ struct WExchangeArgs {
   WUpdateArgs u;
   unsigned char* mbox[16];   // every rank's mailbox as mapped here
   int world, rank, nfl, with_halo;
-  size_t rec_bytes, slot_base, wgflags_off, err_off, hstat_off, top_off, bot_off;
+  size_t rec_bytes, slot_base, wgflags_off, wgrs_off, err_off, hstat_off, top_off, bot_off;   // (wgrs_off: of this sequence number's parity)
   unsigned int seq;
   long long max_ticks;
   const float* halo_h;
@@ -405,16 +408,22 @@ __device__ __forceinline__ void xchg_wait_flag(const unsigned int* flag, unsigne
 
 __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeArgs x) {
   const WUpdateArgs& a = x.u;
-  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP)];
+  __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
   __shared__ float s_part[8][32];
   const int nwg = a.k * a.nbk;
   auto record = [&](int dst, int src_rank) { return x.mbox[dst] + x.slot_base + (size_t)src_rank * x.rec_bytes; };
   auto flag = [&](int dst, int src_rank, int idx) {
     return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + idx) * sizeof(unsigned int));
   };
-  // The extra workgroup is workgroup 0 of the grid: every reduction workgroup waits for ITS flag (of every rank) after posting
-  // its own piece, so it must not be the one workgroup a grid larger than the device holds at once leaves undispatched
-  // (workgroups start in index order; launch_w_exchange_update checks the residency and takes the four-launch path otherwise).
+  // Progress without the whole grid being resident (grids of k n_pad / 32 + 1 workgroups exceed what the device
+  // holds at once from k = 8, n = 8192 on): workgroups are dispatched in index order, every workgroup POSTS before it waits,
+  // and what it waits for was posted by the workgroup of the SAME index on every rank (reduction workgroup wg: the pieces of
+  // the workgroups wg) or by workgroup 0 (the extra workgroup: only reduction workgroup 0, index 1, waits for it).  The
+  // lowest-indexed unfinished workgroup of every rank is therefore resident and can finish; whatever it frees lets the next
+  // one in.  (Round 2 had the extra workgroup LAST and every reduction workgroup waiting for it: a grid beyond the residency
+  // dead-locked for the 2 s bound of the waits.  An occupancy query as a second guard was tried and dropped: on this stack
+  // hipOccupancyMaxActiveBlocksPerMultiprocessor answers 2 workgroups per CU for this 256-thread kernel, which would send
+  // the headline's 321 workgroups down the four-launch path - profiles/r03c_shard_iter_residency_guard.log.)  The waits stay bounded.
   if (blockIdx.x == 0) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
     h_finalize_body(a.fin, fscratch);   // (fin.hstat_out = the statistics of this rank's record in its OWN mailbox)
     __syncthreads();
@@ -453,6 +462,9 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   const int c = 32 * j + col;
   const int e = kk * a.n_pad + c;
   auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
+  auto wgrs = [&](int dst, int src_rank) {
+    return reinterpret_cast<double*>(x.mbox[dst] + x.wgrs_off) + (size_t)src_rank * x.nfl + wg;
+  };
   constexpr int INFLIGHT = 32;
   float v[INFLIGHT];
   const bool live = c < a.n_pad;
@@ -460,6 +472,15 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   for (int u = 0; u < INFLIGHT; ++u) {
     const int b = grp + 8 * u;
     v[u] = (live && b < a.nsrc) ? src(b) : 0.f;
+  }
+  // Row sum kk of THIS rank's new H block from the H-step's records, in the order of h_finalize_body (the same value the extra
+  // workgroup leaves in the statistics): it travels with the piece, so that the W update waits for pieces only - not for the
+  // extra workgroups' record reductions, which only workgroup 0 (the global statistics for the NEXT H-step) still waits for.
+  __shared__ double s_rsw[4];
+  double rsp = 0.0;
+  {
+    const size_t nb = a.nblk_h;
+    for (int b = threadIdx.x; b < a.nblk_h; b += 256) rsp += a.hpart[(ESPM_HP_ROWSUM + kk) * nb + b];
   }
   float acc[8];
 #pragma unroll
@@ -473,8 +494,10 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     for (int u = 0; b < a.nsrc; b += 8, ++u) acc[u & 7] += src(b);
   }
   s_part[grp][col] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  rsp = wave_sum(rsp);
+  if ((threadIdx.x & 63) == 0) s_rsw[threadIdx.x >> 6] = rsp;
   __syncthreads();
-  if (threadIdx.x < 64) {  // wave 0: lanes 0..31 own the 32 entries, lane r < world watches rank r
+  if (threadIdx.x < 64) {  // wave 0: lanes 0..31 own the 32 entries, lane r < world watches rank r, lane 32 + r writes to rank r
     const int lane = threadIdx.x;
     const bool owns = grp == 0 && live;
     float t = 0.f;
@@ -484,31 +507,46 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       for (int r = 0; r < x.world; ++r)   // this rank's piece, to every rank (write-through, system scope)
         __hip_atomic_store(reinterpret_cast<float*>(record(r, x.rank)) + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (lane >= 32 && lane - 32 < x.world)
+      __hip_atomic_store(wgrs(lane - 32, x.rank), ((s_rsw[0] + s_rsw[1]) + s_rsw[2]) + s_rsw[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // wave order, like block_reduce
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's pieces are delivered before its flags are issued (order, not a cache flush)
     if (lane < x.world) __hip_atomic_store(flag(lane, x.rank, wg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane < x.world) {
-      unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
-      xchg_wait_flag(flag(x.rank, lane, wg), x.seq, x.max_ticks, err);
-      xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
-    }
+    unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
+    if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, wg), x.seq, x.max_ticks, err);
     // (every lane's polls are done when the wave goes on: one program counter; the loads below bypass the caches)
+    // all of them requested together, then added in rank order: the same sums on every rank
+    float pv[16];
+    double rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = 0.f;
+      rv[r] = 0.0;
+      if (r < x.world) {
+        if (owns) pv[r] = __hip_atomic_load(reinterpret_cast<const float*>(record(x.rank, r)) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        rv[r] = __hip_atomic_load(wgrs(x.rank, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     float tt = 0.f;
     double rs = 0.0;
-    for (int r = 0; r < x.world; ++r) {   // fixed rank order: the same sums on every rank
-      if (owns) tt += __hip_atomic_load(reinterpret_cast<const float*>(record(x.rank, r)) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      rs += __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + ESPM_HS_ROWSUM + kk, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (wg == 0 && lane < ESPM_HS_STRIDE) {  // global statistics of the new H (as shard_combine)
-      double g = 0.0;
-      for (int r = 0; r < x.world; ++r) {
-        const double v2 = __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + lane, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_SYSTEM);
-        g = lane < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < x.world) {
+        tt += pv[r];
+        rs += rv[r];
       }
-      a.hstat_out[lane] = g;
-    }
     w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg);
+    if (wg == 0) {  // global statistics of the new H (as shard_combine): these need every rank's extra workgroup
+      if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
+      if (lane < ESPM_HS_STRIDE) {
+        double g = 0.0;
+        for (int r = 0; r < x.world; ++r) {
+          const double v2 = __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + lane, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_SYSTEM);
+          g = lane < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+        }
+        a.hstat_out[lane] = g;
+      }
+    }
   }
 }
 
@@ -1418,27 +1456,6 @@ int launch_w_simplex_update(const WFinishArgs& f, float* a_inout, const double* 
   return check_hip(hipGetLastError(), "w_simplex_update tail launch");
 }
 
-// Workgroups of w_exchange_update_kernel the device holds at once.  Its workgroups wait for each other (pieces of every rank,
-// the extra workgroup's flag), so the whole grid has to be resident: the occupancy query, capped by what the hardware admits
-// for 256-thread workgroups (MI355X_MICROARCH.md: min(API, 8, floor(800 / (ceil(sgpr / 16) 16 + 16))) per CU - the API answers
-// one high for 81..112 SGPRs), with one workgroup per CU of margin.
-int w_exchange_resident_workgroups() {
-  static int cached = -1;
-  if (cached >= 0) return cached;
-  int dev = 0, cus = 0, per_cu = 0;
-  hipFuncAttributes fa;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(w_exchange_update_kernel), 256, 0) != hipSuccess ||
-      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(w_exchange_update_kernel)) != hipSuccess) {
-    (void)hipGetLastError();
-    return cached = 0;
-  }
-  if (per_cu > 8) per_cu = 8;
-  per_cu -= 1;   // margin: the occupancy answer is one high for some register counts, and other kernels' workgroups may still be draining
-  if (per_cu < 1) per_cu = 1;
-  return cached = per_cu * cus;
-}
-
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny, int p_pad,
                              int with_halo, hipStream_t stream, WTailArgs* defer_tail) {
@@ -1452,9 +1469,9 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   a.k = f.k;
   a.nbk = (f.n_pad + 31) / 32;
   a.a_out = a_out;
-  a.hpart = nullptr;
+  a.hpart = fin.hpart;       // (every reduction workgroup forms the row sum it needs from the H-step's records itself)
   a.hstat_rs = nullptr;
-  a.nblk_h = 0;
+  a.nblk_h = fin.nblk;
   a.rec_hstat_off = 0;
   a.hstat_out = hstat_out;
   a.w_old = f.w_old;
@@ -1481,6 +1498,7 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.rec_bytes = xc->record_bytes;
   x.slot_base = (size_t)(seq & 1u) * xc->world * xc->record_bytes;
   x.wgflags_off = xc->off_wgflags;
+  x.wgrs_off = xc->off_wgrs + (size_t)(seq & 1u) * xc->world * xc->wgflags * sizeof(double);
   x.err_off = xc->off_err;
   x.hstat_off = (size_t)f.k * f.n_pad * 4;
   x.top_off = x.hstat_off + ESPM_HS_STRIDE * 8;
@@ -1493,8 +1511,6 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.halo_ny = ny;
   x.halo_ppad = p_pad;
   a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
-  if (nwg + 1 > w_exchange_resident_workgroups())   // (espm_mu_shard_exchange_finish takes the four-launch path before it gets here)
-    return set_error(ESPM_EUNSUPPORTED, "exchange: %d workgroups that wait for each other, the device holds %d at once", nwg + 1, w_exchange_resident_workgroups());
   hipLaunchKernelGGL(w_exchange_update_kernel, dim3(nwg + 1), dim3(256), 0, stream, x);
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)

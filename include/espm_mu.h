@@ -119,6 +119,8 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_HP_MAX (4 + ESPM_KP)      /* [4+KP, 4+2KP): max_j H_out[k, j]  (12 with KP = 8)           */
 #define ESPM_HP_RELH (4 + 2 * ESPM_KP) /* (20) max |H_in - H_prev| / (H_in + tol mean H_in) over the block (base.py:324) */
 #define ESPM_HP_PGQ (5 + 2 * ESPM_KP)  /* (21) projected-gradient rule only: sum <H' - H, grad> + gamma_H ||H' - H||^2 over the block */
+#define ESPM_HP_RELW (6 + 2 * ESPM_KP)  /* (22) the block's share of rel_W of the W update that produced the input state (max over its slice of
+                                         * the entries of W, base.py:323), where the launch carried that update's tail; else -1           */
 #define ESPM_HP_NSCALAR 5  /* KL, REG, LAP, BAD, RELH                                  */
 #define ESPM_HP_STRIDE (8 + 2 * ESPM_KP) /* (24) */
 

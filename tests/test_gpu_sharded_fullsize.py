@@ -1,5 +1,5 @@
 """The sharded HIP path at BASELINE.json's FULL geometries: configuration 4 - the headline image,
-2048 channels x 512 x 512 pixels, k = 5, simplex_H + Laplacian, cut into 256-row shards (the full-geometry fused kernel +
+2048 channels x 512 x 512 pixels, k = 5, simplex_H + Laplacian, cut into 256-row shards (the fused kernel on 512-pixel blocks +
 espm_mu_shard_combine_finish) - and the shard configuration 5 names - 128 image rows of 1024 pixels per rank, 1980
 channels, k = 8, a fixed dictionary G 1980 x 17, mu = 0.05 (the one-workgroup W finish behind the combine).
 
@@ -85,7 +85,8 @@ def test_config4_256_row_shards_of_the_headline_image():
     from test_gpu_fullsize_parity import sparse_from_device
     c = C4
     res = _run_sharded(c)
-    assert all(res[r]["transport"] == "collective" and res[r]["store"] == "ell" and res[r]["fused"] and res[r]["tile_px"] == 512 and res[r]["bad"] == 0
+    # (a 256-row shard fills the chip with 512-pixel blocks - two H tiles of 256: the fused launch at its run-time geometry)
+    assert all(res[r]["transport"] == "collective" and res[r]["store"] == "ell" and res[r]["fused"] and res[r]["tile_px"] == 256 and res[r]["bad"] == 0
                for r in res), {r: (res[r]["transport"], res[r]["store"], res[r]["fused"], res[r]["tile_px"]) for r in res}
     np.testing.assert_array_equal(res[1]["W"], res[0]["W"])           # W is replicated: the same bits on every rank
     np.testing.assert_array_equal(res[1]["loss"], res[0]["loss"])

@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ESPM_MU_LIB"] = os.path.join(ROOT, "tools", "analysis", "libespm_mu_phase.so")
+os.environ["ESPM_MU_LIB"] = os.path.join(ROOT, "tools", "analysis", os.environ.get("PHASE_LIB", "libespm_mu_phase.so"))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -23,13 +23,14 @@ dev = torch.device("cuda", 0)
 prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0, row0=0, nx_total=512)
 X = synth.sample_torch(prob, dev, seed=1000, row0=0)
 W0, H0 = synth.random_init(N_CH, K, 512 * 512, seed=0, scale=500.0 / N_CH)
-eng = MUEngine(X, K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=600, device=dev)
+eng = MUEngine(X, K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=600, device=dev,
+               fused={"0": False, "1": True}.get(os.environ.get("FUSED", "1"), os.environ.get("FUSED", "1")))
 del X
 eng.load_state(W0, H0[:, :NX * NY])
 eng.iterate(300, final_loss=False)
 torch.cuda.synchronize()
 nblk = eng.st.nblk_w
-SLOTS = 40
+SLOTS = 56
 buf = torch.zeros((nblk + 1, SLOTS), dtype=torch.int64, device=dev)
 fn = _lib.lib.espm_debug_phase_buffer
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
@@ -44,9 +45,18 @@ print(f"{nblk} workgroups; kernel span (first entry -> last exit) {t[:, 7].max()
 for i, nm in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print(f"  {nm:36s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+tail = buf[nblk].cpu().numpy().astype(np.float64) * 0.01
+if tail[7] > 0:
+    print(f"  extra workgroup (tail of the previous W update): enters {tail[0] - t0:7.2f} us after the first entry, done at {tail[7] - t0:7.2f} us "
+          f"(last regular workgroup exits at {t[:, 7].max() - t0:7.2f})")
 tot = t[:, 7] - t[:, 0]
 print(f"  {'workgroup total':36s} mean {tot.mean():7.2f}  min {tot.min():7.2f}  max {tot.max():7.2f} us")
 print(f"  exits spread over {t[:, 7].max() - t[:, 7].min():5.2f} us")
+if t[:, 40].max() > 0:   # stamps inside the per-pixel update (thread 0): partial sums | regularisers + stencil (loads arrived) | simplex root | stores (= stamp 4)
+    sub = [("sum of the partial numerators", 3, 40), ("regularisers, stencil (loads arrived)", 40, 41), ("simplex multiplier", 41, 42), ("H', table row, statistics", 42, 4)]
+    for nm, a_, b_ in sub:
+        d = t[:, b_] - t[:, a_]
+        print(f"    {nm:38s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 # per wave: end of the H walk / of the W walk relative to the stamp that started it (1: table ready, 5: H' table ready)
 hw = t[:, 8:24] - t[:, 1:2]
 ww = t[:, 24:40] - t[:, 5:6]

@@ -18,7 +18,7 @@ int run_h(const HStepArgs& args, int p, hipStream_t stream) {
   constexpr int K = 5;
   const int nblk = (p + 64 * PX - 1) / (64 * PX);
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
-  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K) * sizeof(double);
+  const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   if (args.compute_loss)
     hipLaunchKernelGGL((h_step_kernel<K, xt_t, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min, stream, args);
   else
