@@ -88,9 +88,11 @@ static int check_state(const espm_mu_state* st) {
 static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / st->tile_px; }
 
 // Both half-steps in one launch (mu_fused_kernel.hpp): sparse store, the default H rule, LDS for the table and the numerators
-// of a block of ell_pb pixels.  One record per pixel BLOCK.  Below blocks of ESPM_FUSED_MIN_PB pixels (images under 2^17
-// pixels, shards) one workgroup per CU leaves the CU idle through its serial phases and the two launches with two
-// workgroups per CU are as fast or faster (profiles/r02o_small_variants.log): fused there only on request (no_fused = 3).
+// of a block of ell_pb pixels.  One record per pixel BLOCK.  (Round 2 kept the two launches below blocks of 512 pixels - images
+// under 2^17 pixels, shards - where one workgroup per CU left the CU idle through its serial phases.  With those phases cut
+// in round 3 - prologue loads issued together, the update's inputs staged by the prologue, one barrier around the record
+// reduction, no extra workgroup for the W update's tail - the fused launch wins at every block size: a 64-row shard 47.4 -> 42.8 us
+// per iteration, profiles/r03d_shard_iter*.log.  ESPM_FUSED_MIN_PB = 128, the smallest block there is.)
 static bool fused_ok(const espm_mu_state* st) {
   return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->h_rule == 0 && st->no_fused != 1 &&
          (st->ell_pb >= ESPM_FUSED_MIN_PB || st->no_fused == 3) &&

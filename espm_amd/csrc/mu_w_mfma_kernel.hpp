@@ -56,11 +56,26 @@ typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
 #ifndef ESPM_MFMA_K32
 #define ESPM_MFMA_K32 1
 #endif
+// The four-register operands of the 32-slot form must outlive the instruction's issue by a few cycles: hipcc (ROCm 7.2) lets a
+// vector instruction overwrite one of them two or three instructions later, and the result then depends on timing - 70 % of the
+// entries of H differed from run to run at the headline image (profiles/r03d_wide_repro.log).  The empty asm keeps both operands
+// allocated across ESPM_MFMA_K32_NOPS + 1 wait states after the matrix instruction.
+#ifndef ESPM_MFMA_K32_NOPS
+#define ESPM_MFMA_K32_NOPS 1
+#endif
+#define ESPM_STR2(x) #x
+#define ESPM_STR(x) ESPM_STR2(x)
+#define ESPM_MFMA_K32_HOLD(a, b) asm volatile("s_nop " ESPM_STR(ESPM_MFMA_K32_NOPS) : : "v"(a), "v"(b))
 __device__ __forceinline__ mf_f4 mf_mma3(const mf_s4 ah, const mf_s4 al, const mf_s4 bh, const mf_s4 bl, mf_f4 c) {
 #if ESPM_MFMA_K32
   const mf_b8 a = __builtin_bit_cast(mf_b8, __builtin_shufflevector(ah, al, 0, 1, 2, 3, 4, 5, 6, 7));
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(mf_b8, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 4, 5, 6, 7)), c, 0, 0, 0);   // small terms first
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(mf_b8, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 4, 5, 6, 7)), c, 0, 0, 0);
+  const mf_b8 b1 = __builtin_bit_cast(mf_b8, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 4, 5, 6, 7));
+  const mf_b8 b2 = __builtin_bit_cast(mf_b8, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 4, 5, 6, 7));
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, c, 0, 0, 0);   // small terms first
+  ESPM_MFMA_K32_HOLD(a, b1);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c, 0, 0, 0);
+  ESPM_MFMA_K32_HOLD(a, b2);
+  return c;
 #else
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);   // small terms first
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);

@@ -388,7 +388,7 @@ struct WExchangeArgs {
   WUpdateArgs u;
   unsigned char* mbox[16];   // every rank's mailbox as mapped here
   int world, rank, nfl, with_halo;
-  size_t rec_bytes, slot_base, wgflags_off, wgrs_off, err_off, hstat_off, top_off, bot_off;   // (wgrs_off: of this sequence number's parity)
+  size_t rec_bytes, slot_base, wgflags_off, gran_off, err_off, hstat_off, top_off, bot_off;   // (gran_off: of this sequence number's parity)
   unsigned int seq;
   long long max_ticks;
   const float* halo_h;
@@ -462,8 +462,9 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   const int c = 32 * j + col;
   const int e = kk * a.n_pad + c;
   auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
-  auto wgrs = [&](int dst, int src_rank) {
-    return reinterpret_cast<double*>(x.mbox[dst] + x.wgrs_off) + (size_t)src_rank * x.nfl + wg;
+  // granule g of rank src_rank's contribution, in rank dst's mailbox: g = 32 wg + column for the piece, 32 nfl + 2 wg + half for the row sum
+  auto gran = [&](int dst, int src_rank, int g) {
+    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * 34 * x.nfl + g;
   };
   constexpr int INFLIGHT = 32;
   float v[INFLIGHT];
@@ -497,42 +498,60 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   rsp = wave_sum(rsp);
   if ((threadIdx.x & 63) == 0) s_rsw[threadIdx.x >> 6] = rsp;
   __syncthreads();
-  if (threadIdx.x < 64) {  // wave 0: lanes 0..31 own the 32 entries, lane r < world watches rank r, lane 32 + r writes to rank r
+  if (threadIdx.x < 64) {  // wave 0: lanes 0..31 own the 32 entries, lanes 32 and 33 the two halves of the row sum
     const int lane = threadIdx.x;
     const bool owns = grp == 0 && live;
     float t = 0.f;
     if (owns) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += s_part[g][col];
-      for (int r = 0; r < x.world; ++r)   // this rank's piece, to every rank (write-through, system scope)
-        __hip_atomic_store(reinterpret_cast<float*>(record(r, x.rank)) + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (lane >= 32 && lane - 32 < x.world)
-      __hip_atomic_store(wgrs(lane - 32, x.rank), ((s_rsw[0] + s_rsw[1]) + s_rsw[2]) + s_rsw[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // wave order, like block_reduce
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's pieces are delivered before its flags are issued (order, not a cache flush)
-    if (lane < x.world) __hip_atomic_store(flag(lane, x.rank, wg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // A value travels as ONE 8-byte granule {bits, sequence number} (system scope, write-through): the store that delivers it is
+    // also what says it is there - no drain, no flag, no second trip over the link (MI355X_MICROARCH.md, handoff-1to1 against
+    // handoff-flag; an aligned 8-byte store is observed whole).  The slot of a sequence number's parity is rewritten two
+    // exchanges later, which a peer can only do after this rank posted the exchange in between (mu_xchg.hip).
+    const double rs_mine = ((s_rsw[0] + s_rsw[1]) + s_rsw[2]) + s_rsw[3];   // wave order, like block_reduce
+    const unsigned long long rs_bits = __builtin_bit_cast(unsigned long long, rs_mine);
+    const bool sends = owns || lane == 32 || lane == 33;
+    const int g_idx = lane < 32 ? 32 * wg + col : 32 * x.nfl + 2 * wg + (lane - 32);
+    const unsigned int bits = lane < 32 ? __float_as_uint(t) : (lane == 32 ? (unsigned int)rs_bits : (unsigned int)(rs_bits >> 32));
+    const unsigned long long mine = ((unsigned long long)x.seq << 32) | bits;
+    if (sends)
+      for (int r = 0; r < x.world; ++r) __hip_atomic_store(gran(r, x.rank, g_idx), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // every rank's granule of the same index: polled together (one load per rank in flight), bounded
     unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
-    if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, wg), x.seq, x.max_ticks, err);
-    // (every lane's polls are done when the wave goes on: one program counter; the loads below bypass the caches)
-    // all of them requested together, then added in rank order: the same sums on every rank
-    float pv[16];
-    double rv[16];
+    unsigned int got[16];
+    {
+      const long long t0 = wall_clock64();
+      bool all = !sends;
+      for (;;) {
+        unsigned long long v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = 0.f;
-      rv[r] = 0.0;
-      if (r < x.world) {
-        if (owns) pv[r] = __hip_atomic_load(reinterpret_cast<const float*>(record(x.rank, r)) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        rv[r] = __hip_atomic_load(wgrs(x.rank, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 0; r < 16; ++r)
+          v[r] = (sends && r < x.world) ? __hip_atomic_load(gran(x.rank, r, g_idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)x.seq << 32);
+        all = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          all = all && (unsigned int)(v[r] >> 32) == x.seq;
+          got[r] = (unsigned int)v[r];
+        }
+        if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+        if (wall_clock64() - t0 > x.max_ticks) {   // a peer that never delivers must not hang the device: give up, count it
+          if (!all) atomicAdd(err, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
     }
+    // added in rank order: the same sums on every rank
     float tt = 0.f;
     double rs = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (r < x.world) {
-        tt += pv[r];
-        rs += rv[r];
+        tt += __uint_as_float(got[r]);
+        const unsigned long long lo = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 32), hi = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 33);
+        rs += __builtin_bit_cast(double, (hi << 32) | lo);
       }
     w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg);
     if (wg == 0) {  // global statistics of the new H (as shard_combine): these need every rank's extra workgroup
@@ -1498,7 +1517,7 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.rec_bytes = xc->record_bytes;
   x.slot_base = (size_t)(seq & 1u) * xc->world * xc->record_bytes;
   x.wgflags_off = xc->off_wgflags;
-  x.wgrs_off = xc->off_wgrs + (size_t)(seq & 1u) * xc->world * xc->wgflags * sizeof(double);
+  x.gran_off = xc->off_gran + (size_t)(seq & 1u) * xc->world * 34 * xc->wgflags * sizeof(unsigned long long);
   x.err_off = xc->off_err;
   x.hstat_off = (size_t)f.k * f.n_pad * 4;
   x.top_off = x.hstat_off + ESPM_HS_STRIDE * 8;

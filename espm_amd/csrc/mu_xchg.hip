@@ -12,7 +12,9 @@
 //     flags   [world] x 64 bytes         flag[r] = last sequence number rank r has delivered here
 //     errors  1 x uint32                 waits that gave up (bounded spin: a lost peer must not hang the device)
 //     wgflags [world][k n_pad / 32 + 1]  one flag per reduction workgroup of a rank (+ its extra workgroup): the in-launch exchange
-//     wgrs    [2][world][...]            the row sum of its new H block a reduction workgroup ships with its piece
+//     gran    [2][world][34 x ...]       8-byte granules {value, sequence number} of the in-launch exchange: a reduction workgroup's 32
+//                                        entries of A and the two halves of its row sum of the new H - value and "it is there" in ONE
+//                                        store, so a piece costs one trip over the link instead of data, drain, flag
 //   post(seq): one workgroup per destination copies the staged record into slot [seq & 1][rank] of that destination with
 //              16-byte stores, fences at system scope, then one lane stores the flag (release, system scope).
 //   (espm_mu_shard_exchange_finish, mu_w_step.hip, does all of this INSIDE the slab-reduction launch, piece by piece, with
@@ -90,8 +92,8 @@ int espm_xchg_create(int world, int rank, size_t record_bytes, espm_xchg** out) 
   x->off_err = x->off_flags + (size_t)world * XCHG_FLAG_STRIDE;
   x->off_wgflags = x->off_err + XCHG_FLAG_STRIDE;
   x->wgflags = (int)(record_bytes / 128) + 2;   // >= k * ceil(n_pad / 32) + 1 for any record that holds k * n_pad floats
-  x->off_wgrs = (x->off_wgflags + (size_t)world * x->wgflags * sizeof(uint32_t) + 63) / 64 * 64;
-  x->mailbox_bytes = x->off_wgrs + 2 * (size_t)world * x->wgflags * sizeof(double);
+  x->off_gran = (x->off_wgflags + (size_t)world * x->wgflags * sizeof(uint32_t) + 63) / 64 * 64;
+  x->mailbox_bytes = x->off_gran + 2 * (size_t)world * 34 * x->wgflags * sizeof(uint64_t);
   x->mailbox_bytes = (x->mailbox_bytes + 255) / 256 * 256;
   for (int r = 0; r < XCHG_MAX_WORLD; ++r) {
     x->peers[r] = nullptr;
