@@ -92,10 +92,11 @@ static int nblk_h(const espm_mu_state* st) { return (st->p + st->tile_px - 1) / 
 // under 2^17 pixels, shards - where one workgroup per CU left the CU idle through its serial phases.  With those phases cut
 // in round 3 - prologue loads issued together, the update's inputs staged by the prologue, one barrier around the record
 // reduction, no extra workgroup for the W update's tail - the fused launch wins at every block size: a 64-row shard 47.4 -> 42.8 us
-// per iteration, profiles/r03d_shard_iter*.log.  ESPM_FUSED_MIN_PB = 128, the smallest block there is.)
+// per iteration, profiles/r03d_shard_iter*.log - where the blocks cover the chip (ESPM_FUSED_MIN_BLOCKS); an image of fewer, small
+// blocks keeps the two launches, whose smaller workgroups spread over more CUs.)
 static bool fused_ok(const espm_mu_state* st) {
   return ESPM_MIN_K <= 8 && st->x_dtype == ESPM_X_ELL && st->h_rule == 0 && st->no_fused != 1 &&
-         (st->ell_pb >= ESPM_FUSED_MIN_PB || st->no_fused == 3) &&
+         (st->ell_pb >= ESPM_FUSED_MIN_PB || st->nblk_w >= ESPM_FUSED_MIN_BLOCKS || st->no_fused == 3) &&
          fused_ell_lds_bytes(st->n_pad, st->k, st->ell_pb) <= ESPM_ELL_LDS_MAX;
 }
 static HStepArgs fused_h_args(const espm_mu_state* st, int src) {

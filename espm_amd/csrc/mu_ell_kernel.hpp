@@ -400,7 +400,7 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_ker
     walk_rows(gi, (int)((long)len * si / nsplit), (int)((long)len * (si + 1) / nsplit), si);
     nparts = nsplit;
   }
-  h_epilogue<K, true, RULE, 8>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f, cs_lds);   // (at most 8 partial numerators: read together)
+  h_epilogue<K, true, RULE>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f, cs_lds);
 }
 
 // ---- W accumulation ---------------------------------------------------------------------------------

@@ -15,9 +15,6 @@
 #define ESPM_FUSED_FULL_PERM_LDS 0
 #endif
 #define ESPM_FUSED_LDS_LIMIT (160 * 1024)   // a workgroup's LDS on gfx950
-#ifndef ESPM_FUSED_SMALL_EPI_LDS
-#define ESPM_FUSED_SMALL_EPI_LDS 1
-#endif
 
 namespace espm {
 
@@ -42,13 +39,6 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   // (the full geometry: the copies are an extra where the workgroup's 160 KB still hold them)
   args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
   if (args.perm_lds) bytes += perm_bytes;
-  args.epi_lds_off = -1;   // below the full geometry: the per-pixel update's inputs staged by the prologue, where [6 K][pb] floats still fit
-  if (ESPM_FUSED_SMALL_EPI_LDS && K <= 6 && pb != ESPM_ELL_PB && 6 * K * pb <= 16 * ESPM_FUSED_SMALL_THREADS &&
-      bytes + (size_t)6 * K * pb * sizeof(float) + 4096 <= ESPM_ELL_LDS_MAX) {
-    bytes = (bytes + 15) / 16 * 16;
-    args.epi_lds_off = (int)bytes;
-    bytes += (size_t)6 * K * pb * sizeof(float);
-  }
   args.red_lds_off = -1;
   if (ESPM_FUSED_RED_ONE_BARRIER && bytes + (ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double) + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
     bytes = (bytes + 7) / 8 * 8;

@@ -70,7 +70,6 @@ struct FusedArgs {
   int perm_lds_off; // below the full geometry: byte offset of the block's copy of pix_perm (pb ints) and chan_perm (64 n_cg ints) in LDS
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
   int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
-  int epi_lds_off;  // below the full geometry: byte offset of the staging area of the per-pixel update's inputs ([6 K][pb] floats), < 0: requested by the update itself
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
 };
 
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   float rwn[RW], rwo[RW];
 #pragma unroll
   for (int u = 0; u < RW; ++u) rwn[u] = rwo[u] = 1.f;
-  bool staged = false, epi_staged = false;
+  bool staged = false;
   if constexpr (ESPM_FUSED_PROLOGUE_BATCH) {
     constexpr int TR = 4, PC = 4;   // table rows / permutation entries a thread stages
     const int n_perm = perm_lds ? PB + 64 * fa.w.n_cg : 0, n_woff = 2 * fa.w.n_cg + 1;
@@ -186,35 +185,11 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
           rwo[u] = i < rw_hi ? a.tail.w_old[i] : 1.f;
         }
       }
-      // what the per-pixel update needs of its pixels from memory - H, the previous H, the four stencil neighbours - is known
-      // now: requested here, it is in LDS long before the walk ends (requested when the walk ended, 2 us of a 64-row shard's
-      // update were the wait for it: profiles/r03d_phase_clock_64rows.log, "sum of the partial numerators")
-      constexpr int EP = (!FULL && K <= 6) ? 16 : 1;   // values a thread stages (7, 8 components: the registers are not there)
-      float ev[EP];
-      const bool epi = !FULL && K <= 6 && fa.epi_lds_off >= 0 && 6 * K * PB <= EP * NT;   // (uniform)
-      const bool stencil_p = a.lambda_l != 0.f && a.grid_mode;
-      if (epi) {
-#pragma unroll
-        for (int i = 0; i < EP; ++i) {
-          const int v = threadIdx.x + i * NT, f = v / PB, jj = v - f * PB, q = blockIdx.x * PB + jj;
-          const float* src = (v < 6 * K * PB && q < a.p) ? h_epi_src<K>(a, f, q, stencil_p) : nullptr;
-          ev[i] = src ? *src : 0.f;
-        }
-      }
       // ---- consume
 #pragma unroll
       for (int i = 0; i < TR; ++i) {
         const int r = threadIdx.x + i * NT;
         if (r < a.n_pad) lds_table_put<K>(tab, a.n_pad, r, tlo[i], thi[i]);
-      }
-      if (epi) {
-        float* el = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem) + fa.epi_lds_off);
-#pragma unroll
-        for (int i = 0; i < EP; ++i) {
-          const int v = threadIdx.x + i * NT;
-          if (v < 6 * K * PB) el[v] = ev[i];
-        }
-        epi_staged = true;
       }
 #pragma unroll
       for (int i = 0; i < PC; ++i) {
@@ -327,10 +302,9 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0, FULL ? FusedGeom<K>::S : (K <= 5 ? 8 : 0)>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,   // (6+ components: 8 x (K + 1) partials at once spill)
+  h_epilogue<K, true, 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
                                                      fa.red_lds_off >= 0 ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr,
-                                                     relw,
-                                                     epi_staged ? reinterpret_cast<const float*>(reinterpret_cast<unsigned char*>(smem) + fa.epi_lds_off) : nullptr);
+                                                     relw);
 
   ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----

@@ -76,43 +76,6 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
   }
 }
 
-// The same inputs from a staging area in LDS (the fused half-steps below their full geometry fill it in their prologue: field-major,
-// `stride` floats per field; fields: H_in | previous H | left | right | upper | lower neighbour, K components each): h_epi_src is where
-// value (field f, pixel q) comes from (null: zero), h_epilogue_from_lds the reader.
-template <int K>
-__device__ __forceinline__ const float* h_epi_src(const HStepArgs& a, int f, int q, bool stencil) {
-  const int g = f / K, kk = f - g * K;
-  const float* hrow = a.h_in + (size_t)kk * a.p_pad;
-  if (g == 0) return hrow + q;
-  if (g == 1) return a.have_prev ? a.h_out + (size_t)kk * a.p_pad + q : nullptr;
-  if (!stencil) return nullptr;
-  const int i = q / a.ny, j = q - i * a.ny;
-  if (g == 2) return hrow + (j > 0 ? q - 1 : q);
-  if (g == 3) return hrow + (j < a.ny - 1 ? q + 1 : q);
-  if (g == 4) return i > 0 ? hrow + (q - a.ny) : (a.halo_top ? a.halo_top + (size_t)kk * a.ny + j : hrow + q);
-  return i < a.nx - 1 ? hrow + (q + a.ny) : (a.halo_bot ? a.halo_bot + (size_t)kk * a.ny + j : hrow + q);
-}
-template <int K>
-__device__ __forceinline__ void h_epilogue_from_lds(const HStepArgs& a, int q, bool stencil, const float* lds, int stride, int jj, HEpiIn<K>& v) {
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) {
-    v.hin[kk] = lds[(size_t)kk * stride + jj];
-    v.hprev[kk] = lds[(size_t)(K + kk) * stride + jj];
-    v.l[kk] = stencil ? lds[(size_t)(2 * K + kk) * stride + jj] : 0.f;
-    v.r[kk] = stencil ? lds[(size_t)(3 * K + kk) * stride + jj] : 0.f;
-    v.u[kk] = stencil ? lds[(size_t)(4 * K + kk) * stride + jj] : 0.f;
-    v.d[kk] = stencil ? lds[(size_t)(5 * K + kk) * stride + jj] : 0.f;
-  }
-  v.wl = v.wr = v.wu = v.wd = 0.f;
-  if (stencil) {
-    const int i = q / a.ny, j = q - i * a.ny;
-    v.wl = j > 0 ? 1.f : 0.f;
-    v.wr = j < a.ny - 1 ? 1.f : 0.f;
-    v.wu = (i > 0 || a.halo_top) ? 1.f : 0.f;
-    v.wd = (i < a.nx - 1 || a.halo_bot) ? 1.f : 0.f;
-  }
-}
-
 // Epilogue shared by the H-step kernels: `smem` holds `nparts` partial numerators [part][K][TP] (written by
 // the caller, not yet synchronised); one thread per pixel adds the regularisation terms, solves the simplex
 // multiplier, clamps, writes H', H'^T and the per-workgroup record.  kl_lane = this lane's part of
@@ -125,16 +88,17 @@ __device__ __forceinline__ void h_epilogue_from_lds(const HStepArgs& a, int q, b
 // kl_rows (fused half-steps): every partial carries K + 1 rows of TP floats, the last being the pixel's part of
 // sum X log2(X / Y) (summed per pixel in slot order: the loss does not depend on which wave walked which slot); kl_lane
 // is then unused and the per-pixel loss constant ell_klc is added here.
-// MAXP > 0: at most MAXP partials - their LDS reads are then requested together (as a loop over the run-time count every read
-// waited for the one before: 2.1 us of a 64-row shard's 33 with 8 partials of 6 rows); the sum keeps the slot order.
+// MAXP > 0: at most MAXP partials - their LDS reads are then requested together; the sum keeps the slot order.  (Measured: no gain.  What
+// a 64-row shard's update spends between its barrier and the sums - 2.1 us - is not the wait for these reads, nor for the pixel's inputs
+// from memory (staging those in LDS in the prologue made it 3.1): the once-executed code of this kernel is fetched from L2 by every CU at
+// every launch, and more unrolled code is more of that: profiles/r03c / r03d / r03e_phase_clock_64rows.log.  The callers pass 0.)
 // relw_lane: this lane's share of rel_W of the W update that produced the input state (record field ESPM_HP_RELW), -1: none.
 template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
                                            float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false,
                                            double* red_scratch = nullptr,   // fused half-steps: scratch of its own for the waves' sums -> ONE barrier after the per-pixel work
-                                           float relw_lane = -1.f,
-                                           const float* epi_lds = nullptr) {   // the pixels' inputs staged in LDS ([6 K][TP], h_epi_src) instead of requested here
+                                           float relw_lane = -1.f) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K + 1;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima + RELW
   float red[NRED];   // per-thread partials in fp32 (one or two pixels per thread); fp64 from the wave results on (block_reduce_f32)
 #pragma unroll
@@ -147,7 +111,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   const bool stencil = a.lambda_l != 0.f && a.grid_mode;
   HEpiIn<K> in;
   bool loaded = false;
-  if (EARLY && !epi_lds && K <= 6 && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {   // (k = 7, 8: too many registers to hold across the barrier)
+  if (EARLY && K <= 6 && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {   // (k = 7, 8: too many registers to hold across the barrier)
     h_epilogue_load<K>(a, tile0 + (int)threadIdx.x, stencil, in);
     loaded = true;
   }
@@ -190,8 +154,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       if (lds_tab) lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f));
       continue;
     }
-    if (epi_lds) h_epilogue_from_lds<K>(a, q, stencil, epi_lds, TP, jj, in);
-    else if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
+    if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
     loaded = false;
     const float klc = klc_loaded ? klc_first : (want_klc ? a.ell_klc[q] : 0.f);
     klc_loaded = false;

@@ -424,36 +424,63 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   // dead-locked for the 2 s bound of the waits.  An occupancy query as a second guard was tried and dropped: on this stack
   // hipOccupancyMaxActiveBlocksPerMultiprocessor answers 2 workgroups per CU for this 256-thread kernel, which would send
   // the headline's 321 workgroups down the four-launch path - profiles/r03c_shard_iter_residency_guard.log.)  The waits stay bounded.
+  // granule g of rank src_rank's contribution, in rank dst's mailbox (GRAN granules per source rank): g = 32 wg + column for a
+  // reduction workgroup's piece, 32 nfl + 2 wg + half for its row sum, 34 nfl + 2 i + half for statistic i of the new H block
+  const size_t GRAN = (size_t)34 * x.nfl + 2 * ESPM_HS_STRIDE;
+  auto gran = [&](int dst, int src_rank, int g) {
+    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
+  };
   if (blockIdx.x == 0) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
-    h_finalize_body(a.fin, fscratch);   // (fin.hstat_out = the statistics of this rank's record in its OWN mailbox)
-    __syncthreads();
-    const double* mine = reinterpret_cast<const double*>(record(x.rank, x.rank) + x.hstat_off);
+    // the boundary rows first - they are in memory since the launch before this one, and nobody needs them before the NEXT
+    // launch: their stores are long acknowledged when the flag that covers them is raised at the end
     // (every store into a mailbox is a system-scope write-through store: whatever memory type a peer's mapping has here,
     //  the data is on its way to that rank's memory when the store is acknowledged, and `s_waitcnt vmcnt(0)` orders the flag)
-    for (int i = threadIdx.x; i < x.world * ESPM_HS_STRIDE; i += 256) {
-      const int r = i / ESPM_HS_STRIDE, j = i - r * ESPM_HS_STRIDE;
-      if (r != x.rank)
-        __hip_atomic_store(reinterpret_cast<double*>(record(r, x.rank) + x.hstat_off) + j, mine[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     if (x.with_halo) {
       for (int d = -1; d <= 1; ++d) {   // the neighbours read these rows as their halo; this rank keeps a copy (record layout)
         const int r = x.rank + d;
         if (r < 0 || r >= x.world) continue;
         float* top = reinterpret_cast<float*>(record(r, x.rank) + x.top_off);
         float* bot = reinterpret_cast<float*>(record(r, x.rank) + x.bot_off);
-        for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += 256) {
-          const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
-          __hip_atomic_store(top + e, x.halo_h[(size_t)kk * x.halo_ppad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(bot + e, x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j], __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((x.halo_ny & 3) == 0) {   // rows of whole quads: 16-byte write-through stores (a 4-byte store to a peer is a fabric write of its own)
+          typedef float xf4 __attribute__((ext_vector_type(4)));
+          for (int e = 4 * threadIdx.x; e < x.halo_k * x.halo_ny; e += 4 * 256) {
+            const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+            const xf4 vt = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + j);
+            const xf4 vb = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(top + e), "v"(vt) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(bot + e), "v"(vb) : "memory");
+          }
+        } else {
+          for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += 256) {
+            const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+            __hip_atomic_store(top + e, x.halo_h[(size_t)kk * x.halo_ppad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(bot + e, x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
     }
+    // the statistics: reduced into LDS, then one granule {half of a double, sequence number} per half and destination - value and
+    // "it is there" in one store, like the pieces: workgroup 1 of every rank has them one trip over the link after the reduction
+    __shared__ double s_hstat[ESPM_HS_STRIDE];
+    HFinalizeArgs fin = a.fin;
+    double* rec_hstat = fin.hstat_out;   // this rank's record in its OWN mailbox (the plain copy: espm_xchg_records' readers)
+    fin.hstat_out = s_hstat;
+    h_finalize_body(fin, fscratch);
+    // the boundary rows' stores were issued a record reduction ago: this wait returns at once, and their flag goes out BEFORE
+    // the statistics (workgroup 1 of every rank polls both: neither waits behind the other's trip over the link)
     // (the mailboxes are uncached memory: a store is delivered once it is acknowledged - no cache to write back, so no
     //  system-scope fence, which would flush this XCD's whole L2 - only ORDER: every thread's stores before any flag)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = threadIdx.x; i < x.world * 2 * ESPM_HS_STRIDE; i += 256) {
+      const int r = i / (2 * ESPM_HS_STRIDE), j = i - r * 2 * ESPM_HS_STRIDE;
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, s_hstat[j >> 1]);
+      const unsigned int half = (j & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+      __hip_atomic_store(gran(r, x.rank, 34 * x.nfl + j), ((unsigned long long)x.seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x < ESPM_HS_STRIDE) rec_hstat[threadIdx.x] = s_hstat[threadIdx.x];
     return;
   }
   const int wg = (int)blockIdx.x - 1;   // reduction workgroup (component kk, 32 channels)
@@ -462,10 +489,6 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   const int c = 32 * j + col;
   const int e = kk * a.n_pad + c;
   auto src = [&](int b) { return reinterpret_cast<const float*>(a.src + (size_t)b * a.src_stride)[e]; };
-  // granule g of rank src_rank's contribution, in rank dst's mailbox: g = 32 wg + column for the piece, 32 nfl + 2 wg + half for the row sum
-  auto gran = [&](int dst, int src_rank, int g) {
-    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * 34 * x.nfl + g;
-  };
   constexpr int INFLIGHT = 32;
   float v[INFLIGHT];
   const bool live = c < a.n_pad;
@@ -554,17 +577,45 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         rs += __builtin_bit_cast(double, (hi << 32) | lo);
       }
     w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg);
-    if (wg == 0) {  // global statistics of the new H (as shard_combine): these need every rank's extra workgroup
-      if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
-      if (lane < ESPM_HS_STRIDE) {
-        double g = 0.0;
-        for (int r = 0; r < x.world; ++r) {
-          const double v2 = __hip_atomic_load(reinterpret_cast<const double*>(record(x.rank, r) + x.hstat_off) + lane, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_SYSTEM);
-          g = lane < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+    if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
+      static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
+      const bool polls = lane < 2 * ESPM_HS_STRIDE;
+      unsigned int hv[16];
+      {
+        const long long t0 = wall_clock64();
+        bool all = !polls;
+        for (;;) {
+          unsigned long long v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            v[r] = (polls && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                          : ((unsigned long long)x.seq << 32);
+          all = true;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            all = all && (unsigned int)(v[r] >> 32) == x.seq;
+            hv[r] = (unsigned int)v[r];
+          }
+          if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+          if (wall_clock64() - t0 > x.max_ticks) {
+            if (!all) atomicAdd(err, 1u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
         }
-        a.hstat_out[lane] = g;
       }
+      double g = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r < x.world) {   // lane 2 i holds the low half of statistic i, lane 2 i + 1 the high half
+          const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
+          const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
+          const double v2 = __builtin_bit_cast(double, bits);
+          g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+        }
+      if (polls && !(lane & 1)) a.hstat_out[lane >> 1] = g;
+      // the boundary rows of the neighbours (the next launch reads them): their flag
+      if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
     }
   }
 }
@@ -1517,7 +1568,7 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.rec_bytes = xc->record_bytes;
   x.slot_base = (size_t)(seq & 1u) * xc->world * xc->record_bytes;
   x.wgflags_off = xc->off_wgflags;
-  x.gran_off = xc->off_gran + (size_t)(seq & 1u) * xc->world * 34 * xc->wgflags * sizeof(unsigned long long);
+  x.gran_off = xc->off_gran + (size_t)(seq & 1u) * xc->world * ((size_t)34 * xc->wgflags + 2 * ESPM_HS_STRIDE) * sizeof(unsigned long long);
   x.err_off = xc->off_err;
   x.hstat_off = (size_t)f.k * f.n_pad * 4;
   x.top_off = x.hstat_off + ESPM_HS_STRIDE * 8;

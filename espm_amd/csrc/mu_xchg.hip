@@ -93,7 +93,7 @@ int espm_xchg_create(int world, int rank, size_t record_bytes, espm_xchg** out) 
   x->off_wgflags = x->off_err + XCHG_FLAG_STRIDE;
   x->wgflags = (int)(record_bytes / 128) + 2;   // >= k * ceil(n_pad / 32) + 1 for any record that holds k * n_pad floats
   x->off_gran = (x->off_wgflags + (size_t)world * x->wgflags * sizeof(uint32_t) + 63) / 64 * 64;
-  x->mailbox_bytes = x->off_gran + 2 * (size_t)world * 34 * x->wgflags * sizeof(uint64_t);
+  x->mailbox_bytes = x->off_gran + 2 * (size_t)world * ((size_t)34 * x->wgflags + 2 * ESPM_HS_STRIDE) * sizeof(uint64_t);
   x->mailbox_bytes = (x->mailbox_bytes + 255) / 256 * 256;
   for (int r = 0; r < XCHG_MAX_WORLD; ++r) {
     x->peers[r] = nullptr;

@@ -349,6 +349,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         # base.py:243-247.  For a large array that will be uploaded anyway the finiteness scan of validate_data (a full
         # host pass: 0.18 s at 2048 x 512^2 fp32) moves to the device copy below; everything else
         # (dtype, shape, n_features_in_, feature names) is still scikit-learn's.
+        # ESPM_FIT_TIMING=1: host-side time stamps of the fit's sections (no device synchronisation), printed at its end
+        marks = [("enter", time.perf_counter())] if os.environ.get("ESPM_FIT_TIMING") else None
+        mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
         big = False
         try:
             import torch
@@ -363,6 +366,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             Xv = validate_data(self, X.T, **vkw)
         else:
             Xv = validate_data(self, X, **vkw)
+        mark("validate_data")
         if self.hspy_comp is False:
             try:  # base.py:249-259
                 import inspect
@@ -373,6 +377,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                           "If this argument is not set correctly, the function will not work properly!!!")
             except Exception:
                 pass
+        mark("caller check (inspect)")
         if self.l2 and getattr(self, "algo", None) != "l2_surrogate":
             raise NotImplementedError("the Frobenius loss (l2=True) is built for SmoothNMF(algo='l2_surrogate'), the one "
                                       "combination in which the reference keeps it (smooth_nmf.py:223-237)")
@@ -397,7 +402,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     host = np.ascontiguousarray(Xv)
                 lazy = _HostCopy(Xv, dev_layout)
                 try:
+                    mark("host copy thread created")
                     Xd_raw = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
+                    mark("upload returned")
                     Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
                     if big and not bool(torch.isfinite(Xd).all()):   # the scan validate_data was told to skip, same message
                         raise ValueError(f"Input X contains {'NaN' if bool(torch.isnan(Xd).any()) else 'infinity'}.")
@@ -406,6 +413,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 except BaseException:
                     lazy.cancel()
                     raise
+        mark("finite / sign checks read back")
         if big and Xd is None:   # (no device after all: scikit-learn's own check)
             from sklearn.utils import assert_all_finite
             assert_all_finite(Xv, input_name="X")
@@ -431,6 +439,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             # X_ is the estimator's own array, like the reference's (remove_zeros_lines copies): the worker thread that is
             # copying it now fills the empty lines and applies the normalisation
             X_fixed = lazy
+        mark("empty lines, mean read back")
         if self.normalize:
             self.norm_factor_ = (normalization_factor(X_fixed, self.n_components) if mean_x is None
                                  else self.n_components / (mean_x * X_fixed.shape[0]))
@@ -455,6 +464,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             self._const_KL_dev = float(total)
             del xs, rows_of
 
+        mark("const_KL read back")
         if _is_physical_model(self.G):
             self.physics_model_ = self.G
             G = self.physics_model_.NMF_update()
@@ -467,6 +477,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,
                                                           physics_model=self.physics_model_, X_device=X_init_dev)
         del X_init_dev
+        mark("initialize_algorithms")
         # one fit over several GPUs (shard()): this rank's block of image rows; every rank starts from rank 0's W, H, G
         grp = getattr(self, "_shard_group", None)
         shard = None
@@ -492,7 +503,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                 autotune=Xd is not None and self.max_iter >= 5000,
                                                 shard=shard)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
+        mark("engine built")
         del X_fixed, Xd, Xd_raw
+        mark("device copies of X released")
         eng.load_state(self.W_, self.H_ if shard is None else shard.cols(self.H_))
         if shard is not None and getattr(eng, "sharded", False) and eng.exchange.ctx is not None:
             # the one-shot record exchange is rehearsed with the fit's own kernels before the loop depends on it; every rank
@@ -505,6 +518,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             self.const_KL_ = float(np.sum(self.X_ * np.log(np.maximum(self.X_, self.log_shift))) - np.sum(self.X_))
         self._const_KL_dev = None
 
+        mark("state loaded, const_KL")
         algo_start = time.time()
         self.n_iter_ = 0
         self._begin_fit()
@@ -590,10 +604,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         except KeyboardInterrupt:
             pass
         finally:
+            mark("loop (losses read back)")
             if lazy is not None:   # the host copy that was made meanwhile - also when the loop raised: X_ must not stay a stand-in
                 self.X_ = lazy.result()   # (holding a thread and an event: not picklable)
+        mark("host copy X_ joined")
         self.W_ = eng.get_W().astype(out_dtype)
         self.H_ = self._full_H(eng).astype(out_dtype)
+        mark("W, H read back")
+        if marks is not None:
+            print("[fit timing, ms] " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f}" for i, (n, t) in enumerate(marks[1:])) +
+                  f" | total {1e3 * (marks[-1][1] - marks[0][1]):.1f}", flush=True)
         if not self.simplex_H and not self.simplex_W:
             self.W_, self.H_ = rescaled_DH(self.W_, self.H_)  # base.py:399-400
 

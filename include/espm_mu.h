@@ -99,7 +99,10 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_UNIT_ROWS 8 /* sparse store: the unit rows of a list group are a multiple of this (16 entries: one per bank quad) */
 #define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
-#define ESPM_FUSED_MIN_PB 128 /* sparse store: smallest W block (ell_pb) for which the fused launch is the default (every block size since round 3) */
+#define ESPM_FUSED_MIN_PB 512 /* sparse store: W blocks (ell_pb) from which the fused launch is the default whatever their number           */
+#define ESPM_FUSED_MIN_BLOCKS 192 /* ... and smaller blocks when there are at least this many (one per CU, or nearly: a 64-row shard of the
+                                   * headline image has 256 of 128 pixels; config 2's 128 blocks leave half the chip to the two launches,
+                                   * which then win: 27.6 against 35.2 us per iteration, profiles/r03e_c2_iter.log)                              */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
 #define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */

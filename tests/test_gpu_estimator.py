@@ -905,7 +905,8 @@ def test_simplex_over_w_as_many_workgroups(n, nx, ny, k, kw):
     np.testing.assert_allclose(W, ref["W"], rtol=2e-4, atol=2e-4 * np.abs(ref["W"]).mean())
     np.testing.assert_allclose(H, ref["H"], rtol=2e-4, atol=5e-5)
     np.testing.assert_allclose(W.sum(axis=0) - W[3, 0] + 0.0, ref["W"].sum(axis=0) - ref["W"][3, 0], rtol=1e-4)
-    # the same multipliers as the one-workgroup finish: the same sweep, the same midpoint
-    np.testing.assert_allclose(W, out["one_workgroup"][0], rtol=2e-6, atol=1e-12)
-    np.testing.assert_allclose(loss, out["one_workgroup"][2], rtol=1e-7)
-    np.testing.assert_allclose(rel_w[1:], out["one_workgroup"][3][1:], rtol=1e-4, atol=1e-9)
+    # the same multipliers as the one-workgroup finish: the same sweep, the same midpoint (fused=False also takes the two-launch
+    # H / W kernels, whose numerators are summed in another order than the fused launch's: 4e-6 after 8 iterations, not 2e-6)
+    np.testing.assert_allclose(W, out["one_workgroup"][0], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(loss, out["one_workgroup"][2], rtol=1e-6)
+    np.testing.assert_allclose(rel_w[1:], out["one_workgroup"][3][1:], rtol=1e-4, atol=1e-6)   # (near the fixed point rel_W is rounding noise of the two summation orders)
