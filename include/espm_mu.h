@@ -419,7 +419,11 @@ int espm_xchg_destroy(espm_xchg* x);
  * espm_mu_w_reduce_pack -> espm_xchg_post -> espm_xchg_wait -> espm_mu_shard_combine_finish): every workgroup of the slab
  * reduction delivers its 32 entries of A to all ranks itself, waits for the same piece of every rank, sums them in rank
  * order and updates its entries of W; the statistics of the new H block go to every rank, its boundary rows to the
- * neighbours.  Afterwards espm_xchg_records(x, seq & 1) holds the gathered records like after an exchange. */
+ * neighbours.  Pieces and statistics travel as 8-byte granules {value, sequence number} in an area of the mailbox of their
+ * own (value and "it is there" in one store); afterwards the records of espm_xchg_records(x, seq & 1) hold what the NEXT
+ * launch reads in place - the neighbours' boundary rows (and this rank's own statistics) - not the pieces of A, which went
+ * straight into st->a.  The grid need not be resident at once: workgroups are dispatched in index order, each posts before it
+ * waits, and waits only for the workgroup of its own index on the other ranks (csrc/mu_w_step.hip). */
 int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_t seq, int src, int slot, espm_stream_t stream);
 
 /* n_iter iterations of a SHARDED image (pixel rows split over the ranks of x) without host synchronisation and without a
