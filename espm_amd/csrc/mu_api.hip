@@ -539,6 +539,22 @@ int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_
   ESPM_REQUIRE(slot >= 0 && slot + 1 < st->hist_len, "history slot %d + 1 outside [0, %d)", slot, st->hist_len);
   ESPM_REQUIRE(x->record_bytes == espm_mu_shard_record_bytes(st), "shard_exchange_finish: the exchange was created for records of %zu bytes, the state packs %zu",
                x->record_bytes, espm_mu_shard_record_bytes(st));
+  if (!w_update_is_local(st) && st->no_fused != 1) {
+    // a dictionary G without a simplex over W: every rank contracts its own A with G and the m k results cross the links as
+    // granules (w_gxchg_update_kernel): slab reduction + record reduction, exchange + W update, rows of G W' - three launches
+    const WFinishArgs f = finish_args(st, src, 1 - src, slot + 1, 1);
+    if (w_gsplit_applies(f)) {
+      HFinalizeArgs fin = finalize_args(st, src, slot, true);
+      // (this rank's statistics go to its own record in its own mailbox: the exchange launch sends them on, and writes the global ones)
+      double* local = reinterpret_cast<double*>(x->mailbox + (size_t)(seq & 1u) * x->world * x->record_bytes + (size_t)x->rank * x->record_bytes +
+                                                (size_t)st->k * st->n_pad * 4);
+      fin.hstat_out = local;
+      if (int rc = launch_w_reduce(st->a_slab, st->a, st->nblk_w, st->k * st->n_pad, &fin, static_cast<hipStream_t>(stream))) return rc;
+      const int with_halo_g = st->grid_mode && st->lambda_l != 0.f;
+      return launch_w_gxchg_update(f, x, seq, local, st->hstat[1 - src], st->h[1 - src], st->nx, st->ny, st->p_pad, with_halo_g,
+                                   static_cast<hipStream_t>(stream));
+    }
+  }
   if (!w_update_is_local(st) || st->no_fused == 1) {   // W' needs a global finish (G given, simplex over W): the four steps
     if (int rc = espm_mu_w_reduce_pack(st, src, slot, x->staging, stream)) return rc;
     if (int rc = espm_xchg_post(x, seq, stream)) return rc;

@@ -828,6 +828,9 @@ int launch_w_update_tail(const WTailArgs& t, hipStream_t stream);
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const struct ::espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny,
                              int p_pad, int with_halo, hipStream_t stream, WTailArgs* defer_tail);
+bool w_gsplit_applies(const WFinishArgs& args);   // the W finish with a dictionary G as many-workgroup launches (mu_w_step.hip)
+int launch_w_gxchg_update(const WFinishArgs& f, const struct ::espm_xchg* xc, unsigned int seq, const double* hstat_local, double* hstat_out,
+                          const float* h_new, int nx, int ny, int p_pad, int with_halo, hipStream_t stream);
 WTailArgs make_w_tail_args(const WFinishArgs& f);
 int launch_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, int n, int p, void* x_cm, void* x_pm,
                   int x_dtype, int n_pad, int p_pad, int x_tile, int n_cm, hipStream_t stream);

@@ -149,12 +149,23 @@ struct WUpdateArgs {
 
 // The update of the 32 entries of W (component kk, channels c of the lanes that own one) from their summed A and the row
 // sum rs of the new H, by wave 0 of a reduction workgroup; the per-workgroup partials of what is global go to a.parts.
-__device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, int c, int e, bool owns, float t, double rs, int nwg, int wg) {   // wg: index of the reduction workgroup (its slot of the partials)
+__device__ __forceinline__ void w_update_preload(const WUpdateArgs& a, int kk, int c, bool mine, float& wo, float& fx) {
+  wo = 1.f;
+  fx = -1.f;
+  if (mine && c < a.n) {
+    wo = a.w_old[(size_t)c * a.k + kk];
+    if (a.fixed_w) fx = a.fixed_w[(size_t)c * a.k + kk];
+  }
+}
+// wo_pre / fx_pre: the entry's old value and fixed value (negative: none), requested by the caller at its start - here they would
+// be one more trip to memory at the end of a kernel that is nothing but latency.
+__device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, int c, int e, bool owns, float t, double rs, int nwg, int wg,   // wg: index of the reduction workgroup (its slot of the partials)
+                                                 float wo_pre, float fx_pre) {
   double cs = 0.0, sw = 0.0, qw = 0.0;
   if (owns) {
     a.a_out[e] = t;
     if (c < a.n) {
-      const float wo = a.w_old[(size_t)c * a.k + kk];
+      const float wo = wo_pre;
       float v;
       if (a.pg_gamma_w > 0.f) {  // W - grad / gamma with grad = rowsum(H) - (X / GWH) H^T (G = I), updates.py:353-362
         v = fmaxf(wo - ((float)rs - t) / a.pg_gamma_w, a.log_shift);
@@ -166,10 +177,7 @@ __device__ __forceinline__ void w_update_entries(const WUpdateArgs& a, int kk, i
       } else {
         v = fmaxf((wo * t) / (float)rs, a.log_shift);   // updates.py:59-60, :70-72 (G = I: colsum(G) = 1)
       }
-      if (a.fixed_w) {
-        const float fx = a.fixed_w[(size_t)c * a.k + kk];
-        if (fx >= 0.f) v = fx;                              // updates.py:75-76
-      }
+      if (fx_pre >= 0.f) v = fx_pre;                        // updates.py:75-76
       a.w_new[(size_t)c * a.k + kk] = v;
       const float gv = fmaxf(v, a.gw_floor);
       a.gw_s[(size_t)c * KP + kk] = gv * (1.f / a.xscale);
@@ -214,6 +222,8 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
     const int b = grp + 8 * u;
     v[u] = (live && b < a.nsrc) ? src(b) : 0.f;
   }
+  float wo_pre, fx_pre;
+  w_update_preload(a, kk, c, threadIdx.x < 32, wo_pre, fx_pre);   // (lanes 0..31 of wave 0 own the 32 entries)
   double rsp = 0.0;   // slab mode: this thread's share of row sum kk of the new H (the order of h_finalize_body: same value as hstat's)
   if (a.hpart) {
     const size_t nb = a.nblk_h;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += s_part[g][col];
     }
-    w_update_entries(a, kk, c, e, owns, t, rs, nwg, blockIdx.x);
+    w_update_entries(a, kk, c, e, owns, t, rs, nwg, blockIdx.x, wo_pre, fx_pre);
   }
 }
 
@@ -293,6 +303,8 @@ __global__ __launch_bounds__(64) void w_simplex_update_kernel(const WSimplexArgs
   const int e = kk * a.n_pad + c;
   const bool owns = lane < 32 && c < a.n_pad;
   const float t_e = owns ? a.a_out[e] : 0.f;
+  float wo_pre, fx_pre;
+  w_update_preload(a, kk, c, owns, wo_pre, fx_pre);
   double ssum[KP], smax[KP], spos[KP], rs[KP];
 #pragma unroll
   for (int q = 0; q < KP; ++q) {
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(64) void w_simplex_update_kernel(const WSimplexArgs
 #pragma unroll
   for (int q = 0; q < KP; ++q)
     if (q == kk) delta = solve[q] ? ad[q] + width[q] * mid_frac(uu[q], t_stop) : (double)(float)rs[q];
-  w_update_entries(a, kk, c, e, owns, t_e, delta, nwg, blockIdx.x);
+  w_update_entries(a, kk, c, e, owns, t_e, delta, nwg, blockIdx.x, wo_pre, fx_pre);
 }
 
 // ---- Slab reduction, record exchange and W update of a SHARDED image in ONE launch (espm_mu_shard_exchange_finish) ----------
@@ -497,6 +509,8 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     const int b = grp + 8 * u;
     v[u] = (live && b < a.nsrc) ? src(b) : 0.f;
   }
+  float wo_pre, fx_pre;
+  w_update_preload(a, kk, c, threadIdx.x < 32, wo_pre, fx_pre);
   // Row sum kk of THIS rank's new H block from the H-step's records, in the order of h_finalize_body (the same value the extra
   // workgroup leaves in the statistics): it travels with the piece, so that the W update waits for pieces only - not for the
   // extra workgroups' record reductions, which only workgroup 0 (the global statistics for the NEXT H-step) still waits for.
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         const unsigned long long lo = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 32), hi = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 33);
         rs += __builtin_bit_cast(double, (hi << 32) | lo);
       }
-    w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg);
+    w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg, wo_pre, fx_pre);
     if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
       static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
       const bool polls = lane < 2 * ESPM_HS_STRIDE;
@@ -1619,9 +1633,361 @@ static void launch_fast(const WFinishArgs& args, int rows, int crows, size_t lds
     hipLaunchKernelGGL((w_finish_fast_kernel<KK, 4, NT>), dim3(1), dim3(NT), lds, stream, args);
 }
 
+// ---- W finish with a dictionary G (n x m, few columns) as TWO launches (C5: 1980 x 17, k = 8) ----------------------------------
+// The one-workgroup finish spends its 24-36 us on one CU: the m k dot products G^T A over the n channels (butterfly sums across a
+// wave) and the rows of G W'.  The W update needs nothing global but the row sums of H' (no simplex over W here), so:
+//   w_gfinish_update_kernel  one workgroup per entry (row of G, component): G^T A over the channels from the transposed copy of G
+//                            (coalesced), a fixed-order block sum, W' = max(W (G^T A) / (colsum(G) rowsum(H')), eps), fixed_W
+//                            (updates.py:58-60, :70-76)
+//   w_gfinish_gw_kernel      256 channels per workgroup: W' (m k floats) into LDS, the rows of G W' (a thread per channel: m k
+//                            multiply-adds from LDS), partial column sums; the workgroup that finishes last (a ticket) adds the
+//                            partials in workgroup order; workgroup 0 forms mean(W') and rel_W (base.py:323)
+// ESPM_W_GSPLIT=0 keeps the one-workgroup finish (A/B).
+__global__ __launch_bounds__(256) void w_gfinish_update_kernel(const WFinishArgs a) {
+  __shared__ float s_wave[4];
+  const int e = blockIdx.x, mm = e / a.k, kk = e - mm * a.k;
+  const float* gt = a.g_t + (size_t)mm * a.n_pad;
+  const float* av = a.a + (size_t)kk * a.n_pad;
+  float s = 0.f;
+  for (int c0 = threadIdx.x; c0 < a.n; c0 += 8 * 256) {   // eight channels per thread requested together (a loop of single loads waits for each)
+    float gv[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * 256;
+      gv[u] = c < a.n ? gt[c] : 0.f;
+      vv[u] = c < a.n ? av[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = fmaf(gv[u], vv[u], s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gta = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+    const float num = a.w_old[e] * gta;
+    const float den = a.colsum_g[mm] * (float)a.hstat[ESPM_HS_ROWSUM + kk];
+    float wn = fmaxf(num / den, a.log_shift);
+    if (a.fixed_w && a.fixed_w[e] >= 0.f) wn = a.fixed_w[e];
+    a.w_new[e] = wn;
+  }
+}
+
+// workgroup b: channels 256 b .. 256 b + 255, one per thread; partial column sums -> scratch; the workgroup that finishes last adds
+// them in workgroup order (the same bits whoever is last) and forms mean(W') and rel_W
+__global__ __launch_bounds__(256) void w_gfinish_gw_kernel(const WFinishArgs a) {
+  extern __shared__ float s_w[];   // [m * k] the new W
+  __shared__ double scratch[(256 / 64 + 1) * 2 * KP];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, mk = a.m * a.k, k = a.k, nwg = gridDim.x;
+  double* parts = reinterpret_cast<double*>(a.scratch);                       // [nwg][KP]
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(parts + (size_t)nwg * KP);   // zero between launches
+  for (int e = tid; e < mk; e += 256) s_w[e] = a.w_new[e];
+  __syncthreads();
+  // GW = G W' (updates.py:107 of the next half step), stored / xscale with a positive floor
+  double cs[KP];
+#pragma unroll
+  for (int kk = 0; kk < KP; ++kk) cs[kk] = 0.0;
+  const float inv_scale = 1.f / a.xscale;
+  const int c = blockIdx.x * 256 + tid;
+  if (c < a.n_pad) {
+    float row[KP];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) row[kk] = (kk < k && c >= a.n) ? 1.f : 0.f;   // padding channels: X = 0 there, any positive value keeps X / Y = 0
+    if (c < a.n) {
+      const float* gc = a.g_t + c;   // (the transposed copy: the lanes of a wave read neighbouring channels of one column of G)
+      for (int m0 = 0; m0 < a.m; m0 += 32) {   // up to 32 entries of the row of G requested together (a dictionary has a few tens of columns)
+        float gv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) gv[u] = m0 + u < a.m ? gc[(size_t)(m0 + u) * a.n_pad] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          if (m0 + u < a.m) {
+#pragma unroll
+            for (int kk = 0; kk < KP; ++kk)
+              if (kk < k) row[kk] = fmaf(gv[u], s_w[(m0 + u) * k + kk], row[kk]);
+          }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KP; ++kk)
+        if (kk < k) {
+          const float v = fmaxf(row[kk], a.gw_floor);
+          cs[kk] += (double)v;
+          row[kk] = v * inv_scale;
+        }
+    }
+    store_row_kp(a.gw_s + (size_t)c * KP, row);
+  }
+  block_reduce<KP, KP>(cs, scratch);
+  if (tid == 0) {
+    // publish, then take a ticket.  No fences (a release writes back the XCD's whole L2: 20 us for this kernel with them): the
+    // partials are 8-byte agent-scope stores (write-through), drained by this lane before its ticket; the workgroup whose ticket
+    // is the last reads them with agent-scope loads after its add has returned (MI355X_MICROARCH.md, hand-offs with sc1 on both sides)
+    for (int kk = 0; kk < KP; ++kk) __hip_atomic_store(parts + (size_t)blockIdx.x * KP + kk, cs[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned int)nwg - 1u);
+  }
+  __syncthreads();
+  if (s_last && tid < KP) {   // (wave 0, the wave whose lane took the ticket) component tid: the partials in workgroup order - the same bits whoever is last
+    double v = 0.0;
+    for (int b0 = 0; b0 < nwg; b0 += 8) {
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t8[u] = b0 + u < nwg ? __hip_atomic_load(parts + (size_t)(b0 + u) * KP + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t8[u];
+    }
+    a.colsum_gw[tid] = v;
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
+  }
+  if (blockIdx.x == 0 && a.hist_slot) {   // mean(W') and rel_W (base.py:323) over the m k entries: workgroup 0, from its copy of W' (needs nobody else)
+    double sum_l = 0.0;
+    for (int e = tid; e < mk; e += 256) sum_l += (double)s_w[e];
+    const double mean_w = block_sum1(sum_l, scratch) / (double)mk;
+    double rel_l = 0.0;
+    for (int e = tid; e < mk; e += 256) {
+      const double wn = s_w[e], wo = a.w_old[e];
+      rel_l = fmax(rel_l, fabs(wn - wo) / (wn + (double)a.rel_tol * mean_w));
+    }
+    const double rel_w = block_max1(rel_l, scratch);
+    if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = rel_w;
+  }
+}
+
+// ---- the same on a SHARDED image: what crosses the links is G^T A (m k values), not A (k n) -------------------------------------
+// G^T (sum over the ranks of A_r) = sum over the ranks of G^T A_r: every rank contracts its OWN A with G (the update kernel's dot
+// products), sends the m k results - one granule each, with the statistics and the boundary rows as in w_exchange_update_kernel -
+// and adds the ranks' values in rank order: the same W' on every rank.  For C5 a rank ships 136 granules instead of a 63 KB record,
+// and the sharded W step is three launches behind the accumulation (slab reduction + record reduction, this kernel, the rows of
+// G W') instead of seven (reduce + pack, post, wait, combine, and the finish).
+// grid: workgroup 0 = the extra workgroup (boundary rows, statistics, their flag), workgroup 1 + e = entry e = (row of G, component).
+struct WGxchgArgs {
+  WFinishArgs f;
+  const double* hstat_local;   // this rank's statistics of the new H (the slab reduction's finalize left them in its own record)
+  double* hstat_out;           // the global ones
+  unsigned char* mbox[16];
+  int world, rank, nfl, with_halo;
+  size_t rec_bytes, slot_base, wgflags_off, gran_off, err_off, top_off, bot_off;
+  unsigned int seq;
+  long long max_ticks;
+  const float* halo_h;
+  int halo_k, halo_nx, halo_ny, halo_ppad;
+};
+
+__global__ __launch_bounds__(256) void w_gxchg_update_kernel(const WGxchgArgs x) {
+  const WFinishArgs& a = x.f;
+  __shared__ float s_wave[4];
+  const int mk = a.m * a.k;
+  auto record = [&](int dst, int src_rank) { return x.mbox[dst] + x.slot_base + (size_t)src_rank * x.rec_bytes; };
+  auto flag = [&](int dst, int src_rank) {   // (the extra workgroup's flag: index nfl - 1 of a rank's flags)
+    return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + (x.nfl - 1)) * sizeof(unsigned int));
+  };
+  const size_t GRAN = (size_t)34 * x.nfl + 2 * ESPM_HS_STRIDE;
+  auto gran = [&](int dst, int src_rank, int g) {
+    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
+  };
+  unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
+  if (blockIdx.x == 0) {   // boundary rows (16-byte write-through stores), statistics as granules, the rows' flag
+    if (x.with_halo) {
+      for (int d = -1; d <= 1; ++d) {
+        const int r = x.rank + d;
+        if (r < 0 || r >= x.world) continue;
+        float* top = reinterpret_cast<float*>(record(r, x.rank) + x.top_off);
+        float* bot = reinterpret_cast<float*>(record(r, x.rank) + x.bot_off);
+        if ((x.halo_ny & 3) == 0) {
+          typedef float xf4 __attribute__((ext_vector_type(4)));
+          for (int e = 4 * threadIdx.x; e < x.halo_k * x.halo_ny; e += 4 * 256) {
+            const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+            const xf4 vt = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + j);
+            const xf4 vb = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(top + e), "v"(vt) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(bot + e), "v"(vb) : "memory");
+          }
+        } else {
+          for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += 256) {
+            const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+            __hip_atomic_store(top + e, x.halo_h[(size_t)kk * x.halo_ppad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(bot + e, x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+    }
+    for (int i = threadIdx.x; i < x.world * 2 * ESPM_HS_STRIDE; i += 256) {
+      const int r = i / (2 * ESPM_HS_STRIDE), j = i - r * 2 * ESPM_HS_STRIDE;
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, x.hstat_local[j >> 1]);
+      const unsigned int half = (j & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+      __hip_atomic_store(gran(r, x.rank, 34 * x.nfl + j), ((unsigned long long)x.seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const int e = (int)blockIdx.x - 1, mm = e / a.k, kk = e - mm * a.k;
+  const float* gt = a.g_t + (size_t)mm * a.n_pad;
+  const float* av = a.a + (size_t)kk * a.n_pad;
+  const float wo = a.w_old[e];
+  const float fx = a.fixed_w ? a.fixed_w[e] : -1.f;
+  float s = 0.f;
+  for (int c0 = threadIdx.x; c0 < a.n; c0 += 8 * 256) {
+    float gv[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * 256;
+      gv[u] = c < a.n ? gt[c] : 0.f;
+      vv[u] = c < a.n ? av[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s = fmaf(gv[u], vv[u], s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const float gta_mine = ((s_wave[0] + s_wave[1]) + s_wave[2]) + s_wave[3];
+  if (lane < x.world)   // this rank's value of entry e, to every rank
+    __hip_atomic_store(gran(lane, x.rank, e), ((unsigned long long)x.seq << 32) | __float_as_uint(gta_mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // lanes 0..15: rank r's value of entry e; 16..31 / 32..47: the low / high half of rank r's row sum kk of its new H block
+  const int r_of = lane & 15, what = lane >> 4;
+  const bool polls = what < 3 && r_of < x.world;
+  const int g_idx = what == 0 ? e : 34 * x.nfl + 2 * (ESPM_HS_ROWSUM + kk) + (what - 1);
+  unsigned int got = 0;
+  {
+    const long long t0 = wall_clock64();
+    for (;;) {
+      const unsigned long long v = polls ? __hip_atomic_load(gran(x.rank, r_of, g_idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)x.seq << 32);
+      const bool ok = (unsigned int)(v >> 32) == x.seq;
+      got = (unsigned int)v;
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+      if (wall_clock64() - t0 > x.max_ticks) {
+        if (!ok) atomicAdd(err, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  float gta = 0.f;
+  double rs = 0.0;
+  for (int r = 0; r < x.world; ++r) {   // rank order: the same sums on every rank
+    gta += __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)got, r));
+    const unsigned long long lo = (unsigned int)__builtin_amdgcn_readlane((int)got, 16 + r), hi = (unsigned int)__builtin_amdgcn_readlane((int)got, 32 + r);
+    rs += __builtin_bit_cast(double, (hi << 32) | lo);
+  }
+  if (lane == 0) {   // updates.py:58-60, :70-76
+    const float num = wo * gta, den = a.colsum_g[mm] * (float)rs;
+    float wn = fmaxf(num / den, a.log_shift);
+    if (fx >= 0.f) wn = fx;
+    a.w_new[e] = wn;
+  }
+  if (e == 0) {   // the global statistics of the new H (the NEXT launch reads them) and the neighbours' boundary rows' flag
+    const bool p2 = lane < 2 * ESPM_HS_STRIDE;
+    unsigned int hv[16];
+    const long long t0 = wall_clock64();
+    for (;;) {
+      unsigned long long v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                   : ((unsigned long long)x.seq << 32);
+      bool all = true;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        all = all && (unsigned int)(v[r] >> 32) == x.seq;
+        hv[r] = (unsigned int)v[r];
+      }
+      if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+      if (wall_clock64() - t0 > x.max_ticks) {
+        if (!all) atomicAdd(err, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < x.world) {
+        const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
+        const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
+        const double v2 = __builtin_bit_cast(double, bits);
+        g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+      }
+    if (p2 && !(lane & 1)) x.hstat_out[lane >> 1] = g;
+    if (lane < x.world) xchg_wait_flag(flag(x.rank, lane), x.seq, x.max_ticks, err);
+  }
+}
+
+static bool w_gsplit_enabled();
+bool w_gsplit_applies(const WFinishArgs& args) {
+  const long mk = (long)args.m * args.k;
+  const int nwg_b = (args.n_pad + 255) / 256;
+  return args.g && args.g_t && args.m > 0 && args.update_w && !args.simplex_w && args.pg_gamma_w <= 0.f && !args.breg_sr && mk <= 8192 && args.scratch &&
+         (size_t)2 * mk * sizeof(float) >= (size_t)nwg_b * KP * sizeof(double) + 16 && w_gsplit_enabled();
+}
+int launch_w_gfinish_gw(const WFinishArgs& args, hipStream_t stream);
+
+int launch_w_gxchg_update(const WFinishArgs& f, const espm_xchg* xc, unsigned int seq, const double* hstat_local, double* hstat_out,
+                          const float* h_new, int nx, int ny, int p_pad, int with_halo, hipStream_t stream) {
+  WGxchgArgs x;
+  x.f = f;
+  const int mk = f.m * f.k;
+  ESPM_REQUIRE((size_t)mk <= (size_t)34 * xc->wgflags, "exchange: %d entries of G^T A, the mailbox holds granules for %d", mk, 34 * xc->wgflags);
+  for (int r = 0; r < 16; ++r) x.mbox[r] = r < xc->world ? xc->peers[r] : nullptr;
+  for (int r = 0; r < xc->world; ++r) ESPM_REQUIRE(x.mbox[r], "exchange: rank %d is not connected (espm_xchg_connect)", r);
+  x.hstat_local = hstat_local;
+  x.hstat_out = hstat_out;
+  x.world = xc->world;
+  x.rank = xc->rank;
+  x.nfl = xc->wgflags;
+  x.with_halo = with_halo;
+  x.rec_bytes = xc->record_bytes;
+  x.slot_base = (size_t)(seq & 1u) * xc->world * xc->record_bytes;
+  x.wgflags_off = xc->off_wgflags;
+  x.gran_off = xc->off_gran + (size_t)(seq & 1u) * xc->world * ((size_t)34 * xc->wgflags + 2 * ESPM_HS_STRIDE) * sizeof(unsigned long long);
+  x.err_off = xc->off_err;
+  const size_t hstat_off = (size_t)f.k * f.n_pad * 4;
+  x.top_off = hstat_off + ESPM_HS_STRIDE * 8;
+  x.bot_off = x.top_off + (size_t)f.k * (ny > 0 ? ny : 0) * 4;
+  x.seq = seq;
+  x.max_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  x.halo_h = h_new;
+  x.halo_k = f.k;
+  x.halo_nx = nx;
+  x.halo_ny = ny;
+  x.halo_ppad = p_pad;
+  hipLaunchKernelGGL(w_gxchg_update_kernel, dim3(mk + 1), dim3(256), 0, stream, x);
+  if (int rc = check_hip(hipGetLastError(), "w_gxchg_update launch")) return rc;
+  return launch_w_gfinish_gw(f, stream);
+}
+
+static bool w_gsplit_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ESPM_W_GSPLIT");
+    on = !(e && e[0] == '0');
+  }
+  return on != 0;
+}
+
+int launch_w_gfinish_gw(const WFinishArgs& args, hipStream_t stream) {
+  const int nwg_b = (args.n_pad + 255) / 256;
+  hipLaunchKernelGGL(w_gfinish_gw_kernel, dim3(nwg_b), dim3(256), (size_t)args.m * args.k * sizeof(float), stream, args);
+  return check_hip(hipGetLastError(), "w_finish (dictionary G: rows of G W')");
+}
+
 int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const int M = args.m > 0 ? args.m : args.n;
   const long mk = (long)M * args.k;
+  // dictionary G, W' = max(W (G^T A) / (colsum G rowsum H'), eps): the two-launch finish above
+  // (scratch: w_scratch's 2 m k floats must hold the second launch's partial column sums and its ticket - zero between launches)
+  if (w_gsplit_applies(args)) {
+    hipLaunchKernelGGL(w_gfinish_update_kernel, dim3((unsigned)mk), dim3(256), 0, stream, args);
+    if (int rc = check_hip(hipGetLastError(), "w_finish (dictionary G: update)")) return rc;
+    return launch_w_gfinish_gw(args, stream);
+  }
   const int span = M > args.n_cm ? M : args.n_cm;
   // G = identity, up to 8 components (the narrow build), up to 2048 rows: 8 waves with 256 registers each (with the simplex
   // over W at the headline size 49 -> 37 us at k = 5, iteration 278 -> 248 us at k = 8); a dictionary G keeps the 16 waves

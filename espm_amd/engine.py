@@ -709,7 +709,15 @@ class MUEngine:
         # sparse store, local W update: its tail is left to the next H-step's launch (eval_current) or to _flush_finalize
         defer = (self.ell is not None and self.pg_q is None and bool(self.lib.espm_mu_w_update_is_local(C.byref(st))))
         st.tail_mode = _lib.TAIL_DEFER if defer else 0
-        if self.sharded:
+        if self.sharded and self.exchange.ctx is not None and ride:
+            # one-shot transport, and the H-step's records are still the workspace's content (their reduction is pending): the
+            # library's exchange launch(es), as in the batch loop (espm_mu_iterate_sharded) - slab reduction, record reduction,
+            # granule exchange, W update.  (Once the records have been reduced, other launches may have reused the workspace -
+            # the projected gradient's linesearch evaluates a loss in between - and the pieces below carry the statistics along.)
+            self.exchange.seq.value += 1
+            self._check(self.lib.espm_mu_shard_exchange_finish(C.byref(st), self.exchange.ctx, self.exchange.seq, cur, slot, s))
+            self._set_halo_from_records()
+        elif self.sharded:
             if ride:   # slab reduction + record reduction + this rank's record, one launch
                 self._check(self.lib.espm_mu_w_reduce_pack(C.byref(st), cur, slot, C.c_void_p(self.exchange.send_ptr), s))
             else:

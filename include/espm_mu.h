@@ -198,7 +198,7 @@ typedef struct espm_mu_state {
   double* hstat[2];         /* (ESPM_HS_STRIDE) statistics of h[0] / h[1] (global)       */
   float* a_slab;            /* (nblk_w, k, n_pad)                                        */
   float* a;                 /* (k, n_pad)                                                */
-  float* w_scratch;         /* (2, m or n, k)                                            */
+  float* w_scratch;         /* (2, m or n, k), zero before the first call (a ticket of the dictionary-G W finish lives there) */
   double* hist;             /* (hist_len, ESPM_HI_STRIDE), zero-initialised              */
   int32_t hist_len;
   int32_t cur;              /* index of the current W/H buffers (0/1), flipped by iterate */
