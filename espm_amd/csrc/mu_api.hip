@@ -555,6 +555,22 @@ int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_
                                    static_cast<hipStream_t>(stream));
     }
   }
+  if (w_simplex_split(st) && nblk_h(st) > 0) {
+    // the simplex over W with G = identity (the estimator's default constraints): the pieces of A cross the links as granules like
+    // the local update's, the workgroup that sums 32 entries leaves the bracket's partials, w_simplex_update_kernel follows - two launches
+    if (st->log_shift > 0.f && (double)st->n * (double)st->log_shift >= 1.0)
+      return set_error(ESPM_ENOSOLUTION, "No solution exists! (rows * log_shift >= 1)");
+    const HFinalizeArgs fin = finalize_args(st, src, slot, true);
+    WTailArgs left_out;
+    const int with_halo = st->grid_mode && st->lambda_l != 0.f;
+    double* bparts = simplex_bparts(st);
+    if (int rc = launch_w_exchange_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a_slab, (size_t)st->k * st->n_pad * sizeof(float), st->nblk_w,
+                                          st->a, st->hstat[1 - src], fin, x, seq, st->h[1 - src], st->nx, st->ny, st->p_pad, with_halo,
+                                          static_cast<hipStream_t>(stream), nullptr, bparts))
+      return rc;
+    return launch_w_simplex_update(finish_args(st, src, 1 - src, slot + 1, 1), st->a, bparts, (double)ESPM_W_DICOTOMY_TOL,
+                                   static_cast<hipStream_t>(stream), (st->tail_mode & ESPM_TAIL_DEFER) ? &left_out : nullptr);
+  }
   if (!w_update_is_local(st) || st->no_fused == 1) {   // W' needs a global finish (G given, simplex over W): the four steps
     if (int rc = espm_mu_w_reduce_pack(st, src, slot, x->staging, stream)) return rc;
     if (int rc = espm_xchg_post(x, seq, stream)) return rc;
@@ -575,7 +591,7 @@ int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int 
   ESPM_REQUIRE(st->it + n_iter < st->hist_len, "history too short: it=%d + %d >= %d", st->it, n_iter, st->hist_len);
   ESPM_REQUIRE(x->record_bytes == espm_mu_shard_record_bytes(st), "iterate_sharded: the exchange was created for records of %zu bytes, the state packs %zu",
                x->record_bytes, espm_mu_shard_record_bytes(st));
-  const bool defer = st->x_dtype == ESPM_X_ELL && w_update_is_local(st) && !(st->pg_q && st->pg_gamma_w > 0.f);
+  const bool defer = st->x_dtype == ESPM_X_ELL && (w_update_is_local(st) || w_simplex_split(st)) && !(st->pg_q && st->pg_gamma_w > 0.f);
   const bool with_halo = st->grid_mode && st->lambda_l != 0.f;
   // byte offsets inside a record: [A | statistics | first owned image row | last owned image row]
   const size_t off_top = (size_t)st->k * st->n_pad * 4 + ESPM_HS_STRIDE * 8, off_bot = off_top + (size_t)st->k * (st->ny > 0 ? st->ny : 0) * 4;

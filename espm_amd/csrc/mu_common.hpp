@@ -827,7 +827,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
 int launch_w_update_tail(const WTailArgs& t, hipStream_t stream);
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const struct ::espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny,
-                             int p_pad, int with_halo, hipStream_t stream, WTailArgs* defer_tail);
+                             int p_pad, int with_halo, hipStream_t stream, WTailArgs* defer_tail, double* simplex_bparts = nullptr);
 bool w_gsplit_applies(const WFinishArgs& args);   // the W finish with a dictionary G as many-workgroup launches (mu_w_step.hip)
 int launch_w_gxchg_update(const WFinishArgs& f, const struct ::espm_xchg* xc, unsigned int seq, const double* hstat_local, double* hstat_out,
                           const float* h_new, int nx, int ny, int p_pad, int with_halo, hipStream_t stream);

@@ -405,6 +405,9 @@ struct WExchangeArgs {
   long long max_ticks;
   const float* halo_h;
   int halo_k, halo_nx, halo_ny, halo_ppad;
+  // simplex over W with G = identity: the summed A and, per reduction workgroup, what the bracket of its component's multiplier
+  // needs (the three doubles w_reduce_kernel leaves) go out INSTEAD of the update - w_simplex_update_kernel follows; else null
+  double* bparts;
 };
 
 __device__ __forceinline__ void xchg_wait_flag(const unsigned int* flag, unsigned int seq, long long max_ticks, unsigned int* err) {
@@ -590,7 +593,25 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         const unsigned long long lo = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 32), hi = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 33);
         rs += __builtin_bit_cast(double, (hi << 32) | lo);
       }
-    w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg, wo_pre, fx_pre);
+    if (x.bparts) {   // the numerators' sum, maximum and count of positives (dicotomy.py:29-49), as w_reduce_kernel forms them
+      if (owns) a.a_out[e] = tt;
+      const float num = (owns && c < a.n) ? wo_pre * tt : 0.f;   // updates.py:59 (G = identity)
+      double sum = num > 0.f ? (double)num : 0.0, cnt = num > 0.f ? 1.0 : 0.0;
+      float mx = fmaxf(num, 0.f);
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      }
+      if (lane == 0) {
+        x.bparts[3 * (size_t)wg] = sum;
+        x.bparts[3 * (size_t)wg + 1] = (double)mx;
+        x.bparts[3 * (size_t)wg + 2] = cnt;
+      }
+    } else {
+      w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg, wo_pre, fx_pre);
+    }
     if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
       static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
       const bool polls = lane < 2 * ESPM_HS_STRIDE;
@@ -1542,8 +1563,9 @@ int launch_w_simplex_update(const WFinishArgs& f, float* a_inout, const double* 
 
 int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t slab_stride, int nslab, float* a_out, double* hstat_out,
                              const HFinalizeArgs& fin, const espm_xchg* xc, unsigned int seq, const float* h_new, int nx, int ny, int p_pad,
-                             int with_halo, hipStream_t stream, WTailArgs* defer_tail) {
+                             int with_halo, hipStream_t stream, WTailArgs* defer_tail, double* bparts) {
   WExchangeArgs x;
+  x.bparts = bparts;
   WUpdateArgs& a = x.u;
   a.src = static_cast<const unsigned char*>(slabs);
   a.src_stride = slab_stride;
@@ -1596,6 +1618,7 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.halo_ppad = p_pad;
   a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
   hipLaunchKernelGGL(w_exchange_update_kernel, dim3(nwg + 1), dim3(256), 0, stream, x);
+  if (bparts) return check_hip(hipGetLastError(), "w_exchange_update launch");   // (the caller's w_simplex_update_kernel updates W and owns the tail)
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)
     *defer_tail = t;

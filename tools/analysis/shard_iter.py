@@ -20,7 +20,8 @@ N_CH, NY, K, M = (1980, 1024, 8, 17) if C5 else (2048, 512, 5, None)
 prob = synth.make_problem(N_CH, ROWS, NY, K, N=500.0, seed=0, row0=0, nx_total=NY, m=M)
 X = synth.sample_torch(prob, dev, seed=1000, row0=0)
 W0, H0 = synth.random_init(M if C5 else N_CH, K, NY * NY, seed=0, scale=500.0 / N_CH)
-kw = dict(layout="pm", shape_2d=(ROWS, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=2000, device=dev)
+SIMPLEX_W = os.environ.get("SIMPLEX_W") == "1"   # the simplex over W as well (with G = identity: the many-workgroup multiplier search)
+kw = dict(layout="pm", shape_2d=(ROWS, NY), lambda_L=1.0, simplex_H=True, simplex_W=SIMPLEX_W, tol=0.0, max_iter=2000, device=dev)
 if C5:
     kw.update(G=prob["G"], mu=0.05)
 
