@@ -67,21 +67,28 @@ def cpu_baseline_and_parity(X_crop_pm, device, skip_full=None):
     X = np.ascontiguousarray(X_crop_pm.T.astype(np.float64))            # (n, p_crop)
     p_crop = X.shape[1]
     W0, H0 = synth.random_init(N_CH, K, p_crop, seed=0, scale=COUNTS / N_CH)
-    t0 = time.perf_counter()
-    r = oc.fit(X, K, W=W0.copy(), H=H0.copy(), lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(CROP_ROWS, ny),
-               tol=0, no_stop_criterion=True, max_iter=CROP_ITERS)
-    dt = time.perf_counter() - t0
-    its_crop = r["n_iter"] / dt
-    threads = os.cpu_count()
+    # The pools run with the CPUs this process may USE (cgroup quota: 16 on the MI355X boxes), not the 256 it can see: sized by the
+    # visible cores they exhaust the quota and the kernel stops the whole container for the rest of every 100 ms period
+    # (espm_amd/_cpu_budget.py) - a throttled baseline would flatter the GPU.  `cores` is that budget.
+    from espm_amd._cpu_budget import cpu_budget, limited_thread_pools
+    budget = cpu_budget()
+    threads = budget
     pools = None
-    try:
-        from threadpoolctl import threadpool_info
-        pools = [{k: info.get(k) for k in ("user_api", "internal_api", "num_threads", "version", "threading_layer")} for info in threadpool_info()]
-        for info in pools:
-            if info.get("user_api") == "blas":
-                threads = info.get("num_threads", threads)
-    except Exception:
-        pass
+    with limited_thread_pools(budget):
+        t0 = time.perf_counter()
+        r = oc.fit(X, K, W=W0.copy(), H=H0.copy(), lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(CROP_ROWS, ny),
+                   tol=0, no_stop_criterion=True, max_iter=CROP_ITERS)
+        dt = time.perf_counter() - t0
+        its_crop = r["n_iter"] / dt
+        try:
+            from threadpoolctl import threadpool_info
+            pools = [{k: info.get(k) for k in ("user_api", "internal_api", "num_threads", "version", "threading_layer")} for info in threadpool_info()]
+            for info in pools:
+                if info.get("user_api") == "blas":
+                    threads = min(budget, info.get("num_threads", threads))
+            pools.append({"cpu_budget": budget, "visible_cores": os.cpu_count()})
+        except Exception:
+            pass
     eng = MUEngine(X, K, layout="cm", shape_2d=(CROP_ROWS, ny), lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, tol=0.0,
                    max_iter=CROP_ITERS + 2, device=device)
     eng.load_state(W0, H0)
@@ -110,8 +117,10 @@ def cpu_full_size_iteration(X_dev):
     from espm_amd import synth
     X = X_dev.cpu().numpy().T.astype(np.float64)                        # (n, p) C-order, like the reference's input
     W0, H0 = synth.random_init(N_CH, K, NX * NY, seed=0, scale=COUNTS / N_CH)
-    r = oc.fit(X, K, W=W0, H=H0, lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(NX, NY), tol=0, no_stop_criterion=True,
-               max_iter=1, time_iterations=True)
+    from espm_amd._cpu_budget import cpu_budget, limited_thread_pools
+    with limited_thread_pools(cpu_budget()):   # (the CPUs the container may use, as in the crop leg)
+        r = oc.fit(X, K, W=W0, H=H0, lambda_L=LAMBDA_L, simplex_H=True, simplex_W=False, shape_2d=(NX, NY), tol=0, no_stop_criterion=True,
+                   max_iter=1, time_iterations=True)
     return dict(value=1.0 / r["seconds"], unit="it/s", seconds_per_iteration=r["seconds"], iterations=1, loss=float(r["losses"][-1]))
 
 
@@ -129,6 +138,10 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="two launches per iteration pair instead of the fused kernel (A/B)")
     args = ap.parse_args()
 
+    # host thread pools no larger than the CPUs the container grants (espm_amd/_cpu_budget.py: pools sized by the 256 visible cores
+    # exhaust a 16-CPU quota, and a throttled host cannot feed the device)
+    from espm_amd._cpu_budget import cpu_budget
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -6,6 +6,7 @@ from copy import deepcopy
 
 import numpy as np
 
+from espm_amd._cpu_budget import limited_thread_pools
 from espm_amd.conf import dicotomy_tol, log_shift, sigmaL
 from espm_amd.estimators.base import NMFEstimator
 
@@ -170,7 +171,9 @@ class SmoothNMF(NMFEstimator):
                 raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
         self.gamma_ = None
         self._pg_gamma_cache = None
-        return super().fit_transform(X, y=y, W=W, H=H)
+        # (thread pools sized by the visible cores exhaust a container's CPU quota and get the whole process throttled: _cpu_budget.py)
+        with limited_thread_pools():
+            return super().fit_transform(X, y=y, W=W, H=H)
 
     def _iteration(self, W, H):
         """One H update then one W update from host arrays (espm/estimators/smooth_nmf.py:284-455)."""
