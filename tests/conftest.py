@@ -8,10 +8,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# (the ranks the multi-process tests start size their pools at import: keep them within the container's CPUs as well)
+from espm_amd._cpu_budget import cpu_budget  # noqa: E402
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_v, str(max(1, cpu_budget() // 2)))
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _pools_within_the_cpu_budget():
+    """Thread pools of the test process no larger than the CPUs its container grants (espm_amd/_cpu_budget.py): sized by the visible
+    cores they exhaust the quota and the whole session is throttled - the oracle's BLAS calls and every CPU-side torch op."""
+    from espm_amd._cpu_budget import cpu_budget, limited_thread_pools
+    with limited_thread_pools(cpu_budget()):
+        yield
 
 
 @pytest.fixture(scope="session")
