@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
         for (int j = 0; j < 4; ++j) {
           float x[4], r[4];
           xr[s & 1].quad(j, x);
-          mf_f4 y = mf_mma3(a1h[j], a1l[j], hh[s], hl[s], mf_f4{0.f, 0.f, 0.f, 0.f});
+          mf_f4 y = mf_mma3<1>(a1h[j], a1l[j], hh[s], hl[s], mf_f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // The first reader of a matrix-core result must be an instruction the compiler knows (it owes the wait states
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
           }
           mf_s4 rh, rl;
           mf_split(r, rh, rl);
-          acc[s] = mf_mma3(rh, rl, b3h[j], b3l[j], acc[s]);
+          acc[s] = mf_mma3<2>(rh, rl, b3h[j], b3l[j], acc[s]);
         }
         // the four sub-tile chains of a step are enough to keep the matrix and the vector pipes busy; without the fence the
         // scheduler interleaves all eight steps and spills 250 registers (with the loss term)

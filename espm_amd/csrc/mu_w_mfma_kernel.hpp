@@ -44,7 +44,7 @@ __device__ __forceinline__ void mf_split(const float (&v)[4], mf_s4& hi, mf_s4& 
   lo = __builtin_bit_cast(mf_s4, mf_u2{l0, l1});
 }
 // c += (ah + al) . (bh + bl) over the 16 slots of the contraction.
-// ESPM_MFMA_K32 (gfx950's own shape): v_mfma_f32_16x16x32_bf16 contracts over 32 slots in the cycles the CDNA3-era 16x16x16 form
+// The 32-slot form (gfx950's own shape): v_mfma_f32_16x16x32_bf16 contracts over 32 slots in the cycles the CDNA3-era 16x16x16 form
 // takes for 16, and the hi / lo split supplies exactly two 16-slot halves: with the A operand [ah | al] (the two halves side by
 // side in one 8-element operand - slot i of either half is the same component, so the order inside the 32 does not matter as
 // long as both operands agree) one instruction against [bl | bl] gives ah bl + al bl and one against [bh | bh] gives
@@ -53,26 +53,33 @@ __device__ __forceinline__ void mf_split(const float (&v)[4], mf_s4& hi, mf_s4& 
 // already held twice.
 typedef short mf_s8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
-// NOT the default: measured 6.5 % faster per iteration at k = 16 (630 against 674 us at the headline image on the 8-bit store) and NOT
-// reproducible from run to run - 60-75 % of the entries of H differ in their last bits (max 3e-5) between two runs from the same
-// state, with every variant tried: operands held across 1, 2, 4, 8 wait states after the issue (ESPM_MFMA_K32_NOPS), 20 wait states
-// behind the second instruction (256 entries still differ), profiles/r03d_wide_repro.log, r03e_wide_repro.log.  The 16-slot form
-// below is bit-reproducible in the same harness (tests/test_gpu_fullsize.py::test_matrix_core_kernels_of_the_wide_build_at_full_size),
-// so the cause sits with this instruction in this compiler's code (a wait state it does not insert, or a register it reuses too
-// early) and has not been found; a result that changes from run to run is not shipped for 6 %.
-#ifndef ESPM_MFMA_K32
-#define ESPM_MFMA_K32 0
+// Where it is used (ESPM_MFMA_K32_MASK, one bit per call site - 1: Y of the H-step, 2: the H-step's numerator, 4: Y of the W
+// accumulation, 8: the W accumulation's sums; default 12 = the W accumulation, both sites):
+//  * W accumulation: bit-reproducible from run to run at k = 9, 12, 16 and 0.6-1.4 % of the iteration faster than the 16-slot form
+//    (k = 16: 662 against 667 us, k = 12: 632.5 against 641.5; profiles/r03z_wide_repro_*.log).
+//  * H-step: NOT reproducible with either of its sites alone (mask 1, mask 2: 2-3 million of the 4 million entries of H differ in
+//    their last bits - max 3e-5 - between two runs from the same state), with every variant tried: operands held across 1, 2, 4, 8
+//    wait states after the issue (ESPM_MFMA_K32_NOPS), 20 wait states behind the second instruction (256 entries still differ:
+//    delay helps, so it is an ordering hazard, not arithmetic), profiles/r03d_wide_repro.log, r03e_wide_repro.log, r03z_wide_repro_m{1,2}.log.
+//    The same call, the same operand construction and the same first reader (fmaxf, then the in-place reciprocal) are fine in the
+//    W kernel; what the H-step kernel has and the W kernel has not is 183 spilled scalar registers (v_writelane / v_readlane next to
+//    the matrix instructions) and the scheduling fence per pixel step.  Not found; all four sites together would be 6.5 % at
+//    k = 16 (630 against 674 us).  A result that changes from run to run is not shipped for that.
+#ifndef ESPM_MFMA_K32_MASK
+#define ESPM_MFMA_K32_MASK 12
 #endif
 // (Diagnosis knob: the empty asm keeps both four-register operands allocated across ESPM_MFMA_K32_NOPS + 1 wait states after the
-// matrix instruction - hipcc reuses one of them two or three instructions later.  It did not restore reproducibility.)
-#ifndef ESPM_MFMA_K32_NOPS
-#define ESPM_MFMA_K32_NOPS 1
-#endif
+// matrix instruction - hipcc reuses one of them two or three instructions later.  It did not restore reproducibility in the H-step.)
+#ifdef ESPM_MFMA_K32_NOPS
 #define ESPM_STR2(x) #x
 #define ESPM_STR(x) ESPM_STR2(x)
 #define ESPM_MFMA_K32_HOLD(a, b) asm volatile("s_nop " ESPM_STR(ESPM_MFMA_K32_NOPS) : : "v"(a), "v"(b))
+#else
+#define ESPM_MFMA_K32_HOLD(a, b)
+#endif
+template <int SITE>
 __device__ __forceinline__ mf_f4 mf_mma3(const mf_s4 ah, const mf_s4 al, const mf_s4 bh, const mf_s4 bl, mf_f4 c) {
-#if ESPM_MFMA_K32
+  if constexpr ((ESPM_MFMA_K32_MASK & SITE) != 0) {
   const mf_b8 a = __builtin_bit_cast(mf_b8, __builtin_shufflevector(ah, al, 0, 1, 2, 3, 4, 5, 6, 7));
   const mf_b8 b1 = __builtin_bit_cast(mf_b8, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 4, 5, 6, 7));
   const mf_b8 b2 = __builtin_bit_cast(mf_b8, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -81,11 +88,11 @@ __device__ __forceinline__ mf_f4 mf_mma3(const mf_s4 ah, const mf_s4 al, const m
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c, 0, 0, 0);
   ESPM_MFMA_K32_HOLD(a, b2);
   return c;
-#else
+  } else {
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);   // small terms first
   c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
-#endif
+  }
 }
 
 // 16 consecutive pixels of one channel row of the tile-major X; quad(s) = the 4 pixels of step s as floats
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) r[i] = x[i];
         } else {
-          mf_f4 y = mf_mma3(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
+          mf_f4 y = mf_mma3<4>(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // The first reader of a matrix-core result must be an instruction the compiler knows: it owes the wait states
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
         }
         mf_s4 rh, rl;
         mf_split(r, rh, rl);
-        acc[t] = mf_mma3(rh, rl, b3h[s], b3l[s], acc[t]);
+        acc[t] = mf_mma3<8>(rh, rl, b3h[s], b3l[s], acc[t]);
       }
     }
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A variant of the WIDE library (9..16 components) whose matrix-core translation units (mu_w_step, mu_h_step in its four parts)
 # are compiled with extra flags; the rest are the product's objects (espm_amd/lib/wide_*.o).
-#   bash tools/analysis/build_variant_wide.sh k16 "-DESPM_MFMA_K32=0"   -> tools/analysis/libespm_mu_wide_<name>.so (ESPM_MU_WIDE_LIB=<path>)
+#   bash tools/analysis/build_variant_wide.sh k16 "-DESPM_MFMA_K32_MASK=0"   -> tools/analysis/libespm_mu_wide_<name>.so (ESPM_MU_WIDE_LIB=<path>)
 set -e
 NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/../.." && pwd)
