@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
         }
         // the four sub-tile chains of a step are enough to keep the matrix and the vector pipes busy; without the fence the
         // scheduler interleaves all eight steps and spills 250 registers (with the loss term)
+#ifndef ESPM_H_MFMA_NO_FENCE   // (diagnosis of the 32-slot form's run-to-run differences)
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     // partial numerators of this wave: num[component l16, pixels 16 s + 4 q + r of the pass]

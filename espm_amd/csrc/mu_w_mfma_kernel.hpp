@@ -61,10 +61,15 @@ typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
 //    their last bits - max 3e-5 - between two runs from the same state), with every variant tried: operands held across 1, 2, 4, 8
 //    wait states after the issue (ESPM_MFMA_K32_NOPS), 20 wait states behind the second instruction (256 entries still differ:
 //    delay helps, so it is an ordering hazard, not arithmetic), profiles/r03d_wide_repro.log, r03e_wide_repro.log, r03z_wide_repro_m{1,2}.log.
-//    The same call, the same operand construction and the same first reader (fmaxf, then the in-place reciprocal) are fine in the
-//    W kernel; what the H-step kernel has and the W kernel has not is 183 spilled scalar registers (v_writelane / v_readlane next to
-//    the matrix instructions) and the scheduling fence per pixel step.  Not found; all four sites together would be 6.5 % at
-//    k = 16 (630 against 674 us).  A result that changes from run to run is not shipped for that.
+//    What separates the two kernels is how many waves share a SIMD: the W kernel needs 256 + 36 registers and runs ONE wave per SIMD;
+//    the H-step kernel (245 registers, two workgroups per CU) runs TWO - and built for one (ESPM_H_MFMA_MINBLK=1) it is bit-reproducible
+//    with the 32-slot form on all four sites too, only slower than everything else (792 us; profiles/r03ab_wide_repro_h3one.log;
+//    without its scheduling fence it still differs, r03ab_wide_repro_h3nofence.log).  So: with two waves interleaving 32-slot matrix
+//    instructions on one SIMD, either a result is read (site 1: by the vector ALU eight wait states later, the compiler's count)
+//    or an operand is rewritten (site 2) before the matrix pipe - busy with the other wave's instruction - has got to it; the
+//    16-slot form does not show it.  A hardware interlock the new shape lacks or a wait-state table this compiler has too short:
+//    not decided here.  All four sites together would be 6.5 % at k = 16 (630 against 674 us); a result that changes from run to
+//    run is not shipped for that.
 #ifndef ESPM_MFMA_K32_MASK
 #define ESPM_MFMA_K32_MASK 12
 #endif

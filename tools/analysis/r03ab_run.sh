@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, run ab: the 32-slot form in the H-step kernel without the scheduling fence, and with one workgroup per CU
+set -e
+O=gpurun_out/r03ab; mkdir -p $O
+for v in h3nofence h3one; do
+  ESPM_MU_WIDE_LIB=$(pwd)/tools/analysis/libespm_mu_wide_$v.so timeout -k 10 200 python tools/analysis/wide_repro.py > $O/wide_repro_$v.log 2>&1 || { tail -20 $O/wide_repro_$v.log; exit 1; }
+  echo "== $v"; grep "run \|us / iteration" $O/wide_repro_$v.log
+done
