@@ -44,9 +44,7 @@ class _HostCopy:
     anything else (``__array__``, ``.T``, indexing ...) waits for the copy.
 
     ``finish`` hands over what the device scans found, ``start`` lets the copy run - ONE pass over row blocks on a few threads:
-    copy, scale, fill - once the fit is in its iteration loop: overlapping the upload it competed with it for the host's memory
-    bandwidth (upload 47 -> 140 ms, copy 160 -> 340 ms), overlapping the initialisation or the engine set-up its page faults
-    stalled those (50 -> 220 ms)."""
+    copy, scale, fill - behind the upload (overlapping the upload the two halved each other's host bandwidth)."""
 
     THREADS = 4
 
@@ -122,9 +120,8 @@ class _HostCopy:
         self._st.params = (zp, zc, fill, scale)
 
     def start(self):
-        """Lets the copy run: called when the fit enters its iteration loop (the main thread then sits in one C call per chunk
-        of iterations; started earlier, the copy's page faults and memory traffic stalled whatever host phase it overlapped -
-        upload, initialisation, set-up - by 100 ms at a time)."""
+        """Lets the copy run (once the upload is through and the scans of X have said what to fill; at the latest when the fit
+        enters its iteration loop)."""
         self._st.go.set()
 
     def cancel(self):
@@ -377,6 +374,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                           "If this argument is not set correctly, the function will not work properly!!!")
             except Exception:
                 pass
+            finally:
+                # the list holds THIS frame, this frame holds the list: left alone, the cycle keeps every local of the fit - the
+                # estimator, its 2 GB X_, the engine's device memory - alive until the cyclic collector runs, at some random moment
+                # of a later fit (tools/analysis/est_cycle_probe.py)
+                calframe = None
         mark("caller check (inspect)")
         if self.l2 and getattr(self, "algo", None) != "l2_surrogate":
             raise NotImplementedError("the Frobenius loss (l2=True) is built for SmoothNMF(algo='l2_surrogate'), the one "
@@ -448,6 +450,12 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             lazy.finish(zp.cpu().numpy() if fill else None, zc.cpu().numpy() if fill else None, self.log_shift,
                         self.norm_factor_ if self.normalize else None)
             self.X_ = lazy
+            # the copy runs from here on - behind the upload, next to the initialisation, the engine set-up and the loop (~120 ms
+            # for its ~45): joined at the end of the fit it has long finished.  (Rounds 2-3 started it at the loop, because
+            # started earlier it "stalled" whatever phase it overlapped: that was the container's CPU quota, _cpu_budget.py.
+            # ESPM_HOSTCOPY_START=loop restores that; profiles/r03ac_fit_timing_*.log.)
+            if os.environ.get("ESPM_HOSTCOPY_START", "early") == "early":
+                lazy.start()
         else:
             self.X_ = self.norm_factor_ * X_fixed if self.normalize else X_fixed
         X_init_dev = None
