@@ -106,6 +106,8 @@ SYMBOLS = {
     "espm_mu_l2_w_finish": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp]),
     "espm_dichotomy_simplex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "espm_mu_laplacian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
+    "espm_lu_pl_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "espm_lu_pl": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp, C.c_size_t, _vp]),
 }
 
 

@@ -13,6 +13,8 @@ NNDSVD sign logic - stays in numpy / scipy in fp64, so the result equals scikit-
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -28,7 +30,13 @@ def _lu_pl(A):
     passes over a (rows x k) matrix.  torch.linalg.lu_factor took 6 ms per call on the 262144 x 15 matrices of the headline
     size (14 calls: half of the initialisation); this takes 1 ms.  Row i of P L holds the multipliers of the steps before row
     i became a pivot, 1 at its own step, 0 after; rows never chosen hold all k multipliers.  Same pivots as LAPACK's getrf
-    (first row of the largest modulus), hence the same factors up to the rounding of a different order of operations."""
+    (first row of the largest modulus), hence the same factors up to the rounding of a different order of operations.
+
+    On the device this is espm_lu_pl of libespm_mu (csrc/mu_init.hip: ONE launch per column, 0.1 ms instead of the 1.35 ms the
+    torch operations below take at any height - launch latency); the torch formulation remains for host tensors (the CPU tests of
+    the algorithm against scipy) and is what the kernel's arithmetic follows."""
+    if A.is_cuda and A.shape[0] >= A.shape[1] and A.shape[1] <= 64 and os.environ.get("ESPM_INIT_LU") != "torch":   # (a wide matrix - fewer channels than columns - takes the torch route)
+        return _lu_pl_device(A)
     m, k = A.shape
     r = min(m, k)
     M = A.clone()
@@ -49,6 +57,54 @@ def _lu_pl(A):
     return out
 
 
+def _lu_pl_device(A):
+    import ctypes as C
+    from . import _lib
+    if A.dtype not in (torch.float32, torch.float64) or A.dim() != 2 or A.shape[0] < A.shape[1] or A.shape[1] > 64:
+        raise ValueError(f"_lu_pl: a tall fp32 / fp64 matrix of at most 64 columns is expected, got {tuple(A.shape)} {A.dtype}")
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    m, r = A.shape
+    dt = _lib.SRC_F64 if A.dtype == torch.float64 else _lib.SRC_F32
+    nbytes = int(_lib.lib.espm_lu_pl_scratch_bytes(m, r, dt))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    out = torch.empty((m, r), dtype=A.dtype, device=A.device)
+    with torch.cuda.device(A.device):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.lib.espm_lu_pl(C.c_void_p(A.data_ptr()), dt, m, r, A.stride(0), C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()),
+                                       nbytes, stream))
+    return out
+
+
+def _qr_tall(A):
+    """Q of the reduced QR factorisation of a tall matrix (m >> r columns), up to the signs of its columns - which the randomized
+    SVD does not see: U = Q Uhat with Uhat from the SVD of Q^T M is the same for Q and Q D, D = diag(+-1).
+
+    torch.linalg.qr takes 10 ms on the 262144 x 15 matrix of the headline size (Householder reflections, a launch per column and
+    more); here: Cholesky QR, twice (A = Q1 R1 with R1 = chol(A^T A), then the same on Q1, whose Gram matrix is the identity to
+    cond(A)^2 eps: the second pass restores orthonormality to rounding - Yamamoto et al., "Roundoff error analysis of the
+    CholeskyQR2 algorithm", ETNA 44, 2015), Gram matrices, factors and products in fp64 whatever the dtype of A: two r x r
+    Gram products over A, two r x r factorisations on the host and two products with R^-1, under 1 ms.  The triangular factors keep the nesting of the column spaces, so this is
+    THE QR factor up to signs, not just some orthonormal basis.  A Gram matrix that is not numerically positive definite
+    (rank-deficient A: fewer independent directions in X than n_components + 10) goes to torch.linalg.qr."""
+    Ad = A.to(torch.float64)
+    for _ in range(2):
+        # the r x r factor on the host (numpy / scipy, fp64): the device only forms the Gram matrix and multiplies by R^-1 - a
+        # triangular solve with 262144 right-hand rows takes rocBLAS 60 ms, the product with the explicit inverse 0.1
+        G = (Ad.T @ Ad).cpu().numpy()
+        try:
+            R = np.linalg.cholesky(G).T                      # upper factor: G = R^T R
+        except np.linalg.LinAlgError:
+            return torch.linalg.qr(A, mode="reduced")[0]
+        d = np.diagonal(R)
+        if not np.isfinite(R).all() or d.min() <= 1e-7 * d.max():      # cond(A) beyond what two passes repair: the Householder route
+            return torch.linalg.qr(A, mode="reduced")[0]
+        from scipy.linalg import solve_triangular
+        Rinv = solve_triangular(R, np.eye(R.shape[0]), lower=False)
+        Ad = Ad @ torch.from_numpy(Rinv).to(Ad.device)
+    return Ad.to(A.dtype)
+
+
 def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     """sklearn.utils.extmath._randomized_svd(M, n_components, random_state=...) with its defaults, M on the device.
 
@@ -67,7 +123,7 @@ def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     for _ in range(n_iter):
         Q = normalize(M @ Q)
         Q = normalize(M.T @ Q)
-    Q, _ = torch.linalg.qr(M @ Q, mode="reduced")
+    Q = _qr_tall(M @ Q) if os.environ.get("ESPM_INIT_QR") != "torch" else torch.linalg.qr(M @ Q, mode="reduced")[0]
     B = (Q.T @ M).cpu().numpy()
     Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
     U = (Q @ torch.from_numpy(Uhat).to(device=Xd.device, dtype=Xd.dtype)).cpu().numpy()

@@ -489,6 +489,16 @@ int espm_surrogate_terms(const float* h_old, const float* h_new, int k, int p, i
 int espm_mu_laplacian(const float* h, int k, int nx, int ny, int64_t ld, float* out,
                       espm_stream_t stream);
 
+/* ---- initialisation on the device (host side: espm_amd/init_device.py) ----------------------------------
+ * The LU normaliser of the randomized range finder behind the reference's NNDSVD initialisation
+ * (espm/estimators/updates.py:179 -> sklearn _initialize_nmf -> _randomized_range_finder, power_iteration_normalizer "LU":
+ * `Q, _ = scipy.linalg.lu(A, permute_l=True)`), called 2 * n_iter = 14 times per fit on matrices of n_components + 10 columns.
+ * out (m, r) contiguous = P L of A = P L U, partial pivoting with LAPACK's pivot choice (largest modulus, first row on ties).
+ * a: (m, r) with leading dimension ld, dtype ESPM_SRC_F32 / ESPM_SRC_F64 (out has the same); m >= r, r <= 64.
+ * scratch: espm_lu_pl_scratch_bytes(m, r, dtype) bytes of device memory, contents irrelevant.  r + 1 launches on `stream`. */
+size_t espm_lu_pl_scratch_bytes(int m, int r, int dtype);
+int espm_lu_pl(const void* a, int dtype, int m, int r, int64_t ld, void* out, void* scratch, size_t scratch_bytes, espm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -435,3 +435,35 @@ def test_surrogates_and_reporting_measures(golden):
     ang, mse_, cfg, warn = ms.find_min_config(tm, ts, am, as_)
     assert list(cfg) == perm and not warn and max(ang) < 1e-4 and max(mse_) < 1e-3   # algo phase i <-> true phase cfg[i]
     assert ms.ordered_mae(tm, am, cfg)[0] < 0.01 and abs(ms.mse(tm[0], tm[0])) == 0
+
+
+def test_lu_normaliser_kernel_equals_scipy_and_the_torch_formulation():
+    """espm_lu_pl (csrc/mu_init.hip: the LU normaliser of the randomized range finder, one launch per column) against
+    scipy.linalg.lu(A, permute_l=True)[0] - what scikit-learn calls, espm/estimators/updates.py:179 - and, to rounding (torch divides
+    by a scalar through its reciprocal on the host), against the torch formulation of the same elimination on the host
+    (espm_amd/init_device._lu_pl): tall matrices up to the headline height, square ones, both precisions, rows that tie for a
+    pivot, a zero column, a strided input."""
+    import scipy.linalg as sl
+    import torch
+    from espm_amd import _lib
+    from espm_amd.init_device import _lu_pl
+    rs = np.random.RandomState(11)
+    for shape in [(5000, 15), (262144, 15), (2048, 15), (257, 13), (15, 15), (40, 3), (1, 1), (70000, 40)]:
+        for dt, tol in ((np.float64, 5e-13), (np.float32, 2e-5)):
+            A = rs.normal(size=shape).astype(dt)
+            host = _lu_pl(torch.from_numpy(A)).numpy()
+            got = _lu_pl(torch.from_numpy(A).cuda())
+            assert got.is_cuda and tuple(got.shape) == shape and got.dtype == torch.from_numpy(A).dtype
+            np.testing.assert_allclose(got.cpu().numpy(), host, rtol=0, atol=tol, err_msg=f"{shape} {dt.__name__}")
+            if shape[0] <= 5000:
+                np.testing.assert_allclose(got.cpu().numpy(), sl.lu(A, permute_l=True)[0], rtol=0, atol=tol, err_msg=f"{shape} {dt.__name__}")
+    A = rs.normal(size=(600, 15))
+    A[100] = A[7] = A[431] = 50.0 * A[3]     # identical rows, the largest of every column: the first of them is the pivot
+    np.testing.assert_allclose(_lu_pl(torch.from_numpy(A).cuda()).cpu().numpy(), sl.lu(A, permute_l=True)[0], rtol=0, atol=5e-13)
+    A = rs.normal(size=(900, 6))
+    A[:, 2] = 0.0                            # a zero column: zero pivot, multipliers stay zero
+    np.testing.assert_allclose(_lu_pl(torch.from_numpy(A).cuda()).cpu().numpy(), _lu_pl(torch.from_numpy(A)).numpy(), rtol=0, atol=5e-13)
+    wide = torch.from_numpy(rs.normal(size=(3000, 32))).cuda()[:, ::2]   # columns 2 apart in memory
+    np.testing.assert_allclose(_lu_pl(wide).cpu().numpy(), _lu_pl(wide.cpu().contiguous()).numpy(), rtol=0, atol=5e-13)
+    with pytest.raises(ValueError, match="NULL pointer"):
+        _lib.check(_lib.lib.espm_lu_pl(None, 0, 10, 3, 3, None, None, 0, None))
