@@ -36,6 +36,68 @@ def _is_physical_model(G):
     return G is not None and not isinstance(G, np.ndarray) and hasattr(G, "NMF_update")
 
 
+def _upload_with_scans(host, device, log_shift):
+    """Uploads a C-contiguous host array in row chunks and has the device scan every chunk while the next one is on the bus: the
+    passes the reference makes over X before its loop (finiteness - validate_data was told to skip it -, sign, line sums for the
+    empty-line test base.py:519-528, the mean for `normalize`, const_KL_ = sum(X log X - X) in fp64, base.py:200-201) cost 16 ms
+    as passes over the uploaded image; behind the 38 ms upload (a blocking copy from pageable memory per chunk, the device idle
+    otherwise) they cost nothing.  Returns the device array and the scans' results as device tensors (nothing is read back here):
+    row_sum / col_sum of the array as it lies in memory, `bad` = [non-finite entries, NaNs, negative entries], s1 = sum x and
+    s2 = sum x log(max(x, log_shift)), both fp64."""
+    import threading
+    import torch
+    rows, cols = host.shape
+    out = torch.empty(host.shape, dtype=torch.from_numpy(host[:0]).dtype, device=device)
+    step = max(1, (int(os.environ.get("ESPM_UPLOAD_CHUNK_MB", "256")) << 20) // max(1, cols * host.itemsize))
+    f64 = dict(dtype=torch.float64, device=device)
+    row_sum = torch.empty(rows, **f64)
+    col_sum = torch.zeros(cols, **f64)
+    bad = torch.zeros(3, dtype=torch.int64, device=device)
+    s1, s2 = torch.zeros((), **f64), torch.zeros((), **f64)
+    chunks = [(a, min(rows, a + step)) for a in range(0, rows, step)]
+    # the copies go back to back from a thread of their own (a blocking copy from pageable memory per chunk, the GIL released
+    # inside it); this thread queues the scans of a chunk as soon as it has arrived
+    main = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(main)                                        # (the allocator may hand out memory with work still queued on it)
+    arrived = [threading.Event() for _ in chunks]
+    done = [torch.cuda.Event() for _ in chunks]
+    err = []
+
+    def copier():
+        try:
+            with torch.cuda.stream(side):
+                for i, (a, b) in enumerate(chunks):
+                    out[a:b].copy_(torch.from_numpy(host[a:b]))
+                    done[i].record(side)
+                    arrived[i].set()
+        except BaseException as e:   # noqa: BLE001 - re-raised below
+            err.append(e)
+            for ev in arrived:
+                ev.set()
+    th = threading.Thread(target=copier, daemon=True)
+    th.start()
+    for i, (a, b) in enumerate(chunks):
+        arrived[i].wait()
+        if err:
+            break
+        main.wait_event(done[i])
+        x = out[a:b]
+        fin = torch.isfinite(x)
+        bad += torch.stack(((~fin).sum(), torch.isnan(x).sum(), (x < 0).sum()))
+        xd = x.to(torch.float64)
+        rs = xd.sum(dim=1)
+        row_sum[a:b] = rs
+        col_sum += xd.sum(dim=0)
+        s1 += rs.sum()
+        s2 += (xd * torch.log(xd.clamp_min(log_shift))).sum()
+        del x, fin, xd, rs
+    th.join()
+    if err:
+        raise err[0]
+    return out, dict(row_sum=row_sum, col_sum=col_sum, bad=bad, s1=s1, s2=s2)
+
+
 class _HostCopy:
     """``X_`` of a large fit in the making.  The reference keeps its own copy of the data (remove_zeros_lines copies,
     base.py:519-528; normalize scales it, base.py:264-267): at 2048 x 512^2 fp32 those host passes are 0.2-0.4 s of a fit whose
@@ -405,12 +467,13 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 lazy = _HostCopy(Xv, dev_layout)
                 try:
                     mark("host copy thread created")
-                    Xd_raw = torch.from_numpy(host).to(f"cuda:{torch.cuda.current_device()}")
+                    Xd_raw, scans = _upload_with_scans(host, torch.device("cuda", torch.cuda.current_device()), self.log_shift)
                     mark("upload returned")
                     Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
-                    if big and not bool(torch.isfinite(Xd).all()):   # the scan validate_data was told to skip, same message
-                        raise ValueError(f"Input X contains {'NaN' if bool(torch.isnan(Xd).any()) else 'infinity'}.")
-                    if bool((Xd < 0).any()):
+                    n_bad, n_nan, n_neg = (int(v) for v in scans["bad"].cpu())
+                    if big and n_bad:   # the scan validate_data was told to skip, same message
+                        raise ValueError(f"Input X contains {'NaN' if n_nan else 'infinity'}.")
+                    if n_neg:
                         raise ValueError("Negative values in data")
                 except BaseException:
                     lazy.cancel()
@@ -428,13 +491,18 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             empty_ch, empty_px = Xv.sum(axis=1) == 0, Xv.sum(axis=0) == 0
         else:
             try:
-                zp, zc = Xd.sum(dim=0) == 0, Xd.sum(dim=1) == 0
+                # (the line sums of the array as it lies in memory, from the upload's scans: channels are its rows in the "cm" layout)
+                zc, zp = ((scans["row_sum"] == 0, scans["col_sum"] == 0) if dev_layout == "cm"
+                          else (scans["col_sum"] == 0, scans["row_sum"] == 0))
                 empty_ch, empty_px = zc, zp
-                fill = bool(zp.any()) or bool(zc.any())
+                n_zero_lines, s1 = (float(v) for v in torch.stack(((zp.sum() + zc.sum()).to(torch.float64), scans["s1"])).cpu())
+                fill = n_zero_lines > 0
                 if fill:
                     Xd[:, zp] = self.log_shift
                     Xd[zc, :] = self.log_shift
-                mean_x = float(Xd.mean(dtype=torch.float64))
+                    mean_x = float(Xd.mean(dtype=torch.float64))
+                else:
+                    mean_x = s1 / Xd.numel()
             except BaseException:   # (the worker must not wait for a finish() that will not come)
                 lazy.cancel()
                 raise
@@ -461,8 +529,12 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         X_init_dev = None
         if Xd is not None:
             X_init_dev = Xd * xscale if self.normalize else Xd
-            # const_KL_ = sum(X log X - X) in fp64 (base.py:200-201), in row chunks of 64 M entries: in one piece its fp64 copy
-            # and the three temporaries of the expression were 17 GB next to a 2 GB image
+        if Xd is not None and not fill and not self.normalize:
+            # const_KL_ = sum(X log X - X) (base.py:200-201): both sums came with the upload
+            self._const_KL_dev = float(scans["s2"]) - s1
+        elif Xd is not None:
+            # (lines filled or the image rescaled: the sums belong to another array)  In fp64, in row chunks of 64 M entries: in one
+            # piece its fp64 copy and the three temporaries of the expression were 17 GB next to a 2 GB image
             rows_of = X_init_dev if X_init_dev.is_contiguous() else X_init_dev.t()   # (the orientation the memory lies in)
             step = max(1, (64 << 20) // max(1, int(rows_of.shape[1])))
             total = torch.zeros((), dtype=torch.float64, device=rows_of.device)
