@@ -64,7 +64,10 @@ class MUEngine:
                  tol=1e-4, sigmaL=8.0, fixed_H=None, fixed_W=None, simplex_rows=None, xscale=1.0,
                  x_store="auto", max_iter=200, device=None, group=None, compute_loss=True,
                  fix_zero_lines=True, gw_floor=1e-30, x_tile=None, tile_px=None, h_variant=None, bregman=False, h_rule=0, pg_gamma_w=0.0,
-                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True, force_sharded=False, autotune=False):
+                 filled_channels=None, filled_pixels=None, frobenius=False, fused=True, force_sharded=False, autotune=False, x_facts=None):
+        # x_facts: what the caller already knows about X exactly as handed over (espm_amd/estimators/base.py: the scans that ride
+        # behind the upload) - {"nonneg": True, "sum_x": float, "is_count": integers <= 255, "nnz": int}: the passes over X that
+        # would establish the same here (9 ms at the headline size) are skipped.  One GPU, no lines to fill.
         self.device = require_gpu(device)
         self.group = group
         self.world = torch.distributed.get_world_size(group) if group is not None else 1
@@ -104,7 +107,9 @@ class MUEngine:
             raise ValueError("layout must be 'cm' or 'pm'")
         self.n, self.p = int(n), int(p)
         self.out_dtype = np.float64 if Xd.dtype == torch.float64 else np.float32
-        if bool((Xd < 0).any()):
+        if x_facts is not None and (group is not None or fix_zero_lines):
+            x_facts = None
+        if not (x_facts and x_facts.get("nonneg")) and bool((Xd < 0).any()):
             raise ValueError("Negative values in data")  # espm/estimators/base.py:528
         # channels that hold nothing but the log_shift fill (all ranks see the same mask): the sparse store may leave them empty
         empty_ch = None
@@ -133,10 +138,13 @@ class MUEngine:
                 else:
                     Xd[zp, :] = log_shift
                     Xd[:, zc] = log_shift
-        self.sum_x = Xd.sum(dtype=torch.float64)
-        if group is not None:
-            torch.distributed.all_reduce(self.sum_x, group=group)
-        self.sum_x = float(self.sum_x)
+        if x_facts and "sum_x" in x_facts:
+            self.sum_x = float(x_facts["sum_x"])
+        else:
+            self.sum_x = Xd.sum(dtype=torch.float64)
+            if group is not None:
+                torch.distributed.all_reduce(self.sum_x, group=group)
+            self.sum_x = float(self.sum_x)
         _tick("sign check, empty lines, sum of X")
         self.bregman = bool(bregman)
         if self.bregman:
@@ -185,7 +193,8 @@ class MUEngine:
                                               or (empty_px is not None and bool(empty_px.any()))))
             if unfilled:
                 set_empty(0)
-            is_count = (Xd == Xd.round()).all() & (Xd.max() <= 255)
+            known = x_facts if (x_facts and not unfilled and "is_count" in x_facts and "nnz" in x_facts) else None
+            is_count = known["is_count"] if known else ((Xd == Xd.round()).all() & (Xd.max() <= 255))
             if bool(is_count):
                 code = 2
             else:   # (the bf16 round trip is two more passes over X and two temporaries of its size: only when it decides)
@@ -194,7 +203,7 @@ class MUEngine:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
                 fits = k <= _lib.WIDE_MAX_K and self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
-                sparse = float((Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
+                sparse = float(known["nnz"] if known else (Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
             flag = torch.tensor([code], device=dev, dtype=torch.int32)

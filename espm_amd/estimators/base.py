@@ -43,7 +43,7 @@ def _upload_with_scans(host, device, log_shift):
     as passes over the uploaded image; behind the 38 ms upload (a blocking copy from pageable memory per chunk, the device idle
     otherwise) they cost nothing.  Returns the device array and the scans' results as device tensors (nothing is read back here):
     row_sum / col_sum of the array as it lies in memory, `bad` = [non-finite entries, NaNs, negative entries], s1 = sum x and
-    s2 = sum x log(max(x, log_shift)), both fp64."""
+    s2 = sum x log(max(x, log_shift)), both fp64; `facts` = [entries that are not integers, non-zero entries, largest entry]."""
     import threading
     import torch
     rows, cols = host.shape
@@ -54,6 +54,7 @@ def _upload_with_scans(host, device, log_shift):
     col_sum = torch.zeros(cols, **f64)
     bad = torch.zeros(3, dtype=torch.int64, device=device)
     s1, s2 = torch.zeros((), **f64), torch.zeros((), **f64)
+    facts = torch.zeros(3, **f64)                                # entries that are not integers, non-zero entries, the largest entry
     chunks = [(a, min(rows, a + step)) for a in range(0, rows, step)]
     # the copies go back to back from a thread of their own (a blocking copy from pageable memory per chunk, the GIL released
     # inside it); this thread queues the scans of a chunk as soon as it has arrived
@@ -91,11 +92,14 @@ def _upload_with_scans(host, device, log_shift):
         col_sum += xd.sum(dim=0)
         s1 += rs.sum()
         s2 += (xd * torch.log(xd.clamp_min(log_shift))).sum()
+        # (what the engine's choice of a store asks of X - integer counts up to 255, how many non-zero: engine.py - while the data pass by)
+        facts[:2] += torch.stack(((x != x.round()).sum(), (x != 0).sum())).to(torch.float64)
+        facts[2] = torch.maximum(facts[2], x.max().to(torch.float64))
         del x, fin, xd, rs
     th.join()
     if err:
         raise err[0]
-    return out, dict(row_sum=row_sum, col_sum=col_sum, bad=bad, s1=s1, s2=s2)
+    return out, dict(row_sum=row_sum, col_sum=col_sum, bad=bad, s1=s1, s2=s2, facts=facts)
 
 
 class _HostCopy:
@@ -329,7 +333,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False, shard=None):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False, shard=None, x_facts=None):
         """The device engine of a fit; with ``shard`` (a _Shard) X_fixed is the WHOLE image and the engine takes this rank's
         block of it."""
         from espm_amd.engine import MUEngine
@@ -339,6 +343,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             shape_2d, group = shard.shape_2d, shard.group
             fixed_H = shard.cols(np.asarray(fixed_H)) if fixed_H is not None else None
             filled_pixels = shard.cols(filled_pixels)
+            x_facts = None      # (they describe the whole image)
 
         rows = None
         if self.physics_model_ is not None and self.simplex_W:
@@ -350,14 +355,14 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             # simplex there (updates.py:31-36); the engine's Frobenius mode takes the scaled X itself
             simplex_W = False
             if xscale != 1.0:
-                X_fixed, xscale = X_fixed * xscale, 1.0
+                X_fixed, xscale, x_facts = X_fixed * xscale, 1.0, None
         # (and the projected-gradient W step of a fit is called without fixed_W, smooth_nmf.py:430-437)
         fixed_W = None if getattr(self, "algo", None) == "projected_gradient" else self.fixed_W
         return MUEngine(X_fixed, self.n_components, G=G, shape_2d=shape_2d, simplex_H=self.simplex_H,
                         simplex_W=simplex_W, log_shift=self.log_shift, tol=self.tol, fixed_H=fixed_H,
                         fixed_W=fixed_W, simplex_rows=rows, xscale=xscale, max_iter=self.max_iter,
                         fix_zero_lines=False, filled_channels=filled_channels, filled_pixels=filled_pixels, layout=layout,
-                        autotune=autotune, group=group, **self._engine_kwargs())
+                        autotune=autotune, group=group, x_facts=x_facts, **self._engine_kwargs())
 
     def _engine_G(self):
         G = self.G_
@@ -453,6 +458,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         # (pixel-major is also the layout the engine ingests natively: no host transpose, no device transpose); Xd below
         # is the logical (n, p) view of the device copy either way.
         Xd = Xd_raw = None
+        x_facts = None   # (large X on the device: what the upload's scans found out about it, for the engine)
         dev_layout = "cm"
         lazy = None    # the estimator's own host copy X_ of a large X, made on a worker thread (_HostCopy)
         if Xv.size >= _DEVICE_PREP_MIN_SIZE:
@@ -495,8 +501,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 zc, zp = ((scans["row_sum"] == 0, scans["col_sum"] == 0) if dev_layout == "cm"
                           else (scans["col_sum"] == 0, scans["row_sum"] == 0))
                 empty_ch, empty_px = zc, zp
-                n_zero_lines, s1 = (float(v) for v in torch.stack(((zp.sum() + zc.sum()).to(torch.float64), scans["s1"])).cpu())
+                n_zero_lines, s1, n_nonint, nnz, x_max = (float(v) for v in torch.cat((torch.stack(((zp.sum() + zc.sum()).to(torch.float64), scans["s1"])),
+                                                                                             scans["facts"])).cpu())
                 fill = n_zero_lines > 0
+                if not fill:   # what the scans know about X as it goes to the engine (a filled X is another array: the engine looks itself)
+                    x_facts = dict(nonneg=True, sum_x=s1, is_count=bool(n_nonint == 0 and x_max <= 255), nnz=int(nnz))
                 if fill:
                     Xd[:, zp] = self.log_shift
                     Xd[zc, :] = self.log_shift
@@ -575,9 +584,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._L_pixels = int(self.X_.shape[1])
 
         out_dtype = self.X_.dtype
+        no_fill = Xd is not None and not fill      # (known from the upload's scans: no read-back to ask again)
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
-                                                filled_channels=empty_ch if bool(empty_ch.any()) else None,
-                                                filled_pixels=empty_px if bool(empty_px.any()) else None, layout=dev_layout,
+                                                filled_channels=None if no_fill or not bool(empty_ch.any()) else empty_ch,
+                                                filled_pixels=None if no_fill or not bool(empty_px.any()) else empty_px, layout=dev_layout,
+                                                x_facts=x_facts,
                                                 # (timing the launch plans costs ~30 ms of device time and gains a few per cent
                                                 #  per iteration: it pays for itself only in very long fits of large images)
                                                 autotune=Xd is not None and self.max_iter >= 5000,
