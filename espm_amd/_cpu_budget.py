@@ -71,6 +71,19 @@ def fit_threads():
     return max(1, min(8, cpu_budget() // 2))
 
 
+_CTL = None
+
+
+def _controllers():
+    """threadpoolctl's controllers of the BLAS / OpenMP libraries in the process, looked up once: a ThreadpoolController walks every
+    loaded shared object (several ms with torch in the process) - per fit that is time inside fit_transform."""
+    global _CTL
+    if _CTL is None:
+        from threadpoolctl import ThreadpoolController
+        _CTL = list(ThreadpoolController().lib_controllers)
+    return _CTL
+
+
 @contextlib.contextmanager
 def limited_thread_pools(n=None):
     """Pools LARGER than ``n`` (torch's intra-op pool; BLAS / OpenMP pools threadpoolctl finds) are cut to ``n`` and restored on
@@ -87,8 +100,7 @@ def limited_thread_pools(n=None):
         except Exception:   # noqa: BLE001 - no torch, nothing to cut
             pass
         try:
-            from threadpoolctl import ThreadpoolController
-            for lc in ThreadpoolController().lib_controllers:
+            for lc in _controllers():
                 cur = lc.num_threads
                 if cur is not None and cur > n:
                     lc.set_num_threads(n)

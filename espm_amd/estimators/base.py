@@ -433,8 +433,14 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         mark("validate_data")
         if self.hspy_comp is False:
             try:  # base.py:249-259
-                import inspect
-                calframe = inspect.getouterframes(inspect.currentframe(), 2)
+                # (the reference asks inspect.getouterframes(inspect.currentframe(), 2) for calframe[1][3] and calframe[1][1]: the
+                #  caller's function name and file.  The frame object has both; inspect also loads two lines of source context for
+                #  EVERY frame of the stack - linecache stat calls that took 76 ms in one fit of five - and its list of frames
+                #  holds this frame, which holds the list: a cycle that kept every local of the fit alive until the collector ran.)
+                import sys
+                caller = sys._getframe(1)
+                calframe = [None, (caller, caller.f_code.co_filename, caller.f_lineno, caller.f_code.co_name)]
+                caller = None
                 if calframe[1][3] == "decomposition" and "hyperspy" in calframe[1][1]:
                     print("Are you calling the function decomposition from Hyperspy?\n"
                           "If so, please set the compatibility argument 'hspy_comp' to True.\n\n"
@@ -442,10 +448,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             except Exception:
                 pass
             finally:
-                # the list holds THIS frame, this frame holds the list: left alone, the cycle keeps every local of the fit - the
-                # estimator, its 2 GB X_, the engine's device memory - alive until the cyclic collector runs, at some random moment
-                # of a later fit (tools/analysis/est_cycle_probe.py)
-                calframe = None
+                calframe = None      # (no frame reference outlives the check: tools/analysis/est_cycle_probe.py)
         mark("caller check (inspect)")
         if self.l2 and getattr(self, "algo", None) != "l2_surrogate":
             raise NotImplementedError("the Frobenius loss (l2=True) is built for SmoothNMF(algo='l2_surrogate'), the one "
