@@ -40,6 +40,8 @@
  *                            + smooth_nmf.py:382-401, :438-447 (its linesearch)
  *   espm_dichotomy_simplex_acc / _pg <- dicotomy.py:57-108 (module-level functions)
  *   espm_surrogate_terms  <- espm/estimators/surrogates.py:6-149 (module-level surrogates)
+ *   espm_lu_pl            <- espm/estimators/updates.py:179 -> scikit-learn's _initialize_nmf -> _randomized_range_finder: the LU
+ *                            normaliser of its power iterations (scipy.linalg.lu(A, permute_l=True)[0]) on tall device matrices
  *
  * Conventions
  *   - extern "C", plain pointers and sizes.  All array pointers are DEVICE pointers owned by the
