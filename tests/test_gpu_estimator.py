@@ -961,3 +961,57 @@ def test_fitted_estimator_is_freed_with_its_last_reference(SmoothNMF, shape):
     finally:
         if was:
             gc.enable()
+
+
+@pytest.mark.parametrize("layout", ["channels_first", "pixels_first"])
+@pytest.mark.parametrize("normalize,dtype,holes", [(False, np.float32, False), (False, np.float32, True), (True, np.float64, True), (True, np.float32, False)])
+def test_device_preparation_of_a_large_x_matches_the_oracle(SmoothNMF, layout, normalize, dtype, holes):
+    """An X large enough for the device preparation (one upload in chunks, the reference's pre-loop passes over X - finiteness,
+    sign, empty lines base.py:519-528, mean for `normalize` base.py:264-267, const_KL_ base.py:200-201 - riding behind the
+    chunks; the engine's store chosen from the same scans) against the oracle fed the same array on the host: with and without
+    empty channels / pixels (the filled branch takes its own passes), `normalize`, both precisions, and a (pixels, channels)
+    array handed over with hspy_comp (uploaded as it lies)."""
+    from espm_amd import synth
+    from espm_amd.estimators import base as est_base
+    n, nx, ny, k = 600, 90, 80, 3
+    assert n * nx * ny >= est_base._DEVICE_PREP_MIN_SIZE
+    prob = synth.make_problem(n, nx, ny, k, N=40.0, seed=5)
+    X = synth.sample_numpy(prob, seed=5).astype(dtype)
+    X[0, X.sum(axis=0) == 0] = 1.0                     # (no accidental holes: the parameter decides)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    if holes:
+        X[:5] = 0
+        X[300:303] = 0
+        X[:, 1000:1040] = 0
+        X[:, -7:] = 0
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=5, scale=0.07)
+    kw = dict(lambda_L=1.0, simplex_H=True, simplex_W=False, shape_2d=(nx, ny), max_iter=6, tol=0, normalize=normalize)
+    ref = oc.fit(X.astype(np.float64), k, W=W0.copy(), H=H0.copy(), exact_root=True, no_stop_criterion=True, **kw)
+    est = SmoothNMF(n_components=k, no_stop_criterion=True, verbose=0, hspy_comp=(layout == "pixels_first"), **kw)
+    if layout == "pixels_first":
+        out = quiet(est.fit_transform, np.ascontiguousarray(X.T), W=W0.copy(), H=H0.copy())
+        assert est._ingest_layout == "pm" and out.shape == (nx * ny, k)
+        np.testing.assert_allclose(out, ref["H"].T, rtol=2e-4, atol=5e-5)
+    else:
+        GW = quiet(est.fit_transform, X, W=W0.copy(), H=H0.copy())
+        np.testing.assert_allclose(GW, ref["GW"], rtol=2e-4, atol=2e-4 * np.abs(ref["GW"]).mean())
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-4, atol=5e-5)
+    scale = np.abs(ref["W"]).mean()
+    np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-4, atol=2e-4 * scale)
+    Xh = np.asarray(est.X_)
+    assert Xh.shape == X.shape and Xh.dtype == X.dtype
+    if not normalize:
+        filled = X.copy()
+        if holes:
+            filled[:, X.sum(axis=0) == 0] = est.log_shift
+            filled[X.sum(axis=1) == 0, :] = est.log_shift
+        np.testing.assert_array_equal(Xh, filled)        # the estimator's own copy, lines filled like remove_zeros_lines
+    # what must NOT pass the device preparation
+    bad = X.copy()
+    bad[3, 17] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        quiet(SmoothNMF(n_components=k, verbose=0, **kw).fit_transform, bad)
+    bad[3, 17] = -1.0
+    with pytest.raises(ValueError, match="Negative values in data"):
+        quiet(SmoothNMF(n_components=k, verbose=0, **kw).fit_transform, bad)
