@@ -57,7 +57,14 @@ static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
   constexpr int STEPS = ESPM_H_MFMA_STEPS, PASSES = TILE / (16 * STEPS);   // pixel steps of 16 per pass, passes per tile
   const size_t lds = (size_t)4 * K * 16 * STEPS * PASSES * sizeof(float);
   const size_t lds_min = (size_t)(4 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
-  const size_t bytes = lds > lds_min ? lds : lds_min;
+  size_t bytes = lds > lds_min ? lds : lds_min;
+#ifdef ESPM_H_MFMA_PAD_LDS   // diagnosis (mu_w_mfma_kernel.hpp, the 32-slot form): the SAME code with one workgroup per CU, by an LDS request nobody uses
+  bytes += ESPM_H_MFMA_PAD_LDS;
+  if (bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h_step_mfma_kernel<K, XT, STEPS, PASSES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  }
+#endif
   if (args.compute_loss)
     hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), dim3(nblk), dim3(256), bytes, stream, args);
   else

@@ -64,7 +64,12 @@ typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
 //    What separates the two kernels is how many waves share a SIMD: the W kernel needs 256 + 36 registers and runs ONE wave per SIMD;
 //    the H-step kernel (245 registers, two workgroups per CU) runs TWO - and built for one (ESPM_H_MFMA_MINBLK=1) it is bit-reproducible
 //    with the 32-slot form on all four sites too, only slower than everything else (792 us; profiles/r03ab_wide_repro_h3one.log;
-//    without its scheduling fence it still differs, r03ab_wide_repro_h3nofence.log).  So: with two waves interleaving 32-slot matrix
+//    without its scheduling fence it still differs, r03ab_wide_repro_h3nofence.log).  The clean form of that experiment: the SAME
+//    machine code, launched with 24 KB of LDS nobody uses so that one workgroup fits a CU instead of two (ESPM_H_MFMA_PAD_LDS,
+//    mu_h_step.hip) - bit-reproducible, twice; launched normally - 2.7-3.1 million entries differ, twice
+//    (profiles/r03an_wide_repro_h3{pad,two}.log).  Occupancy, not code.  (Keeping the small terms in a register set of their own,
+//    so that no matrix instruction takes the result of the one before it, made differences rarer - one run in six - and the
+//    iteration 20 % slower: r03ao_*.)  So: with two waves interleaving 32-slot matrix
 //    instructions on one SIMD, either a result is read (site 1: by the vector ALU eight wait states later, the compiler's count)
 //    or an operand is rewritten (site 2) before the matrix pipe - busy with the other wave's instruction - has got to it; the
 //    16-slot form does not show it.  A hardware interlock the new shape lacks or a wait-state table this compiler has too short:
