@@ -61,15 +61,19 @@ typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
 //    their last bits - max 3e-5 - between two runs from the same state), with every variant tried: operands held across 1, 2, 4, 8
 //    wait states after the issue (ESPM_MFMA_K32_NOPS), 20 wait states behind the second instruction (256 entries still differ:
 //    delay helps, so it is an ordering hazard, not arithmetic), profiles/r03d_wide_repro.log, r03e_wide_repro.log, r03z_wide_repro_m{1,2}.log.
-//    What separates the two kernels is how many waves share a SIMD: the W kernel needs 256 + 36 registers and runs ONE wave per SIMD;
-//    the H-step kernel (245 registers, two workgroups per CU) runs TWO - and built for one (ESPM_H_MFMA_MINBLK=1) it is bit-reproducible
+//    In the H-step kernel it is a matter of how many waves share a SIMD (245 registers, two workgroups per CU: TWO): built for one
+//    (ESPM_H_MFMA_MINBLK=1) it is bit-reproducible
 //    with the 32-slot form on all four sites too, only slower than everything else (792 us; profiles/r03ab_wide_repro_h3one.log;
 //    without its scheduling fence it still differs, r03ab_wide_repro_h3nofence.log).  The clean form of that experiment: the SAME
 //    machine code, launched with 24 KB of LDS nobody uses so that one workgroup fits a CU instead of two (ESPM_H_MFMA_PAD_LDS,
 //    mu_h_step.hip) - bit-reproducible, twice; launched normally - 2.7-3.1 million entries differ, twice
 //    (profiles/r03an_wide_repro_h3{pad,two}.log).  Occupancy, not code.  (Keeping the small terms in a register set of their own,
 //    so that no matrix instruction takes the result of the one before it, made differences rarer - one run in six - and the
-//    iteration 20 % slower: r03ao_*.)  So: with two waves interleaving 32-slot matrix
+//    iteration 20 % slower: r03ao_*.)  Two waves per SIMD are not SUFFICIENT, though: the W kernel on the 8-bit store takes 256
+//    registers (36 of them accumulation registers) - two waves per SIMD as well - and has not shown one differing bit in some thirty
+//    runs of three iterations (masks 4, 8, 12, the product; k = 9, 12, 16); forced down to one wave per SIMD (LDS reserved at the
+//    launch, or amdgpu_waves_per_eu(1, 1)) it loses 9 % (724 against 662 us, profiles/r03ap_*) and stays as it was.  What the
+//    H-step kernel has on top: LDS traffic, 183 spilled scalar registers (lane writes / reads), the logarithm.  So: with two waves interleaving 32-slot matrix
 //    instructions on one SIMD, either a result is read (site 1: by the vector ALU eight wait states later, the compiler's count)
 //    or an operand is rewritten (site 2) before the matrix pipe - busy with the other wave's instruction - has got to it; the
 //    16-slot form does not show it.  A hardware interlock the new shape lacks or a wait-state table this compiler has too short:
@@ -144,8 +148,9 @@ struct MfRow<float> {
   }
 };
 
-template <int K, typename XT, bool L2 = false>
-__global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
+// (The Frobenius variant - L2: no Y product - keeps the 16-slot form: it was not part of the reproducibility runs above.)
+template <int K, typename XT, bool L2>
+__device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
   static_assert(KP == 16 || KP == 8, "component stride 8 or 16: the 16-wide tile is zero-filled beyond it");
   constexpr int CT = 8;                          // channel tiles of 16 per wave
   const int lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) r[i] = x[i];
         } else {
-          mf_f4 y = mf_mma3<4>(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
+          mf_f4 y = mf_mma3<L2 ? 0 : 4>(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // The first reader of a matrix-core result must be an instruction the compiler knows: it owes the wait states
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
         }
         mf_s4 rh, rl;
         mf_split(r, rh, rl);
-        acc[t] = mf_mma3<8>(rh, rl, b3h[s], b3l[s], acc[t]);
+        acc[t] = mf_mma3<L2 ? 0 : 8>(rh, rl, b3h[s], b3l[s], acc[t]);
       }
     }
   }
@@ -239,6 +244,16 @@ __global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
         *reinterpret_cast<float4*>(a.a_slab + ((size_t)blockIdx.x * K + l16) * a.n_pad + c0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
     }
   }
+}
+
+template <int K, typename XT, bool L2 = false>
+__global__ __launch_bounds__(256) void w_accum_mfma_kernel(const WAccumArgs a) {
+  static_assert(!L2, "the Frobenius variant is w_accum_mfma_l2_kernel");
+  w_accum_mfma_body<K, XT, false>(a);
+}
+template <int K>
+__global__ __launch_bounds__(256) void w_accum_mfma_l2_kernel(const WAccumArgs a) {
+  w_accum_mfma_body<K, float, true>(a);
 }
 
 }  // namespace espm

@@ -1383,7 +1383,7 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
     } else if (x_dtype == ESPM_X_BF16) {
       hipLaunchKernelGGL((w_accum_mfma_kernel<K, bf16_t>), grid, dim3(256), 0, stream, args);
     } else if (args.l2) {
-      hipLaunchKernelGGL((w_accum_mfma_kernel<K, float, true>), grid, dim3(256), 0, stream, args);
+      hipLaunchKernelGGL((w_accum_mfma_l2_kernel<K>), grid, dim3(256), 0, stream, args);
     } else {
       hipLaunchKernelGGL((w_accum_mfma_kernel<K, float>), grid, dim3(256), 0, stream, args);
     }
