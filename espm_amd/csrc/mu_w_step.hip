@@ -396,6 +396,9 @@ __global__ __launch_bounds__(64) void w_simplex_update_kernel(const WSimplexArgs
 // rank (the global row sums are in the denominator of W'), so by the end of the launch the halo rows of the next H-step
 // have arrived too.  Every workgroup posts before it waits and the grid (k n_pad / 32 + 1 workgroups of 256 threads) is
 // resident at once: no deadlock; waits are bounded (a lost peer is counted in the mailbox's error word).
+#ifndef ESPM_XCHG_SMALL_WORLD
+#define ESPM_XCHG_SMALL_WORLD 8
+#endif
 struct WExchangeArgs {
   WUpdateArgs u;
   unsigned char* mbox[16];   // every rank's mailbox as mapped here
@@ -421,6 +424,7 @@ __device__ __forceinline__ void xchg_wait_flag(const unsigned int* flag, unsigne
   }
 }
 
+template <int MAXW>   // ranks the unrolled polls are laid out for (8: a node; 16: the mailbox's limit) - the kernel's code size follows it
 __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeArgs x) {
   const WUpdateArgs& a = x.u;
   __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
@@ -560,18 +564,18 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       for (int r = 0; r < x.world; ++r) __hip_atomic_store(gran(r, x.rank, g_idx), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // every rank's granule of the same index: polled together (one load per rank in flight), bounded
     unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
-    unsigned int got[16];
+    unsigned int got[MAXW];
     {
       const long long t0 = wall_clock64();
       bool all = !sends;
       for (;;) {
-        unsigned long long v[16];
+        unsigned long long v[MAXW];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < MAXW; ++r)
           v[r] = (sends && r < x.world) ? __hip_atomic_load(gran(x.rank, r, g_idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)x.seq << 32);
         all = true;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < MAXW; ++r) {
           all = all && (unsigned int)(v[r] >> 32) == x.seq;
           got[r] = (unsigned int)v[r];
         }
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     float tt = 0.f;
     double rs = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < MAXW; ++r)
       if (r < x.world) {
         tt += __uint_as_float(got[r]);
         const unsigned long long lo = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 32), hi = (unsigned int)__builtin_amdgcn_readlane((int)got[r], 33);
@@ -615,19 +619,19 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
       static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
       const bool polls = lane < 2 * ESPM_HS_STRIDE;
-      unsigned int hv[16];
+      unsigned int hv[MAXW];
       {
         const long long t0 = wall_clock64();
         bool all = !polls;
         for (;;) {
-          unsigned long long v[16];
+          unsigned long long v[MAXW];
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
+          for (int r = 0; r < MAXW; ++r)
             v[r] = (polls && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                           : ((unsigned long long)x.seq << 32);
           all = true;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int r = 0; r < MAXW; ++r) {
             all = all && (unsigned int)(v[r] >> 32) == x.seq;
             hv[r] = (unsigned int)v[r];
           }
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       }
       double g = 0.0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < MAXW; ++r)
         if (r < x.world) {   // lane 2 i holds the low half of statistic i, lane 2 i + 1 the high half
           const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
           const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
@@ -1617,7 +1621,10 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.halo_ny = ny;
   x.halo_ppad = p_pad;
   a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
-  hipLaunchKernelGGL(w_exchange_update_kernel, dim3(nwg + 1), dim3(256), 0, stream, x);
+  if (xc->world <= ESPM_XCHG_SMALL_WORLD)
+    hipLaunchKernelGGL(w_exchange_update_kernel<ESPM_XCHG_SMALL_WORLD>, dim3(nwg + 1), dim3(256), 0, stream, x);
+  else
+    hipLaunchKernelGGL(w_exchange_update_kernel<16>, dim3(nwg + 1), dim3(256), 0, stream, x);
   if (bparts) return check_hip(hipGetLastError(), "w_exchange_update launch");   // (the caller's w_simplex_update_kernel updates W and owns the tail)
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)
