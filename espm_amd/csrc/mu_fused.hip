@@ -4,6 +4,12 @@
 #ifndef ESPM_ELL_UNR_H
 #define ESPM_ELL_UNR_H 4
 #endif
+#ifndef ESPM_FUSED_SMALL_UNR_H   // list dwords per batch in the run-time-sized instance (shards, small images): A/B knob (code size against rows in flight)
+#define ESPM_FUSED_SMALL_UNR_H ESPM_ELL_UNR_H
+#endif
+#ifndef ESPM_FUSED_SMALL_UNR_W
+#define ESPM_FUSED_SMALL_UNR_W ESPM_ELL_UNR_W
+#endif
 #ifndef ESPM_ELL_UNR_W
 #define ESPM_ELL_UNR_W 4
 #endif
@@ -65,8 +71,8 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   if (pb == ESPM_ELL_PB)   // the full geometry: 16 waves, sizes known at compile time
     return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true>, ESPM_ELL_WTHREADS)
                                : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true>, ESPM_ELL_WTHREADS);
-  return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS)
-                             : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS);
+  return args.h.compute_loss ? go(mu_fused_ell_kernel<K, true, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS)
+                             : go(mu_fused_ell_kernel<K, false, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_FUSED_SMALL_THREADS, false>, ESPM_FUSED_SMALL_THREADS);
 }
 #endif
 
