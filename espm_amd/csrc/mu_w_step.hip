@@ -616,7 +616,11 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
     } else {
       w_update_entries(a, kk, c, e, owns, tt, rs, nwg, wg, wo_pre, fx_pre);
     }
+#ifdef ESPM_EXPERIMENT_XCHG_NO_STATS_WAIT   // TIMING ONLY: is the statistics' path (record reduction in the extra workgroup, granules, this wait) what the launch ends with?
+    if (false) {
+#else
     if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
+#endif
       static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
       const bool polls = lane < 2 * ESPM_HS_STRIDE;
       unsigned int hv[MAXW];
