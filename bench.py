@@ -27,6 +27,8 @@ Prints ONE JSON line on rank 0.  Beside the contract's fields:
                 SAME image scaled by 64/512 beside it (`crop`); BLAS thread pool from threadpoolctl in `threadpools`
   loss_parity_rel  final loss of the HIP path against the oracle's on that crop, same W0 / H0
   product_default  the same loop on an engine built the way SmoothNMF.fit builds it (no launch-plan timing at set-up)
+  whole_fit     five consecutive 200-iteration fits of the benchmark's image through SmoothNMF.fit_transform, host fp32 array in, host
+                arrays out: seconds each
   c5            BASELINE configuration 5 on ONE GPU (1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05): iteration time and
                 its fused kernel against its own algorithmic bytes
   per_rank      (N > 1) every rank's launch times from HIP events: the local half-steps, and the W step with the record
@@ -353,6 +355,29 @@ def main():
                                note="autotune off: the engine of SmoothNMF.fit for max_iter < 5000")
         del e3
 
+    # ---- a whole fit through the estimator: the benchmark's image as a HOST fp32 array in, host arrays out, 200 iterations
+    # (upload, the reference's passes over X, NNDSVD initialisation, store build, loop, read-back), five in a row ----
+    whole_fit = None
+    if world == 1 and not args.no_extras and eng.x_store == "ell" and args.x_store == "auto":
+        import contextlib
+        import io
+        from espm_amd.estimators import SmoothNMF
+        Xh = X.t().contiguous().cpu().numpy()            # (n, p) fp32, C order: what a caller of the reference hands over
+        secs = []
+        for rep in range(6):
+            est = SmoothNMF(n_components=K, lambda_L=args.lambda_l, simplex_H=True, simplex_W=False, shape_2d=(NX, NY), max_iter=200, tol=0,
+                            no_stop_criterion=True, verbose=0, random_state=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                est.fit_transform(Xh)
+            torch.cuda.synchronize()
+            if rep:                                       # (the first fit of a process loads kernels and libraries)
+                secs.append(time.perf_counter() - t0)
+        whole_fit = dict(seconds=secs, iterations=int(est.n_iter_), loss_last=float(est.losses_[-1]),
+                         note="SmoothNMF(...).fit_transform(host fp32 array (2048, 262144)): five consecutive fits after one warm-up fit")
+        del est, Xh
+
     # ---- BASELINE configuration 5 on one GPU: 1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05, lambda = 1, simplex_H ----
     c5 = None
     if world == 1 and not args.no_extras and args.x_store == "auto":
@@ -408,6 +433,8 @@ def main():
             out["product_default"] = product_default
         if c5:
             out["c5"] = c5
+        if whole_fit:
+            out["whole_fit"] = whole_fit
         if X_crop is not None:
             # a full-size faithful iteration where the host can hold it (checked, not assumed)
             full, skip = None, None
