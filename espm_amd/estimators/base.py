@@ -567,7 +567,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self.G_, self.W_, self.H_ = initialize_algorithms(X=self.X_, G=G, W=W, H=H, n_components=self.n_components,
                                                           init=self.init, random_state=self.random_state,
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,
-                                                          physics_model=self.physics_model_, X_device=X_init_dev)
+                                                          physics_model=self.physics_model_, X_device=X_init_dev,
+                                                          # (the mean of what the initialisation sees: known from the upload's scans)
+                                                          X_mean=(mean_x * xscale if (Xd is not None and mean_x is not None) else None))
         del X_init_dev
         mark("initialize_algorithms")
         # one fit over several GPUs (shard()): this rank's block of image rows; every rank starts from rank 0's W, H, G

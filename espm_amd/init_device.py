@@ -141,11 +141,11 @@ def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     return U[:, :n_components], s[:n_components], Vt[:n_components, :]
 
 
-def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None):
+def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None, X_mean=None):
     """sklearn.decomposition._nmf._initialize_nmf for the NNDSVD family with the passes over X on the GPU.
 
     X: (n_samples, n_features) numpy array, fp32 or fp64 (kept in its dtype, like scikit-learn); X_device: the same
-    matrix already on the GPU (then X is only consulted for its shape and dtype)."""
+    matrix already on the GPU (then X is only consulted for its shape and dtype); X_mean: its mean, if the caller has it."""
     from sklearn.utils import check_random_state
 
     if X_device is None and (X < 0).any():
@@ -163,7 +163,8 @@ def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-
         dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
     U, S, V = randomized_svd_device(Xd, n_components, random_state)
-    avg = float(Xd.mean(dtype=torch.float64)) if init != "nndsvd" else 0.0
+    # (X_mean: the caller knows the mean of X_device already - one pass over X less)
+    avg = (float(X_mean) if X_mean is not None else float(Xd.mean(dtype=torch.float64))) if init != "nndsvd" else 0.0
     del Xd
     U, S, V = U.astype(X.dtype, copy=False), S.astype(X.dtype, copy=False), V.astype(X.dtype, copy=False)
     # (the randomized SVD hands back transposed views: rows of V 15 floats apart in memory - every pass below over a row of 262144
