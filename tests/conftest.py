@@ -8,10 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# espm_amd/_cpu_budget.py loaded by path: importing the PACKAGE loads libespm_mu.so (and fails loudly without it), which the
+# oracle's tests do not need and the build fixtures of the others produce first
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("_espm_cpu_budget", os.path.join(ROOT, "espm_amd", "_cpu_budget.py"))
+_cpu_budget = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_cpu_budget)
 # (the ranks the multi-process tests start size their pools at import: keep them within the container's CPUs as well)
-from espm_amd._cpu_budget import cpu_budget  # noqa: E402
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-    os.environ.setdefault(_v, str(max(1, cpu_budget() // 2)))
+    os.environ.setdefault(_v, str(max(1, _cpu_budget.cpu_budget() // 2)))
 
 
 def pytest_configure(config):
@@ -22,8 +27,7 @@ def pytest_configure(config):
 def _pools_within_the_cpu_budget():
     """Thread pools of the test process no larger than the CPUs its container grants (espm_amd/_cpu_budget.py): sized by the visible
     cores they exhaust the quota and the whole session is throttled - the oracle's BLAS calls and every CPU-side torch op."""
-    from espm_amd._cpu_budget import cpu_budget, limited_thread_pools
-    with limited_thread_pools(cpu_budget()):
+    with _cpu_budget.limited_thread_pools(_cpu_budget.cpu_budget()):
         yield
 
 

@@ -4,7 +4,11 @@ import os
 import pytest
 import torch
 
-from espm_amd import _cpu_budget as cb
+# (by path: importing the package loads libespm_mu.so, which this module does not need)
+import importlib.util
+_spec = importlib.util.spec_from_file_location("_espm_cpu_budget_t", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "espm_amd", "_cpu_budget.py"))
+cb = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(cb)
 
 
 def test_budget_is_positive_and_within_the_visible_cores():
