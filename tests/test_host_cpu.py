@@ -281,3 +281,26 @@ def test_host_copy_of_a_large_fit_equals_the_reference_passes(layout, fill_lines
     cancelled = _HostCopy(X, layout)
     cancelled.cancel()
     assert cancelled.result() is None
+
+
+def test_bench_line_keeps_the_drivers_contract():
+    """bench.py (run by the driver on the GPU box): the flags it is called with and the keys of its one JSON line - checked in the
+    source, since running it needs the device (profiles/r03ax_bench_default.json is a line it printed)."""
+    import ast
+    import json
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ast.parse(src)
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src, flag
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert f'"{key}":' in src, key
+    assert 'out["cpu_baseline"]' in src or '"cpu_baseline"' in src
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03ax_bench_default.json")).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and abs(line["ms_per_step"] * line["value"] / 1e3 - 1.0) < 1e-6
