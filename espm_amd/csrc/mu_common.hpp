@@ -713,6 +713,66 @@ __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* 
   }
 }
 
+// ONE value of h_finalize_body by a whole workgroup of 256 threads, and the outputs that depend on that value alone.  Nothing in
+// h_finalize_body combines two reduced values (every entry of the history slot and of hstat is one of them, SUMY needs none), so
+// the record reduction splits into H_FINALIZE_JOBS independent jobs: job i < NV reduces v[i] of the body - the same order of
+// operations (a thread's blocks 256 apart in ascending order, the wave stage, the waves in order), hence the same bits -, job NV
+// forms SUMY, job NV + 1 the projected gradient's quadratic bound.  As ONE workgroup the body is a launch's tail: at the headline it
+// ends 2.6 us after the workgroups that reduce the slabs, on a 64-row shard 3.7 us (profiles/r03ay_*); as 23 workgroups of two
+// loads and one reduction each it ends before them.
+constexpr int H_FINALIZE_NV = ESPM_HP_NSCALAR + 2 * KP + 1;
+constexpr int H_FINALIZE_JOBS = H_FINALIZE_NV + 2;
+__device__ __forceinline__ void h_finalize_one(const HFinalizeArgs& a, int job, double* scratch) {
+  constexpr int NV = H_FINALIZE_NV, V_RELH = 4 + KP, V_MAX = 5 + KP, V_RELW = 5 + 2 * KP;
+  const size_t nb = a.nblk;
+  if (job == NV) {   // sum_k colsum(GW)_k rowsum(H)_k of the INPUT state (hstat_in): no records
+    if (threadIdx.x == 0) {
+      double sumy = 0.0;
+      for (int kk = 0; kk < a.k; ++kk) sumy += a.colsum_gw[kk] * a.hstat_in[ESPM_HS_ROWSUM + kk];
+      a.hist_slot[ESPM_HI_SUMY] = sumy;
+    }
+    return;
+  }
+  if (job == NV + 1) {
+    if (a.pg_q) {  // (uniform) the quadratic bound of the projected gradient's linesearch
+      double q1[1] = {0.0};
+      for (int b = threadIdx.x; b < a.nblk; b += 256) q1[0] += a.hpart[(size_t)ESPM_HP_PGQ * nb + b];
+      block_reduce<1, 1>(q1, scratch);
+      if (threadIdx.x == 0) *a.pg_q = q1[0];
+    }
+    return;
+  }
+  const bool is_sum = job < 4 + KP;
+  const int field = is_sum ? job : (job == V_RELH ? ESPM_HP_RELH : (job == V_RELW ? ESPM_HP_RELW : ESPM_HP_MAX + (job - V_MAX)));
+  double v[1] = {job == V_RELW ? -1.0 : 0.0};
+  for (int b = threadIdx.x; b < a.nblk; b += 256) {
+    const double t = a.hpart[(size_t)field * nb + b];
+    v[0] = is_sum ? v[0] + t : fmax(v[0], t);
+  }
+  if (is_sum)
+    block_reduce<1, 1>(v, scratch);
+  else
+    block_reduce<1, 0>(v, scratch);
+  if (threadIdx.x != 0) return;
+  if (job == ESPM_HP_KL) {
+    if (a.compute_loss) a.hist_slot[ESPM_HI_KLX] = (double)a.xscale * 0.6931471805599453 * v[0];
+  } else if (job == ESPM_HP_REG) {
+    a.hist_slot[ESPM_HI_REG] = v[0];
+  } else if (job == ESPM_HP_LAP) {
+    a.hist_slot[ESPM_HI_LAP] = v[0];
+  } else if (job == ESPM_HP_BAD) {
+    a.hist_slot[ESPM_HI_BAD] = v[0];
+  } else if (is_sum) {
+    if (a.hstat_out) a.hstat_out[ESPM_HS_ROWSUM + (job - ESPM_HP_ROWSUM)] = v[0];
+  } else if (job == V_RELH) {
+    if (a.have_prev) a.hist_slot[ESPM_HI_REL_H] = v[0];
+  } else if (job == V_RELW) {
+    if (v[0] >= 0.0) a.hist_slot[ESPM_HI_REL_W] = v[0];
+  } else {
+    if (a.hstat_out) a.hstat_out[ESPM_HS_MAX + (job - V_MAX)] = v[0];
+  }
+}
+
 
 // argument blocks from the public state (shared by the C ABI and the tuning harness)
 inline HStepArgs make_h_args(const espm_mu_state* st, int src, int write_h) {

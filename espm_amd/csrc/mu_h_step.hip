@@ -32,10 +32,10 @@
 namespace espm {
 
 #if ESPM_H_PART == 0
-// ---- reduction of the per-workgroup records (one workgroup) ---------------------------------
+// ---- reduction of the per-workgroup records (one workgroup per value: h_finalize_one) --------
 __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) {
   __shared__ double scratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
-  h_finalize_body(a, scratch);
+  h_finalize_one(a, (int)blockIdx.x, scratch);
 }
 #endif
 
@@ -168,7 +168,7 @@ int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, h
 }
 
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream) {
-  hipLaunchKernelGGL(h_finalize_kernel, dim3(1), dim3(256), 0, stream, args);
+  hipLaunchKernelGGL(h_finalize_kernel, dim3(H_FINALIZE_JOBS), dim3(256), 0, stream, args);
   return check_hip(hipGetLastError(), "h_finalize launch");
 }
 #endif

@@ -49,15 +49,16 @@ struct WReduceArgs {
 __global__ __launch_bounds__(256) void w_reduce_kernel(const WReduceArgs a) {
   __shared__ double fscratch[5 * (ESPM_HP_NSCALAR + 2 * KP + 1)];
   __shared__ float s_part[8][32];
-  if ((int)blockIdx.x >= a.nred_blocks) {  // the extra workgroup
-    if (a.halo_top) {
+  if ((int)blockIdx.x >= a.nred_blocks) {  // the extra workgroups: one value of the record reduction each (h_finalize_one); the boundary rows with the one that needs no records
+    const int job = (int)blockIdx.x - a.nred_blocks;
+    if (a.halo_top && job == H_FINALIZE_NV) {
       for (int e = threadIdx.x; e < a.halo_k * a.halo_ny; e += 256) {
         const int kk = e / a.halo_ny, j = e - kk * a.halo_ny;
         a.halo_top[e] = a.halo_h[(size_t)kk * a.halo_ppad + j];
         a.halo_bot[e] = a.halo_h[(size_t)kk * a.halo_ppad + (size_t)(a.halo_nx - 1) * a.halo_ny + j];
       }
     }
-    h_finalize_body(a.fin, fscratch);
+    h_finalize_one(a.fin, job, fscratch);
     return;
   }
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -202,8 +203,10 @@ __global__ __launch_bounds__(256) void w_reduce_update_kernel(const WUpdateArgs 
   __shared__ float s_part[8][32];
   __shared__ double s_rsw[4];
   const int nwg = a.k * a.nbk;
-  if ((int)blockIdx.x >= nwg) {  // the extra workgroup
-    h_finalize_body(a.fin, fscratch);
+  if ((int)blockIdx.x >= nwg) {  // the extra workgroups: one value of the H-step's record reduction each (h_finalize_one)
+#ifndef ESPM_EXPERIMENT_NO_FINALIZE   // (TIMING ONLY when defined: is the record reduction what this launch ends with?)
+    h_finalize_one(a.fin, (int)blockIdx.x - nwg, fscratch);
+#endif
     return;
   }
   const int kk = blockIdx.x / a.nbk, j = blockIdx.x - kk * a.nbk;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   // Progress without the whole grid being resident (grids of k n_pad / 32 + 1 workgroups exceed what the device
   // holds at once from k = 8, n = 8192 on): workgroups are dispatched in index order, every workgroup POSTS before it waits,
   // and what it waits for was posted by the workgroup of the SAME index on every rank (reduction workgroup wg: the pieces of
-  // the workgroups wg) or by workgroup 0 (the extra workgroup: only reduction workgroup 0, index 1, waits for it).  The
+  // the workgroups wg) or by the first H_FINALIZE_JOBS workgroups (the record reduction's: only reduction workgroup 0 waits for them).  The
   // lowest-indexed unfinished workgroup of every rank is therefore resident and can finish; whatever it frees lets the next
   // one in.  (Round 2 had the extra workgroup LAST and every reduction workgroup waiting for it: a grid beyond the residency
   // dead-locked for the 2 s bound of the waits.  An occupancy query as a second guard was tried and dropped: on this stack
@@ -449,12 +452,16 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
   auto gran = [&](int dst, int src_rank, int g) {
     return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
   };
-  if (blockIdx.x == 0) {  // the extra workgroup: statistics and boundary rows of this rank's new H block
+  constexpr int NJ = H_FINALIZE_JOBS;
+  if ((int)blockIdx.x < NJ) {  // the extra workgroups, FIRST in the grid: one value of the record reduction each (h_finalize_one);
+    // the one whose value needs no records (SUMY) also posts the boundary rows of this rank's new H block
+    const int job = (int)blockIdx.x;
+    const bool halo_job = job == H_FINALIZE_NV;
     // the boundary rows first - they are in memory since the launch before this one, and nobody needs them before the NEXT
     // launch: their stores are long acknowledged when the flag that covers them is raised at the end
     // (every store into a mailbox is a system-scope write-through store: whatever memory type a peer's mapping has here,
     //  the data is on its way to that rank's memory when the store is acknowledged, and `s_waitcnt vmcnt(0)` orders the flag)
-    if (x.with_halo) {
+    if (halo_job && x.with_halo) {
       for (int d = -1; d <= 1; ++d) {   // the neighbours read these rows as their halo; this rank keeps a copy (record layout)
         const int r = x.rank + d;
         if (r < 0 || r >= x.world) continue;
@@ -479,30 +486,38 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
         }
       }
     }
-    // the statistics: reduced into LDS, then one granule {half of a double, sequence number} per half and destination - value and
-    // "it is there" in one store, like the pieces: workgroup 1 of every rank has them one trip over the link after the reduction
+    // a statistic: reduced, then one granule {half of a double, sequence number} per half and destination - value and "it is
+    // there" in one store, like the pieces: reduction workgroup 0 of every rank has it one trip over the link after the reduction
     __shared__ double s_hstat[ESPM_HS_STRIDE];
     HFinalizeArgs fin = a.fin;
     double* rec_hstat = fin.hstat_out;   // this rank's record in its OWN mailbox (the plain copy: espm_xchg_records' readers)
     fin.hstat_out = s_hstat;
-    h_finalize_body(fin, fscratch);
-    // the boundary rows' stores were issued a record reduction ago: this wait returns at once, and their flag goes out BEFORE
-    // the statistics (workgroup 1 of every rank polls both: neither waits behind the other's trip over the link)
-    // (the mailboxes are uncached memory: a store is delivered once it is acknowledged - no cache to write back, so no
-    //  system-scope fence, which would flush this XCD's whole L2 - only ORDER: every thread's stores before any flag)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int i = threadIdx.x; i < x.world * 2 * ESPM_HS_STRIDE; i += 256) {
-      const int r = i / (2 * ESPM_HS_STRIDE), j = i - r * 2 * ESPM_HS_STRIDE;
-      const unsigned long long bits = __builtin_bit_cast(unsigned long long, s_hstat[j >> 1]);
-      const unsigned int half = (j & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
-      __hip_atomic_store(gran(r, x.rank, 34 * x.nfl + j), ((unsigned long long)x.seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    h_finalize_one(fin, job, fscratch);
+    if (halo_job) {
+      // the boundary rows' stores were issued long ago: this wait returns at once
+      // (the mailboxes are uncached memory: a store is delivered once it is acknowledged - no cache to write back, so no
+      //  system-scope fence, which would flush this XCD's whole L2 - only ORDER: every thread's stores before any flag)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
     }
-    if (threadIdx.x < ESPM_HS_STRIDE) rec_hstat[threadIdx.x] = s_hstat[threadIdx.x];
+    // which entry of the statistics this job's value is (row sums [0, KP), maxima [KP, 2 KP)); the others go to the history only
+    int js = -1;
+    if (job >= ESPM_HP_ROWSUM && job < ESPM_HP_ROWSUM + KP) js = ESPM_HS_ROWSUM + (job - ESPM_HP_ROWSUM);
+    if (job >= 5 + KP && job < 5 + 2 * KP) js = ESPM_HS_MAX + (job - (5 + KP));
+    if (js < 0) return;
+    __syncthreads();   // (thread 0 of h_finalize_one wrote s_hstat[js])
+    if ((int)threadIdx.x < 2 * x.world) {
+      const int r = threadIdx.x >> 1, half_i = threadIdx.x & 1;
+      const unsigned long long bits = __builtin_bit_cast(unsigned long long, s_hstat[js]);
+      const unsigned int half = half_i ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+      __hip_atomic_store(gran(r, x.rank, 34 * x.nfl + 2 * js + half_i), ((unsigned long long)x.seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) rec_hstat[js] = s_hstat[js];
     return;
   }
-  const int wg = (int)blockIdx.x - 1;   // reduction workgroup (component kk, 32 channels)
+  const int wg = (int)blockIdx.x - NJ;   // reduction workgroup (component kk, 32 channels)
   const int kk = wg / a.nbk, j = wg - kk * a.nbk;
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = 32 * j + col;
@@ -1440,7 +1455,7 @@ int launch_w_reduce(const float* slab, float* out, int nblk, int total, const HF
   a.halo_h = nullptr;
   a.halo_top = a.halo_bot = nullptr;
   a.halo_k = a.halo_nx = a.halo_ny = a.halo_ppad = 0;
-  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + (fused_finalize ? H_FINALIZE_JOBS : 0)), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce launch");
 }
 
@@ -1468,7 +1483,7 @@ int launch_w_reduce_pack(const float* slab, int nblk, int k, int n_pad, const HF
   a.bw_old = nullptr;
   a.bparts = nullptr;
   a.bn = a.bk = a.bn_pad = 0;
-  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + 1), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(w_reduce_kernel, dim3(a.nred_blocks + H_FINALIZE_JOBS), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "w_reduce_pack launch");
 }
 
@@ -1518,7 +1533,7 @@ int launch_w_reduce_update(const WFinishArgs& f, const void* src, size_t src_str
   a.xscale = f.xscale;
   a.fuse_finalize = fused_finalize != nullptr;
   if (fused_finalize) a.fin = *fused_finalize;
-  hipLaunchKernelGGL(w_reduce_update_kernel, dim3(a.k * a.nbk + (fused_finalize ? 1 : 0)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(w_reduce_update_kernel, dim3(a.k * a.nbk + (fused_finalize ? H_FINALIZE_JOBS : 0)), dim3(256), 0, stream, a);
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)   // (espm_mu_iterate: the tail rides in the next H-step's launch, or in launch_w_update_tail at the end)
     *defer_tail = t;
@@ -1626,9 +1641,9 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.halo_ppad = p_pad;
   a.fin.hstat_out = reinterpret_cast<double*>(xc->mailbox + x.slot_base + (size_t)xc->rank * xc->record_bytes + x.hstat_off);
   if (xc->world <= ESPM_XCHG_SMALL_WORLD)
-    hipLaunchKernelGGL(w_exchange_update_kernel<ESPM_XCHG_SMALL_WORLD>, dim3(nwg + 1), dim3(256), 0, stream, x);
+    hipLaunchKernelGGL(w_exchange_update_kernel<ESPM_XCHG_SMALL_WORLD>, dim3(nwg + H_FINALIZE_JOBS), dim3(256), 0, stream, x);
   else
-    hipLaunchKernelGGL(w_exchange_update_kernel<16>, dim3(nwg + 1), dim3(256), 0, stream, x);
+    hipLaunchKernelGGL(w_exchange_update_kernel<16>, dim3(nwg + H_FINALIZE_JOBS), dim3(256), 0, stream, x);
   if (bparts) return check_hip(hipGetLastError(), "w_exchange_update launch");   // (the caller's w_simplex_update_kernel updates W and owns the tail)
   const WTailArgs t = make_w_tail_args(f);
   if (defer_tail)
