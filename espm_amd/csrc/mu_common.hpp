@@ -271,12 +271,71 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* scratch) {
 // The same in two halves for a caller that has a barrier of its own between them: `block_reduce_f32_wave` (every wave, BEFORE the
 // barrier: its sums / maxima into scratch that nothing else uses meanwhile), `block_reduce_f32_finish` (after it: thread i < NV adds
 // the waves' values of item i in wave order - the same value as block_reduce_f32 - and emits it; no further barrier).
+// The wave stage of NV values at once.  One value at a time (wave_sum / wave_max) is 6 dependent cross-lane steps per value:
+// 16 values x 16 waves of the fused kernel's record were 3.5 us of every workgroup's critical path at the headline
+// (profiles/r03bc_*: timing without them).  Packed: gfx950's half- and row-exchanges (v_permlane32_swap / v_permlane16_swap) take a PAIR
+// of values per instruction - after the swap the lower half (the even rows) holds both halves' copies of the first value, the upper
+// half (the odd rows) both copies of the second, one add or max folds them - so two rounds leave a quarter of the values per lane,
+// each already combined over the four rows, and only those take the four in-row steps: 8 + 4 exchanges and 4 x 4 row steps for
+// 16 values instead of 16 x 6.  The total of slot 4 m + 2 (row & 1) + (row >> 1) ends up in register m of lane 15 of each row.
+// Sums and maxima are packed separately (P = 8 or 16 slots each, padded with the operation's identity).
+template <int P, bool SUM>
+__device__ __forceinline__ void wave_reduce_packed(float (&x)[P]) {   // on return x[m], m < P / 4, lane 15 of row r: total of slot 4 m + 2 (r & 1) + (r >> 1)
+  static_assert(P == 8 || P == 16, "8 or 16 slots");
+  auto fold = [](float a, float b) { return SUM ? a + b : fmaxf(a, b); };
+  float y[P / 2];
+#pragma unroll
+  for (int j = 0; j < P / 2; ++j) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[2 * j]), __float_as_uint(x[2 * j + 1]), false, false);
+    y[j] = fold(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+#pragma unroll
+  for (int m = 0; m < P / 4; ++m) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[2 * m]), __float_as_uint(y[2 * m + 1]), false, false);
+    float z = fold(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const float id = SUM ? 0.f : -INFINITY;
+    z = fold(z, dpp_move<0x111, 0xf>(z, id));   // row_shr:1
+    z = fold(z, dpp_move<0x112, 0xf>(z, id));   // row_shr:2
+    z = fold(z, dpp_move<0x114, 0xf>(z, id));   // row_shr:4
+    z = fold(z, dpp_move<0x118, 0xf>(z, id));   // row_shr:8
+    x[m] = z;
+  }
+}
+// (the same contract as block_reduce_f32_wave: the waves' values in scratch[wave * NV + i]; another order of the additions inside a wave)
+template <int NV, int NSUM>
+__device__ __forceinline__ void block_reduce_f32_wave_packed(const float (&v)[NV], double* scratch) {
+  constexpr int NMAX = NV - NSUM;
+  constexpr int PS = NSUM <= 8 ? 8 : 16, PM = NMAX <= 8 ? 8 : 16;
+  static_assert(NSUM <= 16 && NMAX <= 16, "at most 16 sums and 16 maxima");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[PS], m[PM];
+#pragma unroll
+  for (int i = 0; i < PS; ++i) s[i] = i < NSUM ? v[i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < PM; ++i) m[i] = i < NMAX ? v[NSUM + i] : -INFINITY;
+  wave_reduce_packed<PS, true>(s);
+  wave_reduce_packed<PM, false>(m);
+  if ((lane & 15) == 15) {
+    const int row = lane >> 4, c = 2 * (row & 1) + (row >> 1);
+#pragma unroll
+    for (int q = 0; q < PS / 4; ++q)
+      if (4 * q + c < NSUM) scratch[wave * NV + 4 * q + c] = (double)s[q];
+#pragma unroll
+    for (int q = 0; q < PM / 4; ++q)
+      if (4 * q + c < NMAX) scratch[wave * NV + NSUM + 4 * q + c] = (double)m[q];
+  }
+}
 template <int NV, int NSUM>
 __device__ __forceinline__ void block_reduce_f32_wave(const float (&v)[NV], double* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float r[NV];
+#ifdef ESPM_EXPERIMENT_NO_WAVE_REDUCE   // TIMING ONLY: what the cross-lane stage of the fused kernel's record reduction costs
+#pragma unroll
+  for (int i = 0; i < NV; ++i) r[i] = (i < NSUM) ? 64.f * v[i] : v[i];
+#else
 #pragma unroll
   for (int i = 0; i < NV; ++i) r[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
+#endif
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = (double)r[i];

@@ -1,6 +1,10 @@
 // The H-step kernel template (see mu_h_step.hip for the description); in a header so that the tuning
 // harness (tools/tune) can instantiate variants next to the product's dispatch table.
 #pragma once
+// the wave stage of the fused kernel's record reduction through gfx950's half / row exchanges (mu_common.hpp, wave_reduce_packed)
+#ifndef ESPM_FUSED_RED_PACKED
+#define ESPM_FUSED_RED_PACKED 1
+#endif
 #include "mu_common.hpp"
 
 namespace espm {
@@ -386,7 +390,10 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     // a wave reduces its own values as soon as its pixels are done (while slower waves are still at theirs) into scratch nobody
     // else touches; the one barrier that follows is also the one the W walk needs (H' table complete); 15 threads then add the
     // waves' values and store the record while everybody else is already walking
-    block_reduce_f32_wave<NRED, R_RELH>(red, red_scratch);
+    if constexpr (ESPM_FUSED_RED_PACKED && R_RELH <= 16 && NRED - R_RELH <= 16)
+      block_reduce_f32_wave_packed<NRED, R_RELH>(red, red_scratch);
+    else   // (more than 12 components: the wide build's fused instances)
+      block_reduce_f32_wave<NRED, R_RELH>(red, red_scratch);
     __syncthreads();
     block_reduce_f32_finish<NRED, R_RELH>(red_scratch, emit);
   } else {
