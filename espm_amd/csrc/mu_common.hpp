@@ -359,14 +359,11 @@ __device__ __forceinline__ void block_reduce_f32_finish(const double* scratch, E
 
 template <int NV, int NSUM, typename Emit>
 __device__ __forceinline__ void block_reduce_f32(const float (&v)[NV], double* scratch, Emit emit) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float r[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) r[i] = (i < NSUM) ? wave_sum(v[i]) : wave_max(v[i]);
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = (double)r[i];
-  }
+  const int nw = blockDim.x >> 6;
+  if constexpr (NSUM <= 16 && NV - NSUM <= 16)   // (the wave stage as in the fused kernel: the same order of the additions in both paths)
+    block_reduce_f32_wave_packed<NV, NSUM>(v, scratch);
+  else
+    block_reduce_f32_wave<NV, NSUM>(v, scratch);
   __syncthreads();
   if (threadIdx.x < NV) {
     const int i = threadIdx.x;
