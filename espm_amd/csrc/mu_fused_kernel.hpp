@@ -73,18 +73,29 @@ struct FusedArgs {
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
 };
 
+// (the cuts of four segments, cumulative per cent of a group's rows: A/B knobs - profiles/r03bf_*)
+#ifndef ESPM_FUSED_CUT4_A
+#define ESPM_FUSED_CUT4_A 45
+#endif
+#ifndef ESPM_FUSED_CUT4_B
+#define ESPM_FUSED_CUT4_B 75
+#endif
+#ifndef ESPM_FUSED_CUT4_C
+#define ESPM_FUSED_CUT4_C 92
+#endif
 // segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of pb floats each)
 template <int K>
 struct FusedGeom {
   static constexpr int S = K <= 5 ? 4 : (K == 6 ? 3 : 2);
   static constexpr int PROWS = K + 1;   // K numerators + the KL part
-  // first row of segment s of a group of `len` rows: the segments shrink (35 / 30 / 20 / 15 % of the rows), so that the
+  // first row of segment s of a group of `len` rows: the segments shrink (45 / 30 / 17 / 8 % of the rows; 35 / 30 / 20 / 15 until the end
+  // of round 3: with the last units half as long the waves of a walk end 1.5 us closer together, profiles/r03bf_*), so that the
   // units handed out last are the short ones and the waves end close together
   // A group of fewer than MIN_SPLIT rows (low doses) is ONE unit: starting a unit costs a chain of dependent loads.
   static constexpr int MIN_SPLIT = 48;
   static __device__ __forceinline__ int seg_begin(int len, int s) {
     if (len < MIN_SPLIT) return s == 0 ? 0 : len;
-    constexpr int cut4[5] = {0, 35, 65, 85, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, ESPM_FUSED_CUT2, 100};
+    constexpr int cut4[5] = {0, ESPM_FUSED_CUT4_A, ESPM_FUSED_CUT4_B, ESPM_FUSED_CUT4_C, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, ESPM_FUSED_CUT2, 100};
     const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
     return (int)((long)len * c / 100);
   }
