@@ -350,7 +350,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     ESPM_PHASE_STAMP(41);   // regularisers, stencil (the pixel's loads have arrived)
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) nv[kk] *= hin[kk];          // updates.py:142
+#ifdef ESPM_EXPERIMENT_NO_SIMPLEX_ROOT   // TIMING ONLY: what the per-pixel multiplier search costs on the critical path
+    if (false) {
+#else
     if (a.simplex_h) {
+#endif
       float delta, e[K];
       if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.f;
 #pragma unroll
