@@ -711,6 +711,8 @@ struct WFinishArgs {
 
 
 // ---- reduction of the H-step's per-workgroup records (one workgroup of 256 threads) ---------------
+// (The one-workgroup form: the definition of the order of operations.  What the launches run since the end of round 3 is
+//  h_finalize_one below - one workgroup per value, same order, same bits.)
 __device__ __forceinline__ void h_finalize_body(const HFinalizeArgs& a, double* scratch) {
   // 256 threads; records are field-major (hpart[field][block]) so every load is coalesced, and U blocks
   // per thread are in flight at once.  Few waves on purpose: the cross-lane part costs per wave.
