@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0.  Beside the contract's fields:
                 host has the memory for its dense fp64 temporaries (~30 GB), and 8 iterations on a 64-row crop of the
                 SAME image scaled by 64/512 beside it (`crop`); BLAS thread pool from threadpoolctl in `threadpools`
   loss_parity_rel  final loss of the HIP path against the oracle's on that crop, same W0 / H0
-  product_default  the same loop on an engine built the way SmoothNMF.fit builds it (no launch-plan timing at set-up)
+  short_fit     the same loop on the engine of a 200-iteration fit (`value` is measured on the engine of a 10000-iteration fit;
+                both are built with autotune="auto", MUEngine's own policy, exactly as SmoothNMF.fit builds them)
   whole_fit     five consecutive 200-iteration fits of the benchmark's image through SmoothNMF.fit_transform, host fp32 array in, host
                 arrays out: seconds each
   c5            BASELINE configuration 5 on ONE GPU (1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05): iteration time and
@@ -52,6 +53,7 @@ HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
 BF16_PEAK = 2.5e15      # dense bf16 MFMA FLOP/s (spec)
 VALU_F32_PEAK = 157.3e12
 CROP_ROWS, CROP_ITERS = 64, 8
+FIT_LENGTH = 10000      # the fit whose engine `value` is measured on: SmoothNMF(max_iter=FIT_LENGTH)
 
 
 def cpu_baseline_and_parity(X_crop_pm, device, skip_full=None):
@@ -126,6 +128,25 @@ def cpu_full_size_iteration(X_dev):
     return dict(value=1.0 / r["seconds"], unit="it/s", seconds_per_iteration=r["seconds"], iterations=1, loss=float(r["losses"][-1]))
 
 
+def self_launch(n):
+    """Starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <the same arguments>` as a child and returns
+    its exit code (rank 0's JSON line goes to the inherited stdout).  The parent never initialises a GPU (counting the devices
+    does not, on this stack).  Fewer GPUs than ranks (a rehearsal on a one-GPU box): the ranks share the devices that exist
+    and the process group is gloo - RCCL wants a device per rank - unless ESPM_BENCH_BACKEND says otherwise."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL and the exchange's hipIpc mailboxes need it on this host driver
+    if torch.cuda.device_count() < n:
+        env.setdefault("ESPM_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,12 +165,16 @@ def main():
     # exhaust a 16-CPU quota, and a throttled host cannot feed the device)
     from espm_amd._cpu_budget import cpu_budget
     torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: this process - which has not touched a GPU - starts the N ranks the way the
+        # driver does (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and relays their output and exit code
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"bench.py --gpus {args.gpus}, or plain `python bench.py --gpus {args.gpus}` (starts the ranks itself)")
     # (rehearsal of the N > 1 path on a box with fewer GPUs than ranks: ESPM_BENCH_BACKEND=gloo puts the ranks on the
     #  GPUs that exist and exchanges the records through gloo; the driver's runs use RCCL, one rank per GPU)
     backend = os.environ.get("ESPM_BENCH_BACKEND", "nccl")
@@ -157,11 +182,30 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     group = None
+    backend_fell_back = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            # RCCL must come up AND carry a collective; if it does not (on every rank alike: a missing peer mapping, an IPC
+            # mode the driver refuses), the line still comes out - process group on gloo, records through the one-shot
+            # exchange if its self-test passes, else through gloo - with `backend_fell_back_from` saying so
+            import datetime
+            try:
+                dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all_reduce returned {probe.item()} on {world} ranks")
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench rank {rank}] RCCL did not come up ({type(e).__name__}: {e}); process group on gloo", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                backend, backend_fell_back = "gloo", "nccl"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
@@ -186,9 +230,13 @@ def main():
     W0d, H0d = torch.from_numpy(W0).to(device, torch.float32), torch.from_numpy(H0).to(device, torch.float32)
     X = synth.sample_torch(prob, device, seed=1000, row0=row0)            # (p_local, n) f32 counts
     X_crop = X[:CROP_ROWS * NY].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
+    # The engine is built the way SmoothNMF(max_iter=FIT_LENGTH).fit builds it - autotune="auto": MUEngine's own policy, which times
+    # the launch plans at set-up for fits of engine.AUTOTUNE_MIN_ITERS iterations or more (`value` is the
+    # product's figure for a fit of that length, not a bench-only configuration; `short_fit` below is the engine of a
+    # 200-iteration fit, which does not time its plans)
     eng = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                   tol=0.0, max_iter=total_iters + 600, group=group, device=device, x_store=args.x_store, fused=not args.no_fused,
-                   autotune=not (args.no_fused or args.no_autotune))
+                   tol=0.0, max_iter=max(FIT_LENGTH, total_iters + 600), group=group, device=device, x_store=args.x_store, fused=not args.no_fused,
+                   autotune=False if (args.no_fused or args.no_autotune) else "auto")
     # (W0 / H0 go up before the engine is built and load_state takes device tensors: nothing crosses the host here)
     eng.load_state(W0d, H0d)
 
@@ -340,11 +388,12 @@ def main():
             del e2
         dense["note"] = "dense 8-bit / bf16 stores, 100 iterations after 20 warm-up, same image and state"
 
-    # ---- the engine as SmoothNMF.fit builds it (espm_amd/estimators/base.py: no launch-plan timing below 5000 iterations) ----
+    # ---- the engine SmoothNMF.fit builds for a SHORT fit (max_iter = 200 < engine.AUTOTUNE_MIN_ITERS: no launch-plan timing, so the
+    # timed steps sit in the clock ramp that follows the ingest) ----
     product_default = None
     if world == 1 and not args.no_extras and eng.x_store == "ell" and not (args.no_fused or args.no_autotune):
         e3 = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False,
-                      tol=0.0, max_iter=total_iters + 10, device=device, x_store=args.x_store)
+                      tol=0.0, max_iter=max(200, total_iters + 10), device=device, x_store=args.x_store, autotune="auto")
         e3.load_state(W0d, H0d)
         e3.iterate(args.warmup, final_loss=False)
         torch.cuda.synchronize()
@@ -352,7 +401,7 @@ def main():
         e3.iterate(args.steps, final_loss=False)
         torch.cuda.synchronize()
         product_default = dict(value=args.steps / (time.perf_counter() - t0), unit="it/s", steps=args.steps, warmup=args.warmup,
-                               note="autotune off: the engine of SmoothNMF.fit for max_iter < 5000")
+                               note="the engine of SmoothNMF(max_iter=200).fit: autotune='auto' leaves the launch plans untimed below 5000 iterations")
         del e3
 
     # ---- a whole fit through the estimator: the benchmark's image as a HOST fp32 array in, host arrays out, 200 iterations
@@ -417,8 +466,11 @@ def main():
                                    "X stored %s, W/H fp32" % (args.lambda_l, eng.x_store),
                        "n": N_CH, "shape_2d": [NX, NY], "k": K, "lambda_L": args.lambda_l, "simplex_H": True,
                        "parallelism": f"pixel-row shard x{world}" if world > 1 else "single GPU",
+                       "process_group": (dict(backend=backend, fell_back_from=backend_fell_back, ranks_per_device=max(1, world // max(torch.cuda.device_count(), 1)))
+                                         if world > 1 else None),
                        "record_exchange": (dict(eng.exchange.selftest_result or {}, transport=transport) if world > 1 else None),
-                       "autotune": bool(eng.plan_timings is not None), "per_rank": per_rank,
+                       "autotune": bool(eng.plan_timings is not None), "engine_policy": f"autotune='auto', as SmoothNMF(max_iter={FIT_LENGTH}).fit builds it",
+                       "per_rank": per_rank,
                        "loss_every_iteration": True, "launches_per_iteration": 2 if fused else 3,
                        "launch_plan": getattr(eng, "plan", None), "launch_plan_timings_us": eng.plan_timings,
                        "nnz_frac": nnz_frac, "counts_per_pixel": COUNTS},
@@ -430,7 +482,7 @@ def main():
         if dense:
             out["dense_store"] = dense
         if product_default:
-            out["product_default"] = product_default
+            out["short_fit"] = product_default
         if c5:
             out["c5"] = c5
         if whole_fit:

@@ -35,6 +35,16 @@ static __device__ unsigned long long* espm_phase_buf = nullptr;
   do {                                                                                                                       \
     if (threadIdx.x == 0 && espm_phase_buf) espm_phase_buf[(size_t)blockIdx.x * ESPM_PHASE_SLOTS + (id)] = wall_clock64();   \
   } while (0)
+// slot 43: where the workgroup ran - HW_ID (wave / SIMD / CU / SH / SE fields) in the low word, XCC_ID in the high one
+#define ESPM_PHASE_WHERE()                                                                                                   \
+  do {                                                                                                                       \
+    if (threadIdx.x == 0 && espm_phase_buf) {                                                                                \
+      unsigned hw, xcc;                                                                                                      \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                                       \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                                     \
+      espm_phase_buf[(size_t)blockIdx.x * ESPM_PHASE_SLOTS + 43] = ((unsigned long long)xcc << 32) | hw;                     \
+    }                                                                                                                        \
+  } while (0)
 #define ESPM_WAVE_STAMP(base)                                                                                                              \
   do {                                                                                                                                     \
     if ((threadIdx.x & 63) == 0 && espm_phase_buf)                                                                                         \
@@ -46,6 +56,9 @@ static __device__ unsigned long long* espm_phase_buf = nullptr;
   } while (0)
 #define ESPM_WAVE_STAMP(base) \
   do {                        \
+  } while (0)
+#define ESPM_PHASE_WHERE() \
+  do {                     \
   } while (0)
 #endif
 

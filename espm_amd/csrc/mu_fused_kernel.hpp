@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   float* tab = smem;   // [n_pad] rows of GW, later [PB] rows of H'
   ell_table_at_lds_zero(tab);
   ESPM_PHASE_STAMP(0);
+  ESPM_PHASE_WHERE();
   const int tab_rows = a.n_pad > PB ? a.n_pad : PB;
   float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
   int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk

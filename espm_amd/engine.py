@@ -29,6 +29,8 @@ from . import _lib
 from ._lib import MUState
 
 # the sparse count store is chosen (x_store='auto') when at most this fraction of X is non-zero
+# launch plans are timed at set-up (MUEngine.autotune_plan) for fits at least this long when autotune="auto"
+AUTOTUNE_MIN_ITERS = 5000
 ELL_MAX_DENSITY = 0.5   # measured crossover with the dense 8-bit store at k = 5: 42 % non-zero 312 vs 394 us, 58 % 410 vs 399 us
 
 
@@ -393,7 +395,9 @@ class MUEngine:
         self._accum_done = False
         # autotune: at the first load_state the launch plans that apply to this problem are timed on the ingested image and
         # the fastest is kept (see autotune_plan)
-        self._autotune = bool(autotune)
+        # "auto": the policy of the product (SmoothNMF.fit hands it down, bench.py too): timing the plans costs ~35 ms of device
+        # time and a plan is worth a few per cent of an iteration - only fits of AUTOTUNE_MIN_ITERS iterations or more pay it back
+        self._autotune = (int(max_iter) >= AUTOTUNE_MIN_ITERS) if autotune == "auto" else bool(autotune)
         self.plan_timings = None
 
         # ---- sharding -----------------------------------------------------------------------------------

@@ -596,7 +596,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                 x_facts=x_facts,
                                                 # (timing the launch plans costs ~30 ms of device time and gains a few per cent
                                                 #  per iteration: it pays for itself only in very long fits of large images)
-                                                autotune=Xd is not None and self.max_iter >= 5000,
+                                                autotune="auto" if Xd is not None else False,   # (MUEngine: from AUTOTUNE_MIN_ITERS iterations on)
                                                 shard=shard)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         mark("engine built")

@@ -1,0 +1,43 @@
+"""`python bench.py --gpus N` as a plain command: with no WORLD_SIZE in the environment the parent starts the N
+ranks itself (torch.distributed.run on 127.0.0.1) and relays rank 0's JSON line and the exit code.  Rehearsed with two ranks on the
+one GPU of the box: fewer devices than ranks puts the process group on gloo; the one-shot record exchange between two
+processes that share a device stalls at this shard size, which the bench must notice after its warm-up
+and answer with the collective transport - the line comes out either way."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ESPM_BENCH_BACKEND")}
+    env["ESPM_XCHG_SELFTEST"] = "64"
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-extras", "--no-cpu"],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["value"] > 0 and out["nonfinite"] == 0
+    cfg = out["config"]
+    assert cfg["parallelism"] == "pixel-row shard x2"
+    assert cfg["process_group"]["backend"] == "gloo" and cfg["process_group"]["ranks_per_device"] == 2
+    assert len(cfg["per_rank"]) == 2 and all(r["rows"] == 256 and r["lost_peers"] == 0 for r in cfg["per_rank"])
+    xr = cfg["record_exchange"]
+    assert xr["transport"] in ("p2p", "collective")
+    if xr["transport"] == "collective":
+        assert xr.get("fell_back_from") == "p2p"
+    assert out["loss_last"] < out["loss_first"]
+    assert out["roofline"]["frac"] > 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert pr.returncode != 0 and "WORLD_SIZE=1" in (pr.stderr + pr.stdout)

@@ -3,7 +3,8 @@
 espm_mu_shard_combine_finish) - and the shard configuration 5 names - 128 image rows of 1024 pixels per rank, 1980
 channels, k = 8, a fixed dictionary G 1980 x 17, mu = 0.05 (the one-workgroup W finish behind the combine).
 
-Two ranks share the one GPU of the box on the collective transport (gloo carries the records; RCCL needs a GPU per rank, and
+Two ranks (and, round 4, four - 128-row shards - as processes and eight - 64-row shards - as threads, tests/thread_ranks.py)
+share the one GPU of the box on the collective transport (gloo carries the records; RCCL needs a GPU per rank, and
 the one-shot exchange dead-locks between processes that share a device once their workgroups fill it: DESIGN.md section 5).
 Checked: W bit-identical across the ranks, W / H against the unsharded engine, the loss history against the fp64 sparse
 oracle on the whole image (C4), fp64 evaluations of the update formulas on pixel rows that straddle the shard boundary and on
@@ -78,40 +79,106 @@ def _run_sharded(c, world=2):
         return {r: dict(out[r]) for r in range(world)}
 
 
-def test_config4_256_row_shards_of_the_headline_image():
+@pytest.fixture(scope="module")
+def c4_reference():
+    """What every shard geometry of configuration 4 is compared with, computed once: the unsharded engine on the whole image and
+    the fp64 oracle on its non-zero entries (pinned to the reference's F6 by tests/test_oracle_golden.py)."""
     import ctypes
     from espm_amd.engine import MUEngine
     from oracle import mu_oracle_sparse as osp
     from test_gpu_fullsize_parity import sparse_from_device
     c = C4
-    res = _run_sharded(c)
-    # (a 256-row shard fills the chip with 512-pixel blocks - two H tiles of 256: the fused launch at its run-time geometry)
-    assert all(res[r]["transport"] == "collective" and res[r]["store"] == "ell" and res[r]["fused"] and res[r]["tile_px"] == 256 and res[r]["bad"] == 0
-               for r in res), {r: (res[r]["transport"], res[r]["store"], res[r]["fused"], res[r]["tile_px"]) for r in res}
-    np.testing.assert_array_equal(res[1]["W"], res[0]["W"])           # W is replicated: the same bits on every rank
-    np.testing.assert_array_equal(res[1]["loss"], res[0]["loss"])
-    H = np.concatenate([res[r]["H"] for r in sorted(res)], axis=1)
-    # the unsharded engine on the whole image
     prob, X, W0, H0 = _problem(c)
     eng = MUEngine(X, c["k"], layout="pm", shape_2d=(c["nx"], c["ny"]), max_iter=c["iters"] + 2, device="cuda:0", **c["kw"])
     assert bool(eng.lib.espm_mu_fused_applies(ctypes.byref(eng.st)))
     eng.load_state(W0, H0)
     eng.iterate(c["iters"], final_loss=True)
     torch.cuda.synchronize()
-    ref = eng.history()
-    np.testing.assert_allclose(res[0]["W"], eng.get_W(), rtol=2e-5, atol=1e-8)
-    np.testing.assert_allclose(H, eng.get_H(), rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(res[0]["loss"], ref["loss"], rtol=1e-6)
-    np.testing.assert_allclose(res[0]["rel_W"][1:], ref["rel_W"][1:], rtol=1e-3, atol=1e-7)
-    np.testing.assert_allclose(res[0]["rel_H"][1:], ref["rel_H"][1:], rtol=1e-3, atol=1e-7)
+    one = dict(hist=eng.history(), W=eng.get_W(), H=eng.get_H())
     del eng
-    # the fp64 oracle on the non-zero entries of the whole image (pinned to the reference's F6 by tests/test_oracle_golden.py)
     ora = osp.fit(sparse_from_device(X), c["k"], W=W0, H=H0, shape_2d=(c["nx"], c["ny"]), max_iter=c["iters"], **c["kw"])
+    del X
+    torch.cuda.empty_cache()
+    return dict(one=one, ora=ora)
+
+
+def _check_config4(res, ref, tile_px):
+    """`res`: rank -> result of a sharded run of configuration 4; every rank on the sparse store and the fused launch at H tiles of
+    `tile_px` pixels (the block geometry of that shard size), collective transport."""
+    world = len(res)
+    assert all(res[r]["transport"] == "collective" and res[r]["store"] == "ell" and res[r]["fused"] and res[r]["tile_px"] == tile_px
+               and res[r]["bad"] == 0 for r in res), {r: (res[r]["transport"], res[r]["store"], res[r]["fused"], res[r]["tile_px"]) for r in res}
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[r]["W"], res[0]["W"])           # W is replicated: the same bits on every rank
+        np.testing.assert_array_equal(res[r]["loss"], res[0]["loss"])
+    H = np.concatenate([res[r]["H"] for r in sorted(res)], axis=1)
+    one, ora = ref["one"], ref["ora"]
+    np.testing.assert_allclose(res[0]["W"], one["W"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(H, one["H"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res[0]["loss"], one["hist"]["loss"], rtol=1e-6)
+    np.testing.assert_allclose(res[0]["rel_W"][1:], one["hist"]["rel_W"][1:], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(res[0]["rel_H"][1:], one["hist"]["rel_H"][1:], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(res[0]["loss"][1:], ora["losses"], rtol=1e-5)
     np.testing.assert_allclose(res[0]["loss"][0], ora["eval_init"], rtol=1e-5)
     np.testing.assert_allclose(H, ora["H"], atol=5e-5, rtol=0)
     np.testing.assert_allclose(res[0]["W"], ora["W"], rtol=2e-4, atol=2e-4 * np.abs(ora["W"]).max())
     np.testing.assert_allclose(H.sum(axis=0), 1.0, atol=5e-6)
+
+
+def test_config4_256_row_shards_of_the_headline_image(c4_reference):
+    # (a 256-row shard fills the chip with 512-pixel blocks - two H tiles of 256: the fused launch at its run-time geometry)
+    _check_config4(_run_sharded(C4, world=2), c4_reference, tile_px=256)
+
+
+def test_config4_128_row_shards_four_ranks(c4_reference):
+    """BASELINE configuration 4 at FOUR GPUs: four processes with 128-row shards of the 2048 x 512^2 image share
+    the one GPU - the fused launch on 256-pixel blocks (H tiles of 128), four records summed in rank order."""
+    _check_config4(_run_sharded(C4, world=4), c4_reference, tile_px=128)
+
+
+def _thread_rank(c):
+    def body(group, rank):
+        import ctypes
+        from espm_amd import sharding
+        from espm_amd.engine import MUEngine
+        world = group.shared.world
+        row0, rows = sharding.split_rows(c["nx"], world, rank)
+        prob, X, W0, H0 = _problem(c, row0, rows)
+        sl = slice(row0 * c["ny"], (row0 + rows) * c["ny"])
+        eng = MUEngine(X, c["k"], layout="pm", G=prob["G"], shape_2d=(rows, c["ny"]), max_iter=c["iters"] + 2, group=group,
+                       device="cuda:0", **c["kw"])
+        del X
+        fused = bool(eng.lib.espm_mu_fused_applies(ctypes.byref(eng.st)))
+        eng.load_state(W0, H0[:, sl])
+        eng.iterate(c["iters"], final_loss=True)
+        torch.cuda.synchronize()
+        h = eng.history()
+        return dict(W=eng.get_W(), H=eng.get_H(), loss=h["loss"], rel_W=h["rel_W"], rel_H=h["rel_H"], bad=float(h["bad"].sum()),
+                    transport=eng.exchange.transport, store=eng.x_store, fused=fused, tile_px=int(eng.st.tile_px))
+    return body
+
+
+def test_config4_64_row_shards_eight_ranks(c4_reference, monkeypatch):
+    """BASELINE configuration 4 at EIGHT GPUs: 64-row shards - the run-time-sized fused instance on 128-pixel blocks (H tiles of 64)
+    at the full width of 2048 channels, eight records per sum.  The box admits six processes on its card, so the eight ranks
+    are THREADS of this process (tests/thread_ranks.py): each with its own engine, the collective calls of the engine and of
+    espm_amd.sharding served by a rendezvous in rank order; the kernels and the C-ABI sequence are the ones eight processes run."""
+    from thread_ranks import run_ranks
+    monkeypatch.setenv("ESPM_XCHG", "collective")
+    res = dict(enumerate(run_ranks(8, _thread_rank(C4))))
+    _check_config4(res, c4_reference, tile_px=64)
+
+
+def test_thread_ranks_agree_with_process_ranks(c4_reference, monkeypatch):
+    """The thread harness against real processes on the same geometry (two 256-row shards): identical bits."""
+    from thread_ranks import run_ranks
+    monkeypatch.setenv("ESPM_XCHG", "collective")
+    thr = run_ranks(2, _thread_rank(C4))
+    prc = _run_sharded(C4, world=2)
+    for r in range(2):
+        np.testing.assert_array_equal(thr[r]["W"], prc[r]["W"])
+        np.testing.assert_array_equal(thr[r]["H"], prc[r]["H"])
+        np.testing.assert_array_equal(thr[r]["loss"], prc[r]["loss"])
 
 
 def test_config5_128_row_shards():
