@@ -30,30 +30,48 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   FusedArgs args = args_in;
   const int pb = args.w.pb;
   const int tab_rows = args.h.n_pad > pb ? args.h.n_pad : pb;
-  size_t part = (size_t)(pb == ESPM_ELL_PB ? FusedGeom<K>::S : ESPM_ELL_PB / pb) * FusedGeom<K>::PROWS * pb * sizeof(float);
+  size_t part0 = (size_t)(pb == ESPM_ELL_PB ? FusedGeom<K>::S : ESPM_ELL_PB / pb) * FusedGeom<K>::PROWS * pb * sizeof(float);
   const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
-  if (red > part) part = red;
-  if (tail_scratch > part) part = tail_scratch;
-  size_t bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
-  args.cnt_lds_off = (int)bytes;   // the two unit counters
-  bytes += 16;
-  args.meta_lds_off = (int)bytes;  // the block's list offsets
-  bytes += (size_t)(3 * (pb / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
-  args.perm_lds_off = (int)bytes;  // below the full geometry: the block's pix_perm and chan_perm
-  const size_t perm_bytes = (size_t)(pb + 64 * args.w.n_cg) * sizeof(int);
-  // (the full geometry: the copies are an extra where the workgroup's 160 KB still hold them)
-  args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
-  if (args.perm_lds) bytes += perm_bytes;
-  args.red_lds_off = -1;
-  if (ESPM_FUSED_RED_ONE_BARRIER && bytes + (ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double) + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
-    bytes = (bytes + 7) / 8 * 8;
-    args.red_lds_off = (int)bytes;
-    bytes += (size_t)(ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
-  }
-  if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators (and, for the shared tail, the sums of W')
-    args.h.cs_lds_off = (int)bytes;
-    bytes += 2 * KP * sizeof(double);
+  if (red > part0) part0 = red;
+  if (tail_scratch > part0) part0 = tail_scratch;
+  size_t bytes = 0;
+  auto layout = [&](size_t part) {   // the workgroup's LDS with `part` bytes for the numerators' region
+    bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
+    args.cnt_lds_off = (int)bytes;   // the two unit counters
+    bytes += 16;
+    args.meta_lds_off = (int)bytes;  // the block's list offsets
+    bytes += (size_t)(3 * (pb / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
+    args.perm_lds_off = (int)bytes;  // below the full geometry: the block's pix_perm and chan_perm
+    const size_t perm_bytes = (size_t)(pb + 64 * args.w.n_cg) * sizeof(int);
+    // (the full geometry: the copies are an extra where the workgroup's 160 KB still hold them)
+    args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
+    if (args.perm_lds) bytes += perm_bytes;
+    args.red_lds_off = -1;
+    if (ESPM_FUSED_RED_ONE_BARRIER && bytes + (ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double) + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
+      bytes = (bytes + 7) / 8 * 8;
+      args.red_lds_off = (int)bytes;
+      bytes += (size_t)(ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
+    }
+    if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators (and, for the shared tail, the sums of W')
+      args.h.cs_lds_off = (int)bytes;
+      bytes += 2 * KP * sizeof(double);
+    }
+  };
+  // the slab of the block collected in the numerators' region (mu_fused_kernel.hpp, ESPM_FUSED_SLAB_LDS): needs that region to itself from
+  // the epilogue's barrier on (the record reduction's scratch elsewhere) and k n_pad floats of it - below the full geometry the
+  // region is grown to that where the workgroup's LDS allows
+  const size_t slab = (size_t)K * args.w.n_pad * sizeof(float);
+  args.slab_lds = 0;
+  layout(part0);
+  if (ESPM_FUSED_SLAB_LDS && args.w.n_pad % 4 == 0) {
+    if (slab > part0) {
+      layout(slab);
+      if (bytes > ESPM_FUSED_LDS_LIMIT || args.red_lds_off < 0) layout(part0);
+      else args.slab_lds = 1;
+    } else {
+      args.slab_lds = args.red_lds_off >= 0;
+    }
   }
   // the tail of the previous W update is shared by the launch's own workgroups (mu_fused_kernel.hpp) unless it carries the
   // projected gradient's quadratic term, which only the extra workgroup sums

@@ -59,6 +59,18 @@
 #define ESPM_FUSED_PROLOGUE_BATCH 1
 #endif
 
+// the per-pixel sum of the partial numerators with all its LDS reads in flight together (h_epilogue, MAXP)
+#ifndef ESPM_FUSED_SUM_BATCHED
+#define ESPM_FUSED_SUM_BATCHED 1
+#endif
+// the block's slab of R H'^T collected in LDS (the numerators' region, free from the epilogue's barrier on) and written out as whole
+// rows in 16-byte write-through stores, instead of 4-byte stores scattered by the channel order: 2.6 M scattered dword stores per
+// launch become 0.66 M coalesced 16-byte ones, and the launch ends without 10.5 MB of dirty lines for the boundary to write back
+// (MI355X_MICROARCH.md: + B / 6 TB/s behind B dirty bytes; write-through wins for tens of KB per workgroup)
+#ifndef ESPM_FUSED_SLAB_LDS
+#define ESPM_FUSED_SLAB_LDS 1
+#endif
+
 namespace espm {
 
 struct FusedArgs {
@@ -71,6 +83,7 @@ struct FusedArgs {
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
   int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
+  int slab_lds;     // the W walk collects the block's slab in the numerators' region and the workgroup writes it out as rows (the launcher: where k n_pad floats fit there and the record reduction has scratch of its own)
 };
 
 // (the cuts of four segments, cumulative per cent of a group's rows: A/B knobs - profiles/r03bf_*)
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
+  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : 8) : 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
                                                      fa.red_lds_off >= 0 ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr,
                                                      relw);
 
@@ -343,12 +356,37 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     });
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (c >= 0) {
+      if (ESPM_FUSED_SLAB_LDS && fa.slab_lds) {   // (uniform)
 #pragma unroll
-      for (int kk = 0; kk < K; ++kk) w.a_slab[((size_t)b * K + kk) * w.n_pad + c] = acc[kk];
+        for (int kk = 0; kk < K; ++kk) part[(size_t)kk * w.n_pad + c] = acc[kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) w.a_slab[((size_t)b * K + kk) * w.n_pad + c] = acc[kk];
+      }
     }
   }
   ESPM_PHASE_STAMP(6);   // wave 0 found no channel group left
   ESPM_WAVE_STAMP(24);
+  if (ESPM_FUSED_SLAB_LDS && fa.slab_lds) {
+    __syncthreads();
+    // rows of the slab, 16 bytes per store, write-through (sc0 sc1: the line leaves the XCD's L2 now, not at the end of the launch);
+    // the entries of the channels n .. n_pad - 1 belong to no list: zeros, as the scattered stores left them
+    float* dst = w.a_slab + (size_t)b * K * w.n_pad;
+    typedef float xf4 __attribute__((ext_vector_type(4)));
+    for (int i = threadIdx.x; i < (K * w.n_pad) / 4; i += NT) {
+      xf4 v = reinterpret_cast<const xf4*>(part)[i];
+      const int c0 = (4 * i) % w.n_pad;
+      if (c0 + 3 >= a.n) {
+        if (c0 >= a.n) v[0] = 0.f;
+        if (c0 + 1 >= a.n) v[1] = 0.f;
+        if (c0 + 2 >= a.n) v[2] = 0.f;
+        v[3] = 0.f;
+      }
+      // (s_nop: the hardware wants wait states between a store of more than 64 bits and a write of its data registers, which
+      //  the compiler cannot place for an instruction it does not see)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst + 4 * i), "v"(v) : "memory");
+    }
+  }
 #ifdef ESPM_PHASE_CLOCK
   __syncthreads();
   ESPM_PHASE_STAMP(7);   // the workgroup is done

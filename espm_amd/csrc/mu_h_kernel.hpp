@@ -165,11 +165,20 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     float hin[K], nv[K], dv[K];
     const int prows = kl_rows ? K + 1 : K;   // rows of TP floats per partial
     if constexpr (MAXP > 0) {
+      // every read unconditional, from the address of a slot that exists (a conditional LDS load compiles to a branch around it, and the
+      // reads then wait for one another: 48 dependent round trips of ~100 cycles were the 2.06 us a 64-row shard's update spent here,
+      // 24 of them the 0.82 us at the headline, profiles/r03bh_phase_clock_*rows.log); the values of slots beyond nparts are dropped by a select
       float pv[MAXP][K + 1];
+#pragma unroll
+      for (int w = 0; w < MAXP; ++w) {
+        const int wc = w < nparts ? w : 0;
+#pragma unroll
+        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = smem[((size_t)wc * prows + (kk < K || kl_rows ? kk : 0)) * TP + jj];
+      }
 #pragma unroll
       for (int w = 0; w < MAXP; ++w)
 #pragma unroll
-        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = (w < nparts && (kk < K || kl_rows)) ? smem[((size_t)w * prows + kk) * TP + jj] : 0.f;
+        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = (w < nparts && (kk < K || kl_rows)) ? pv[w][kk] : 0.f;
       if (kl_rows) {
         float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
 #pragma unroll

@@ -238,6 +238,26 @@ class _Shard:
             row0, rows = blocks[self.rank]
             self.sl, self.shape_2d = slice(row0, row0 + rows), None
 
+    def combine_scans(self, scans, layout):
+        """The upload's scans of this rank's block (_upload_with_scans) turned into the image's: counts and sums added over the
+        ranks, the largest entry their maximum, the channel sums added (the rows of the array as it lies in the channel-major
+        layout, its columns in the pixel-major one); the pixel sums stay the block's."""
+        import torch
+        dist = torch.distributed
+        ch = "row_sum" if layout == "cm" else "col_sum"
+        vec = torch.cat((scans["bad"].to(torch.float64), scans["s1"].view(1), scans["s2"].view(1), scans["facts"][:2]))
+        dist.all_reduce(vec, group=self.group)
+        xmax = scans["facts"][2:3].clone()
+        dist.all_reduce(xmax, op=dist.ReduceOp.MAX, group=self.group)
+        chs = scans[ch].clone()
+        dist.all_reduce(chs, group=self.group)
+        out = dict(scans)
+        out["bad"] = vec[:3].round().to(torch.int64)
+        out["s1"], out["s2"] = vec[3], vec[4]
+        out["facts"] = torch.cat((vec[5:7], xmax))
+        out[ch] = chs
+        return out
+
     def cols(self, a):
         """This rank's columns of an (.., p) array (None stays None)."""
         return None if a is None else a[..., self.sl]
@@ -333,16 +353,18 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         return [lkl]
 
     # ---- loss -----------------------------------------------------------------------------------------
-    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False, shard=None, x_facts=None):
+    def _make_engine(self, X_fixed, xscale, G, filled_channels=None, filled_pixels=None, layout="cm", autotune=False, shard=None, x_facts=None,
+                     x_local=False):
         """The device engine of a fit; with ``shard`` (a _Shard) X_fixed is the WHOLE image and the engine takes this rank's
-        block of it."""
+        block of it - or, with ``x_local``, that block already (then ``filled_pixels`` is the block's mask too)."""
         from espm_amd.engine import MUEngine
         shape_2d, fixed_H, group = self.shape_2d, self.fixed_H, None
         if shard is not None:
-            X_fixed = X_fixed[shard.sl] if layout == "pm" else X_fixed[:, shard.sl]
+            if not x_local:
+                X_fixed = X_fixed[shard.sl] if layout == "pm" else X_fixed[:, shard.sl]
+                filled_pixels = shard.cols(filled_pixels)
             shape_2d, group = shard.shape_2d, shard.group
             fixed_H = shard.cols(np.asarray(fixed_H)) if fixed_H is not None else None
-            filled_pixels = shard.cols(filled_pixels)
             x_facts = None      # (they describe the whole image)
 
         rows = None
@@ -464,6 +486,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         x_facts = None   # (large X on the device: what the upload's scans found out about it, for the engine)
         dev_layout = "cm"
         lazy = None    # the estimator's own host copy X_ of a large X, made on a worker thread (_HostCopy)
+        # one fit over several GPUs (shard()): decided BEFORE the upload, so that a large X goes to the device as this rank's block
+        # of image rows only - its scans are combined over the ranks, the initialisation's passes run on the blocks
+        # (espm_amd/init_device.py), the engine takes the block as it is.  Set-up time and device memory per rank shrink with the
+        # number of ranks like the iteration does (the reference: base.py:243-295, updates.py:160-223).
+        grp = getattr(self, "_shard_group", None)
+        shard = None
+        if grp is not None:
+            import torch
+            if torch.distributed.get_world_size(grp) > 1:
+                shard = _Shard(grp, self.shape_2d, int(Xv.shape[1]))
+        x_local = False   # Xd_raw is this rank's block (sharded fit of a large X)
         if Xv.size >= _DEVICE_PREP_MIN_SIZE:
             import torch
             if torch.cuda.is_available():
@@ -476,7 +509,13 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 lazy = _HostCopy(Xv, dev_layout)
                 try:
                     mark("host copy thread created")
+                    if shard is not None:
+                        x_local = True
+                        # (pixel-major: the block is a run of rows of the array as it lies; channel-major: a strided copy of 1 / world of it)
+                        host = host[shard.sl] if dev_layout == "pm" else np.ascontiguousarray(host[:, shard.sl])
                     Xd_raw, scans = _upload_with_scans(host, torch.device("cuda", torch.cuda.current_device()), self.log_shift)
+                    if shard is not None:
+                        scans = shard.combine_scans(scans, dev_layout)
                     mark("upload returned")
                     Xd = Xd_raw if dev_layout == "cm" else Xd_raw.t()
                     n_bad, n_nan, n_neg = (int(v) for v in scans["bad"].cpu())
@@ -501,20 +540,28 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         else:
             try:
                 # (the line sums of the array as it lies in memory, from the upload's scans: channels are its rows in the "cm" layout)
+                # (sharded: the channel sums are the image's, the pixel sums this rank's block's)
                 zc, zp = ((scans["row_sum"] == 0, scans["col_sum"] == 0) if dev_layout == "cm"
                           else (scans["col_sum"] == 0, scans["row_sum"] == 0))
                 empty_ch, empty_px = zc, zp
-                n_zero_lines, s1, n_nonint, nnz, x_max = (float(v) for v in torch.cat((torch.stack(((zp.sum() + zc.sum()).to(torch.float64), scans["s1"])),
+                n_zero_px = zp.sum().to(torch.float64)
+                if x_local:
+                    torch.distributed.all_reduce(n_zero_px, group=shard.group)
+                n_zero_lines, s1, n_nonint, nnz, x_max = (float(v) for v in torch.cat((torch.stack((n_zero_px + zc.sum(), scans["s1"])),
                                                                                              scans["facts"])).cpu())
+                numel = float(Xv.size)
                 fill = n_zero_lines > 0
-                if not fill:   # what the scans know about X as it goes to the engine (a filled X is another array: the engine looks itself)
+                if not fill and not x_local:   # what the scans know about X as it goes to the engine (a filled X is another array: the engine looks itself)
                     x_facts = dict(nonneg=True, sum_x=s1, is_count=bool(n_nonint == 0 and x_max <= 255), nnz=int(nnz))
                 if fill:
                     Xd[:, zp] = self.log_shift
                     Xd[zc, :] = self.log_shift
-                    mean_x = float(Xd.mean(dtype=torch.float64))
+                    total = Xd.sum(dtype=torch.float64)
+                    if x_local:
+                        torch.distributed.all_reduce(total, group=shard.group)
+                    mean_x = float(total) / numel
                 else:
-                    mean_x = s1 / Xd.numel()
+                    mean_x = s1 / numel
             except BaseException:   # (the worker must not wait for a finish() that will not come)
                 lazy.cancel()
                 raise
@@ -527,7 +574,10 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                  else self.n_components / (mean_x * X_fixed.shape[0]))
             xscale = float(self.norm_factor_)
         if lazy is not None:
-            lazy.finish(zp.cpu().numpy() if fill else None, zc.cpu().numpy() if fill else None, self.log_shift,
+            zp_all = zp
+            if fill and x_local:   # (the host copy is the whole image: it fills the empty pixels of every rank's block)
+                zp_all = torch.from_numpy(shard.gather_cols(zp.to(torch.uint8)[None, :])[0].astype(bool))
+            lazy.finish(zp_all.cpu().numpy() if fill else None, zc.cpu().numpy() if fill else None, self.log_shift,
                         self.norm_factor_ if self.normalize else None)
             self.X_ = lazy
             # the copy runs from here on - behind the upload, next to the initialisation, the engine set-up and the loop (~120 ms
@@ -553,6 +603,8 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             for a in range(0, int(rows_of.shape[0]), step):
                 xs = rows_of[a:a + step].to(torch.float64)
                 total += (xs * torch.log(xs.clamp_min(self.log_shift))).sum() - xs.sum()
+            if x_local:
+                torch.distributed.all_reduce(total, group=shard.group)
             self._const_KL_dev = float(total)
             del xs, rows_of
 
@@ -568,19 +620,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                           init=self.init, random_state=self.random_state,
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,
                                                           physics_model=self.physics_model_, X_device=X_init_dev,
+                                                          shard=shard if x_local else None,   # (X_device is this rank's block of pixels)
                                                           # (the mean of what the initialisation sees: known from the upload's scans)
                                                           X_mean=(mean_x * xscale if (Xd is not None and mean_x is not None) else None))
         del X_init_dev
         mark("initialize_algorithms")
         # one fit over several GPUs (shard()): this rank's block of image rows; every rank starts from rank 0's W, H, G
-        grp = getattr(self, "_shard_group", None)
-        shard = None
-        if grp is not None:
+        if shard is not None:
             import torch
-            if torch.distributed.get_world_size(grp) > 1:
-                shard = _Shard(grp, self.shape_2d, int(self.X_.shape[1]))
-                dev = f"cuda:{torch.cuda.current_device()}"
-                self.G_, self.W_, self.H_ = shard.broadcast([self.G_, self.W_, self.H_], dev)
+            dev = f"cuda:{torch.cuda.current_device()}"
+            self.G_, self.W_, self.H_ = shard.broadcast([self.G_, self.W_, self.H_], dev)
         self._shard = shard
         say = print if shard is None or shard.rank == 0 else (lambda *a, **k: None)   # (the reference's messages: once, not per rank)
         # L_ (base.py:286-291) is only an attribute here - the kernels apply the Laplacian as a stencil - and building the
@@ -597,7 +646,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                                                 # (timing the launch plans costs ~30 ms of device time and gains a few per cent
                                                 #  per iteration: it pays for itself only in very long fits of large images)
                                                 autotune="auto" if Xd is not None else False,   # (MUEngine: from AUTOTUNE_MIN_ITERS iterations on)
-                                                shard=shard)
+                                                shard=shard, x_local=x_local)
         self._ingest_layout = dev_layout   # "pm": the (pixels, channels) input went to the device without a transpose
         mark("engine built")
         del X_fixed, Xd, Xd_raw

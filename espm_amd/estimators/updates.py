@@ -230,20 +230,22 @@ def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=log_shift, saf
     return out.astype(np.result_type(W.dtype, np.float32) if W.dtype == np.float32 else np.float64)
 
 
-def _initial_factors(X, n_components, init, random_state, sklearn_init, X_device=None, X_mean=None):
+def _initial_factors(X, n_components, init, random_state, sklearn_init, X_device=None, X_mean=None, shard=None):
     from espm_amd import init_device
 
     nndsvd = init in (None, "nndsvd", "nndsvda", "nndsvdar") and n_components <= min(X.shape)
     if nndsvd and X.size >= init_device.DEVICE_INIT_MIN_SIZE:
         import torch
         if torch.cuda.is_available():
+            if shard is not None and X.shape[0] >= X.shape[1]:   # (more channels than pixels: the sharded routine does not apply, and the image is small)
+                shard, X_device = None, None
             return init_device.initialize_nmf_device(X, n_components, init=init, random_state=random_state,
-                                                     X_device=X_device, X_mean=X_mean)
+                                                     X_device=X_device, X_mean=X_mean, shard=shard)
     return sklearn_init(X, n_components=n_components, init=init, random_state=random_state)
 
 
 def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_H, simplex_W, logshift=log_shift,
-                          physics_model=None, X_device=None, X_mean=None):
+                          physics_model=None, X_device=None, X_mean=None, shard=None):
     """Initial G, W, H (espm/estimators/updates.py:160-223).
 
     Like the reference: scikit-learn's NNDSVD / random initialisation and small least-squares fits, once per
@@ -258,7 +260,8 @@ def initialize_algorithms(X, G, W, H, n_components, init, random_state, simplex_
         skip_second = False
     if W is None:
         if H is None:
-            D, H = _initial_factors(X, n_components, init, random_state, _initialize_nmf, X_device, X_mean)
+            # (shard: X_device is one rank's block of pixels of a sharded fit, espm_amd/estimators/base.py - the factors come back whole)
+            D, H = _initial_factors(X, n_components, init, random_state, _initialize_nmf, X_device, X_mean, shard)
             if simplex_H:
                 H = np.nan_to_num(H, nan=1.0 / H.shape[0])
                 scale = np.sum(H, axis=0, keepdims=True)

@@ -141,11 +141,84 @@ def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     return U[:, :n_components], s[:n_components], Vt[:n_components, :]
 
 
-def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None, X_mean=None):
+def _cholqr_rows_sharded(A, group, passes):
+    """Orthonormal basis of the column space of a tall matrix whose ROWS are spread over the ranks of ``group`` (A: this rank's
+    rows): Cholesky QR - the r x r Gram matrix added over the ranks (fp64), its factor on the host, A R^-1 - once as the
+    normaliser of a power iteration, twice for the final basis (_qr_tall's argument).  Every rank factors the same all-reduced
+    Gram matrix: the same R everywhere.  A Gram matrix that is not numerically positive definite gets a relative ridge (the
+    basis is then orthonormal only to that, which the second pass repairs or the SVD of the projection absorbs)."""
+    from scipy.linalg import solve_triangular
+    Ad = A.to(torch.float64)
+    for _ in range(passes):
+        G = Ad.T @ Ad
+        torch.distributed.all_reduce(G, group=group)
+        Gh = G.cpu().numpy()
+        Gh = 0.5 * (Gh + Gh.T)
+        ridge = 0.0
+        for _try in range(8):
+            try:
+                R = np.linalg.cholesky(Gh + ridge * np.eye(Gh.shape[0])).T
+                if np.isfinite(R).all() and np.diagonal(R).min() > 0:
+                    break
+            except np.linalg.LinAlgError:
+                pass
+            ridge = max(ridge * 100.0, 1e-14 * float(np.trace(Gh)) / Gh.shape[0])
+        Rinv = solve_triangular(R, np.eye(R.shape[0]), lower=False)
+        Ad = Ad @ torch.from_numpy(Rinv).to(Ad.device)
+    return Ad.to(A.dtype)
+
+
+def randomized_svd_sharded(Xd, n_components, random_state, shard, n_oversamples=10):
+    """``randomized_svd_device`` for an image whose PIXELS are spread over the ranks: Xd is this rank's (n_samples = channels,
+    block of pixels) matrix, ``shard`` the estimator's _Shard.  The algorithm is the same - Gaussian test matrix from the same
+    ``RandomState`` (replicated: every rank draws it), power iterations, QR, SVD of the small projection, ``svd_flip`` - with the
+    contractions over the pixels added over the ranks (n x r and r x r matrices: ~100 KB per all-reduce) and nothing of the
+    size of the image ever leaving its rank.  One deviation from scikit-learn: the power iterations normalise the TALL factor
+    (pixels x r, its rows on different ranks) by Cholesky QR instead of by the L of a partially pivoted LU, whose pivot search
+    would be a collective per column; both span the same column space, which is all a normaliser of the iteration is asked for,
+    so U, s, V agree with the one-GPU routine to rounding (tests/test_gpu_sharded_estimator.py).  The channel-side factor (n x r,
+    replicated) keeps the LU.  Returns numpy (U (n, k) replicated, s (k), Vt (k, p) assembled from the ranks' blocks)."""
+    from scipy import linalg
+    from sklearn.utils import check_random_state
+
+    group = shard.group
+    rs = check_random_state(random_state)
+    n_random = n_components + n_oversamples
+    n_samples = Xd.shape[0]
+    p_total = sum(shard.counts)
+    if n_samples >= p_total:
+        raise NotImplementedError("sharded initialisation: more channels than pixels")   # (the caller falls back on the whole image)
+    n_iter = 7 if n_components < 0.1 * min(n_samples, p_total) else 4
+    # (transpose = True in scikit-learn's routine: M = X^T, pixels x channels; Q starts on the channel side)
+    Q = torch.from_numpy(rs.normal(size=(n_samples, n_random))).to(device=Xd.device, dtype=Xd.dtype)
+    lu = _lu_pl if n_iter > 2 else (lambda A: A)
+    for _ in range(n_iter):
+        Y = Xd.T @ Q                                            # (pixels of this rank, r)
+        if n_iter > 2:
+            Y = _cholqr_rows_sharded(Y, group, 1)
+        Z = Xd @ Y                                              # (n, r): a sum over the pixels
+        torch.distributed.all_reduce(Z, group=group)
+        Q = lu(Z)
+    Y = _cholqr_rows_sharded(Xd.T @ Q, group, 2)
+    B = Y.T @ Xd.T                                              # (r, n): a sum over the pixels
+    torch.distributed.all_reduce(B, group=group)
+    Uhat, s, Vt = linalg.svd(B.cpu().numpy(), full_matrices=False, lapack_driver="gesdd")
+    U_loc = Y @ torch.from_numpy(Uhat).to(device=Xd.device, dtype=Xd.dtype)     # this rank's rows of the pixel-side factor
+    idx = np.argmax(np.abs(Vt), axis=1)                                         # svd_flip, u_based_decision=False
+    signs = np.sign(Vt[np.arange(Vt.shape[0]), idx])
+    Vt *= signs[:, np.newaxis]
+    U_loc = U_loc * torch.from_numpy(signs).to(device=Xd.device, dtype=Xd.dtype)[None, :]
+    V_full = shard.gather_cols(U_loc[:, :n_components].T.contiguous())          # (k, p): every rank's block, in rank order
+    return Vt[:n_components, :].T, s[:n_components], V_full
+
+
+def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None, X_mean=None, shard=None):
     """sklearn.decomposition._nmf._initialize_nmf for the NNDSVD family with the passes over X on the GPU.
 
     X: (n_samples, n_features) numpy array, fp32 or fp64 (kept in its dtype, like scikit-learn); X_device: the same
-    matrix already on the GPU (then X is only consulted for its shape and dtype); X_mean: its mean, if the caller has it."""
+    matrix already on the GPU (then X is only consulted for its shape and dtype); X_mean: its mean, if the caller has it.
+    shard (the estimator's _Shard): X_device holds this rank's block of pixels only - the randomized SVD runs sharded
+    (randomized_svd_sharded), its small factors are replicated and the post-processing below is the same on every rank."""
     from sklearn.utils import check_random_state
 
     if X_device is None and (X < 0).any():
@@ -162,7 +235,12 @@ def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-
     else:
         dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
-    U, S, V = randomized_svd_device(Xd, n_components, random_state)
+    if shard is not None:   # X_device is this rank's block of pixels (and X_mean the image's mean)
+        if X_device is None or (X_mean is None and init != "nndsvd"):
+            raise ValueError("sharded initialisation needs the device block and the mean of the image")
+        U, S, V = randomized_svd_sharded(Xd, n_components, random_state, shard)
+    else:
+        U, S, V = randomized_svd_device(Xd, n_components, random_state)
     # (X_mean: the caller knows the mean of X_device already - one pass over X less)
     avg = (float(X_mean) if X_mean is not None else float(Xd.mean(dtype=torch.float64))) if init != "nndsvd" else 0.0
     del Xd

@@ -107,3 +107,83 @@ def test_sharded_estimator_reproduces_the_golden_fits(world, transport, group):
             np.testing.assert_array_equal(res[r][1][i][0], W)        # replicated W: bit-identical on all ranks
             np.testing.assert_array_equal(res[r][1][i][1], H)        # the assembled H too
             np.testing.assert_array_equal(res[r][1][i][2], losses)   # and the loss history (same stop decisions)
+
+
+# ---- a LARGE X (the device-prep path of fit_transform): shard-local upload, scans and initialisation ----
+def _large_problem(n, nx, ny, k, holes):
+    from espm_amd import synth
+    prob = synth.make_problem(n, nx, ny, k, N=200.0, seed=5)
+    X = synth.sample_numpy(prob, seed=11).astype(np.float32)            # (n, p) counts
+    if holes:   # channels and pixels without a single count: filled with log_shift (base.py:519-528), jointly over the ranks
+        X[3, :] = 0
+        X[n - 2, :] = 0
+        X[:, 5] = 0
+        X[:, nx * ny - 7] = 0          # (one empty pixel in each rank's block)
+    return X
+
+
+def _fit_large(X, k, nx, ny, group, hspy):
+    from espm_amd.estimators import SmoothNMF
+    est = SmoothNMF(n_components=k, lambda_L=1.0, simplex_H=True, simplex_W=False, shape_2d=(nx, ny), max_iter=25, tol=0, no_stop_criterion=True,
+                    verbose=0, random_state=0, hspy_comp=hspy)
+    if group is not None:
+        est.shard(group)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with contextlib.redirect_stdout(io.StringIO()):
+        est.fit_transform(X.T if hspy else X)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    return dict(W=np.asarray(est.W_), H=np.asarray(est.H_), losses=np.asarray(est.losses_), peak=int(peak), store=est._engine.x_store,
+                layout=est._ingest_layout, X_sum=float(np.asarray(est.X_, dtype=np.float64).sum()), X_min=float(np.asarray(est.X_).min()), const_KL=float(est.const_KL_))
+
+
+def _large_worker(rank, world, port, out, cfg):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESPM_XCHG="collective")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    try:
+        torch.cuda.set_device(0)
+        n, nx, ny, k, holes, hspy = cfg
+        X = _large_problem(n, nx, ny, k, holes)
+        res = _fit_large(X, k, nx, ny, dist.group.WORLD, hspy)
+        # the sharded randomized SVD against the one-GPU routine on the whole image (same random stream)
+        from espm_amd import init_device
+        from espm_amd.estimators.base import _Shard
+        sh = _Shard(dist.group.WORLD, (nx, ny), nx * ny)
+        Xd = torch.from_numpy(X).cuda()
+        U1, s1, V1 = init_device.randomized_svd_device(Xd, k, 0)
+        U2, s2, V2 = init_device.randomized_svd_sharded(Xd[:, sh.sl].contiguous(), k, 0, sh)
+        res["svd"] = (float(np.abs(s2 - s1).max() / s1.max()), float(np.abs(U2 - U1).max()), float(np.abs(V2 - V1).max() / np.abs(V1).max()))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [(512, 256, 256, 4, False, False), (384, 128, 128, 3, True, False), (384, 128, 128, 3, False, True)],
+                         ids=["counts-2ranks", "holes", "pixel-major"])
+def test_large_x_is_ingested_and_initialised_shard_locally(cfg):
+    """A fit whose X takes the device-prep path (>= 4 M entries), sharded over two ranks: every rank uploads, scans and initialises on ITS
+    block of image rows only - the same fit as on one GPU to the rounding of another order of summation (NNDSVD from a randomized SVD whose
+    sums over the pixels are all-reduced), W bit-identical across the ranks, and a peak of device memory per rank that follows its share."""
+    n, nx, ny, k, holes, hspy = cfg
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_large_worker, args=(world, _free_port(), out, cfg), nprocs=world, join=True)
+        res = {r: dict(out[r]) for r in range(world)}
+    X = _large_problem(n, nx, ny, k, holes)
+    one = _fit_large(X, k, nx, ny, None, hspy)
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[r]["W"], res[0]["W"])
+        np.testing.assert_array_equal(res[r]["H"], res[0]["H"])
+        np.testing.assert_array_equal(res[r]["losses"], res[0]["losses"])
+    assert res[0]["store"] == one["store"] and res[0]["layout"] == one["layout"] == ("pm" if hspy else "cm")
+    ds, du, dv = res[0]["svd"]
+    assert ds < 1e-5 and du < 2e-4 and dv < 2e-4, res[0]["svd"]
+    np.testing.assert_allclose(res[0]["const_KL"], one["const_KL"], rtol=1e-12)
+    assert res[0]["X_sum"] == one["X_sum"] and res[0]["X_min"] == one["X_min"]      # the estimator's own copy of the data, empty lines filled
+    np.testing.assert_allclose(res[0]["losses"], one["losses"], rtol=2e-5)
+    np.testing.assert_allclose(res[0]["H"], one["H"], atol=2e-3)
+    np.testing.assert_allclose(res[0]["W"], one["W"], rtol=5e-3, atol=5e-3 * np.abs(one["W"]).max())
+    if not holes:   # the image dominates the peak: a rank's follows its share (X as uploaded fp32 + the store's build), not the image
+        assert max(res[r]["peak"] for r in res) <= 0.65 * one["peak"], (res[0]["peak"], res[1]["peak"], one["peak"])
