@@ -276,22 +276,38 @@ def main():
         eng.iterate(150, final_loss=False)
         eng.load_state(W0d, H0d)
         eng.iterate(args.warmup, final_loss=False)
-    dt = timed(args.steps)
-    its = args.steps / dt
-    steady = None
-    if not args.no_extras:
-        n_ss = 300
-        steady = dict(steps=n_ss, value=n_ss / timed(n_ss), unit="it/s",
-                      note="300 further iterations, same bracket: the device clocks have ramped by then")
+    def timed_legs():
+        dt_ = timed(args.steps)
+        steady_ = None
+        if not args.no_extras:
+            n_ss = 300
+            steady_ = dict(steps=n_ss, value=n_ss / timed(n_ss), unit="it/s",
+                           note="300 further iterations, same bracket: the device clocks have ramped by then")
+        # ---- N > 1: every rank's launch times (HIP events on the launch stream), so that a scaling curve can be read: the local
+        # half-steps against the W step that holds the record exchange - a rank that waits for a slower peer shows it there ----
+        mine_ = None
+        if world > 1:
+            hs, ws = eng.timed_iterations(40)
+            mine_ = dict(rank=rank, rows=rows, half_steps_us=float(np.median(hs)), w_step_with_exchange_us=float(np.median(ws)),
+                         w_step_with_exchange_p90_us=float(np.percentile(ws, 90)), lost_peers=int(eng.exchange.lost_peers()),
+                         exchange_selftest=eng.exchange.selftest_result)
+        return dt_, steady_, mine_
 
-    # ---- N > 1: every rank's launch times (HIP events on the launch stream), so that a scaling curve can be read: the local
-    # half-steps against the W step that holds the record exchange - a rank that waits for a slower peer shows it there ----
+    dt, steady, mine = timed_legs()
+    if world > 1 and eng.exchange.ctx is not None:
+        # a bounded wait of the one-shot exchange can also give up AFTER a clean warm-up (ranks that share a device stall
+        # each other depending on who is resident when: profiles/r04c_*): the health is asked again behind the timed legs, jointly, and
+        # a run that lost a peer anywhere is timed once more on the collective transport - its first figures measured 2 s waits
+        barrier()
+        if eng.exchange_health() > 0:
+            eng.use_collective_exchange()
+            transport = eng.exchange.transport
+            eng.load_state(W0d, H0d)
+            eng.iterate(args.warmup, final_loss=False)
+            dt, steady, mine = timed_legs()
+    its = args.steps / dt
     per_rank = None
     if world > 1:
-        hs, ws = eng.timed_iterations(40)
-        mine = dict(rank=rank, rows=rows, half_steps_us=float(np.median(hs)), w_step_with_exchange_us=float(np.median(ws)),
-                    w_step_with_exchange_p90_us=float(np.percentile(ws, 90)), lost_peers=int(eng.exchange.lost_peers()),
-                    exchange_selftest=eng.exchange.selftest_result)
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, mine)
 

@@ -92,6 +92,8 @@ SYMBOLS = {
     "espm_xchg_post": (C.c_int, [_vp, C.c_uint32, _vp]),
     "espm_xchg_wait": (C.c_int, [_vp, C.c_uint32, _vp]),
     "espm_xchg_timeouts": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "espm_xchg_set_order": (C.c_int, [_vp, C.c_int]),
+    "espm_xchg_order": (C.c_int, [_vp]),
     "espm_xchg_destroy": (C.c_int, [_vp]),
     "espm_mu_shard_exchange_finish": (C.c_int, [_SP, _vp, C.c_uint32, C.c_int, C.c_int, _vp]),
     "espm_mu_iterate_sharded": (C.c_int, [_SP, _vp, C.POINTER(C.c_uint32), C.c_int, C.c_int, _vp]),

@@ -64,6 +64,7 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   const size_t slab = (size_t)K * args.w.n_pad * sizeof(float);
   args.slab_lds = 0;
   layout(part0);
+  args.w_split = 0;
   if (ESPM_FUSED_SLAB_LDS && args.w.n_pad % 4 == 0) {
     if (slab > part0) {
       layout(slab);
@@ -71,6 +72,8 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
       else args.slab_lds = 1;
     } else {
       args.slab_lds = args.red_lds_off >= 0;
+      // the full geometry: two copies of the slab where the region holds them - the W walk then hands out half channel groups
+      args.w_split = ESPM_FUSED_W_SPLIT && args.slab_lds && pb == ESPM_ELL_PB && 2 * slab <= part0;
     }
   }
   // the tail of the previous W update is shared by the launch's own workgroups (mu_fused_kernel.hpp) unless it carries the

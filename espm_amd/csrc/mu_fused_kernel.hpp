@@ -70,6 +70,15 @@
 #ifndef ESPM_FUSED_SLAB_LDS
 #define ESPM_FUSED_SLAB_LDS 1
 #endif
+// half channel groups as the units of the W walk at the full geometry (FusedArgs::w_split).  Measured (round 4, profiles/r04e_w_split_ab_*.log): SLOWER -
+// 140.5 against 138.1 us per iteration at the headline, 118.3 against 115.2 at k = 3, 48.5 against 47.0 at 100 counts per pixel: 64 unit
+// starts per workgroup (GW rows, first list rows: a memory round trip each) cost more than the shorter tail returns.  Off.
+#ifndef ESPM_FUSED_W_SPLIT
+#define ESPM_FUSED_W_SPLIT 0
+#endif
+#ifndef ESPM_FUSED_SLAB_WT   // the rows written through (sc0 sc1) or as plain stores (A/B)
+#define ESPM_FUSED_SLAB_WT 1
+#endif
 
 namespace espm {
 
@@ -83,6 +92,7 @@ struct FusedArgs {
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
   int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
+  int w_split;      // the W walk's units are half channel groups, summed through two copies of the slab in LDS (needs slab_lds and room for the second copy)
   int slab_lds;     // the W walk collects the block's slab in the numerators' region and the workgroup writes it out as rows (the launcher: where k n_pad floats fit there and the record reduction has scratch of its own)
 };
 
@@ -335,7 +345,14 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
   const WAccumArgs& w = fa.w;
   const int b = blockIdx.x;
-  for (int cg = next_unit(1); cg < w.n_cg; cg = next_unit(1)) {
+  // Units of the W walk: the block's channel groups, or - w_split, where the LDS holds TWO copies of the slab - their halves: the rows
+  // of a group cut in two (unit rows and general rows each), half h adding up in copy h, the two copies summed at the write-out in that
+  // order whoever walked them.  Why: 32 units on 16 waves leave nothing to hand to the wave that is done early, and the waves of a
+  // SIMD are served oldest first - the W walk's youngest waves ended 5 us after wave 0 (profiles/r04c_phase_clock_512rows.log).
+  const bool w_split = ESPM_FUSED_W_SPLIT && fa.w_split;   // (uniform)
+  const int w_units = w_split ? 2 * w.n_cg : w.n_cg;
+  for (int wu = next_unit(1); wu < w_units; wu = next_unit(1)) {
+    const int cg = w_split ? wu >> 1 : wu, whalf = w_split ? wu & 1 : 0;
     const int c = perm_lds ? lchan[cg * 64 + lane] : w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane];
     const float* gsrc = w.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
@@ -346,19 +363,31 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     }
     const int* off = meta + 3 * NGRP + 2 * cg;
     const int beg = off[0], mid = off[1], end = off[2];
+    int u0 = beg, u1 = mid, g0 = mid, g1 = end;   // unit rows [u0, u1), general rows [g0, g1) of this unit
+    if (w_split) {
+      const int hu = beg + (mid - beg) / 2, hg = mid + (end - mid) / 2;
+      if (whalf == 0) {
+        u1 = hu;
+        g1 = hg;
+      } else {
+        u0 = hu;
+        g0 = hg;
+      }
+    }
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk<K, UNR_W, PF, PRIO>(lrow, mid - beg, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     });
-    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(mid - beg) * 64, end - mid, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (c >= 0) {
       if (ESPM_FUSED_SLAB_LDS && fa.slab_lds) {   // (uniform)
+        float* copy = part + (size_t)whalf * K * w.n_pad;
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) part[(size_t)kk * w.n_pad + c] = acc[kk];
+        for (int kk = 0; kk < K; ++kk) copy[(size_t)kk * w.n_pad + c] = acc[kk];
       } else {
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) w.a_slab[((size_t)b * K + kk) * w.n_pad + c] = acc[kk];
@@ -375,6 +404,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     typedef float xf4 __attribute__((ext_vector_type(4)));
     for (int i = threadIdx.x; i < (K * w.n_pad) / 4; i += NT) {
       xf4 v = reinterpret_cast<const xf4*>(part)[i];
+      if (w_split) v += reinterpret_cast<const xf4*>(part + (size_t)K * w.n_pad)[i];   // (copy 0 + copy 1, in this order)
       const int c0 = (4 * i) % w.n_pad;
       if (c0 + 3 >= a.n) {
         if (c0 >= a.n) v[0] = 0.f;
@@ -384,7 +414,11 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
       // (s_nop: the hardware wants wait states between a store of more than 64 bits and a write of its data registers, which
       //  the compiler cannot place for an instruction it does not see)
+#if ESPM_FUSED_SLAB_WT
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst + 4 * i), "v"(v) : "memory");
+#else
+      *reinterpret_cast<xf4*>(dst + 4 * i) = v;
+#endif
     }
   }
 #ifdef ESPM_PHASE_CLOCK

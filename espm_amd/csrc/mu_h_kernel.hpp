@@ -167,33 +167,22 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     if constexpr (MAXP > 0) {
       // every read unconditional, from the address of a slot that exists (a conditional LDS load compiles to a branch around it, and the
       // reads then wait for one another: 48 dependent round trips of ~100 cycles were the 2.06 us a 64-row shard's update spent here,
-      // 24 of them the 0.82 us at the headline, profiles/r03bh_phase_clock_*rows.log); the values of slots beyond nparts are dropped by a select
-      float pv[MAXP][K + 1];
+      // 24 of them the 0.82 us at the headline, profiles/r03bh_phase_clock_*rows.log); the values of slots beyond nparts are dropped by a
+      // select.  Row by row: MAXP reads in flight, the next row's behind them as far as the registers allow (all (K + 1) MAXP at once
+      // spilled 111 registers in the k = 8 instance below the full geometry).
+      auto row_sum = [&](int kk, float s) {
+        float pv[MAXP];
 #pragma unroll
-      for (int w = 0; w < MAXP; ++w) {
-        const int wc = w < nparts ? w : 0;
+        for (int w = 0; w < MAXP; ++w) pv[w] = smem[((size_t)(w < nparts ? w : 0) * prows + kk) * TP + jj];
 #pragma unroll
-        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = smem[((size_t)wc * prows + (kk < K || kl_rows ? kk : 0)) * TP + jj];
-      }
-#pragma unroll
-      for (int w = 0; w < MAXP; ++w)
-#pragma unroll
-        for (int kk = 0; kk <= K; ++kk) pv[w][kk] = (w < nparts && (kk < K || kl_rows)) ? pv[w][kk] : 0.f;
-      if (kl_rows) {
-        float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
-#pragma unroll
-        for (int w = 0; w < MAXP; ++w)
-          if (w < nparts) s += pv[w][K];
-        red[ESPM_HP_KL] += s;
-      }
+        for (int w = 0; w < MAXP; ++w) s += w < nparts ? pv[w] : 0.f;
+        return s;
+      };
+      if (kl_rows) red[ESPM_HP_KL] += row_sum(K, fmaxf(klc, 0.f));   // (negative: the mark of a pixel without counts, no constant)
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < MAXP; ++w)
-          if (w < nparts) s += pv[w][kk];
         hin[kk] = in.hin[kk];
-        nv[kk] = s * a.xscale;
+        nv[kk] = row_sum(kk, 0.f) * a.xscale;
         dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
       }
     } else {

@@ -409,12 +409,22 @@ struct WExchangeArgs {
   size_t rec_bytes, slot_base, wgflags_off, gran_off, err_off, hstat_off, top_off, bot_off;   // (gran_off: of this sequence number's parity)
   unsigned int seq;
   long long max_ticks;
+  int release;               // flags stored with release order at system scope (espm_xchg_set_order) instead of behind s_waitcnt vmcnt(0) alone
   const float* halo_h;
   int halo_k, halo_nx, halo_ny, halo_ppad;
   // simplex over W with G = identity: the summed A and, per reduction workgroup, what the bracket of its component's multiplier
   // needs (the three doubles w_reduce_kernel leaves) go out INSTEAD of the update - w_simplex_update_kernel follows; else null
   double* bparts;
 };
+
+// The flag behind a record's stores (the ordering contract: mu_xchg.hip).  Default: a relaxed system-scope store - the data stores were
+// write-through, every storing wave drained them (s_waitcnt vmcnt(0)) and the workgroup's barrier lies in between.  release != 0
+// (ESPM_XCHG_ORDER=release, espm_xchg_set_order): the same store with release order at system scope - the compiler's full recipe
+// (write back this XCD's L2, wait, store), by the flag-storing lanes only.
+__device__ __forceinline__ void xchg_store_flag(unsigned int* flag, unsigned int seq, int release) {
+  if (release) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void xchg_wait_flag(const unsigned int* flag, unsigned int seq, long long max_ticks, unsigned int* err) {
   const long long t0 = wall_clock64();
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
       //  system-scope fence, which would flush this XCD's whole L2 - only ORDER: every thread's stores before any flag)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank, nwg), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((int)threadIdx.x < x.world) xchg_store_flag(flag(threadIdx.x, x.rank, nwg), x.seq, x.release);
       return;
     }
     // which entry of the statistics this job's value is (row sums [0, KP), maxima [KP, 2 KP)); the others go to the history only
@@ -1634,6 +1644,7 @@ int launch_w_exchange_update(const WFinishArgs& f, const void* slabs, size_t sla
   x.bot_off = x.top_off + (size_t)f.k * (ny > 0 ? ny : 0) * 4;
   x.seq = seq;
   x.max_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  x.release = xc->order;
   x.halo_h = h_new;
   x.halo_k = f.k;
   x.halo_nx = nx;
@@ -1821,6 +1832,7 @@ struct WGxchgArgs {
   size_t rec_bytes, slot_base, wgflags_off, gran_off, err_off, top_off, bot_off;
   unsigned int seq;
   long long max_ticks;
+  int release;
   const float* halo_h;
   int halo_k, halo_nx, halo_ny, halo_ppad;
 };
@@ -1872,7 +1884,7 @@ __global__ __launch_bounds__(256) void w_gxchg_update_kernel(const WGxchgArgs x)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if ((int)threadIdx.x < x.world) __hip_atomic_store(flag(threadIdx.x, x.rank), x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < x.world) xchg_store_flag(flag(threadIdx.x, x.rank), x.seq, x.release);
     return;
   }
   const int e = (int)blockIdx.x - 1, mm = e / a.k, kk = e - mm * a.k;
@@ -2002,6 +2014,7 @@ int launch_w_gxchg_update(const WFinishArgs& f, const espm_xchg* xc, unsigned in
   x.bot_off = x.top_off + (size_t)f.k * (ny > 0 ? ny : 0) * 4;
   x.seq = seq;
   x.max_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  x.release = xc->order;
   x.halo_h = h_new;
   x.halo_k = f.k;
   x.halo_nx = nx;

@@ -16,13 +16,33 @@
 //                                        entries of A and the two halves of its row sum of the new H - value and "it is there" in ONE
 //                                        store, so a piece costs one trip over the link instead of data, drain, flag
 //   post(seq): one workgroup per destination copies the staged record into slot [seq & 1][rank] of that destination with
-//              16-byte stores, fences at system scope, then one lane stores the flag (release, system scope).
+//              write-through system-scope stores; every thread drains its stores (s_waitcnt vmcnt(0)), the workgroup's barrier,
+//              then ONE lane stores the flag (relaxed, system scope).
+//
+// ORDERING CONTRACT (what makes "flag seen => record there" hold; DESIGN.md section 5 has the long form).
+//   producer: (1) every byte of a record is stored write-through at system scope (sc0 sc1: the store is acknowledged by the memory
+//             it targets, not by a cache on the way - the mailboxes are uncached / fine-grained memory besides); (2) every storing wave
+//             waits for the acknowledgement of ALL its stores (s_waitcnt vmcnt(0)); (3) a workgroup barrier collects the waves;
+//             (4) one lane stores the flag.  This is MI355X_MICROARCH.md's form "sc0 sc1 stores and loads both sides" with its
+//             conditions (2) and (3) of the consumer bullet ("every storing wave ran s_waitcnt vmcnt(0) after its stores, and each
+//             flag store comes after the wait of EVERY wave it signals for: a lane that signals for other waves does so behind a
+//             workgroup barrier"), which that guide measured INSIDE one device and calls "not an architectural guarantee".
+//   consumer: polls the flag with relaxed system-scope loads (sc0 sc1: never served by its L1 / L2); the kernels that read the
+//             records start behind the wait on the stream (a kernel boundary), and the in-launch exchange reads granules - 8-byte
+//             {value, sequence number} words whose own arrival is the signal: no ordering between two stores is relied on there.
+//   What is NOT established on this build's hardware (one GPU): that the acknowledgement of a write-through store to a PEER's
+//   memory over xGMI implies its visibility to that peer's loads before a later store from the same wave becomes visible.  Two
+//   guards: the start-up self-test (espm_amd/sharding.py: patterns that change with every sequence number; a record that arrives
+//   after its flag shows as `corrupt`) runs under BOTH orders on whatever peers a run has, and ESPM_XCHG_ORDER=release /
+//   espm_xchg_set_order(x, 1) replaces step (4) by a release store at system scope (the compiler's recipe: write back the L2,
+//   wait, store) for a node on which the relaxed form shows a single corrupt record.
 //   (espm_mu_shard_exchange_finish, mu_w_step.hip, does all of this INSIDE the slab-reduction launch, piece by piece, with
 //    one flag per reduction workgroup: wgflags)
 //   wait(seq): one workgroup, lane r polls flag[r] (system-scope loads, s_sleep between polls) until it reaches seq or
 //              ~2 s have passed; the kernels that read the records are launched behind it on the same stream.
 // Why the records of sequence s are safe to read until s + 2 is posted: a peer posts s + 2 only after its wait(s + 1)
 // returned, i.e. after this rank posted s + 1, which it does (stream order) after everything that read the records of s.
+#include <stdlib.h>
 #include <string.h>
 
 #include "mu_common.hpp"
@@ -38,6 +58,7 @@ struct XchgPostArgs {
   const unsigned char* src;             // staged record
   size_t record_bytes, slot_off, flag_off;
   unsigned int seq;
+  int release;
 };
 
 __global__ __launch_bounds__(256) void xchg_post_kernel(const XchgPostArgs a) {
@@ -52,8 +73,11 @@ __global__ __launch_bounds__(256) void xchg_post_kernel(const XchgPostArgs a) {
   // this XCD's whole L2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned int*>(mb + a.flag_off), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    unsigned int* flag = reinterpret_cast<unsigned int*>(mb + a.flag_off);
+    if (a.release) __hip_atomic_store(flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ __launch_bounds__(64) void xchg_wait_kernel(unsigned char* mailbox, size_t off_flags, size_t off_err, int world,
@@ -117,9 +141,19 @@ int espm_xchg_create(int world, int rank, size_t record_bytes, espm_xchg** out) 
     return check_hip(e, "xchg_create: staging allocation");
   }
   x->peers[rank] = x->mailbox;
+  const char* order = getenv("ESPM_XCHG_ORDER");
+  x->order = (order && strcmp(order, "release") == 0) ? 1 : 0;
   *out = x;
   return ESPM_OK;
 }
+
+int espm_xchg_set_order(espm_xchg* x, int release) {
+  ESPM_REQUIRE(x && (release == 0 || release == 1), "xchg_set_order: context and 0 (relaxed flag behind the drain) or 1 (release flag)");
+  x->order = release;
+  return ESPM_OK;
+}
+
+int espm_xchg_order(const espm_xchg* x) { return x ? x->order : -1; }
 
 int espm_xchg_handle(const espm_xchg* x, void* handle_out) {
   ESPM_REQUIRE(x && handle_out, "xchg_handle: NULL pointer");
@@ -161,6 +195,7 @@ int espm_xchg_post(espm_xchg* x, uint32_t seq, espm_stream_t stream) {
   a.slot_off = ((size_t)(seq & 1u) * x->world + x->rank) * x->record_bytes;
   a.flag_off = x->off_flags + (size_t)x->rank * XCHG_FLAG_STRIDE;
   a.seq = seq;
+  a.release = x->order;
   hipLaunchKernelGGL(xchg_post_kernel, dim3(x->world), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check_hip(hipGetLastError(), "xchg_post launch");
 }

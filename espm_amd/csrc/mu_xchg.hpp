@@ -14,4 +14,5 @@ struct espm_xchg {
   unsigned char* staging;        // where the rank packs its record before post (device)
   unsigned char* peers[16];      // mailbox of every rank as mapped here (peers[rank] == mailbox)
   bool opened[16];
+  int order;                     // 0: flags as relaxed stores behind the data's drain (default); 1: release stores at system scope (espm_xchg_set_order, ESPM_XCHG_ORDER=release)
 };

@@ -113,18 +113,33 @@ class ShardExchange:
         if ok:
             blob = b"".join(g[1] for g in gathered)
             ok = lib.espm_xchg_connect(ctx, C.create_string_buffer(blob, len(blob))) == 0
+        want = 0
         if ok:   # self-test: exchanges of patterns every rank can check word by word (selftest below), timed
             self.ctx = ctx
             try:
-                self.selftest_result = self.selftest(int(os.environ.get("ESPM_XCHG_SELFTEST", "64")), device=device)
+                # under BOTH flag orders (csrc/mu_xchg.hip, the ordering contract): the one the run will use last; on a node whose
+                # relaxed form lets a record arrive after its flag (`corrupt` > 0) while the release form does not, every rank moves
+                # to the release form - jointly, below - instead of giving the transport up
+                want = int(lib.espm_xchg_order(ctx))
+                n_test = int(os.environ.get("ESPM_XCHG_SELFTEST", "64"))
+                by_order = {}
+                for order in ((1 - want), want):
+                    lib.espm_xchg_set_order(ctx, order)
+                    by_order["release" if order else "relaxed"] = self.selftest(n_test if order == want else max(16, n_test // 4), device=device)
+                self.selftest_result = dict(by_order["release" if want else "relaxed"], order="release" if want else "relaxed", orders=by_order)
                 ok = self.selftest_result["lost"] == 0 and self.selftest_result["corrupt"] == 0
+                if not ok and not want and by_order["release"]["lost"] == 0 and by_order["release"]["corrupt"] == 0:
+                    want, ok = 1, True     # (proposed; adopted below only if every rank ends up healthy)
             except Exception:
-                ok = False
+                ok, want = False, 0
             self.ctx = None
         flags = [None] * self.world
-        torch.distributed.all_gather_object(flags, bool(ok), group=self.group)
-        if all(flags):
+        torch.distributed.all_gather_object(flags, (bool(ok), int(want) if ok else 0), group=self.group)
+        if all(f[0] for f in flags):
             self.ctx = ctx
+            if any(f[1] for f in flags):   # some rank needs (or was asked for) the release form: every rank takes it
+                lib.espm_xchg_set_order(ctx, 1)
+                self.selftest_result = dict(self.selftest_result or {}, order="release")
         else:   # every rank takes the collective
             if ctx:
                 lib.espm_xchg_destroy(ctx)

@@ -415,6 +415,12 @@ const void* espm_xchg_records(const espm_xchg* x, int parity);
 int espm_xchg_post(espm_xchg* x, uint32_t seq, espm_stream_t stream);
 int espm_xchg_wait(espm_xchg* x, uint32_t seq, espm_stream_t stream);
 int espm_xchg_timeouts(const espm_xchg* x, uint32_t* count_out);   /* host-synchronous read of the give-up counter */
+/* How a flag follows its record's stores: 0 (default) a relaxed system-scope store behind the drain of the write-through data
+ * stores and the workgroup's barrier; 1 a release store at system scope.  The initial value is 1 when the environment holds
+ * ESPM_XCHG_ORDER=release at espm_xchg_create.  Every rank must use the same order only in the sense that each protects its
+ * OWN records; mixing is harmless.  (csrc/mu_xchg.hip: the ordering contract.) */
+int espm_xchg_set_order(espm_xchg* x, int release);
+int espm_xchg_order(const espm_xchg* x);
 int espm_xchg_destroy(espm_xchg* x);
 
 /* The sharded W step after the accumulation in ONE launch (where espm_mu_w_update_is_local; otherwise the four calls

@@ -22,11 +22,17 @@ COUNTS = float(os.environ.get("COUNTS", "500"))
 ITERS, REPS = int(os.environ.get("ITERS", "300")), int(os.environ.get("REPS", "4"))
 fused = {"0": False, "1": True}.get(os.environ.get("FUSED", "1"), os.environ.get("FUSED", "1"))
 dev = torch.device("cuda", 0)
-prob = synth.make_problem(2048, ROWS, 512, K, N=COUNTS, seed=0, row0=0, nx_total=512)
+C5 = os.environ.get("CONFIG") == "c5"   # CONFIG=c5 ROWS=128: a rank's share of BASELINE configuration 5 (1980 ch, 1024-pixel rows, k = 8, G 1980 x 17, mu = 0.05)
+N_CH, NY, M = (1980, 1024, 17) if C5 else (2048, 512, None)
+if C5:
+    K = 8
+prob = synth.make_problem(N_CH, ROWS, NY, K, N=COUNTS, seed=0, row0=0, nx_total=NY, m=M)
 X = synth.sample_torch(prob, dev, seed=1000, row0=0)
-W0, H0 = synth.random_init(2048, K, 512 * 512, seed=0, scale=COUNTS / 2048)
-H0 = H0[:, :ROWS * 512]
-kw = dict(layout="pm", shape_2d=(ROWS, 512), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=ITERS * (REPS + 1) + 20, device=dev, fused=fused)
+W0, H0 = synth.random_init(M if C5 else N_CH, K, NY * NY, seed=0, scale=COUNTS / N_CH)
+H0 = H0[:, :ROWS * NY]
+kw = dict(layout="pm", shape_2d=(ROWS, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=ITERS * (REPS + 1) + 20, device=dev, fused=fused)
+if C5:
+    kw.update(G=prob["G"], mu=0.05)
 engs, ref = {}, None
 for spec in sys.argv[1:]:
     name, path = spec.split("=", 1)
