@@ -240,6 +240,8 @@ def main():
     # (W0 / H0 go up before the engine is built and load_state takes device tensors: nothing crosses the host here)
     eng.load_state(W0d, H0d)
 
+    trace = (lambda msg: print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)) if os.environ.get("ESPM_BENCH_TRACE") else (lambda msg: None)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -258,6 +260,7 @@ def main():
             dt = float(t.item())
         return dt
 
+    trace("engine built, state loaded")
     eng.iterate(args.warmup, final_loss=False)
     transport = None
     if world > 1:
@@ -277,7 +280,9 @@ def main():
         eng.load_state(W0d, H0d)
         eng.iterate(args.warmup, final_loss=False)
     def timed_legs():
+        trace(f"timed legs on {eng.exchange.transport if world > 1 else 'one GPU'}")
         dt_ = timed(args.steps)
+        trace("timed steps done")
         steady_ = None
         if not args.no_extras:
             n_ss = 300
@@ -288,6 +293,8 @@ def main():
         mine_ = None
         if world > 1:
             hs, ws = eng.timed_iterations(40)
+            torch.cuda.synchronize()
+            trace("per-launch timing done")
             mine_ = dict(rank=rank, rows=rows, half_steps_us=float(np.median(hs)), w_step_with_exchange_us=float(np.median(ws)),
                          w_step_with_exchange_p90_us=float(np.percentile(ws, 90)), lost_peers=int(eng.exchange.lost_peers()),
                          exchange_selftest=eng.exchange.selftest_result)
@@ -299,10 +306,14 @@ def main():
         # each other depending on who is resident when: profiles/r04c_*): the health is asked again behind the timed legs, jointly, and
         # a run that lost a peer anywhere is timed once more on the collective transport - its first figures measured 2 s waits
         barrier()
+        trace("health check behind the timed legs")
         if eng.exchange_health() > 0:
+            trace("a wait gave up: collective transport")
             eng.use_collective_exchange()
+            trace("exchange replaced")
             transport = eng.exchange.transport
             eng.load_state(W0d, H0d)
+            trace("state reloaded")
             eng.iterate(args.warmup, final_loss=False)
             dt, steady, mine = timed_legs()
     its = args.steps / dt

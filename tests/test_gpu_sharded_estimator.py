@@ -113,7 +113,7 @@ def test_sharded_estimator_reproduces_the_golden_fits(world, transport, group):
 def _large_problem(n, nx, ny, k, holes):
     from espm_amd import synth
     prob = synth.make_problem(n, nx, ny, k, N=200.0, seed=5)
-    X = synth.sample_numpy(prob, seed=11).astype(np.float32)            # (n, p) counts
+    X = np.ascontiguousarray(synth.sample_numpy(prob, seed=11).astype(np.float32))            # (n, p) counts, C order
     if holes:   # channels and pixels without a single count: filled with log_shift (base.py:519-528), jointly over the ranks
         X[3, :] = 0
         X[n - 2, :] = 0
@@ -131,7 +131,7 @@ def _fit_large(X, k, nx, ny, group, hspy):
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
     with contextlib.redirect_stdout(io.StringIO()):
-        est.fit_transform(X.T if hspy else X)
+        est.fit_transform(np.ascontiguousarray(X.T) if hspy else X)   # (hyperspy hands over a C-ordered (pixels, channels) matrix)
     torch.cuda.synchronize()
     peak = torch.cuda.max_memory_allocated() - base
     return dict(W=np.asarray(est.W_), H=np.asarray(est.H_), losses=np.asarray(est.losses_), peak=int(peak), store=est._engine.x_store,
@@ -185,5 +185,5 @@ def test_large_x_is_ingested_and_initialised_shard_locally(cfg):
     np.testing.assert_allclose(res[0]["losses"], one["losses"], rtol=2e-5)
     np.testing.assert_allclose(res[0]["H"], one["H"], atol=2e-3)
     np.testing.assert_allclose(res[0]["W"], one["W"], rtol=5e-3, atol=5e-3 * np.abs(one["W"]).max())
-    if not holes:   # the image dominates the peak: a rank's follows its share (X as uploaded fp32 + the store's build), not the image
+    if n * nx * ny >= 32 << 20:   # where the image dominates the peak (the 25 MB cases sit under the BLAS workspace torch allocates per process): a rank's follows its share (X as uploaded fp32 + the store's build), not the image
         assert max(res[r]["peak"] for r in res) <= 0.65 * one["peak"], (res[0]["peak"], res[1]["peak"], one["peak"])
