@@ -1,4 +1,6 @@
 // Launcher of the fused half-steps of the sparse count store (mu_fused_kernel.hpp).
+#include <stdlib.h>
+
 #include "mu_fused_kernel.hpp"
 
 #ifndef ESPM_ELL_UNR_H
@@ -21,6 +23,9 @@
 #define ESPM_FUSED_FULL_PERM_LDS 0
 #endif
 #define ESPM_FUSED_LDS_LIMIT (160 * 1024)   // a workgroup's LDS on gfx950
+#ifndef ESPM_FUSED_SMALL_SEGS_DEFAULT       // below the full geometry: segments per list group where the LDS holds them (0: 1024 / pb)
+#define ESPM_FUSED_SMALL_SEGS_DEFAULT 0
+#endif
 
 namespace espm {
 
@@ -65,11 +70,24 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   args.slab_lds = 0;
   layout(part0);
   args.w_split = 0;
+  args.h_segs = ESPM_ELL_PB / pb;
   if (ESPM_FUSED_SLAB_LDS && args.w.n_pad % 4 == 0) {
     if (slab > part0) {
       layout(slab);
-      if (bytes > ESPM_FUSED_LDS_LIMIT || args.red_lds_off < 0) layout(part0);
-      else args.slab_lds = 1;
+      if (bytes > ESPM_FUSED_LDS_LIMIT || args.red_lds_off < 0) {
+        layout(part0);
+      } else {
+        args.slab_lds = 1;
+        // the region grown for the slab holds more partial sets than 1024 / pb: more (group, segment) units than waves, so that the
+        // units handed out last level the waves (ESPM_FUSED_SMALL_SEGS: A/B; 0 keeps 1024 / pb)
+        const char* env = getenv("ESPM_FUSED_SMALL_SEGS");
+        const int want = env ? atoi(env) : ESPM_FUSED_SMALL_SEGS_DEFAULT;
+        const int fit = (int)(slab / ((size_t)FusedGeom<K>::PROWS * pb * sizeof(float)));
+        int segs = want > 0 ? want : args.h_segs;
+        if (segs > fit) segs = fit;
+        if (segs > ESPM_FUSED_MAX_SEGS) segs = ESPM_FUSED_MAX_SEGS;
+        if (segs > args.h_segs) args.h_segs = segs;
+      }
     } else {
       args.slab_lds = args.red_lds_off >= 0;
       // the full geometry: two copies of the slab where the region holds them - the W walk then hands out half channel groups

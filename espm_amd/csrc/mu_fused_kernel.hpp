@@ -73,6 +73,15 @@
 // half channel groups as the units of the W walk at the full geometry (FusedArgs::w_split).  Measured (round 4, profiles/r04e_w_split_ab_*.log): SLOWER -
 // 140.5 against 138.1 us per iteration at the headline, 118.3 against 115.2 at k = 3, 48.5 against 47.0 at 100 counts per pixel: 64 unit
 // starts per workgroup (GW rows, first list rows: a memory round trip each) cost more than the shorter tail returns.  Off.
+// most segments per list group below the full geometry (FusedArgs::h_segs; the per-pixel sums unroll to it: at 16 the compiler keeps 96
+// partial values in flight and spills 224 registers).  MORE segments than 1024 / pb - units left over to level the waves - were measured
+// where the region grown for the slab holds them (ESPM_FUSED_SMALL_SEGS): slower everywhere - 64 rows 48.7 -> 50.4 us per iteration at
+// 10-13 segments, 128 rows 62.9 -> 65.5-66.2 at 5-6, 256 rows 96.9 -> 101.4 at 3, configuration 5's 128-row shard 144.1 -> 149.4 at 3
+// (all on the 16-wide build, itself 13 us slower than the 8-wide one: profiles/r04m_small_segs_ab_*.log).  A unit's start costs more
+// than its levelling returns, as in the W walk's half units.
+#ifndef ESPM_FUSED_MAX_SEGS
+#define ESPM_FUSED_MAX_SEGS 8
+#endif
 #ifndef ESPM_FUSED_W_SPLIT
 #define ESPM_FUSED_W_SPLIT 0
 #endif
@@ -92,6 +101,7 @@ struct FusedArgs {
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
   int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
+  int h_segs;       // below the full geometry: segments per list group of the H walk (at least 1024 / pb, at most ESPM_FUSED_MAX_SEGS)
   int w_split;      // the W walk's units are half channel groups, summed through two copies of the slab in LDS (needs slab_lds and room for the second copy)
   int slab_lds;     // the W walk collects the block's slab in the numerators' region and the workgroup writes it out as rows (the launcher: where k n_pad floats fit there and the record reduction has scratch of its own)
 };
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const int GPT_SHIFT = PBITS - 7;                 // log2(list groups per tile)
   constexpr int PROWS = FusedGeom<K>::PROWS;
   // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
-  const int S = FULL ? FusedGeom<K>::S : ESPM_ELL_PB / PB;
+  const int S = FULL ? FusedGeom<K>::S : fa.h_segs;   // (the launcher: 1024 / PB, or more where the numerators' region - grown for the slab - holds them)
   constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
   constexpr int PRIO = FULL ? 0 : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : 8) : 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
+  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : ESPM_FUSED_MAX_SEGS) : 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
                                                      fa.red_lds_off >= 0 ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr,
                                                      relw);
 

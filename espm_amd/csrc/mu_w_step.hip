@@ -1700,8 +1700,8 @@ static void launch_fast(const WFinishArgs& args, int rows, int crows, size_t lds
 //                            (coalesced), a fixed-order block sum, W' = max(W (G^T A) / (colsum(G) rowsum(H')), eps), fixed_W
 //                            (updates.py:58-60, :70-76)
 //   w_gfinish_gw_kernel      256 channels per workgroup: W' (m k floats) into LDS, the rows of G W' (a thread per channel: m k
-//                            multiply-adds from LDS), partial column sums; the workgroup that finishes last (a ticket) adds the
-//                            partials in workgroup order; workgroup 0 forms mean(W') and rel_W (base.py:323)
+//                            multiply-adds from LDS, its row of G requested with W'); workgroup 0 forms the column sums of G W' as
+//                            colsum(G)^T W' (round 4: per-workgroup partials + a ticket before), mean(W') and rel_W (base.py:323)
 // ESPM_W_GSPLIT=0 keeps the one-workgroup finish (A/B).
 __global__ __launch_bounds__(256) void w_gfinish_update_kernel(const WFinishArgs a) {
   __shared__ float s_wave[4];
@@ -1738,30 +1738,35 @@ __global__ __launch_bounds__(256) void w_gfinish_update_kernel(const WFinishArgs
 __global__ __launch_bounds__(256) void w_gfinish_gw_kernel(const WFinishArgs a) {
   extern __shared__ float s_w[];   // [m * k] the new W
   __shared__ double scratch[(256 / 64 + 1) * 2 * KP];
-  __shared__ int s_last;
-  const int tid = threadIdx.x, mk = a.m * a.k, k = a.k, nwg = gridDim.x;
-  double* parts = reinterpret_cast<double*>(a.scratch);                       // [nwg][KP]
-  unsigned int* ticket = reinterpret_cast<unsigned int*>(parts + (size_t)nwg * KP);   // zero between launches
+  const int tid = threadIdx.x, mk = a.m * a.k, k = a.k;
+  // Round 4: ONE trip to memory.  The rows of G do not depend on W': they are requested together with it.  And the column sums of
+  // G W' - the denominator of the next H update, updates.py:132 - are sum_m colsum(G)[m] W'[m, k] (fp64, workgroup 0, from the copy of
+  // W' it holds anyway) instead of the sum of the rows over the channels, which took per-workgroup partials, a drain, a ticket and
+  // the last workgroup's agent-scope loads: four more dependent round trips in a launch that is nothing but latency (14.3 us for 8
+  // workgroups at BASELINE configuration 5, profiles/r03l_ks_c5_128rows_kernel_stats.csv).  The two sums agree to the rounding of
+  // the fp32 rows (~1e-7 relative; an entry below gw_floor counts as itself, not as the floor: < 1e-30 each).
+  const int c = blockIdx.x * 256 + tid;
+  constexpr int GM = 32;   // entries of a row of G requested together (a dictionary has a few tens of columns)
+  float gv[GM];
+  const float* gc = a.g_t + (c < a.n ? c : 0);   // (the transposed copy: the lanes of a wave read neighbouring channels of one column of G)
+#pragma unroll
+  for (int u = 0; u < GM; ++u) gv[u] = (c < a.n && u < a.m) ? gc[(size_t)u * a.n_pad] : 0.f;
   for (int e = tid; e < mk; e += 256) s_w[e] = a.w_new[e];
   __syncthreads();
   // GW = G W' (updates.py:107 of the next half step), stored / xscale with a positive floor
-  double cs[KP];
-#pragma unroll
-  for (int kk = 0; kk < KP; ++kk) cs[kk] = 0.0;
   const float inv_scale = 1.f / a.xscale;
-  const int c = blockIdx.x * 256 + tid;
   if (c < a.n_pad) {
     float row[KP];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) row[kk] = (kk < k && c >= a.n) ? 1.f : 0.f;   // padding channels: X = 0 there, any positive value keeps X / Y = 0
     if (c < a.n) {
-      const float* gc = a.g_t + c;   // (the transposed copy: the lanes of a wave read neighbouring channels of one column of G)
-      for (int m0 = 0; m0 < a.m; m0 += 32) {   // up to 32 entries of the row of G requested together (a dictionary has a few tens of columns)
-        float gv[32];
+      for (int m0 = 0; m0 < a.m; m0 += GM) {
+        if (m0 > 0) {   // (more than GM columns: the further ones in batches of their own)
 #pragma unroll
-        for (int u = 0; u < 32; ++u) gv[u] = m0 + u < a.m ? gc[(size_t)(m0 + u) * a.n_pad] : 0.f;
+          for (int u = 0; u < GM; ++u) gv[u] = m0 + u < a.m ? gc[(size_t)(m0 + u) * a.n_pad] : 0.f;
+        }
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
+        for (int u = 0; u < GM; ++u)
           if (m0 + u < a.m) {
 #pragma unroll
             for (int kk = 0; kk < KP; ++kk)
@@ -1770,37 +1775,15 @@ __global__ __launch_bounds__(256) void w_gfinish_gw_kernel(const WFinishArgs a) 
       }
 #pragma unroll
       for (int kk = 0; kk < KP; ++kk)
-        if (kk < k) {
-          const float v = fmaxf(row[kk], a.gw_floor);
-          cs[kk] += (double)v;
-          row[kk] = v * inv_scale;
-        }
+        if (kk < k) row[kk] = fmaxf(row[kk], a.gw_floor) * inv_scale;
     }
     store_row_kp(a.gw_s + (size_t)c * KP, row);
   }
-  block_reduce<KP, KP>(cs, scratch);
-  if (tid == 0) {
-    // publish, then take a ticket.  No fences (a release writes back the XCD's whole L2: 20 us for this kernel with them): the
-    // partials are 8-byte agent-scope stores (write-through), drained by this lane before its ticket; the workgroup whose ticket
-    // is the last reads them with agent-scope loads after its add has returned (MI355X_MICROARCH.md, hand-offs with sc1 on both sides)
-    for (int kk = 0; kk < KP; ++kk) __hip_atomic_store(parts + (size_t)blockIdx.x * KP + kk, cs[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (unsigned int)nwg - 1u);
-  }
-  __syncthreads();
-  if (s_last && tid < KP) {   // (wave 0, the wave whose lane took the ticket) component tid: the partials in workgroup order - the same bits whoever is last
+  if (blockIdx.x == 0 && tid < KP) {
     double v = 0.0;
-    for (int b0 = 0; b0 < nwg; b0 += 8) {
-      double t8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        t8[u] = b0 + u < nwg ? __hip_atomic_load(parts + (size_t)(b0 + u) * KP + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += t8[u];
-    }
+    if (tid < k)
+      for (int mm = 0; mm < a.m; ++mm) v += (double)a.colsum_g[mm] * (double)s_w[mm * k + tid];
     a.colsum_gw[tid] = v;
-    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
   }
   if (blockIdx.x == 0 && a.hist_slot) {   // mean(W') and rel_W (base.py:323) over the m k entries: workgroup 0, from its copy of W' (needs nobody else)
     double sum_l = 0.0;

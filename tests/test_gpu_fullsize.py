@@ -262,3 +262,36 @@ def test_matrix_core_kernels_of_the_wide_build_at_full_size(store, tile):
     dh = (out["mfma"][0] - out["valu"][0]).abs().max().item()
     dw = ((out["mfma"][1] - out["valu"][1]).abs() / (out["valu"][1].abs() + 1e-6 * out["valu"][1].abs().mean())).max().item()
     assert dh < 2e-5 and dw < 2e-4, (dh, dw)
+
+
+@pytest.mark.parametrize("k", [9, 12, 16])
+@pytest.mark.parametrize("store", ["u8", "bf16"])
+def test_matrix_core_w_accumulation_is_bit_reproducible_over_200_launches(k, store):
+    """The gate on the 32-slot matrix instruction: `w_accum_mfma_kernel` of the wide build runs both its
+    contractions on gfx950's v_mfma_f32_16x16x32_bf16 (ESPM_MFMA_K32_MASK = 12), the form that made the H-step kernel differ from
+    run to run with two waves per SIMD (an ordering hazard that was not pinned down).  Two waves per SIMD is
+    how this kernel runs too; what protects it is that no launch has shown a differing bit.  Here: 200 launches from the same
+    state at the headline size, every slab of every launch compared with the first one on the device - one differing bit in
+    40 000 slabs fails the build.  (tools/ubench/mfma_k32_hazard.hip is the stand-alone reproducer.)"""
+    import ctypes
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine, _stream
+    prob = synth.make_problem(N, NX, NY, k, N=500.0, seed=3)
+    X = synth.sample_torch(prob, "cuda", seed=1003)
+    W0, H0 = synth.random_init(N, k, NX * NY, seed=3, scale=500.0 / N)
+    eng = MUEngine(X, k, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4, x_store=store)
+    del X
+    assert eng.x_store == store and eng.V.KP == 16 and eng.st.no_fused == 0      # matrix-core kernels allowed
+    eng.load_state(W0, H0)
+    eng.eval_current(advance_h=True)          # H' and its transposed copy, the inputs of the accumulation
+    eng._flush_finalize()
+    st, s = eng.st, _stream()
+    eng._check(eng.lib.espm_mu_w_accum(ctypes.byref(st), s))
+    ref = eng.a_slab.clone()
+    assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
+    differing = torch.zeros((), dtype=torch.int64, device=ref.device)
+    for _ in range(200):
+        eng.a_slab.fill_(-1.0)                # (a launch that skipped a slab would show)
+        eng._check(eng.lib.espm_mu_w_accum(ctypes.byref(st), s))
+        differing += (eng.a_slab != ref).any().to(torch.int64)
+    assert int(differing.item()) == 0, f"{int(differing.item())} of 200 launches differ from the first one"

@@ -34,8 +34,13 @@ kw = dict(layout="pm", shape_2d=(ROWS, NY), lambda_L=1.0, simplex_H=True, simple
 if C5:
     kw.update(G=prob["G"], mu=0.05)
 engs, ref = {}, None
+ENVS = {}   # name -> environment the build is RUN under (name=path@VAR=value,VAR2=value: knobs the library reads per launch)
 for spec in sys.argv[1:]:
     name, path = spec.split("=", 1)
+    if "@" in path:
+        path, envs = path.split("@", 1)
+        ENVS[name] = dict(e.split("=", 1) for e in envs.split(","))
+    os.environ.update(ENVS.get(name, {}))
     handle = _lib._load(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
     _lib._narrow = _lib.Variant(handle, _lib.KP, 1, _lib.MAX_K)
     eng = MUEngine(X, K, **kw)
@@ -55,14 +60,19 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     assert np.array_equal(eng.get_W(), out[0]) and np.array_equal(eng.history()["loss"], out[2]), f"{name}: not reproducible run to run"
     engs[name] = eng
+    for var in ENVS.get(name, {}):
+        os.environ.pop(var, None)
 del X
 best = {n: 1e9 for n in engs}
 for rep in range(REPS + 1):      # (the first round is the run-in)
     for name, eng in engs.items():
+        os.environ.update(ENVS.get(name, {}))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.iterate(ITERS, final_loss=False)
         torch.cuda.synchronize()
+        for var in ENVS.get(name, {}):
+            os.environ.pop(var, None)
         us = (time.perf_counter() - t0) / ITERS * 1e6
         if rep:
             best[name] = min(best[name], us)
