@@ -27,7 +27,13 @@
 #define ESPM_FUSED_SMALL_SEGS_DEFAULT 0
 #endif
 
+#ifndef ESPM_FUSED_PLAIN   // the lean instance of the common case (mu_fused_plain.hip); ESPM_FUSED_PLAIN=0 in the environment keeps the generic one (A/B)
+#define ESPM_FUSED_PLAIN 1
+#endif
+
 namespace espm {
+
+int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_plain.hip
 
 #if ESPM_MIN_K <= 8
 template <int K>
@@ -99,6 +105,19 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   if (args.h.tail_on && !args.h.tail.pg_q) args.h.tail_on = 2;
   if (bytes > ((args.perm_lds && pb == ESPM_ELL_PB) || args.red_lds_off >= 0 ? ESPM_FUSED_LDS_LIMIT : ESPM_ELL_LDS_MAX))
     return set_error(ESPM_EUNSUPPORTED, "fused half-steps: %zu bytes of LDS exceed %d", bytes, ESPM_ELL_LDS_MAX);
+  // the common case as its own, leaner instance (mu_fused_kernel.hpp: PLAIN; instantiated in mu_fused_plain.hip): every fact the
+  // kernel takes for granted is checked here
+  {
+    const int NT = ESPM_ELL_WTHREADS;
+    const int n_perm = args.perm_lds ? pb + 64 * args.w.n_cg : 0, n_woff = 2 * args.w.n_cg + 1;
+    const bool staged_ok = args.h.n_pad <= 4 * NT && n_perm <= 4 * NT && n_woff <= NT && args.h.cs_nbk <= 64 && 2 * K <= NT / 64;
+    const char* env = getenv("ESPM_FUSED_PLAIN");
+    const bool plain = ESPM_FUSED_PLAIN && !(env && env[0] == '0') && !args.h.mu && !args.h.fixed_h && !args.h.fill_num && !args.h.breg_sr && !args.h.l2_m &&
+                       args.h.simplex_h && args.h.lambda_l != 0.f && args.h.grid_mode && args.h.have_prev && args.h.write_h && args.h.h_rule == 0 &&
+                       args.h.tail_on != 1 && !args.static_units && args.slab_lds && !args.w_split && args.red_lds_off >= 0 && staged_ok &&
+                       (args.perm_lds != 0) == (pb != ESPM_ELL_PB) && ESPM_FUSED_SMALL_THREADS == ESPM_ELL_WTHREADS;
+    if (plain) return launch_fused_plain(args, K, args.h.compute_loss != 0, pb == ESPM_ELL_PB, nblk, bytes, stream);
+  }
   auto go = [&](auto kern, int threads) -> int {
     if (bytes > 64 * 1024)
       if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),

@@ -139,7 +139,10 @@ struct FusedGeom {
   }
 };
 
-template <int K, bool LOSS, int UNR_H, int UNR_W, int NT, bool FULL>   // FULL: the full geometry, block and tile sizes are constants
+// PLAIN: the common case as compile-time facts (h_epilogue's PLAIN, plus: the prologue's staged form applies, no extra tail workgroup,
+// dynamic units, the slab collected in LDS, scratch of its own for the record reduction) - the launcher checks every one of them on the
+// host (launch_fused_k) and takes the generic instance otherwise.  Instantiated in mu_fused_plain.hip.
+template <int K, bool LOSS, int UNR_H, int UNR_W, int NT, bool FULL, bool PLAIN = false>   // FULL: the full geometry, block and tile sizes are constants
 __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   static_assert(!FULL || NT == ESPM_ELL_WTHREADS, "full geometry: 1024 threads");
   static_assert(ESPM_ELL_PB == 2 * ESPM_ELL_TILE && ESPM_ELL_WTHREADS == ESPM_ELL_PB, "full geometry: a workgroup is two H tiles, one thread per pixel");
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const int tab_rows = a.n_pad > PB ? a.n_pad : PB;
   float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
   int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk
-  if (a.tail_on == 1 && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
+  if (!PLAIN && a.tail_on == 1 && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
     w_tail_body<(10 * ESPM_ELL_WTHREADS) / NT>(a.tail, reinterpret_cast<double*>(smem));
     ESPM_PHASE_STAMP(7);   // (instrumented build: when the extra workgroup got a CU - stamp 0 - and when it was done)
     return;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   int* meta = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.meta_lds_off);
   int* lpix = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.perm_lds_off);
   int* lchan = lpix + PB;
-  const bool perm_lds = !FULL || fa.perm_lds;   // (uniform)
+  const bool perm_lds = PLAIN ? !FULL : (!FULL || fa.perm_lds);   // (uniform)
   // ---- prologue: GW table, the block's list offsets and permutations, the column sums of G W' -> LDS.
   // ESPM_FUSED_PROLOGUE_BATCH: every global load of the prologue is issued before the first result is consumed.  As loops
   // with run-time trip counts (the round-2 form, kept below) each of the five pieces waited for its own loads: five serial
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   if constexpr (ESPM_FUSED_PROLOGUE_BATCH) {
     constexpr int TR = 4, PC = 4;   // table rows / permutation entries a thread stages
     const int n_perm = perm_lds ? PB + 64 * fa.w.n_cg : 0, n_woff = 2 * fa.w.n_cg + 1;
-    staged = a.n_pad <= TR * NT && n_perm <= PC * NT && n_woff <= NT && a.cs_nbk <= 64 && 2 * K <= NT / 64;   // (uniform)
+    staged = PLAIN || (a.n_pad <= TR * NT && n_perm <= PC * NT && n_woff <= NT && a.cs_nbk <= 64 && 2 * K <= NT / 64);   // (uniform; fused_prologue_staged on the host)
     if (staged) {
       float4 tlo[TR], thi[TR];
 #pragma unroll
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
     }
   }
-  if (!staged) {
+  if (!PLAIN && !staged) {
     if (cs_lds) {      // wave w: column sums w, w + NT / 64, ... of G W' from the W update's partials (shared tail: then the sums of W' as well)
       for (int kk = threadIdx.x >> 6; kk < (spread ? 2 * K : K); kk += NT / 64) {
         double v = 0.0;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       for (int kk = 0; kk < K; ++kk) sw += cs_lds[KP + kk];
       const float shift = (float)((double)a.tail.rel_tol * (sw / (double)rw_n));   // tol * mean(W'), base.py:323
       relw = 0.f;
-      if (rw_staged && staged) {
+      if (rw_staged && (PLAIN || staged)) {
 #pragma unroll
         for (int u = 0; u < RW; ++u)
           if (rw_lo + (int)threadIdx.x + u * NT < rw_hi) relw = fmaxf(relw, fabsf(rwn[u] - rwo[u]) / (rwn[u] + shift));
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const int blk0 = blockIdx.x * PB;
   int own_next[2] = {(int)(threadIdx.x >> 6), (int)(threadIdx.x >> 6)};
   auto next_unit = [&](int which) {
-    if (fa.static_units) {
+    if (!PLAIN && fa.static_units) {
       const int u = own_next[which];
       own_next[which] += NT / 64;
       return __builtin_amdgcn_readfirstlane(u);
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
-  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : ESPM_FUSED_MAX_SEGS) : 0>(a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
-                                                     fa.red_lds_off >= 0 ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr,
-                                                     relw);
+  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : ESPM_FUSED_MAX_SEGS) : 0, PLAIN>(
+      a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
+      (PLAIN || fa.red_lds_off >= 0) ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr, relw);
 
   ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
@@ -359,7 +362,8 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   // of a group cut in two (unit rows and general rows each), half h adding up in copy h, the two copies summed at the write-out in that
   // order whoever walked them.  Why: 32 units on 16 waves leave nothing to hand to the wave that is done early, and the waves of a
   // SIMD are served oldest first - the W walk's youngest waves ended 5 us after wave 0 (profiles/r04c_phase_clock_512rows.log).
-  const bool w_split = ESPM_FUSED_W_SPLIT && fa.w_split;   // (uniform)
+  const bool w_split = !PLAIN && ESPM_FUSED_W_SPLIT && fa.w_split;   // (uniform)
+  const bool slab_lds = PLAIN || (ESPM_FUSED_SLAB_LDS && fa.slab_lds);   // (uniform)
   const int w_units = w_split ? 2 * w.n_cg : w.n_cg;
   for (int wu = next_unit(1); wu < w_units; wu = next_unit(1)) {
     const int cg = w_split ? wu >> 1 : wu, whalf = w_split ? wu & 1 : 0;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     });
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (c >= 0) {
-      if (ESPM_FUSED_SLAB_LDS && fa.slab_lds) {   // (uniform)
+      if (slab_lds) {
         float* copy = part + (size_t)whalf * K * w.n_pad;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) copy[(size_t)kk * w.n_pad + c] = acc[kk];
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   }
   ESPM_PHASE_STAMP(6);   // wave 0 found no channel group left
   ESPM_WAVE_STAMP(24);
-  if (ESPM_FUSED_SLAB_LDS && fa.slab_lds) {
+  if (slab_lds) {
     __syncthreads();
     // rows of the slab, 16 bytes per store, write-through (sc0 sc1: the line leaves the XCD's L2 now, not at the end of the launch);
     // the entries of the channels n .. n_pad - 1 belong to no list: zeros, as the scattered stores left them

@@ -1,0 +1,52 @@
+// The fused half-steps' common case as instances of their own (mu_fused_kernel.hpp, template parameter PLAIN): simplex over H, Laplacian
+// on an image grid, a previous H to compare with, no mu / fixed_H / fill numerators / Bregman / Frobenius, the staged prologue, dynamic
+// units, the slab collected in LDS.  launch_fused_k (mu_fused.hip) checks those facts on the host and calls launch_fused_plain; anything
+// else takes the generic instance.  A translation unit of its own so that the two sets of instances compile side by side.
+#include "mu_fused_kernel.hpp"
+
+#ifndef ESPM_ELL_UNR_H
+#define ESPM_ELL_UNR_H 4
+#endif
+#ifndef ESPM_ELL_UNR_W
+#define ESPM_ELL_UNR_W 4
+#endif
+#ifndef ESPM_FUSED_SMALL_UNR_H
+#define ESPM_FUSED_SMALL_UNR_H ESPM_ELL_UNR_H
+#endif
+#ifndef ESPM_FUSED_SMALL_UNR_W
+#define ESPM_FUSED_SMALL_UNR_W ESPM_ELL_UNR_W
+#endif
+
+namespace espm {
+
+#if ESPM_MIN_K <= 8
+template <int K>
+static int launch_plain_k(const FusedArgs& args, bool loss, bool full, int nblk, size_t bytes, hipStream_t stream) {
+  auto go = [&](auto kern) -> int {
+    if (bytes > 64 * 1024)
+      if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                             "fused half-steps (plain)"))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(ESPM_ELL_WTHREADS), bytes, stream, args);
+    return check_hip(hipGetLastError(), "fused half-steps (plain) launch");
+  };
+  if (full)
+    return loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true>)
+                : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true>);
+  return loss ? go(mu_fused_ell_kernel<K, true, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_ELL_WTHREADS, false, true>)
+              : go(mu_fused_ell_kernel<K, false, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_ELL_WTHREADS, false, true>);
+}
+#endif
+
+int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream) {
+  switch (k) {
+#if ESPM_MIN_K <= 8
+#define ESPM_X(KK) case KK: return launch_plain_k<KK>(args, loss, full, nblk, lds_bytes, stream);
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
+#endif
+  }
+  return set_error(ESPM_EUNSUPPORTED, "fused half-steps (plain): k=%d not built", k);
+}
+
+}  // namespace espm

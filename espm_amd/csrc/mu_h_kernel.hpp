@@ -48,12 +48,12 @@ struct HEpiIn {
   float l[K], r[K], u[K], d[K];   // the four neighbours (raw: combined after the barrier, so that nothing waits for them before it)
   float wl, wr, wu, wd;           // 1 where the neighbour exists, else 0
 };
-template <int K>
+template <int K, bool PLAIN = false>
 __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool stencil, HEpiIn<K>& v) {
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) {
     v.hin[kk] = a.h_in[(size_t)kk * a.p_pad + q];
-    v.hprev[kk] = a.have_prev ? a.h_out[(size_t)kk * a.p_pad + q] : 0.f;
+    v.hprev[kk] = (PLAIN || a.have_prev) ? a.h_out[(size_t)kk * a.p_pad + q] : 0.f;
     v.l[kk] = v.r[kk] = v.u[kk] = v.d[kk] = 0.f;
   }
   v.wl = v.wr = v.wu = v.wd = 0.f;
@@ -97,7 +97,11 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // from memory (staging those in LDS in the prologue made it 3.1): the once-executed code of this kernel is fetched from L2 by every CU at
 // every launch, and more unrolled code is more of that: profiles/r03c / r03d / r03e_phase_clock_64rows.log.  The callers pass 0.)
 // relw_lane: this lane's share of rel_W of the W update that produced the input state (record field ESPM_HP_RELW), -1: none.
-template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0>
+// PLAIN (the fused kernel's common case, mu_fused_plain.hip): what the launcher has checked on the host becomes a compile-time fact -
+// simplex over H, Laplacian on an image grid, a previous H to compare with, H' written; no mu, no fixed_H, no fill numerators, neither
+// the Bregman nor the Frobenius variant.  The generic instance keeps ~100 scalar registers of flags and pointers alive through every
+// phase (107-165 of them spilled to vector lanes) and walks their branches in 16 waves that share one scalar unit.
+template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0, bool PLAIN = false>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
                                            float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false,
@@ -112,16 +116,22 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   red[ESPM_HP_KL] = kl_lane;
   red[R_RELW] = relw_lane;
   double pg_q = 0.0;   // rule 2: <H' - H, grad> + gamma ||H' - H||^2 of this thread's pixels (the linesearch's quadratic bound)
-  const bool stencil = a.lambda_l != 0.f && a.grid_mode;
+  static_assert(!PLAIN || RULE == 0, "the plain instance: the default H rule");
+  // the features as facts (PLAIN) or as the run-time flags they are
+  const bool f_fill = PLAIN ? false : a.fill_num != nullptr, f_breg = PLAIN ? false : a.breg_sr != nullptr, f_l2 = PLAIN ? false : a.l2_m != nullptr;
+  const bool f_mu = PLAIN ? false : a.mu != nullptr, f_fixed = PLAIN ? false : a.fixed_h != nullptr;
+  const bool f_prev = PLAIN ? true : a.have_prev != 0, f_lap = PLAIN ? true : a.lambda_l != 0.f, f_grid = PLAIN ? true : a.grid_mode != 0;
+  const bool f_write = PLAIN ? true : a.write_h != 0, f_simplex = PLAIN ? true : a.simplex_h != 0;
+  const bool stencil = f_lap && f_grid;
   HEpiIn<K> in;
   bool loaded = false;
   if (EARLY && K <= 6 && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {   // (k = 7, 8: too many registers to hold across the barrier)
-    h_epilogue_load<K>(a, tile0 + (int)threadIdx.x, stencil, in);
+    h_epilogue_load<K, PLAIN>(a, tile0 + (int)threadIdx.x, stencil, in);
     loaded = true;
   }
   // likewise ahead of the barrier: what every pixel needs of the state's global statistics (scalar loads the compiler may
   // not move across a barrier itself) and the pixel's loss constant / fill mark
-  const bool want_klc = kl_rows || a.fill_num;
+  const bool want_klc = kl_rows || f_fill;
   float klc_first = 0.f;
   bool klc_loaded = false;
   if (want_klc && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {
@@ -129,7 +139,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     klc_loaded = true;
   }
   float rel_shift = 0.f;
-  if (a.have_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
+  if (f_prev) {  // base.py:324: tol * mean(H) of the state being evaluated (global row sums)
     double tot = 0.0;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) tot += a.hstat_in[ESPM_HS_ROWSUM + kk];
@@ -137,7 +147,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
   float mhv[K];   // GLOBAL max over pixels of every row of H, updates.py:139
 #pragma unroll
-  for (int kk = 0; kk < K; ++kk) mhv[kk] = (RULE == 0 && a.lambda_l != 0.f) ? (float)a.hstat_in[ESPM_HS_MAX + kk] : 0.f;
+  for (int kk = 0; kk < K; ++kk) mhv[kk] = (RULE == 0 && f_lap) ? (float)a.hstat_in[ESPM_HS_MAX + kk] : 0.f;
   __syncthreads();
   ESPM_PHASE_STAMP(3);
 
@@ -158,7 +168,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       if (lds_tab) lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f));
       continue;
     }
-    if (!loaded) h_epilogue_load<K>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
+    if (!loaded) h_epilogue_load<K, PLAIN>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
     loaded = false;
     const float klc = klc_loaded ? klc_first : (want_klc ? a.ell_klc[q] : 0.f);
     klc_loaded = false;
@@ -201,7 +211,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       }
     }
     ESPM_PHASE_STAMP(40);   // (instrumented build) partial numerators summed
-    if (a.fill_num) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
+    if (f_fill) {  // (uniform) sparse store: a pixel without counts takes the numerator of its log_shift fill (include/espm_mu.h)
       const float mark = klc;
       if (mark < 0.f) {
         const int idx = (int)(-mark) - 1;
@@ -209,7 +219,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         for (int kk = 0; kk < K; ++kk) nv[kk] += a.fill_num[(size_t)kk * a.fill_n + idx] * a.xscale;
       }
     }
-    if (a.breg_sr) {  // Bregman variant, updates.py:120-125: num = sR / H, denum = colsum(GW) - GW^T (X / GWH) + sR / H
+    if (f_breg) {  // Bregman variant, updates.py:120-125: num = sR / H, denum = colsum(GW) - GW^T (X / GWH) + sR / H
       const float sr = a.xscale * a.breg_sr[q];
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
@@ -218,7 +228,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         nv[kk] = t;
       }
     }
-    if (a.l2_m) {  // Frobenius branch: denum = (GW^T GW) H, updates.py:115-118
+    if (f_l2) {  // Frobenius branch: denum = (GW^T GW) H, updates.py:115-118
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         float d = 0.f;
@@ -227,7 +237,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         dv[kk] = d;
       }
     }
-    if (a.have_prev) {
+    if (f_prev) {
       // rel_H of the update that produced h_in: the other buffer still holds the previous H
       // (each thread reads its own entries before overwriting them below), base.py:324
       float worst = 0.f;
@@ -237,7 +247,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     }
     constexpr bool quad = RULE == 1;   // quadratic surrogate of the Laplacian term (multiplicative_step_hq, updates.py:263-315)
     constexpr bool pgrad = RULE == 2;  // projected gradient (proj_grad_step_h, updates.py:372-395)
-    if (a.mu) {
+    if (f_mu) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         const float m = a.mu[kk];
@@ -248,11 +258,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     float hlv[K];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) hlv[kk] = 0.f;
-    if (a.lambda_l != 0.f) {
+    if (f_lap) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         // (H L)[q] = deg(q) H[q] - sum of the existing neighbours, utils.py:39-76
-        const float hl = a.grid_mode ? ((in.wl + in.wr) + (in.wu + in.wd)) * hin[kk] -
+        const float hl = f_grid ? ((in.wl + in.wr) + (in.wu + in.wd)) * hin[kk] -
                                            (((in.wl * in.l[kk] + in.wr * in.r[kk]) + in.wu * in.u[kk]) + in.wd * in.d[kk])
                                      : hin[kk];
         hlv[kk] = hl;
@@ -265,7 +275,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         if constexpr (pgrad) dv[kk] += a.lambda_l * hl;           // gradient of the Laplacian term, updates.py:349-350
       }
     }
-    if (!a.write_h) continue;
+    if (!f_write) continue;
     if constexpr (pgrad) {
       // H - grad / gamma with grad = -GW^T (X / GWH) + colsum(GW) + mu / (H + eps) + lambda (H L) = dv - nv, then the
       // projection on the simplex: nu with sum_k max(h_k + nu, eps) = 1 (dicotomy.py:84-108).  The sum is convex, piecewise
@@ -279,7 +289,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         hmin = fminf(hmin, hg[kk]);
       }
       float nu = 0.f;
-      if (a.simplex_h) {
+      if (f_simplex) {
         nu = 1.f / (float)K - hmin;
         for (int it = 0; it < K + 2; ++it) {
           float f = -1.f, cnt = 0.f;
@@ -298,7 +308,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         float hn = fmaxf(hg[kk] + nu, a.log_shift);
-        if (a.fixed_h) {
+        if (f_fixed) {
           const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
           if (f >= 0.f) hn = f;
         }
@@ -315,7 +325,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       emit_ht(q, jj, ht);
       continue;
     }
-    if constexpr (quad) if (a.lambda_l != 0.f) {
+    if constexpr (quad) if (f_lap) {
       // a H'^2 + b H' - c = 0 with a = lambda sigma, b = colsum(GW) + lambda (H L) - lambda sigma H (+ nu), c = H GW^T (X / GWH)
       float bq[K], cq[K];
 #pragma unroll
@@ -325,14 +335,14 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       }
       const float inv2a = __builtin_amdgcn_rcpf(2.f * ls);
       float nu = 0.f;
-      if (a.simplex_h && !simplex_root_hq<K>(ls, bq, cq, a.log_shift, 100, nu)) red[ESPM_HP_BAD] += 1.f;
+      if (f_simplex && !simplex_root_hq<K>(ls, bq, cq, a.log_shift, 100, nu)) red[ESPM_HP_BAD] += 1.f;
       float ht[KP];
 #pragma unroll
       for (int kk = 0; kk < KP; ++kk) ht[kk] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         float hn = fmaxf(hq_root(bq[kk] + nu, 4.f * ls * cq[kk]) * inv2a, a.log_shift);   // updates.py:300, :307
-        if (a.fixed_h) {
+        if (f_fixed) {
           const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
           if (f >= 0.f) hn = f;
         }
@@ -351,7 +361,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 #ifdef ESPM_EXPERIMENT_NO_SIMPLEX_ROOT   // TIMING ONLY: what the per-pixel multiplier search costs on the critical path
     if (false) {
 #else
-    if (a.simplex_h) {
+    if (f_simplex) {
 #endif
       float delta, e[K];
       if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.f;
@@ -365,7 +375,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) {
       float hn = fmaxf(nv[kk] * __builtin_amdgcn_rcpf(dv[kk]), a.log_shift);   // updates.py:152 (v_rcp_f32: 1 ulp)
-      if (a.fixed_h) {
+      if (f_fixed) {
         const float f = a.fixed_h[(size_t)kk * a.p_pad + q];
         if (f >= 0.f) hn = f;                                   // updates.py:154-155
       }

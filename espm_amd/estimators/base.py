@@ -679,73 +679,98 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         stop = False
         if lazy is not None:
             lazy.start()
+        G_start = None if self.physics_model_ is None else np.array(self.G_, copy=True)
+        retried = False
         try:
-            eng.eval_current(advance_h=True)  # loss of the initial state rides on the first H-step
-            while not stop:
-                # how many iterations may run before the host has to look at a loss value
-                if sync_each:
-                    chunk = 1
-                else:
-                    chunk = self.max_iter - self.n_iter_
-                    if self.verbose > 0:
-                        chunk = min(chunk, self.eval_print - self.n_iter_ % self.eval_print)
-                    chunk = max(chunk, 1)
-                if pg_ls:  # smooth_nmf.py:382-401: gamma_H from the quadratic bound, before the W-step
-                    self.gamma_[0] = eng.pg_linesearch_h(self.gamma_[0])
-                eng.finish_iteration()
-                if adapt:  # smooth_nmf.py:376-381: gamma_ follows the Laplacian surrogate; in effect from the next H-step
-                    self.gamma_ = eng.linesearch_step(self._gamma_value())
-                if chunk > 1:
-                    eng.iterate(chunk - 1, final_loss=False)
-                    eng.eval_current(advance_h=(self.n_iter_ + chunk) < self.max_iter)
-                else:
-                    last = self.n_iter_ + 1 >= self.max_iter
-                    refresh_G = self.physics_model_ is not None and (self.n_iter_ + 1) % 3 == 0
-                    eng.eval_current(advance_h=not (last or refresh_G))
-                if pg_ls:  # smooth_nmf.py:438-447: gamma_W, once the new state has been evaluated
-                    self.gamma_[1] = eng.pg_linesearch_w(self.gamma_[1])
-                first = self.n_iter_ + 1
-                self.n_iter_ += chunk
-                h = eng.history(upto=self.n_iter_)
-                if eval_init is None:
-                    eval_init = float(h["loss"][0])
-                for t in range(first, self.n_iter_ + 1):
-                    self.losses_.append(float(h["loss"][t]))
-                    self.detailed_losses_.append(self._detailed(float(h["kl"][t]), float(h["reg"][t]),
-                                                                float(h["lap"][t])))
-                    self.rel_.append([float(h["rel_W"][t]), float(h["rel_H"][t])])
-                if track:
-                    self._track_truth(eng)
-                eval_after = self.losses_[-1]
-                rel_W, rel_H = self.rel_[-1]
+            while True:   # (a second pass only after a sharded fit has had to change its record exchange, below)
+                try:
+                    eng.eval_current(advance_h=True)  # loss of the initial state rides on the first H-step
+                    while not stop:
+                        # how many iterations may run before the host has to look at a loss value
+                        if sync_each:
+                            chunk = 1
+                        else:
+                            chunk = self.max_iter - self.n_iter_
+                            if self.verbose > 0:
+                                chunk = min(chunk, self.eval_print - self.n_iter_ % self.eval_print)
+                            chunk = max(chunk, 1)
+                        if pg_ls:  # smooth_nmf.py:382-401: gamma_H from the quadratic bound, before the W-step
+                            self.gamma_[0] = eng.pg_linesearch_h(self.gamma_[0])
+                        eng.finish_iteration()
+                        if adapt:  # smooth_nmf.py:376-381: gamma_ follows the Laplacian surrogate; in effect from the next H-step
+                            self.gamma_ = eng.linesearch_step(self._gamma_value())
+                        if chunk > 1:
+                            eng.iterate(chunk - 1, final_loss=False)
+                            eng.eval_current(advance_h=(self.n_iter_ + chunk) < self.max_iter)
+                        else:
+                            last = self.n_iter_ + 1 >= self.max_iter
+                            refresh_G = self.physics_model_ is not None and (self.n_iter_ + 1) % 3 == 0
+                            eng.eval_current(advance_h=not (last or refresh_G))
+                        if pg_ls:  # smooth_nmf.py:438-447: gamma_W, once the new state has been evaluated
+                            self.gamma_[1] = eng.pg_linesearch_w(self.gamma_[1])
+                        first = self.n_iter_ + 1
+                        self.n_iter_ += chunk
+                        h = eng.history(upto=self.n_iter_)
+                        if eval_init is None:
+                            eval_init = float(h["loss"][0])
+                        for t in range(first, self.n_iter_ + 1):
+                            self.losses_.append(float(h["loss"][t]))
+                            self.detailed_losses_.append(self._detailed(float(h["kl"][t]), float(h["reg"][t]),
+                                                                        float(h["lap"][t])))
+                            self.rel_.append([float(h["rel_W"][t]), float(h["rel_H"][t])])
+                        if track:
+                            self._track_truth(eng)
+                        eval_after = self.losses_[-1]
+                        rel_W, rel_H = self.rel_[-1]
 
-                if self.n_iter_ >= self.max_iter:  # base.py:354-378
-                    say("exits because max_iteration was reached")
+                        if self.n_iter_ >= self.max_iter:  # base.py:354-378
+                            say("exits because max_iteration was reached")
+                            break
+                        if not self.no_stop_criterion:
+                            if max(rel_H, rel_W) < self.tol:
+                                say("exits because of relative change rel_A {} and rel_P {} < tol ".format(rel_H, rel_W))
+                                break
+                            elif abs((eval_before - eval_after) / eval_init) < self.tol:
+                                say("exits because of relative change < tol: {}".format((eval_before - eval_after) / eval_init))
+                                break
+                            elif np.isnan(eval_after):
+                                say("exit because of the presence of NaN")
+                                break
+                            elif (eval_before - eval_after) < 0:
+                                say("exit because of negative decrease {}: {}, {}".format((eval_before - eval_after),
+                                                                                             eval_before, eval_after))
+                                break
+                        if self.verbose > 0 and np.mod(self.n_iter_, self.eval_print) == 0:
+                            say(f"It {self.n_iter_} / {self.max_iter}: loss {eval_after:3e},  "
+                                  f"{self.n_iter_ / (time.time() - algo_start + log_shift):0.3f} it/s")
+                        if self.physics_model_ is not None and self.n_iter_ % 3 == 0:  # base.py:388-392
+                            self.G_ = self.physics_model_.NMF_update(eng.get_W().astype(out_dtype))
+                            eng.set_G(self.G_)
+                            eng.eval_current(advance_h=True)
+                            eval_before = float(eng.history(upto=self.n_iter_)["loss"][self.n_iter_])
+                        else:
+                            eval_before = eval_after
                     break
-                if not self.no_stop_criterion:
-                    if max(rel_H, rel_W) < self.tol:
-                        say("exits because of relative change rel_A {} and rel_P {} < tol ".format(rel_H, rel_W))
-                        break
-                    elif abs((eval_before - eval_after) / eval_init) < self.tol:
-                        say("exits because of relative change < tol: {}".format((eval_before - eval_after) / eval_init))
-                        break
-                    elif np.isnan(eval_after):
-                        say("exit because of the presence of NaN")
-                        break
-                    elif (eval_before - eval_after) < 0:
-                        say("exit because of negative decrease {}: {}, {}".format((eval_before - eval_after),
-                                                                                     eval_before, eval_after))
-                        break
-                if self.verbose > 0 and np.mod(self.n_iter_, self.eval_print) == 0:
-                    say(f"It {self.n_iter_} / {self.max_iter}: loss {eval_after:3e},  "
-                          f"{self.n_iter_ / (time.time() - algo_start + log_shift):0.3f} it/s")
-                if self.physics_model_ is not None and self.n_iter_ % 3 == 0:  # base.py:388-392
-                    self.G_ = self.physics_model_.NMF_update(eng.get_W().astype(out_dtype))
-                    eng.set_G(self.G_)
-                    eng.eval_current(advance_h=True)
-                    eval_before = float(eng.history(upto=self.n_iter_)["loss"][self.n_iter_])
-                else:
-                    eval_before = eval_after
+                except Exception as e:   # noqa: BLE001
+                    # A sharded fit on the one-shot record exchange whose bounded waits gave up AFTER the rehearsal before the loop
+                    # (MUEngine.settle_exchange): history() raises on every rank at the same read-back (the health is a maximum over the ranks).
+                    # Every rank then moves to the collective transport and the fit starts again from its initial W, H, G (the
+                    # estimator needs the fallback bench.py has).  Anything else, or a second failure, is the caller's.
+                    from espm_amd._lib import EspmError
+                    lost = isinstance(e, EspmError) and "lost a peer" in str(e)
+                    if not lost or retried or shard is None or getattr(eng.exchange, "ctx", None) is None:
+                        raise
+                    retried = True
+                    say("record exchange: a peer was lost on the one-shot transport; restarting the fit on the collective transport")
+                    eng.use_collective_exchange()
+                    if G_start is not None:
+                        self.G_ = G_start
+                        eng.set_G(self.G_)
+                    eng.load_state(self.W_, shard.cols(self.H_))
+                    self.n_iter_, stop, eval_before, eval_init = 0, False, np.inf, None
+                    self.losses_, self.rel_, self.detailed_losses_ = [], [], []
+                    self._begin_fit()
+                    track = self._begin_truth_tracking()
         except KeyboardInterrupt:
             pass
         finally:
