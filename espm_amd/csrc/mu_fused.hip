@@ -34,6 +34,9 @@
 namespace espm {
 
 int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_plain.hip
+#ifdef ESPM_PHASE_CLOCK
+int phase_buffer_plain(unsigned long long* p);
+#endif
 
 #if ESPM_MIN_K <= 8
 template <int K>
@@ -175,6 +178,7 @@ int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStrea
 // debug build only (tools/analysis/phase_clock.py): where the fused kernel's workgroups write their phase stamps (8 x uint64 per workgroup)
 extern "C" int espm_debug_phase_buffer(void* dev_ptr) {
   unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+  if (int rc = espm::phase_buffer_plain(p)) return rc;
   return espm::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm::espm_phase_buf), &p, sizeof(p)), "phase buffer");
 }
 #endif

@@ -49,4 +49,9 @@ int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int n
   return set_error(ESPM_EUNSUPPORTED, "fused half-steps (plain): k=%d not built", k);
 }
 
+#ifdef ESPM_PHASE_CLOCK
+// (debug build: this translation unit has its own copy of the stamp buffer's pointer - device globals are per unit without -fgpu-rdc)
+int phase_buffer_plain(unsigned long long* p) { return check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm_phase_buf), &p, sizeof(p)), "phase buffer (plain)"); }
+#endif
+
 }  // namespace espm

@@ -1745,6 +1745,34 @@ __global__ __launch_bounds__(256) void w_gfinish_gw_kernel(const WFinishArgs a) 
   // the last workgroup's agent-scope loads: four more dependent round trips in a launch that is nothing but latency (14.3 us for 8
   // workgroups at BASELINE configuration 5, profiles/r03l_ks_c5_128rows_kernel_stats.csv).  The two sums agree to the rounding of
   // the fp32 rows (~1e-7 relative; an entry below gw_floor counts as itself, not as the floor: < 1e-30 each).
+  // The LAST workgroup has no rows: it forms the column sums, mean(W') and rel_W - two block reductions behind loads of their own (W',
+  // W, colsum(G), all requested at its start) - next to the row workgroups instead of behind workgroup 0's rows.
+  if (blockIdx.x == gridDim.x - 1) {
+    float wo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wo[u] = (tid + 256 * u < mk && a.hist_slot) ? a.w_old[tid + 256 * u] : 1.f;   // (up to 1024 entries requested with W'; beyond that in the loop)
+    for (int e = tid; e < mk; e += 256) s_w[e] = a.w_new[e];
+    __syncthreads();
+    if (tid < KP) {
+      double v = 0.0;
+      if (tid < k)
+        for (int mm = 0; mm < a.m; ++mm) v += (double)a.colsum_g[mm] * (double)s_w[mm * k + tid];
+      a.colsum_gw[tid] = v;
+    }
+    if (a.hist_slot) {   // mean(W') and rel_W (base.py:323) over the m k entries
+      double sum_l = 0.0;
+      for (int e = tid; e < mk; e += 256) sum_l += (double)s_w[e];
+      const double mean_w = block_sum1(sum_l, scratch) / (double)mk;
+      double rel_l = 0.0;
+      for (int e = tid, u = 0; e < mk; e += 256, ++u) {
+        const double wn = s_w[e], wov = u < 4 ? wo[u] : a.w_old[e];
+        rel_l = fmax(rel_l, fabs(wn - wov) / (wn + (double)a.rel_tol * mean_w));
+      }
+      const double rel_w = block_max1(rel_l, scratch);
+      if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = rel_w;
+    }
+    return;
+  }
   const int c = blockIdx.x * 256 + tid;
   constexpr int GM = 32;   // entries of a row of G requested together (a dictionary has a few tens of columns)
   float gv[GM];
@@ -1778,24 +1806,6 @@ __global__ __launch_bounds__(256) void w_gfinish_gw_kernel(const WFinishArgs a) 
         if (kk < k) row[kk] = fmaxf(row[kk], a.gw_floor) * inv_scale;
     }
     store_row_kp(a.gw_s + (size_t)c * KP, row);
-  }
-  if (blockIdx.x == 0 && tid < KP) {
-    double v = 0.0;
-    if (tid < k)
-      for (int mm = 0; mm < a.m; ++mm) v += (double)a.colsum_g[mm] * (double)s_w[mm * k + tid];
-    a.colsum_gw[tid] = v;
-  }
-  if (blockIdx.x == 0 && a.hist_slot) {   // mean(W') and rel_W (base.py:323) over the m k entries: workgroup 0, from its copy of W' (needs nobody else)
-    double sum_l = 0.0;
-    for (int e = tid; e < mk; e += 256) sum_l += (double)s_w[e];
-    const double mean_w = block_sum1(sum_l, scratch) / (double)mk;
-    double rel_l = 0.0;
-    for (int e = tid; e < mk; e += 256) {
-      const double wn = s_w[e], wo = a.w_old[e];
-      rel_l = fmax(rel_l, fabs(wn - wo) / (wn + (double)a.rel_tol * mean_w));
-    }
-    const double rel_w = block_max1(rel_l, scratch);
-    if (tid == 0) a.hist_slot[ESPM_HI_REL_W] = rel_w;
   }
 }
 
@@ -2019,7 +2029,7 @@ static bool w_gsplit_enabled() {
 
 int launch_w_gfinish_gw(const WFinishArgs& args, hipStream_t stream) {
   const int nwg_b = (args.n_pad + 255) / 256;
-  hipLaunchKernelGGL(w_gfinish_gw_kernel, dim3(nwg_b), dim3(256), (size_t)args.m * args.k * sizeof(float), stream, args);
+  hipLaunchKernelGGL(w_gfinish_gw_kernel, dim3(nwg_b + 1), dim3(256), (size_t)args.m * args.k * sizeof(float), stream, args);
   return check_hip(hipGetLastError(), "w_finish (dictionary G: rows of G W')");
 }
 
