@@ -73,3 +73,21 @@ def unit_bank_spread(words, off):
                 good += int((np.diff(q, axis=1) != 0).all(axis=1).sum())
                 total += q.shape[0]
     return good / max(total, 1), total
+
+
+def unit_bank_spread_b32(words, off):
+    """Share of the (unit row, half, 32-lane half of the wave) triples whose 32 table rows fall into 32 different banks of the 4-byte
+    second array (index mod 32: the ds_read_b32 of the components beyond the fourth is served per 32-lane half, banks = dword mod 32)."""
+    words = np.asarray(words).astype(np.int64) & 0xFFFFFFFF
+    good = total = 0
+    for i in range((len(off) - 1) // 2):
+        unit = words[off[2 * i] * 64:off[2 * i + 1] * 64].reshape(-1, 64)
+        if unit.shape[0] == 0:
+            continue
+        for half in (0, 1):
+            bank = (((unit >> (16 * half)) & 0xFFFF) >> 4) & 31
+            for lanes in (slice(0, 32), slice(32, 64)):
+                q = np.sort(bank[:, lanes], axis=1)
+                good += int((np.diff(q, axis=1) != 0).all(axis=1).sum())
+                total += q.shape[0]
+    return good / max(total, 1), total
