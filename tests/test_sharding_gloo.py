@@ -206,3 +206,60 @@ def test_estimator_shard_helper_under_gloo(world):
         assert none_ok and flat_shape is None and sum(flat_counts) == NX * NY
         stops.append(flat_sl)
     assert stops[0][0] == 0 and stops[-1][1] == NX * NY and all(a[1] == b[0] for a, b in zip(stops[:-1], stops[1:]))
+
+
+# ---- shard-local ingest and initialisation on CPU tensors (round 4): the scans' combination and the sharded randomized SVD ----
+def _ingest_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from espm_amd import init_device
+        from espm_amd.estimators.base import _Shard
+        n, nx, ny, k = 48, 12, 16, 3
+        rng = np.random.default_rng(5)
+        Wt, Ht = rng.random((n, k)) + 0.05, rng.random((k, nx * ny)) + 0.05
+        X = rng.poisson(Wt @ Ht * 3).astype(np.float32)
+        X[7, :] = 0                                     # an empty channel: only the all-reduced channel sums can know
+        sh = _Shard(dist.group.WORLD, (nx, ny), nx * ny)
+        Xl = torch.from_numpy(np.ascontiguousarray(X[:, sh.sl]))
+        # the upload's scans of this rank's block (espm_amd/estimators/base.py: _upload_with_scans), formed here on the host tensor
+        xd = Xl.double()
+        scans = dict(row_sum=xd.sum(dim=1), col_sum=xd.sum(dim=0), bad=torch.zeros(3, dtype=torch.int64), s1=xd.sum(),
+                     s2=(xd * torch.log(xd.clamp_min(1e-14))).sum(),
+                     facts=torch.stack(((Xl != Xl.round()).sum().double(), (Xl != 0).sum().double(), Xl.max().double())))
+        comb = sh.combine_scans(scans, "cm")
+        Xd = torch.from_numpy(X).double()
+        res = dict(ch_sum_ok=bool(torch.allclose(comb["row_sum"], Xd.sum(dim=1))), s1=float(comb["s1"]), s1_ref=float(Xd.sum()),
+                   s2=float(comb["s2"]), s2_ref=float((Xd * torch.log(Xd.clamp_min(1e-14))).sum()), nnz=float(comb["facts"][1]),
+                   nnz_ref=float((Xd != 0).sum()), xmax=float(comb["facts"][2]), xmax_ref=float(Xd.max()),
+                   px_local=bool(torch.equal(comb["col_sum"], scans["col_sum"])), empty_ch=int((comb["row_sum"] == 0).sum()))
+        # the sharded randomized SVD on the blocks against the one-process routine on the whole matrix (same random stream)
+        Xf = torch.from_numpy(X)
+        U1, s1, V1 = init_device.randomized_svd_device(Xf, k, 0)
+        U2, s2, V2 = init_device.randomized_svd_sharded(Xl, k, 0, sh)
+        res.update(ds=float(np.abs(s2 - s1).max() / s1.max()), du=float(np.abs(U2 - U1).max()), dv=float(np.abs(V2 - V1).max()),
+                   vshape=tuple(V2.shape), U=U2, V=V2)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_local_scans_and_sharded_randomized_svd(world):
+    """What a sharded fit of a large X does before its loop, on CPU tensors under gloo: every rank scans ITS block of pixels, the sums
+    that are the image's are all-reduced (channel sums, s1, s2, counts; the largest entry as a maximum), the pixel sums stay local; the
+    NNDSVD's randomized SVD runs on the blocks with its contractions over the pixels all-reduced and returns the one-process routine's
+    factors (to rounding: the tall factor is normalised by a Cholesky QR instead of an LU), the same on every rank."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_ingest_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = {r: dict(out[r]) for r in range(world)}
+    for r in range(world):
+        v = res[r]
+        assert v["ch_sum_ok"] and v["px_local"] and v["empty_ch"] == 1
+        for a, b in (("s1", "s1_ref"), ("s2", "s2_ref"), ("nnz", "nnz_ref"), ("xmax", "xmax_ref")):
+            np.testing.assert_allclose(v[a], v[b], rtol=1e-12)
+        assert v["vshape"] == (3, 12 * 16)
+        assert v["ds"] < 1e-5 and v["du"] < 5e-4 and v["dv"] < 5e-4, (v["ds"], v["du"], v["dv"])
+        np.testing.assert_array_equal(v["U"], res[0]["U"])      # replicated factors: the same bits on every rank
+        np.testing.assert_array_equal(v["V"], res[0]["V"])
