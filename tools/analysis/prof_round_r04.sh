@@ -12,7 +12,7 @@ for RW in 512 128 64; do ROWS=$RW python tools/analysis/phase_clock.py > $O/phas
 for RW in 64 128; do ROWS=$RW python tools/analysis/shard_iter.py > $O/shard_iter_$RW.log 2>&1; done
 CONFIG=c5 ROWS=128 python tools/analysis/shard_iter.py > $O/shard_iter_c5_128.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu --no-extras --no-autotune > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu --no-extras > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu --no-extras --no-autotune --steps 20 --warmup 5 > /dev/null 2>&1
 done
