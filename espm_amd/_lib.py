@@ -28,6 +28,7 @@ LAYOUT_CM, LAYOUT_PM = 0, 1
 ABI_VERSION = _D["ESPM_MU_ABI_VERSION"]
 XCHG_HANDLE_BYTES = _D["ESPM_XCHG_HANDLE_BYTES"]
 ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = _D["ESPM_ELL_TILE"], _D["ESPM_ELL_PB"], _D["ESPM_ELL_PBITS"], _D["ESPM_ELL_LDS_MAX"]
+ELL_STREAM_BYTES = _D["ESPM_ELL_STREAM_BYTES"]
 ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = _D["ESPM_ELL_UNIT_ROWS"], _D["ESPM_ELL_UNIT_MAX_N"], _D["ESPM_ELL_PAIR_MAX_K"]
 KP, PPAD, NPAD = _D["ESPM_KP"], _D["ESPM_PPAD"], _D["ESPM_NPAD"]         # (the default build; `variant(k)` below for the wide one)
 MAX_K = KP

@@ -34,7 +34,7 @@ static int roundup(int v, int m) { return (v + m - 1) / m * m; }
   F(halo_top) F(halo_bot) F(hpart) F(hstat) F(a_slab) F(a) F(w_scratch) F(hist) F(hist_len) F(cur) F(it) F(ell_h) \
   F(ell_h_off) F(ell_klc) F(ell_w) F(ell_w_off) F(chan_perm) F(ell_cbits) F(n_cg) F(pix_perm) F(g_t) F(breg_sr_px) \
   F(breg_sr_ch) F(h_rule) F(pg_gamma_w) F(pg_q) F(ell_fill_px) F(ell_fill_num) F(ell_fill_n) F(tail_mode) F(no_fused) \
-  F(ell_pb)
+  F(ell_pb) F(ell_stream)
 
 // the caller's view of the state must be this library's (include/espm_mu.h, ESPM_MU_ABI_VERSION): checked before any field is read
 static int check_abi(const espm_mu_state* st) {
@@ -63,6 +63,7 @@ static int check_state(const espm_mu_state* st) {
                  "sparse count store: tile_px must be 64..%d, ell_pb 2 tile_px, nblk_w ceil(p / ell_pb), n_cg ceil(n / 64); call espm_mu_query",
                  ESPM_ELL_TILE);
   }
+  ESPM_REQUIRE(st->ell_stream == 0 || (st->ell_stream == 1 && st->x_dtype == ESPM_X_ELL), "ell_stream=%d: 0, or 1 with the sparse store", st->ell_stream);
   ESPM_REQUIRE(st->ell_fill_n >= 0 && (st->ell_fill_n == 0 || (st->x_dtype == ESPM_X_ELL && st->ell_fill_px && st->ell_fill_num)),
                "ell_fill_n=%d needs the sparse store, ell_fill_px and ell_fill_num", st->ell_fill_n);
   ESPM_REQUIRE(st->grid_mode == 0 || (st->nx >= 1 && st->ny >= 1 && st->nx * st->ny == st->p),
@@ -394,7 +395,7 @@ int espm_mu_step_hw(const espm_mu_state* st, int src, espm_stream_t stream) {
     if (int rc = launch_ell_fill_num(st->gw_s, st->h[src], st->ell_fill_px, st->ell_fill_n, st->n, st->k, st->p_pad, st->log_shift,
                                      st->ell_fill_num, s))
       return rc;
-  return launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2);
+  return launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2, st->ell_stream);
 }
 
 int espm_mu_w_reduce(const espm_mu_state* st, espm_stream_t stream) {
@@ -506,7 +507,7 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
         a.tail = tail;
       }
       if (fused) {
-        if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2))) return rc;
+        if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2, st->ell_stream))) return rc;
       } else {
         if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
         if ((rc = espm_mu_w_accum(st, stream))) return rc;

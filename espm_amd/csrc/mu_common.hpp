@@ -930,7 +930,7 @@ inline WAccumArgs make_w_args(const espm_mu_state* st) {
 int dispatch_h_step(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream);
 int launch_h_finalize(const HFinalizeArgs& args, hipStream_t stream);
 int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
-int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units = 0);
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units = 0, int stream_lists = 0);
 size_t fused_ell_lds_bytes(int n_pad, int k, int pb);
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);

@@ -177,7 +177,16 @@ __device__ __forceinline__ void ell_walk_prio(int left) {
     else __builtin_amdgcn_s_setprio(0);
   }
 }
-template <int K, int UNR, int PF = 1, int PRIO = 0, typename Get, typename Body, typename Flush = EllNoFlush>
+// STREAM: the list rows with non-temporal loads.  They are read once per launch; where a launch's lists exceed the 256 MB of the
+// last-level cache nothing of them survives until the next launch anyway, and loads that do not allocate leave the cache to the
+// data that is re-read (H, the records): -1.9 us of 135 at the headline, -10 of 672 at configuration 5; on a shard whose lists
+// FIT the cache the same loads cost +5 us of 32 (profiles/r04ac_*) - espm_mu_state.ell_stream, the caller's decision.
+template <bool STREAM>
+__device__ __forceinline__ uint32_t ell_list_load(const uint32_t* p) {
+  if constexpr (STREAM) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, typename Get, typename Body, typename Flush = EllNoFlush>
 __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
@@ -207,7 +216,7 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
     for (int d = 0; d < PF; ++d) {
       const int jd = min(d * UNR, len - UNR);
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) q[d][u] = row[(size_t)(jd + u) * 64];
+      for (int u = 0; u < UNR; ++u) q[d][u] = ell_list_load<STREAM>(row + (size_t)(jd + u) * 64);
     }
     for (; j + UNR <= len; j += UNR) {
       ell_walk_prio<PRIO>(len - j);
@@ -220,12 +229,12 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
         for (int u = 0; u < UNR; ++u) q[d][u] = q[d + 1][u];
       const int jn = min(j + PF * UNR, len - UNR);  // the last batches re-request the last rows (no branch, no overrun)
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) q[PF - 1][u] = row[(size_t)(jn + u) * 64];
+      for (int u = 0; u < UNR; ++u) q[PF - 1][u] = ell_list_load<STREAM>(row + (size_t)(jn + u) * 64);
       batch(e);
     }
   }
   for (; j < len; ++j) {
-    const uint32_t v = row[(size_t)j * 64];
+    const uint32_t v = ell_list_load<STREAM>(row + (size_t)j * 64);
     float g0[K], g1[K];
     const float x0 = get(v, 0, g0), x1 = get(v, 1, g1);
     body(x0, g0);
@@ -275,13 +284,13 @@ struct EllGetUnit {
 #ifndef ESPM_ELL_KLPROD
 #define ESPM_ELL_KLPROD 1
 #endif
-template <int K, bool LOSS, int UNR, int PF, int PRIO = 0>
+template <int K, bool LOSS, int UNR, int PF, int PRIO = 0, bool STREAM = false>
 __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1, int mid, const float* tab, int n_pad, int ell_bits,
                                            const float (&hk)[K], float (&acc)[K], float& kl) {
   if (x0 < mid) {
     if constexpr (LOSS && ESPM_ELL_KLPROD) {
       float prod = 1.f;
-      ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
+      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
         [&](float, const float (&g)[K]) {
           const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
           ell_axpy<K>(acc, g, r);
@@ -297,7 +306,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
           prod = 1.f;
         });
     } else {
-      ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
+      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
         const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
         ell_axpy<K>(acc, g, r);
         if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
@@ -306,7 +315,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
   }
   if (x1 > mid) {
     const int g0 = max(x0, mid);
-    ell_walk<K, UNR, PF, PRIO>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
+    ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
       const float y = ell_dot<K>(g, hk);
       // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
       const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);

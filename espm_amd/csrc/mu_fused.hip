@@ -34,8 +34,10 @@
 namespace espm {
 
 int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_plain.hip
+int launch_fused_plain_stream(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_stream.hip
 #ifdef ESPM_PHASE_CLOCK
 int phase_buffer_plain(unsigned long long* p);
+int phase_buffer_plain_stream(unsigned long long* p);
 #endif
 
 #if ESPM_MIN_K <= 8
@@ -119,6 +121,8 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
                        args.h.simplex_h && args.h.lambda_l != 0.f && args.h.grid_mode && args.h.have_prev && args.h.write_h && args.h.h_rule == 0 &&
                        args.h.tail_on != 1 && !args.static_units && args.slab_lds && !args.w_split && args.red_lds_off >= 0 && staged_ok &&
                        (args.perm_lds != 0) == (pb != ESPM_ELL_PB) && ESPM_FUSED_SMALL_THREADS == ESPM_ELL_WTHREADS;
+    // (the lists too large for the last-level cache, the caller says: the instance that loads them without allocating there)
+    if (plain && args.stream_lists && pb == ESPM_ELL_PB) return launch_fused_plain_stream(args, K, args.h.compute_loss != 0, true, nblk, bytes, stream);
     if (plain) return launch_fused_plain(args, K, args.h.compute_loss != 0, pb == ESPM_ELL_PB, nblk, bytes, stream);
   }
   auto go = [&](auto kern, int threads) -> int {
@@ -153,7 +157,7 @@ size_t fused_ell_lds_bytes(int n_pad, int k, int pb) {
          (pb != ESPM_ELL_PB ? (size_t)(pb + 64 * n_cg) * sizeof(int) : 0);
 }
 
-int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units) {
+int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units, int stream_lists) {
   ESPM_REQUIRE(h.ell && h.ell_off && h.ell_klc && h.ell_pix && w.ell && w.ell_off && w.chan_perm, "fused half-steps: the sparse store's lists are missing");
   ESPM_REQUIRE(w.pb >= 128 && w.pb <= ESPM_ELL_PB && (w.pb & (w.pb - 1)) == 0 && 2 * h.ell_tp == w.pb && h.h_rule == 0 && h.write_h && !h.l2_m,
                "fused half-steps: blocks of two H tiles (tile_px=%d, ell_pb=%d), the default H rule, write_h", h.ell_tp, w.pb);
@@ -162,6 +166,7 @@ int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStrea
   fa.h = h;
   fa.w = w;
   fa.static_units = static_units;
+  fa.stream_lists = stream_lists;
   switch (h.k) {
 #if ESPM_MIN_K <= 8
 #define ESPM_X(KK) case KK: return launch_fused_k<KK>(fa, nblk, stream);
@@ -179,6 +184,7 @@ int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStrea
 extern "C" int espm_debug_phase_buffer(void* dev_ptr) {
   unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
   if (int rc = espm::phase_buffer_plain(p)) return rc;
+  if (int rc = espm::phase_buffer_plain_stream(p)) return rc;
   return espm::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm::espm_phase_buf), &p, sizeof(p)), "phase buffer");
 }
 #endif

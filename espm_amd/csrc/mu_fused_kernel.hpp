@@ -103,6 +103,7 @@ struct FusedArgs {
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
   int h_segs;       // below the full geometry: segments per list group of the H walk (at least 1024 / pb, at most ESPM_FUSED_MAX_SEGS)
   int w_split;      // the W walk's units are half channel groups, summed through two copies of the slab in LDS (needs slab_lds and room for the second copy)
+  int stream_lists; // espm_mu_state.ell_stream: the STREAM instance where one is built (the full geometry's lean instances)
   int slab_lds;     // the W walk collects the block's slab in the numerators' region and the workgroup writes it out as rows (the launcher: where k n_pad floats fit there and the record reduction has scratch of its own)
 };
 
@@ -142,9 +143,11 @@ struct FusedGeom {
 // PLAIN: the common case as compile-time facts (h_epilogue's PLAIN, plus: the prologue's staged form applies, no extra tail workgroup,
 // dynamic units, the slab collected in LDS, scratch of its own for the record reduction) - the launcher checks every one of them on the
 // host (launch_fused_k) and takes the generic instance otherwise.  Instantiated in mu_fused_plain.hip.
-template <int K, bool LOSS, int UNR_H, int UNR_W, int NT, bool FULL, bool PLAIN = false>   // FULL: the full geometry, block and tile sizes are constants
+// STREAM: the lists with non-temporal loads (mu_ell_kernel.hpp: ell_list_load; espm_mu_state.ell_stream) - instances of the full geometry only.
+template <int K, bool LOSS, int UNR_H, int UNR_W, int NT, bool FULL, bool PLAIN = false, bool STREAM = false>   // FULL: the full geometry, block and tile sizes are constants
 __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   static_assert(!FULL || NT == ESPM_ELL_WTHREADS, "full geometry: 1024 threads");
+  static_assert(FULL || !STREAM, "streamed lists: the full geometry (an image below it fits the last-level cache)");
   static_assert(ESPM_ELL_PB == 2 * ESPM_ELL_TILE && ESPM_ELL_WTHREADS == ESPM_ELL_PB, "full geometry: a workgroup is two H tiles, one thread per pixel");
   const int PB = FULL ? ESPM_ELL_PB : fa.w.pb;     // pixels per workgroup
   const int PBITS = FULL ? ESPM_ELL_PBITS : fa.w.pbits;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-        ell_h_rows<K, LOSS, UNR_H, PF, PRIO>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
+        ell_h_rows<K, LOSS, UNR_H, PF, PRIO, STREAM>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
         if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -389,10 +392,10 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
     }
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     });
-    ell_walk<K, UNR_W, PF, PRIO>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     });

@@ -2,7 +2,20 @@
 // on an image grid, a previous H to compare with, no mu / fixed_H / fill numerators / Bregman / Frobenius, the staged prologue, dynamic
 // units, the slab collected in LDS.  launch_fused_k (mu_fused.hip) checks those facts on the host and calls launch_fused_plain; anything
 // else takes the generic instance.  A translation unit of its own so that the two sets of instances compile side by side.
+// ESPM_PLAIN_STREAM = 1 (mu_fused_stream.hip includes this file so): the full geometry's instances with streamed lists
+// (mu_ell_kernel.hpp: ell_list_load), behind launch_fused_plain_stream - a third unit compiling beside the other two.
 #include "mu_fused_kernel.hpp"
+
+#ifndef ESPM_PLAIN_STREAM
+#define ESPM_PLAIN_STREAM 0
+#endif
+#if ESPM_PLAIN_STREAM
+#define ESPM_PLAIN_ENTRY launch_fused_plain_stream
+#define ESPM_PLAIN_PHASE phase_buffer_plain_stream
+#else
+#define ESPM_PLAIN_ENTRY launch_fused_plain
+#define ESPM_PLAIN_PHASE phase_buffer_plain
+#endif
 
 #ifndef ESPM_ELL_UNR_H
 #define ESPM_ELL_UNR_H 4
@@ -31,14 +44,18 @@ static int launch_plain_k(const FusedArgs& args, bool loss, bool full, int nblk,
     return check_hip(hipGetLastError(), "fused half-steps (plain) launch");
   };
   if (full)
-    return loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true>)
-                : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true>);
+    return loss ? go(mu_fused_ell_kernel<K, true, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true, ESPM_PLAIN_STREAM != 0>)
+                : go(mu_fused_ell_kernel<K, false, ESPM_ELL_UNR_H, ESPM_ELL_UNR_W, ESPM_ELL_WTHREADS, true, true, ESPM_PLAIN_STREAM != 0>);
+#if ESPM_PLAIN_STREAM
+  return set_error(ESPM_EUNSUPPORTED, "fused half-steps (plain, streamed lists): the full geometry only");
+#else
   return loss ? go(mu_fused_ell_kernel<K, true, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_ELL_WTHREADS, false, true>)
               : go(mu_fused_ell_kernel<K, false, ESPM_FUSED_SMALL_UNR_H, ESPM_FUSED_SMALL_UNR_W, ESPM_ELL_WTHREADS, false, true>);
+#endif
 }
 #endif
 
-int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream) {
+int ESPM_PLAIN_ENTRY(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream) {
   switch (k) {
 #if ESPM_MIN_K <= 8
 #define ESPM_X(KK) case KK: return launch_plain_k<KK>(args, loss, full, nblk, lds_bytes, stream);
@@ -51,7 +68,7 @@ int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int n
 
 #ifdef ESPM_PHASE_CLOCK
 // (debug build: this translation unit has its own copy of the stamp buffer's pointer - device globals are per unit without -fgpu-rdc)
-int phase_buffer_plain(unsigned long long* p) { return check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm_phase_buf), &p, sizeof(p)), "phase buffer (plain)"); }
+int ESPM_PLAIN_PHASE(unsigned long long* p) { return check_hip(hipMemcpyToSymbol(HIP_SYMBOL(espm_phase_buf), &p, sizeof(p)), "phase buffer (plain)"); }
 #endif
 
 }  // namespace espm

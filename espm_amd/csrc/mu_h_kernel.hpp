@@ -2,6 +2,10 @@
 // harness (tools/tune) can instantiate variants next to the product's dispatch table.
 #pragma once
 // the wave stage of the fused kernel's record reduction through gfx950's half / row exchanges (mu_common.hpp, wave_reduce_packed)
+// H' of the fused launch stored write-through (sc1), so that the launch does not end with its 4 k p bytes dirty in the L2s (0: plain stores, A/B)
+#ifndef ESPM_HOUT_WRITE_THROUGH
+#define ESPM_HOUT_WRITE_THROUGH 1
+#endif
 #ifndef ESPM_FUSED_RED_PACKED
 #define ESPM_FUSED_RED_PACKED 1
 #endif
@@ -380,7 +384,11 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         if (f >= 0.f) hn = f;                                   // updates.py:154-155
       }
       if (!(hn <= 3.0e38f)) red[ESPM_HP_BAD] += 1.f;            // NaN or inf
-      a.h_out[(size_t)kk * a.p_pad + q] = hn;
+      // fused half-steps: H' written through (sc1) - 4 k p bytes that would otherwise sit dirty in the XCDs' L2s until the launch ends and
+      // lengthen the boundary behind it (MI355X_MICROARCH.md: + B / 6 TB/s); nobody in this launch reads them.  Headline 135.3 -> 133.3 us per
+      // iteration, same bits (profiles/r04aa_hout_write_through_ab_512.log)
+      if (ESPM_HOUT_WRITE_THROUGH && lds_tab) __hip_atomic_store(a.h_out + (size_t)kk * a.p_pad + q, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.h_out[(size_t)kk * a.p_pad + q] = hn;
       ht[kk] = hn;
       red[R_ROWSUM + kk] += hn;
       red[R_MAX + kk] = fmaxf(red[R_MAX + kk], hn);

@@ -392,6 +392,10 @@ class MUEngine:
         if os.environ.get("ESPM_FUSED"):   # tests: "always" runs the fused launch on small blocks too, "0" never
             fused = {"0": False, "1": True}.get(os.environ["ESPM_FUSED"], os.environ["ESPM_FUSED"])
         st.no_fused = {"static": 2, "always": 3}.get(fused, 0 if fused else 1)   # ("always": also blocks below ESPM_FUSED_MIN_PB pixels)
+        # lists larger than the last-level cache are read with loads that do not allocate there (include/espm_mu.h: ell_stream;
+        # ESPM_ELL_STREAM_MB: another threshold, for A/B - 0 streams always, a huge one never)
+        limit = float(os.environ["ESPM_ELL_STREAM_MB"]) * 2 ** 20 if os.environ.get("ESPM_ELL_STREAM_MB") else _lib.ELL_STREAM_BYTES
+        st.ell_stream = int(x_store == "ell" and self.x_bytes > limit)
         self._accum_done = False
         # autotune: at the first load_state the launch plans that apply to this problem are timed on the ingested image and
         # the fastest is kept (see autotune_plan)

@@ -101,6 +101,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_UNIT_ROWS 8 /* sparse store: the unit rows of a list group are a multiple of this (16 entries: one per bank quad) */
 #define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
+#define ESPM_ELL_STREAM_BYTES (256 << 20) /* sparse store: list bytes beyond which a caller sets espm_mu_state.ell_stream (the MI355X's last-level cache) */
 #define ESPM_FUSED_MIN_PB 512 /* sparse store: W blocks (ell_pb) from which the fused launch is the default whatever their number           */
 #define ESPM_FUSED_MIN_BLOCKS 192 /* ... and smaller blocks when there are at least this many (one per CU, or nearly: a 64-row shard of the
                                    * headline image has 256 of 128 pixels; config 2's 128 blocks leave half the chip to the two launches,
@@ -149,7 +150,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
  * point that takes a state checks st->struct_size == sizeof(espm_mu_state) and st->abi_version == ESPM_MU_ABI_VERSION
  * first and fails with ESPM_EINVAL otherwise: a binding whose copy of the layout has drifted is refused instead of
  * having its pointers misread.  A binding can also compare its layout field by field with espm_mu_state_layout(). */
-#define ESPM_MU_ABI_VERSION 3
+#define ESPM_MU_ABI_VERSION 4
 
 typedef struct espm_mu_state {
   uint32_t struct_size;   /* sizeof(espm_mu_state) as the CALLER sees it                  */
@@ -283,6 +284,12 @@ typedef struct espm_mu_state {
    * fills the chip with 512-pixel H tiles, 128 .. 512 for smaller images and shards, so that there is about one block per
    * compute unit and one workgroup can own the block through both half-steps. */
   int32_t ell_pb;
+  /* Sparse store: 1 = the lists (256 bytes per row of ell_h and ell_w: the rows[2] of espm_mu_ell_plan) do not fit the device's
+   * last-level cache, i.e. exceed ESPM_ELL_STREAM_BYTES: the one-launch iteration then reads them with non-temporal loads, which
+   * leave that cache to what IS read again (measured: -1.4 % at 2048 x 512^2, where the lists are 0.5 GB; +15 % if set on a
+   * 64-row shard of it, whose lists stay in the cache from one iteration to the next).  A hint: results are the same bits
+   * either way, and a launch without a streamed form (blocks below ESPM_ELL_PB pixels, the generic instances) ignores it. */
+  int32_t ell_stream;
 } espm_mu_state;
 
 const char* espm_mu_version(void);

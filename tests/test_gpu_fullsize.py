@@ -202,6 +202,29 @@ def test_iteration_loop_is_reproducible_across_chunkings(big):
     assert out[0][2]["bad"].sum() == 0 and np.isfinite(out[0][2]["rel_W"][1:]).all()
 
 
+def test_streamed_lists_are_the_default_here_and_change_no_bit(big):
+    """The headline's lists (0.5 GB) exceed the last-level cache: the engine sets espm_mu_state.ell_stream and the one-launch
+    iteration reads them with non-temporal loads (include/espm_mu.h; mu_fused_stream.hip).  A hint about the cache only: the same
+    8 iterations with the switch off are the same bits - W, H, the loss history - and the library refuses other values."""
+    from espm_amd import _lib
+    eng = big["engs"]["ell"]
+    assert eng.x_bytes > _lib.ELL_STREAM_BYTES and eng.st.ell_stream == 1 and eng.st.ell_pb == _lib.ELL_PB
+    out = []
+    for flag in (1, 0, 1):
+        eng.st.ell_stream = flag
+        eng.load_state(big["W0"], big["H0"])
+        eng.iterate(8, final_loss=True)
+        torch.cuda.synchronize()
+        out.append((eng.get_W(), eng.get_H(), eng.history()["loss"].copy()))
+    for W, H, loss in out[1:]:
+        assert np.array_equal(W, out[0][0]) and np.array_equal(H, out[0][1]) and np.array_equal(loss, out[0][2])
+    eng.st.ell_stream = 2
+    with pytest.raises(ValueError, match="ell_stream"):
+        eng.iterate(1, final_loss=False)
+    eng.st.ell_stream = 1
+    eng.load_state(big["W0"], big["H0"])
+
+
 def test_launch_plan_autotune_restores_the_state(big):
     """MUEngine(autotune=True) times the launch plans at the first load_state (fused with dynamic / fixed units, two
     launches) on the ingested image and keeps the fastest; the loaded state must come back bit for bit, and the fit that

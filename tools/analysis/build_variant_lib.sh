@@ -6,7 +6,7 @@ set -e
 NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/tools/analysis/variant_build_$NAME; mkdir -p $O
-for f in mu_api mu_h_step mu_w_step mu_aux mu_ell mu_ell_build mu_l2 mu_fused mu_fused_plain mu_xchg; do
+for f in mu_api mu_h_step mu_w_step mu_aux mu_ell mu_ell_build mu_l2 mu_fused mu_fused_plain mu_fused_stream mu_xchg; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS -c -I $R/include $R/espm_amd/csrc/$f.hip -o $O/$f.o &
 done
 wait

@@ -60,6 +60,7 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     assert np.array_equal(eng.get_W(), out[0]) and np.array_equal(eng.history()["loss"], out[2]), f"{name}: not reproducible run to run"
     engs[name] = eng
+    print(f"{name:10s}: store {eng.x_store}, {eng.x_bytes / 2 ** 20:.0f} MB, ell_pb {eng.st.ell_pb}, ell_stream {eng.st.ell_stream}", flush=True)
     for var in ENVS.get(name, {}):
         os.environ.pop(var, None)
 del X

@@ -10,7 +10,7 @@ O=$R/tools/sanitize/asan_build; mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -fno-sanitize-recover=undefined"
 J=${ESPM_BUILD_JOBS:-7}
 pids=()
-for f in mu_api mu_w_step mu_aux mu_ell mu_ell_build mu_l2 mu_fused mu_fused_plain mu_xchg mu_init; do
+for f in mu_api mu_w_step mu_aux mu_ell mu_ell_build mu_l2 mu_fused mu_fused_plain mu_fused_stream mu_xchg mu_init; do
   /opt/rocm/bin/hipcc $FLAGS -c -I $R/include $R/espm_amd/csrc/$f.hip -o $O/$f.o &
   pids+=($!)
   while [ $(jobs -r | wc -l) -ge $J ]; do sleep 1; done
