@@ -117,7 +117,7 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
     const int n_perm = args.perm_lds ? pb + 64 * args.w.n_cg : 0, n_woff = 2 * args.w.n_cg + 1;
     const bool staged_ok = args.h.n_pad <= 4 * NT && n_perm <= 4 * NT && n_woff <= NT && args.h.cs_nbk <= 64 && 2 * K <= NT / 64;
     const char* env = getenv("ESPM_FUSED_PLAIN");
-    const bool plain = ESPM_FUSED_PLAIN && !(env && env[0] == '0') && !args.h.mu && !args.h.fixed_h && !args.h.fill_num && !args.h.breg_sr && !args.h.l2_m &&
+    const bool plain = ESPM_FUSED_PLAIN && !(env && env[0] == '0') && !args.h.fixed_h && !args.h.fill_num && !args.h.breg_sr && !args.h.l2_m &&
                        args.h.simplex_h && args.h.lambda_l != 0.f && args.h.grid_mode && args.h.have_prev && args.h.write_h && args.h.h_rule == 0 &&
                        args.h.tail_on != 1 && !args.static_units && args.slab_lds && !args.w_split && args.red_lds_off >= 0 && staged_ok &&
                        (args.perm_lds != 0) == (pb != ESPM_ELL_PB) && ESPM_FUSED_SMALL_THREADS == ESPM_ELL_WTHREADS;

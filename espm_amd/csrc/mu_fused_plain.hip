@@ -1,5 +1,5 @@
 // The fused half-steps' common case as instances of their own (mu_fused_kernel.hpp, template parameter PLAIN): simplex over H, Laplacian
-// on an image grid, a previous H to compare with, no mu / fixed_H / fill numerators / Bregman / Frobenius, the staged prologue, dynamic
+// on an image grid, a previous H to compare with, no fixed_H / fill numerators / Bregman / Frobenius, the staged prologue, dynamic
 // units, the slab collected in LDS.  launch_fused_k (mu_fused.hip) checks those facts on the host and calls launch_fused_plain; anything
 // else takes the generic instance.  A translation unit of its own so that the two sets of instances compile side by side.
 // ESPM_PLAIN_STREAM = 1 (mu_fused_stream.hip includes this file so): the full geometry's instances with streamed lists

@@ -102,9 +102,15 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // every launch, and more unrolled code is more of that: profiles/r03c / r03d / r03e_phase_clock_64rows.log.  The callers pass 0.)
 // relw_lane: this lane's share of rel_W of the W update that produced the input state (record field ESPM_HP_RELW), -1: none.
 // PLAIN (the fused kernel's common case, mu_fused_plain.hip): what the launcher has checked on the host becomes a compile-time fact -
-// simplex over H, Laplacian on an image grid, a previous H to compare with, H' written; no mu, no fixed_H, no fill numerators, neither
-// the Bregman nor the Frobenius variant.  The generic instance keeps ~100 scalar registers of flags and pointers alive through every
+// simplex over H, Laplacian on an image grid, a previous H to compare with, H' written; no fixed_H, no fill numerators, neither
+// the Bregman nor the Frobenius variant (mu stays a run-time flag: one uniform branch, and configuration 5 - mu = 0.05 - is a common case too).  The generic instance keeps ~100 scalar registers of flags and pointers alive through every
 // phase (107-165 of them spilled to vector lanes) and walks their branches in 16 waves that share one scalar unit.
+#ifndef ESPM_SUM_ROW_FENCE
+#define ESPM_SUM_ROW_FENCE 1
+#endif
+#ifndef ESPM_SUM_SWITCH
+#define ESPM_SUM_SWITCH 1
+#endif
 template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0, bool PLAIN = false>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
@@ -123,7 +129,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   static_assert(!PLAIN || RULE == 0, "the plain instance: the default H rule");
   // the features as facts (PLAIN) or as the run-time flags they are
   const bool f_fill = PLAIN ? false : a.fill_num != nullptr, f_breg = PLAIN ? false : a.breg_sr != nullptr, f_l2 = PLAIN ? false : a.l2_m != nullptr;
-  const bool f_mu = PLAIN ? false : a.mu != nullptr, f_fixed = PLAIN ? false : a.fixed_h != nullptr;
+  const bool f_mu = a.mu != nullptr, f_fixed = PLAIN ? false : a.fixed_h != nullptr;
   const bool f_prev = PLAIN ? true : a.have_prev != 0, f_lap = PLAIN ? true : a.lambda_l != 0.f, f_grid = PLAIN ? true : a.grid_mode != 0;
   const bool f_write = PLAIN ? true : a.write_h != 0, f_simplex = PLAIN ? true : a.simplex_h != 0;
   const bool stencil = f_lap && f_grid;
@@ -184,19 +190,33 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       // 24 of them the 0.82 us at the headline, profiles/r03bh_phase_clock_*rows.log); the values of slots beyond nparts are dropped by a
       // select.  Row by row: MAXP reads in flight, the next row's behind them as far as the registers allow (all (K + 1) MAXP at once
       // spilled 111 registers in the k = 8 instance below the full geometry).
-      auto row_sum = [&](int kk, float s) {
-        float pv[MAXP];
+      // ESPM_SUM_ROW_FENCE: the scheduler may not carry the reads of one row over into the next (left alone it requests ALL rows' slots at
+      // once: 92 registers spilled to scratch in the k = 8 instance below the full geometry - 30 us of update in a 128-row shard of
+      // configuration 5 instead of 5, profiles/r04af_phase_c5_128.log).  ESPM_SUM_SWITCH: as many reads per row as the launch has slots
+      // (2, 4 or MAXP; uniform branch) instead of MAXP reads of which nparts count.
+      auto row_sum_n = [&](auto nslots, int kk, float s) {
+        constexpr int NS = decltype(nslots)::value;
+        float pv[NS];
 #pragma unroll
-        for (int w = 0; w < MAXP; ++w) pv[w] = smem[((size_t)(w < nparts ? w : 0) * prows + kk) * TP + jj];
+        for (int w = 0; w < NS; ++w) pv[w] = smem[((size_t)(w < nparts ? w : 0) * prows + kk) * TP + jj];
 #pragma unroll
-        for (int w = 0; w < MAXP; ++w) s += w < nparts ? pv[w] : 0.f;
+        for (int w = 0; w < NS; ++w) s += w < nparts ? pv[w] : 0.f;
+#if ESPM_SUM_ROW_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         return s;
       };
-      if (kl_rows) red[ESPM_HP_KL] += row_sum(K, fmaxf(klc, 0.f));   // (negative: the mark of a pixel without counts, no constant)
+      auto sum_rows = [&](auto nslots) {
+        if (kl_rows) red[ESPM_HP_KL] += row_sum_n(nslots, K, fmaxf(klc, 0.f));   // (negative: the mark of a pixel without counts, no constant)
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) nv[kk] = row_sum_n(nslots, kk, 0.f) * a.xscale;
+      };
+      if (ESPM_SUM_SWITCH && MAXP > 2 && nparts <= 2) sum_rows(std::integral_constant<int, 2>());
+      else if (ESPM_SUM_SWITCH && MAXP > 4 && nparts <= 4) sum_rows(std::integral_constant<int, 4>());
+      else sum_rows(std::integral_constant<int, MAXP>());
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
         hin[kk] = in.hin[kk];
-        nv[kk] = row_sum(kk, 0.f) * a.xscale;
         dv[kk] = (float)(colsum ? colsum[kk] : a.colsum_gw[kk]);
       }
     } else {

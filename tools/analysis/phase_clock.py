@@ -18,13 +18,16 @@ import torch  # noqa: E402
 from espm_amd import _lib, synth  # noqa: E402
 from espm_amd.engine import MUEngine  # noqa: E402
 
-N_CH, NX, NY, K = 2048, int(os.environ.get("ROWS", "512")), 512, int(os.environ.get("K", "5"))   # (ROWS < 512: the smaller block geometries)
+C5 = os.environ.get("CONFIG") == "c5"   # CONFIG=c5 ROWS=128: a rank's share of BASELINE configuration 5 (1980 ch, 1024-pixel rows, k = 8, G 1980 x 17, mu = 0.05)
+N_CH, NY, M = (1980, 1024, 17) if C5 else (2048, 512, None)
+NX, K = int(os.environ.get("ROWS", "512")), 8 if C5 else int(os.environ.get("K", "5"))   # (ROWS < 512: the smaller block geometries)
 dev = torch.device("cuda", 0)
-prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0, row0=0, nx_total=512)
+prob = synth.make_problem(N_CH, NX, NY, K, N=float(os.environ.get("COUNTS", "500")), seed=0, row0=0, nx_total=NY, m=M)
 X = synth.sample_torch(prob, dev, seed=1000, row0=0)
-W0, H0 = synth.random_init(N_CH, K, 512 * 512, seed=0, scale=500.0 / N_CH)
+W0, H0 = synth.random_init(M if C5 else N_CH, K, NY * NY, seed=0, scale=500.0 / N_CH)
+kw = dict(G=prob["G"], mu=0.05) if C5 else {}
 eng = MUEngine(X, K, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=600, device=dev,
-               fused={"0": False, "1": True}.get(os.environ.get("FUSED", "1"), os.environ.get("FUSED", "1")))
+               fused={"0": False, "1": True}.get(os.environ.get("FUSED", "1"), os.environ.get("FUSED", "1")), **kw)
 del X
 eng.load_state(W0, H0[:, :NX * NY])
 eng.iterate(300, final_loss=False)
