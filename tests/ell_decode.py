@@ -91,3 +91,26 @@ def unit_bank_spread_b32(words, off):
                 good += int((np.diff(q, axis=1) != 0).all(axis=1).sum())
                 total += q.shape[0]
     return good / max(total, 1), total
+
+
+def general_gather_passes(words, off, bits):
+    """Mean LDS passes per 16-lane read group of the GENERAL rows' 16-byte gathers: the largest number of different table rows that share
+    a bank quad (index mod 16) among the group's 16 entries - padding entries (value 0) gather row 0 like anything else.  1.0 = conflict
+    free; a list in index order gives ~1.8 on count images (NOTEBOOK.md section 8)."""
+    words = np.asarray(words).astype(np.int64) & 0xFFFFFFFF
+    passes = total = 0
+    for i in range((len(off) - 1) // 2):
+        gen = words[off[2 * i + 1] * 64:off[2 * i + 2] * 64].reshape(-1, 64)
+        if gen.shape[0] == 0:
+            continue
+        for half in (0, 1):
+            idx = ((gen >> (16 * half)) & 0xFFFF) & ((1 << bits) - 1)
+            for lanes in B128_GROUPS:
+                sub = idx[:, lanes]
+                for row in sub:
+                    rows_by_quad = {}
+                    for v in row:
+                        rows_by_quad.setdefault(int(v) & 15, set()).add(int(v))
+                    passes += max(len(s) for s in rows_by_quad.values())
+                total += sub.shape[0]
+    return passes / max(total, 1), total

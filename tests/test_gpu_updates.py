@@ -280,7 +280,7 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
     np.testing.assert_allclose(a["klc"].cpu().numpy(), b["klc"].cpu().numpy(), rtol=1e-6, atol=1e-6)
     # which ones of a list sit in its unit rows, and in which order, is the builder's choice (the C builder spreads
     # them over the LDS banks): both sets of lists must decode to X
-    from ell_decode import decode, unit_bank_spread, unit_bank_spread_b32
+    from ell_decode import decode, general_gather_passes, unit_bank_spread, unit_bank_spread_b32
     p, cbits = nx * ny, eng.st.ell_cbits
     Xi = np.ascontiguousarray(X.T).astype(np.int64)
     spread = {}
@@ -291,7 +291,9 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
         assert np.array_equal(Xw[:p], Xi) and not Xw[p:].any(), name
         spread[name] = (unit_bank_spread(host["ell_h"].numpy(), host["ell_h_off"].numpy()),
                         unit_bank_spread(host["ell_w"].numpy(), host["ell_w_off"].numpy()),
-                        unit_bank_spread_b32(host["ell_h"].numpy(), host["ell_h_off"].numpy()))
+                        unit_bank_spread_b32(host["ell_h"].numpy(), host["ell_h_off"].numpy()),
+                        general_gather_passes(host["ell_h"].numpy(), host["ell_h_off"].numpy(), cbits),
+                        general_gather_passes(host["ell_w"].numpy(), host["ell_w_off"].numpy(), (2 * eng.st.tile_px).bit_length() - 1))
     for which in (0, 1):
         (s_hip, rows), (s_torch, _) = spread["hip"][which], spread["torch"][which]
         if rows >= 64:  # conflict-free gathers: most read groups of the C builder's unit rows, few of an index-ordered list
@@ -302,6 +304,9 @@ def test_ell_builders_agree(monkeypatch, n, nx, ny, layout):
     # (round 4: with ESPM_ELL_BUCKETS=32 the 4-byte gathers of a 32-lane half fall on 32 different banks too - spread[...][2] -
     #  measured to buy nothing, profiles/r04u_buckets_ab_*.log; the product keeps 16 buckets, where that share is a few per cent)
     assert spread["hip"][2][0] >= 0.0
+    # (round 4: general rows placed by bank quad - spread[...][3], [4] count their gather passes - were built and withdrawn: 2.6 -> 1.9
+    #  passes per read group on the headline's lists, no time gained, tools/proto/ell_general_rows_placed.patch)
+    assert spread["hip"][3][0] >= 1.0 and spread["hip"][4][0] >= 1.0
 
 
 @pytest.mark.parametrize("n,nx,ny,k,fix", [(70, 9, 13, 6, True), (2048, 16, 32, 5, False), (333, 7, 19, 3, True)])
@@ -471,3 +476,33 @@ def test_lu_normaliser_kernel_equals_scipy_and_the_torch_formulation():
     np.testing.assert_allclose(_lu_pl(wide).cpu().numpy(), _lu_pl(wide.cpu().contiguous()).numpy(), rtol=0, atol=5e-13)
     with pytest.raises(ValueError, match="NULL pointer"):
         _lib.check(_lib.lib.espm_lu_pl(None, 0, 10, 3, 3, None, None, 0, None))
+
+
+def test_sparse_store_of_dense_lists_beyond_the_unit_rows():
+    """Dense data forced into the sparse store with more channels than unit rows exist for (n > 4096): lists of 4200 general entries next to
+    lists of a few, split counts included.  The lists decode to X, and the fit's first iterations equal the dense fp32 store's."""
+    import torch
+    from espm_amd.engine import MUEngine
+    from ell_decode import decode
+    n, nx, ny, k = 4200, 8, 16, 3
+    rng = np.random.default_rng(5)
+    X = rng.poisson(0.4, size=(n, nx * ny)).astype(np.float32)
+    X[:, :40] = rng.integers(2, 9, size=(n, 40))          # 40 pixels whose every channel holds a count >= 2: 262 entries per bucket
+    X[:300, 64:] += rng.integers(2, 5, size=(300, nx * ny - 64))   # 64 pixels with few general entries, 64 with ~300 (19 per bucket)
+    W0 = rng.uniform(0.5, 1.5, size=(n, k)) * X.mean() / k
+    H0 = rng.uniform(0.5, 1.5, size=(k, nx * ny))
+    out = {}
+    for store in ("ell", "f32"):
+        eng = MUEngine(X, k, layout="cm", shape_2d=(nx, ny), lambda_L=0.5, simplex_H=True, simplex_W=False, tol=0.0, max_iter=6, x_store=store)
+        eng.load_state(W0, H0)
+        eng.iterate(4, final_loss=True)
+        torch.cuda.synchronize()
+        out[store] = (eng.get_W(), eng.get_H(), eng.history()["loss"].copy())
+        if store == "ell":
+            host = {kk: (v.cpu() if torch.is_tensor(v) else v) for kk, v in eng.ell.items()}
+            Xh, Xw, _, _ = decode(host, nx * ny, n, eng.st.p_pad, eng.st.ell_cbits, eng.st.tile_px)
+            Xi = np.ascontiguousarray(X.T).astype(np.int64)
+            assert np.array_equal(Xh[:nx * ny], Xi) and np.array_equal(Xw[:nx * ny], Xi)
+    np.testing.assert_allclose(out["ell"][2], out["f32"][2], rtol=2e-6)
+    np.testing.assert_allclose(out["ell"][0], out["f32"][0], rtol=2e-4, atol=1e-6 * out["f32"][0].max())
+    np.testing.assert_allclose(out["ell"][1], out["f32"][1], rtol=2e-4, atol=2e-6)
