@@ -186,8 +186,22 @@ __device__ __forceinline__ uint32_t ell_list_load(const uint32_t* p) {
   if constexpr (STREAM) return __builtin_nontemporal_load(p);
   else return *p;
 }
+// ell_walk_pre: `use_pre` (wave-uniform) - the first PF batches were requested by the caller ahead of time (ell_walk_request: the fused
+// kernel asks for a wave's first rows while its workgroup is still staging the table, so that the walk starts without a round trip to
+// memory of its own) and arrive in `pre`.
+template <int UNR, int PF, bool STREAM>
+__device__ __forceinline__ bool ell_walk_request(const uint32_t* row, int len, uint32_t (&pre)[PF][UNR]) {
+  if (len < UNR) return false;
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    const int jd = min(d * UNR, len - UNR);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) pre[d][u] = ell_list_load<STREAM>(row + (size_t)(jd + u) * 64);
+  }
+  return true;
+}
 template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, typename Get, typename Body, typename Flush = EllNoFlush>
-__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
+__device__ __forceinline__ void ell_walk_pre(const uint32_t* row, int len, Get get, Body body, Flush flush, bool use_pre, const uint32_t (&pre)[PF][UNR]) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
   auto batch = [&](const uint32_t (&e)[UNR]) {
@@ -212,11 +226,18 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
   int j = 0;
   if (len >= UNR) {
     uint32_t q[PF][UNR];
+    if (use_pre) {
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      const int jd = min(d * UNR, len - UNR);
+      for (int d = 0; d < PF; ++d)
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) q[d][u] = ell_list_load<STREAM>(row + (size_t)(jd + u) * 64);
+        for (int u = 0; u < UNR; ++u) q[d][u] = pre[d][u];
+    } else {
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        const int jd = min(d * UNR, len - UNR);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) q[d][u] = ell_list_load<STREAM>(row + (size_t)(jd + u) * 64);
+      }
     }
     for (; j + UNR <= len; j += UNR) {
       ell_walk_prio<PRIO>(len - j);
@@ -246,6 +267,11 @@ __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, 
       alt(y1, a1);
     });
   }
+}
+template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, typename Get, typename Body, typename Flush = EllNoFlush>
+__device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
+  uint32_t none[PF][UNR];   // (never read)
+  ell_walk_pre<K, UNR, PF, PRIO, STREAM>(row, len, get, body, flush, false, none);
 }
 // general entries: count << idx_bits | index
 template <int K>

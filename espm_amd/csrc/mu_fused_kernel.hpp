@@ -41,6 +41,16 @@
 #ifndef ESPM_FUSED_CUT2
 #define ESPM_FUSED_CUT2 60
 #endif
+// Below the full geometry a wave's FIRST unit of the W walk is its own (channel group = wave number; the counter hands out the rest) and
+// what the unit starts with - the group's channels and list offsets (LDS), its rows of G W and first list rows (memory) - is requested
+// behind the wave's pixels' update, ahead of the record reduction and its barrier: all 16 waves start the walk together, so nobody
+// covered that round trip.  64 rows 32.2 -> 31.7 us, 128 rows 44.6 -> 43.6, 256 rows 71.6 -> 70.0 (profiles/r04ax_*); at the full
+// geometry (4 units per wave) nothing - left out there.  The same for the H walk's first unit (offsets, slot -> pixel, H column, first
+// rows requested while the table is staged) was SLOWER at every size (+1.5 ... +6 us, profiles/r04aw_*): its two levels of dependent
+// loads sit in the instruction stream of a wave that issues in order, ahead of or behind the staging loads - withdrawn.
+#ifndef ESPM_FUSED_FIRST_PREFETCH
+#define ESPM_FUSED_FIRST_PREFETCH 1
+#endif
 #ifndef ESPM_FUSED_FULL_PREFETCH
 #define ESPM_FUSED_FULL_PREFETCH 1
 #endif
@@ -195,6 +205,9 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   float rwn[RW], rwo[RW];
 #pragma unroll
   for (int u = 0; u < RW; ++u) rwn[u] = rwo[u] = 1.f;
+  // (ESPM_FUSED_FIRST_PREFETCH: the W walk's first unit per wave is requested ahead, below)
+  constexpr bool PREF_W = PLAIN && !FULL && K <= 6 && ESPM_FUSED_FIRST_PREFETCH != 0;   // (k = 7, 8: the request's registers are spilled ones, configuration 5's shard 100.5 -> 101.1 us)
+  const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   bool staged = false;
   if constexpr (ESPM_FUSED_PROLOGUE_BATCH) {
     constexpr int TR = 4, PC = 4;   // table rows / permutation entries a thread stages
@@ -253,7 +266,10 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
         csv = wave_sum(csv);
         if ((threadIdx.x & 63) == 0) (cw < K ? cs_lds : cs_lds + KP - K)[cw] = csv;   // (sums of W' behind the KP column sums)
       }
-      if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
+      if (threadIdx.x == 0) {
+        cnt[0] = 0;
+        cnt[1] = PREF_W ? NT / 64 : 0;   // (PREF_W: channel group w is wave w's)
+      }
     }
   }
   if (!PLAIN && !staged) {
@@ -353,9 +369,30 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_WAVE_STAMP(8);
   // per-pixel epilogue over the pixels of the block; H' rows go into the LDS table of the W walk (rows of the
   // pixels beyond p: ones, never referenced by an entry with a count)
+  // the wave's first W unit (channel group = wave number), requested behind the pixels' update, ahead of the record reduction and its
+  // barrier: the group's channels and list offsets come from LDS, its rows of G W and first list rows from memory
+  uint32_t fw_rows[PF][UNR_W];
+  float fw_gw[K];
+  int fw_c = -1, fw_kind = 0;
+  auto request_w = [&]() {
+    if constexpr (PREF_W) {
+      if (wave_id < fa.w.n_cg) {
+        const int cg = wave_id;
+        fw_c = perm_lds ? lchan[cg * 64 + lane] : fa.w.chan_perm[((size_t)blockIdx.x * fa.w.n_cg + cg) * 64 + lane];
+        const float* gsrc = fa.w.gw_s + (size_t)(fw_c < 0 ? 0 : fw_c) * KP;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) fw_gw[kk] = gsrc[kk];
+        const int* off = meta + 3 * NGRP + 2 * cg;
+        const int beg = off[0], mid = off[1], end = off[2];
+        const uint32_t* lrow = fa.w.ell + (size_t)beg * 64 + lane;
+        if (ell_walk_request<UNR_W, PF, STREAM>(lrow, mid - beg, fw_rows)) fw_kind = 1;
+        else if (mid == beg && ell_walk_request<UNR_W, PF, STREAM>(lrow, end - mid, fw_rows)) fw_kind = 2;
+      }
+    }
+  };
   h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : ESPM_FUSED_MAX_SEGS) : 0, PLAIN>(
       a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
-      (PLAIN || fa.red_lds_off >= 0) ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr, relw);
+      (PLAIN || fa.red_lds_off >= 0) ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr, relw, request_w);
 
   ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
@@ -368,16 +405,22 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const bool w_split = !PLAIN && ESPM_FUSED_W_SPLIT && fa.w_split;   // (uniform)
   const bool slab_lds = PLAIN || (ESPM_FUSED_SLAB_LDS && fa.slab_lds);   // (uniform)
   const int w_units = w_split ? 2 * w.n_cg : w.n_cg;
-  for (int wu = next_unit(1); wu < w_units; wu = next_unit(1)) {
+  bool first_w = PREF_W;   // (uniform) the unit in hand is the wave's own, requested ahead
+  for (int wu = PREF_W ? wave_id : next_unit(1); wu < w_units; wu = next_unit(1), first_w = false) {
     const int cg = w_split ? wu >> 1 : wu, whalf = w_split ? wu & 1 : 0;
-    const int c = perm_lds ? lchan[cg * 64 + lane] : w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane];
+    const int c = (PREF_W && first_w) ? fw_c : (perm_lds ? lchan[cg * 64 + lane] : w.chan_perm[((size_t)b * w.n_cg + cg) * 64 + lane]);
     const float* gsrc = w.gw_s + (size_t)(c < 0 ? 0 : c) * KP;
     float gw[K], acc[K];
+    if (PREF_W && first_w) {
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) {
-      gw[kk] = gsrc[kk];
-      acc[kk] = 0.f;
+      for (int kk = 0; kk < K; ++kk) gw[kk] = fw_gw[kk];
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) gw[kk] = gsrc[kk];
     }
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) acc[kk] = 0.f;
+    const int wkind = (PREF_W && first_w) ? fw_kind : 0;
     const int* off = meta + 3 * NGRP + 2 * cg;
     const int beg = off[0], mid = off[1], end = off[2];
     int u0 = beg, u1 = mid, g0 = mid, g1 = end;   // unit rows [u0, u1), general rows [g0, g1) of this unit
@@ -392,13 +435,13 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
     }
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
-    });
-    ell_walk<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    }, EllNoFlush(), wkind == 1, fw_rows);
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
-    });
+    }, EllNoFlush(), wkind == 2, fw_rows);
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
     if (c >= 0) {
       if (slab_lds) {

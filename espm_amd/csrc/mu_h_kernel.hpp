@@ -111,12 +111,17 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 #ifndef ESPM_SUM_SWITCH
 #define ESPM_SUM_SWITCH 1
 #endif
-template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0, bool PLAIN = false>
+struct HEpiNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_pixels(): called by every thread behind its pixels' update, ahead of the record reduction and its barrier (the fused kernel
+// requests the first rows of its W walk there).
+template <int K, bool EARLY = true, int RULE = 0, int MAXP = 0, bool PLAIN = false, typename Hook = HEpiNoHook>
 __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int nparts, int TP, int tile0, float kl_lane,
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
                                            float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false,
                                            double* red_scratch = nullptr,   // fused half-steps: scratch of its own for the waves' sums -> ONE barrier after the per-pixel work
-                                           float relw_lane = -1.f) {
+                                           float relw_lane = -1.f, Hook after_pixels = Hook()) {
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K + 1;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima + RELW
   float red[NRED];   // per-thread partials in fp32 (one or two pixels per thread); fp64 from the wave results on (block_reduce_f32)
 #pragma unroll
@@ -417,6 +422,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
 
   ESPM_PHASE_STAMP(4);
+  after_pixels();
   // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced; thread i of the
   // workgroup finishes and writes value i itself
   const size_t nb = a.rec_nb ? (size_t)a.rec_nb : gridDim.x - a.tail_on;   // (an extra workgroup may carry the previous W update's tail: not a record)
