@@ -61,8 +61,11 @@
 #define ESPM_FUSED_RED_ONE_BARRIER 1
 #endif
 // below the full geometry: a wave's issue priority follows the rows it still has to walk, in steps of this many dwords (0: off)
+// (round 4: 4 dwords - only a unit's last dozen rows yield - instead of round 3's 8, which was the worst of 2 ... 24: 128 rows 41.4 ->
+//  40.6 us, 256 rows 67.7 -> 66.8, 64 rows 30.9 -> 30.7, profiles/r04bd_*, r04be_*; 16 is better still on 128-pixel blocks (30.4) and worse
+//  on configuration 5's; a step chosen at run time by the block size lost what it gained to its scalar compares, r04bf_*)
 #ifndef ESPM_FUSED_SMALL_PRIO
-#define ESPM_FUSED_SMALL_PRIO 8
+#define ESPM_FUSED_SMALL_PRIO 4
 #endif
 // the prologue's global loads issued together (the kernel's comment at its prologue)
 #ifndef ESPM_FUSED_PROLOGUE_BATCH
