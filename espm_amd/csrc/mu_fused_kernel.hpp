@@ -67,6 +67,12 @@
 #ifndef ESPM_FUSED_SMALL_PRIO
 #define ESPM_FUSED_SMALL_PRIO 4
 #endif
+// The same at the full geometry (four units per wave and walk, handed out dynamically), from 5 components on - where a table row is more
+// than one 16-byte gather: step 12: headline (k = 5) 131.8 -> 130.2 us, k = 6 146.8 -> 140.7, configuration 5 (k = 8) 648 -> 641; k = 2 ... 4
+// lose 0.1 ... 1 us with any step and stay without (profiles/r04bh_*, r04bi_*).  0 = off.
+#ifndef ESPM_FUSED_FULL_PRIO
+#define ESPM_FUSED_FULL_PRIO 12
+#endif
 // the prologue's global loads issued together (the kernel's comment at its prologue)
 #ifndef ESPM_FUSED_PROLOGUE_BATCH
 #define ESPM_FUSED_PROLOGUE_BATCH 1
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
   const int S = FULL ? FusedGeom<K>::S : fa.h_segs;   // (the launcher: 1024 / PB, or more where the numerators' region - grown for the slab - holds them)
   constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
-  constexpr int PRIO = FULL ? 0 : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
+  constexpr int PRIO = FULL ? (K >= 5 ? ESPM_FUSED_FULL_PRIO : 0) : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
   const HStepArgs& a = fa.h;
   extern __shared__ __attribute__((aligned(16))) float smem[];
