@@ -105,6 +105,9 @@ __device__ __forceinline__ void h_epilogue_load(const HStepArgs& a, int q, bool 
 // simplex over H, Laplacian on an image grid, a previous H to compare with, H' written; no fixed_H, no fill numerators, neither
 // the Bregman nor the Frobenius variant (mu stays a run-time flag: one uniform branch, and configuration 5 - mu = 0.05 - is a common case too).  The generic instance keeps ~100 scalar registers of flags and pointers alive through every
 // phase (107-165 of them spilled to vector lanes) and walks their branches in 16 waves that share one scalar unit.
+#ifndef ESPM_SIMPLEX_FAST_EXIT   // the per-pixel simplex root without its confirming evaluation (mu_common.hpp: simplex_root, fast_exit)
+#define ESPM_SIMPLEX_FAST_EXIT 1
+#endif
 #ifndef ESPM_SUM_ROW_FENCE
 #define ESPM_SUM_ROW_FENCE 1
 #endif
@@ -393,7 +396,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     if (f_simplex) {
 #endif
       float delta, e[K];
-      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e)) red[ESPM_HP_BAD] += 1.f;
+      if (!simplex_root<float, K>(nv, dv, K, a.log_shift, fminf(a.tol, 1e-6f), 100, delta, e, ESPM_SIMPLEX_FAST_EXIT != 0)) red[ESPM_HP_BAD] += 1.f;
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) dv[kk] = e[kk] + delta;  // = den + nu, formed without cancellation
     }
