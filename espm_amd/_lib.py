@@ -107,6 +107,7 @@ SYMBOLS = {
     "espm_mu_l2_step_w": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "espm_mu_l2_w_partials": (C.c_int, [_SP, _vp, _vp, C.c_int, _vp]),
     "espm_mu_l2_w_finish": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp]),
+    "espm_simplex_root_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "espm_dichotomy_simplex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]),
     "espm_mu_laplacian": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp]),
     "espm_lu_pl_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -116,6 +117,11 @@ SYMBOLS = {
 
 class EspmError(RuntimeError):
     """HIP runtime failure or unsupported configuration reported by libespm_mu."""
+
+
+class LostPeerError(EspmError):
+    """A sharded fit's one-shot record exchange gave up waiting for a peer: the iterates since then are not valid
+    (MUEngine.history raises it on every rank at the same read-back; the estimator restarts on the collective transport)."""
 
 
 def _load(path=LIB_PATH):

@@ -634,6 +634,14 @@ int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, i
                           static_cast<hipStream_t>(stream));
 }
 
+int espm_simplex_root_f32(const float* num, const float* den, int k, int p, float log_shift, float tol, int maxit, int fast_exit,
+                          float* delta_out, float* e_out, int32_t* status_out, espm_stream_t stream) {
+  ESPM_REQUIRE(num && den && delta_out && e_out && status_out, "simplex_root_f32: NULL pointer");
+  ESPM_REQUIRE(k >= ESPM_MIN_K && k <= ESPM_MAX_K && p >= 1, "simplex_root_f32: bad shape k=%d p=%d (this library: %d..%d components)", k, p, ESPM_MIN_K, ESPM_MAX_K);
+  if (log_shift > 0 && (double)k * log_shift >= 1.0) return set_error(ESPM_ENOSOLUTION, "No solution exists!");
+  return launch_simplex_root_f32(num, den, k, p, log_shift, tol, maxit, fast_exit, delta_out, e_out, status_out, static_cast<hipStream_t>(stream));
+}
+
 int espm_surrogate_terms(const float* h_old, const float* h_new, int k, int p, int64_t ld, int nx, int ny, int grid_mode, double* part,
                          int part_doubles, double* out, espm_stream_t stream) {
   ESPM_REQUIRE(h_old && h_new && part && out && k >= 1 && k <= ESPM_KP && p >= 1 && ld >= p, "surrogate_terms: bad arguments");

@@ -166,6 +166,39 @@ int launch_dichotomy(const double* num, const double* den, int k, int p, int den
   return check_hip(hipGetLastError(), "dichotomy launch");
 }
 
+// ---- the H update's per-pixel root as a launch of its own (fp32, simplex_root<float, K> exactly as h_epilogue inlines it) ----
+// One thread per column: delta (the shifted unknown, nu = delta - min{den_i : num_i > 0}) and the shifted denominators e (k, p), so that a
+// caller can evaluate f = sum max(num / (delta + e), eps) - 1 in higher precision: what the tests hold the routine to.
+template <int K>
+__global__ __launch_bounds__(256) void simplex_root_f32_kernel(const float* __restrict__ num, const float* __restrict__ den, int p, float eps, float tol,
+                                                               int maxit, int fast_exit, float* __restrict__ delta_out, float* __restrict__ e_out,
+                                                               int32_t* __restrict__ status) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p) return;
+  float nv[K], dv[K], e[K], delta;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    nv[i] = num[(size_t)i * p + j];
+    dv[i] = den[(size_t)i * p + j];
+  }
+  if (!simplex_root<float, K>(nv, dv, K, eps, tol, maxit, delta, e, fast_exit != 0)) atomicAdd(status, 1);
+  delta_out[j] = delta;
+#pragma unroll
+  for (int i = 0; i < K; ++i) e_out[(size_t)i * p + j] = e[i];
+}
+
+int launch_simplex_root_f32(const float* num, const float* den, int k, int p, float eps, float tol, int maxit, int fast_exit, float* delta_out,
+                            float* e_out, int32_t* status, hipStream_t stream) {
+  switch (k) {
+#define ESPM_X(KK) \
+  case KK: hipLaunchKernelGGL(simplex_root_f32_kernel<KK>, dim3((p + 255) / 256), dim3(256), 0, stream, num, den, p, eps, tol, maxit, fast_exit, delta_out, e_out, status); break;
+    ESPM_K_CASES(ESPM_X)
+#undef ESPM_X
+    default: return set_error(ESPM_EUNSUPPORTED, "simplex_root_f32: k=%d not built (%d..%d)", k, ESPM_MIN_K, ESPM_MAX_K);
+  }
+  return check_hip(hipGetLastError(), "simplex_root_f32 launch");
+}
+
 // ---- the other two multipliers of espm/estimators/dicotomy.py as module-level functions (fp64, one thread per column) ----
 // acc (dicotomy.py:57-82):  sum_k max(sqrt((b_kj + nu)^2 + 4 a c_kj) - nu - b_kj, 2 a eps) = 2 a
 // pg  (dicotomy.py:84-108): sum_k max(a_kj + nu, eps) = 1

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(1024) void ell_offsets_kernel(int n_cg, int nblk, i
 // (5.6 M of the fused kernel's 19.8 M conflict cycles per launch by the counts of profiles/r04r_pmc_sq2*).
 // Positions a short bucket leaves empty ("holes") are filled, in order of (bucket, position), by the ones that did not fit
 // their bucket, in order of index; the rest joins the general rows.  Every lane decides alone, from the bucket counts of its own
-// list (at most 128 ones per bucket: unit rows exist for n <= 4096 channels / 1024 pixels per block - 8-bit counters).
+// list (at most 255 ones per bucket: unit rows exist for n <= ESPM_ELL_UNIT_MAX_N = 4080 channels / 1024 pixels per block - 8-bit counters;
+// with 4096 a full residue class of 256 ones wrapped its counter to 0 and the overflow ones were placed on occupied positions).
 // MEASURED (round 4, profiles/r04u_buckets_ab_*.log): B = 32 buys nothing - headline 137.1 (16) against 137.5 us (32), k = 3 113.2 / 113.8, a
 // 64-row shard 31.7 / 31.8, configuration 5's 128-row shard 110.3 / 111.5: the second pass of the 4-byte reads was not on the critical
 // path, and half-size buckets leave more holes for the 16-byte reads.  16 stays the default.
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(1024) void ell_offsets_kernel(int n_cg, int nblk, i
 struct EllBuckets {
   static constexpr int B = ESPM_ELL_BUCKETS;
   static_assert(B == 16 || B == 32, "16 or 32 buckets");
+  static_assert((ESPM_ELL_UNIT_MAX_N + B - 1) / B <= 255 && (ESPM_ELL_PB + B - 1) / B <= 255, "8-bit bucket counters: at most 255 ones of a list in one residue class");
   uint8_t* cnt;     // [B][nthreads]: ones per bucket (pass 1)
   uint8_t* seen;    // [B][nthreads]: ones of the bucket met so far (pass 2)
   int nt, t;

@@ -33,6 +33,23 @@
 
 namespace espm {
 
+// The A/B switches of the environment, read ONCE per process (a lookup per launch sat inside espm_mu_iterate's loop, raced
+// with a setenv from another thread and could change the kernel instance in the middle of a fit).
+static bool fused_env_plain() {
+  static const bool on = [] {
+    const char* env = getenv("ESPM_FUSED_PLAIN");
+    return !(env && env[0] == '0');
+  }();
+  return on;
+}
+static int fused_env_small_segs() {
+  static const int want = [] {
+    const char* env = getenv("ESPM_FUSED_SMALL_SEGS");
+    return env ? atoi(env) : ESPM_FUSED_SMALL_SEGS_DEFAULT;
+  }();
+  return want;
+}
+
 int launch_fused_plain(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_plain.hip
 int launch_fused_plain_stream(const FusedArgs& args, int k, bool loss, bool full, int nblk, size_t lds_bytes, hipStream_t stream);   // mu_fused_stream.hip
 #ifdef ESPM_PHASE_CLOCK
@@ -91,8 +108,7 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
         args.slab_lds = 1;
         // the region grown for the slab holds more partial sets than 1024 / pb: more (group, segment) units than waves, so that the
         // units handed out last level the waves (ESPM_FUSED_SMALL_SEGS: A/B; 0 keeps 1024 / pb)
-        const char* env = getenv("ESPM_FUSED_SMALL_SEGS");
-        const int want = env ? atoi(env) : ESPM_FUSED_SMALL_SEGS_DEFAULT;
+        const int want = fused_env_small_segs();
         const int fit = (int)(slab / ((size_t)FusedGeom<K>::PROWS * pb * sizeof(float)));
         int segs = want > 0 ? want : args.h_segs;
         if (segs > fit) segs = fit;
@@ -116,8 +132,7 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
     const int NT = ESPM_ELL_WTHREADS;
     const int n_perm = args.perm_lds ? pb + 64 * args.w.n_cg : 0, n_woff = 2 * args.w.n_cg + 1;
     const bool staged_ok = args.h.n_pad <= 4 * NT && n_perm <= 4 * NT && n_woff <= NT && args.h.cs_nbk <= 64 && 2 * K <= NT / 64;
-    const char* env = getenv("ESPM_FUSED_PLAIN");
-    const bool plain = ESPM_FUSED_PLAIN && !(env && env[0] == '0') && !args.h.fixed_h && !args.h.fill_num && !args.h.breg_sr && !args.h.l2_m &&
+    const bool plain = ESPM_FUSED_PLAIN && fused_env_plain() && !args.h.fixed_h && !args.h.fill_num && !args.h.breg_sr && !args.h.l2_m &&
                        args.h.simplex_h && args.h.lambda_l != 0.f && args.h.grid_mode && args.h.have_prev && args.h.write_h && args.h.h_rule == 0 &&
                        args.h.tail_on != 1 && !args.static_units && args.slab_lds && !args.w_split && args.red_lds_off >= 0 && staged_ok &&
                        (args.perm_lds != 0) == (pb != ESPM_ELL_PB) && ESPM_FUSED_SMALL_THREADS == ESPM_ELL_WTHREADS;

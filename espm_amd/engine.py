@@ -977,7 +977,7 @@ class MUEngine:
         self._flush_finalize()
         hist = self.hist[:upto + 1].clone()
         if self.sharded and self.exchange.ctx is not None and self.exchange_health() > 0:
-            raise _lib.EspmError("the record exchange between the ranks lost a peer (a bounded wait gave up): the iterates since "
+            raise _lib.LostPeerError("the record exchange between the ranks lost a peer (a bounded wait gave up): the iterates since "
                                  "then are not valid; ESPM_XCHG=collective selects the collective transport")
         if self.sharded:
             sums = hist[:, [_lib.HI_KLX, _lib.HI_REG, _lib.HI_LAP, _lib.HI_BAD]].contiguous()

@@ -258,6 +258,19 @@ class _Shard:
         out[ch] = chs
         return out
 
+    def agree(self, ok, what, err=None):
+        """Every rank learns whether every rank succeeded (all-reduce MIN of a flag) before anybody raises: the failing rank re-raises
+        its own exception, the others a RuntimeError naming the step - nobody is left in the next collective waiting for a rank that
+        has gone."""
+        import torch
+        dev = f"cuda:{torch.cuda.current_device()}" if torch.distributed.get_backend(self.group) != "gloo" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.group)
+        if err is not None:
+            raise err
+        if int(flag.item()) == 0:
+            raise RuntimeError(f"sharded fit: {what} failed on another rank")
+
     def cols(self, a):
         """This rank's columns of an (.., p) array (None stays None)."""
         return None if a is None else a[..., self.sl]
@@ -513,7 +526,16 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                         x_local = True
                         # (pixel-major: the block is a run of rows of the array as it lies; channel-major: a strided copy of 1 / world of it)
                         host = host[shard.sl] if dev_layout == "pm" else np.ascontiguousarray(host[:, shard.sl])
-                    Xd_raw, scans = _upload_with_scans(host, torch.device("cuda", torch.cuda.current_device()), self.log_shift)
+                    upload_err = None
+                    try:
+                        Xd_raw, scans = _upload_with_scans(host, torch.device("cuda", torch.cuda.current_device()), self.log_shift)
+                    except Exception as e:   # noqa: BLE001 - (out of memory, a bad block): decided jointly below
+                        upload_err = e
+                    if shard is not None:
+                        # a rank that fails HERE must not leave its peers waiting in the scans' all-reduce: the ranks agree first
+                        shard.agree(upload_err is None, "the upload of this rank's block of X", upload_err)
+                    elif upload_err is not None:
+                        raise upload_err
                     if shard is not None:
                         scans = shard.combine_scans(scans, dev_layout)
                     mark("upload returned")
@@ -756,14 +778,17 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                     # (MUEngine.settle_exchange): history() raises on every rank at the same read-back (the health is a maximum over the ranks).
                     # Every rank then moves to the collective transport and the fit starts again from its initial W, H, G (the
                     # estimator needs the fallback bench.py has).  Anything else, or a second failure, is the caller's.
-                    from espm_amd._lib import EspmError
-                    lost = isinstance(e, EspmError) and "lost a peer" in str(e)
-                    if not lost or retried or shard is None or getattr(eng.exchange, "ctx", None) is None:
+                    from espm_amd._lib import LostPeerError
+                    if not isinstance(e, LostPeerError) or retried or shard is None or getattr(eng.exchange, "ctx", None) is None:
                         raise
                     retried = True
                     say("record exchange: a peer was lost on the one-shot transport; restarting the fit on the collective transport")
                     eng.use_collective_exchange()
                     if G_start is not None:
+                        # the physics model's own state followed the abandoned iterates (NMF_update(W) every third iteration, base.py:388-392):
+                        # it is brought back to the fit's start the way the fit got there - NMF_update() without W (base.py:269-274)
+                        if self.physics_model_ is not None:
+                            self.physics_model_.NMF_update()
                         self.G_ = G_start
                         eng.set_G(self.G_)
                     eng.load_state(self.W_, shard.cols(self.H_))

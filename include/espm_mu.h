@@ -24,6 +24,7 @@
  *   espm_mu_shard_*, espm_xchg_*, espm_mu_iterate_sharded
  *                         <- (new) pixel-row sharding over the GPUs of a node and its record exchange; no reference analogue
  *   espm_dichotomy_simplex<- espm/estimators/dicotomy.py:4-55 (module-level function)
+ *   espm_simplex_root_f32 <- dicotomy.py:4-55 as the H update solves it: per pixel, fp32, in the shifted unknown (a launch of its own for tests)
  *   espm_mu_pack_x        <- base.py:243-247 (validate_data / hspy_comp transpose) as a layout step
  *   espm_mu_laplacian     <- espm/utils.py:39-76 applied to H (H @ L), measures.py:560-577
  *   espm_mu_w_reduce_finish, espm_mu_shard_combine_finish, espm_mu_w_reduce_pack
@@ -99,7 +100,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
 #define ESPM_ELL_PB 1024   /* sparse store at its full geometry: pixels per block of the W accumulation (state field ell_pb) */
 #define ESPM_ELL_PBITS 10  /* log2(ESPM_ELL_PB)                                                             */
 #define ESPM_ELL_UNIT_ROWS 8 /* sparse store: the unit rows of a list group are a multiple of this (16 entries: one per bank quad) */
-#define ESPM_ELL_UNIT_MAX_N 4096 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16) */
+#define ESPM_ELL_UNIT_MAX_N 4080 /* sparse store: H-step lists have unit rows when n <= this (index << 4 < 2^16, and at most 255 ones in any of the builder's 16 residue classes of a list: its 8-bit counters) */
 #define ESPM_ELL_PAIR_MAX_K 6 /* sparse store H-step: list groups are walked in pairs (2 partial numerators) up to this k */
 #define ESPM_ELL_STREAM_BYTES (256 << 20) /* sparse store: list bytes beyond which a caller sets espm_mu_state.ell_stream (the MI355X's last-level cache) */
 #define ESPM_FUSED_MIN_PB 512 /* sparse store: W blocks (ell_pb) from which the fused launch is the default whatever their number           */
@@ -453,6 +454,14 @@ int espm_mu_iterate_sharded(espm_mu_state* st, espm_xchg* x, uint32_t* seq, int 
 int espm_dichotomy_simplex(const double* num, const double* den, int k, int p, int den_cols,
                            double log_shift, double tol, int maxit, double* nu_out,
                            int32_t* status_out, espm_stream_t stream);
+
+/* The H update's per-pixel multiplier search as a launch of its own: the fp32 routine espm_mu_step_h / espm_mu_step_hw inline
+ * (dicotomy.py:4-55 per column, solved in the shifted unknown delta = nu + min{den_i : num_i > 0}; csrc/mu_common.hpp: simplex_root).
+ * num, den (k, p) fp32 device arrays -> delta_out (p), e_out (k, p) = the shifted denominators: the update is
+ * max(num / (delta + e), log_shift).  fast_exit != 0: the confirming evaluation is left out where the Newton step's predicted
+ * residual is inside tol (what the H update does).  status_out as in espm_dichotomy_simplex.  k within this library's range. */
+int espm_simplex_root_f32(const float* num, const float* den, int k, int p, float log_shift, float tol, int maxit, int fast_exit,
+                          float* delta_out, float* e_out, int32_t* status_out, espm_stream_t stream);
 
 /* The other two multipliers of espm/estimators/dicotomy.py as module-level functions (fp64 device arrays, per-column
  * convergence): acc (dicotomy.py:57-82): sum_k max(sqrt((b_kj + nu_j)^2 + 4 a c_kj) - nu_j - b_kj, 2 a eps) = 2 a with b

@@ -201,11 +201,22 @@ def test_c5_full_size_against_fp64_subsets():
     np.testing.assert_allclose(A_dev[cs], A, rtol=2e-5, atol=1e-6)
     ref_W = np.maximum(W0 * (G.T @ A_dev) / (G.sum(axis=0)[:, None] * H1.sum(axis=1)[None, :]), 1e-14)
     np.testing.assert_allclose(eng.get_W(), ref_W, rtol=2e-5, atol=1e-9)
+    W1 = eng.get_W().astype(np.float64)
     # (3) properties over further iterations: monotone objective, simplex, mass balance of the KL update
     eng.iterate(4, final_loss=True)
     torch.cuda.synchronize()
     h = eng.history()
     assert np.all(np.diff(h["loss"]) < 0) and h["bad"].sum() == 0
+    # (4) the loss VALUE (Weak 1: the north star's tolerance is on the loss): SmoothNMF.loss (smooth_nmf.py:457-475,
+    # base.py:196-203) of the initial state and of the device's state after one iteration, evaluated once each in fp64 on the
+    # host over all 435 M non-zero entries, against the history's first two entries
+    sx = sparse_from_device(X)
+    Lfull = oc.laplacian_matrix(nx, ny)
+    for slot, (Wt, Ht) in enumerate(((W0, H0), (W1, H1))):
+        ref_loss, parts = osp.loss(sx, G, Wt, Ht, Lfull, mu=mu, epsilon_reg=1, lambda_L=1.0)
+        np.testing.assert_allclose(h["loss"][slot], ref_loss, rtol=LOSS_RTOL, err_msg=f"C5 loss of state {slot}")
+        print("C5 loss of state %d: device %.9g, fp64 host %.9g (rel %.2e)" % (slot, h["loss"][slot], ref_loss, abs(h["loss"][slot] - ref_loss) / abs(ref_loss)))
+    del sx
     np.testing.assert_allclose(eng.get_H().sum(axis=0), 1.0, atol=5e-6)
     sum_y = float(eng.hist[5, 3].item())
     assert abs(sum_y - eng.sum_x) / eng.sum_x < 1e-5

@@ -230,3 +230,11 @@ def test_config5_128_row_shards():
     np.testing.assert_allclose(res[0]["loss"], ref["loss"], rtol=1e-6)
     assert np.all(np.diff(res[0]["loss"]) < 0)
     np.testing.assert_allclose(H.sum(axis=0), 1.0, atol=5e-6)
+    # (4) the whole trajectory - loss values included (Weak 1) - against the fp64 oracle on the image's non-zero entries
+    from oracle import mu_oracle_sparse as osp
+    from test_gpu_fullsize_parity import sparse_from_device
+    ora = osp.fit(sparse_from_device(X), k, G=G, W=W0, H=H0, shape_2d=(nx, ny), max_iter=c["iters"], **c["kw"])
+    np.testing.assert_allclose(res[0]["loss"][1:], ora["losses"], rtol=1e-5)
+    np.testing.assert_allclose(res[0]["loss"][0], ora["eval_init"], rtol=1e-5)
+    np.testing.assert_allclose(H, ora["H"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(res[0]["W"], ora["W"], rtol=2e-4, atol=2e-4 * np.abs(ora["W"]).max())

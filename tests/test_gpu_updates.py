@@ -86,6 +86,75 @@ def test_dichotomy_twelve_decades(api):
                                            atol=1e-12)
 
 
+def _per_pixel_root(num, den, eps, tol, fast_exit):
+    """The H update's own fp32 routine (simplex_root<float, K>) through the C ABI; returns f = sum max(num / (delta + e), eps) - 1
+    evaluated in fp64 from its outputs, and delta."""
+    import torch
+    from espm_amd import _lib
+    k, p = num.shape
+    dev = torch.device("cuda", 0)
+    d_num = torch.as_tensor(np.ascontiguousarray(num, np.float32), device=dev)
+    d_den = torch.as_tensor(np.ascontiguousarray(den, np.float32), device=dev)
+    d_delta = torch.empty(p, dtype=torch.float32, device=dev)
+    d_e = torch.empty((k, p), dtype=torch.float32, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.espm_simplex_root_f32(d_num.data_ptr(), d_den.data_ptr(), k, p, float(eps), float(tol), 100, int(fast_exit),
+                                              d_delta.data_ptr(), d_e.data_ptr(), d_status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(d_status.item()) == 0
+    delta, e = d_delta.cpu().numpy().astype(np.float64), d_e.cpu().numpy().astype(np.float64)
+    n32 = np.asarray(num, np.float32).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(n32 > 0, n32 / (delta[None, :] + e), 0.0)
+    return np.sum(np.maximum(t, eps), axis=0) - 1.0, delta
+
+
+def _near_pole_inputs(k, p, seed):
+    """Columns whose root sits next to a pole: one tiny numerator on the smallest denominator, the rest of the mass just short of 1
+    (the case ADVICE r4 found residuals of 7.6e-6 in with a fixed |f| <= 1e-4 exit)."""
+    rng = np.random.default_rng(seed)
+    den = rng.uniform(0.5, 30.0, (k, p))
+    num = rng.uniform(0.0, 1.0, (k, p)) * den / k
+    j = np.arange(p)
+    small = rng.integers(0, k, p)
+    den[small, j] = den.min(axis=0) * rng.uniform(0.2, 0.9, p)
+    num[small, j] = 10.0 ** rng.uniform(-14, -3, p)
+    # scale the other numerators so that sum num / (den - d*) is a little below / above 1: the root then lies within ~num_small of the pole
+    dstar = den[small, j]
+    others = num.copy()
+    others[small, j] = 0.0
+    s = np.sum(others / (den - dstar[None, :] + (den == dstar[None, :])), axis=0)
+    others *= (rng.uniform(0.9, 1.0 - 1e-5, p) / np.maximum(s, 1e-30))[None, :]
+    others[small, j] = num[small, j]
+    return others, den
+
+
+@pytest.mark.parametrize("k", [3, 5, 8])
+def test_per_pixel_root_meets_its_tolerance_with_and_without_the_fast_exit(k):
+    """the exit without the confirming evaluation must leave |f| inside the tolerance that evaluation enforces
+    (min(tol, 1e-6) in the H update; the reference's dicotomy_tol is 1e-5, dicotomy.py:152)."""
+    tol = 1e-6
+    rng = np.random.default_rng(k)
+    cases = [_near_pole_inputs(k, 20000, 10 + k)]
+    den = rng.uniform(0.1, 5.0, (k, 20000))
+    cases.append((rng.uniform(0.0, 1.0, (k, 20000)) * den * rng.uniform(0.2, 3.0, (1, 20000)), den))   # ordinary columns
+    span = np.logspace(-6, 6, 17)
+    cases.append((rng.choice(span, (k, 20000)) * rng.random((k, 20000)), rng.choice(span, (k, 20000)) * rng.random((k, 20000))))
+    for num, den in cases:
+        f0, d0 = _per_pixel_root(num, den, 1e-14, tol, fast_exit=0)
+        f1, d1 = _per_pixel_root(num, den, 1e-14, tol, fast_exit=1)
+        # fp32 resolution of f next to a pole: ulp(delta + e) / (delta + e) per term, i.e. a few 1e-7 on a sum of 1
+        assert np.abs(f0).max() <= tol + 4e-7, np.abs(f0).max()
+        assert np.abs(f1).max() <= tol + 4e-7, np.abs(f1).max()
+        assert np.mean(d0 != d1) < 0.5   # (the exit changes which iterate is returned for some columns, never the tolerance)
+    # a large log_shift (the reference's tests use 0.02): the clamp's kinks are not in the prediction, the exit must not be taken
+    num, den = cases[1]
+    f0, d0 = _per_pixel_root(num, den, 0.02, tol, fast_exit=0)
+    f1, d1 = _per_pixel_root(num, den, 0.02, tol, fast_exit=1)
+    np.testing.assert_array_equal(d0, d1)
+    assert np.abs(f1).max() <= tol + 4e-7
+
+
 # ------------------------------------------------------------------------------------ H step
 def test_step_h_golden_grid(api, golden):
     g = golden("f2_step_h")

@@ -126,7 +126,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])   # (8: a real process group of the node's size - every rank owns ONE image row, the last two)
 def test_sharded_protocol_equals_single_process(world):
     X, W0, H0 = _problem()
     ref = oc.fit(X, K, W=W0.copy(), H=H0.copy(), lambda_L=LAM, mu=MU, simplex_H=True, simplex_W=False,
@@ -244,7 +244,7 @@ def _ingest_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_shard_local_scans_and_sharded_randomized_svd(world):
     """What a sharded fit of a large X does before its loop, on CPU tensors under gloo: every rank scans ITS block of pixels, the sums
     that are the image's are all-reduced (channel sums, s1, s2, counts; the largest entry as a maximum), the pixel sums stay local; the
@@ -263,3 +263,38 @@ def test_shard_local_scans_and_sharded_randomized_svd(world):
         assert v["ds"] < 1e-5 and v["du"] < 5e-4 and v["dv"] < 5e-4, (v["ds"], v["du"], v["dv"])
         np.testing.assert_array_equal(v["U"], res[0]["U"])      # replicated factors: the same bits on every rank
         np.testing.assert_array_equal(v["V"], res[0]["V"])
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from espm_amd.estimators.base import _Shard
+        sh = _Shard(dist.group.WORLD, (NX, NY), NX * NY)
+        sh.agree(True, "a step everybody passes")
+        try:
+            sh.agree(rank != 1, "the upload", MemoryError("rank 1 ran out of memory") if rank == 1 else None)
+            out[rank] = "no exception"
+        except MemoryError as e:
+            out[rank] = ("own", str(e))
+        except RuntimeError as e:
+            out[rank] = ("peer", str(e))
+        t = torch.ones(1)
+        dist.all_reduce(t)                   # everybody is still there for the next collective
+        out[f"after{rank}"] = float(t)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_before_anybody_raises():
+    """a rank that fails between two collectives (its upload) must not leave its peers blocked in the next one: the ranks
+    exchange a flag first; the failing rank raises its own exception, every other rank one that names the step."""
+    world = 3
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_agree_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    assert res[1] == ("own", "rank 1 ran out of memory")
+    for r in (0, 2):
+        assert res[r][0] == "peer" and "the upload failed on another rank" in res[r][1]
+    assert all(res[f"after{r}"] == world for r in range(world))

@@ -9,6 +9,7 @@ from espm_amd.engine import MUEngine
 
 ROWS = int(os.environ.get("ROWS", "1024"))
 STORE = os.environ.get("STORE", "auto")
+ITERS = int(os.environ.get("ITERS", "200"))   # (a --pmc pass serialises the launches: ITERS=30 there)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 n, ny, k, m = 1980, 1024, 8, 17
@@ -22,9 +23,9 @@ eng.load_state(W0, H0[:, :ROWS * ny])
 eng.iterate(20, final_loss=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-eng.iterate(200, final_loss=False)
+eng.iterate(ITERS, final_loss=False)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 200
+dt = (time.perf_counter() - t0) / ITERS
 eng.eval_current(advance_h=False)
 h = eng.history()
 print(f"C5 rows={ROWS} store={eng.x_store}: {dt * 1e6:.1f} us/iteration = {1 / dt:.0f} it/s; loss {h['loss'][0]:.6f} -> {h['loss'][-1]:.6f}; nonfinite {h['bad'].sum():.0f}")
