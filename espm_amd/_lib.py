@@ -78,6 +78,7 @@ SYMBOLS = {
     "espm_mu_w_reduce": (C.c_int, [_SP, _vp]),
     "espm_mu_w_reduce_finalize": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_w_finish": (C.c_int, [_SP, C.c_int, C.c_int, C.c_int, _vp]),
+    "espm_mu_iterate_timed": (C.c_int, [_SP, C.c_int, _vp, _vp, _vp]),
     "espm_mu_iterate": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_shard_record_bytes": (C.c_size_t, [_SP]),
     "espm_mu_shard_pack": (C.c_int, [_SP, C.c_int, _vp, _vp]),

@@ -1,5 +1,6 @@
 // extern "C" surface of libespm_mu.so (declared in include/espm_mu.h): argument checking, kernel
 // selection and launch sequencing.  No allocation, no host synchronisation.
+#include <vector>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -478,7 +479,31 @@ int espm_mu_w_update_tail(const espm_mu_state* st, int src, int slot, espm_strea
   return launch_w_update_tail(make_w_tail_args(finish_args(st, src, 1 - src, slot + 1, 1)), static_cast<hipStream_t>(stream));
 }
 
-int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) {
+// ev (espm_mu_iterate_timed only): 3 HIP events per iteration, recorded on the launch stream ahead of the iteration's first launch,
+// between its first launch (the H update - with the W accumulation where the fused kernel applies) and what follows, and behind its last.
+static int iterate_impl(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream, hipEvent_t* ev);
+
+int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream) { return iterate_impl(st, n_iter, final_loss, stream, nullptr); }
+
+int espm_mu_iterate_timed(espm_mu_state* st, int n_iter, float* first_ms, float* rest_ms, espm_stream_t stream) {
+  if (int rc = check_state(st)) return rc;
+  ESPM_REQUIRE(n_iter >= 1 && n_iter <= 4096 && first_ms && rest_ms, "iterate_timed: 1..4096 iterations, two host arrays of that length");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev((size_t)3 * n_iter, nullptr);
+  int rc = ESPM_OK;
+  for (size_t i = 0; i < ev.size() && !rc; ++i) rc = check_hip(hipEventCreate(&ev[i]), "iterate_timed: event");
+  if (!rc) rc = iterate_impl(st, n_iter, 0, stream, ev.data());
+  if (!rc) rc = check_hip(hipStreamSynchronize(s), "iterate_timed: synchronize");
+  for (int i = 0; i < n_iter && !rc; ++i) {
+    rc = check_hip(hipEventElapsedTime(first_ms + i, ev[3 * i], ev[3 * i + 1]), "iterate_timed: elapsed");
+    if (!rc) rc = check_hip(hipEventElapsedTime(rest_ms + i, ev[3 * i + 1], ev[3 * i + 2]), "iterate_timed: elapsed");
+  }
+  for (hipEvent_t e : ev)
+    if (e) (void)hipEventDestroy(e);
+  return rc;
+}
+
+static int iterate_impl(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t stream, hipEvent_t* ev) {
   if (int rc = check_state(st)) return rc;
   ESPM_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
   ESPM_REQUIRE(st->it + n_iter < st->hist_len, "history too short: it=%d + %d >= %d", st->it, n_iter, st->hist_len);
@@ -506,10 +531,13 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
         a.tail_on = 1;
         a.tail = tail;
       }
+      if (ev && (rc = check_hip(hipEventRecord(ev[3 * i], s), "iterate_timed: record"))) return rc;
       if (fused) {
         if ((rc = launch_fused_ell(a, make_w_args(st), st->nblk_w, s, st->no_fused == 2, st->ell_stream))) return rc;
+        if (ev && (rc = check_hip(hipEventRecord(ev[3 * i + 1], s), "iterate_timed: record"))) return rc;
       } else {
         if ((rc = launch_h_ell(a, nblk_h(st), s))) return rc;
+        if (ev && (rc = check_hip(hipEventRecord(ev[3 * i + 1], s), "iterate_timed: record"))) return rc;
         if ((rc = espm_mu_w_accum(st, stream))) return rc;
       }
       const HFinalizeArgs fin = finalize_args(st, cur, slot, true);
@@ -519,11 +547,15 @@ int espm_mu_iterate(espm_mu_state* st, int n_iter, int final_loss, espm_stream_t
                                               st->nblk_w, st->a, st->hpart, nblk_h(st), nullptr, 0, nullptr, &fin, s, &tail))) {
         return rc;
       }
+      if (ev && (rc = check_hip(hipEventRecord(ev[3 * i + 2], s), "iterate_timed: record"))) return rc;
       pending = true;
     } else {
+      if (ev && (rc = check_hip(hipEventRecord(ev[3 * i], s), "iterate_timed: record"))) return rc;
       if ((rc = espm_mu_step_hw(st, cur, stream))) return rc;   // (one launch where the fused kernel applies, else H-step + W accumulation)
+      if (ev && (rc = check_hip(hipEventRecord(ev[3 * i + 1], s), "iterate_timed: record"))) return rc;
       // slab reduction with the H-step's finalize riding in the same launch, then (or, when W' is local, in it) the W update
       if ((rc = espm_mu_w_reduce_finish(st, cur, slot, 1, stream))) return rc;
+      if (ev && (rc = check_hip(hipEventRecord(ev[3 * i + 2], s), "iterate_timed: record"))) return rc;
     }
     st->cur = 1 - cur;
     st->it = slot + 1;

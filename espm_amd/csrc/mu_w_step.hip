@@ -9,6 +9,7 @@
 //   w_finish: numerator / denominator, optional simplex over the columns of W with the reference's
 //             global-stop bisection (dicotomy.py:111-173), clamp, fixed_W, then GW = G W for the
 //             next half step, its column sums, and rel_W (base.py:323).
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1974,6 +1975,299 @@ __global__ __launch_bounds__(256) void w_gxchg_update_kernel(const WGxchgArgs x)
   }
 }
 
+// ---- the dictionary-G W step by COLUMNS: one launch behind the slab reduction (round 5) ------------------------------------------------
+// With a dictionary of few columns (C5: G 1980 x 17, k = 8) component kk of the whole W update is small enough for ONE workgroup:
+//   G^T A[:, kk]   m dot products over the n channels (a thread holds its 1 or 2 channels' rows of G^T in registers, and A[kk, :] once for all m),
+//   (sharded) the m values cross the links as granules and come back summed in rank order, with the ranks' row sums of H'[kk, :],
+//   W'[:, kk] = max(W (G^T A) / (colsum(G) rowsum(H')), eps), fixed_W                                        (updates.py:58-60, :70-76)
+//   G W'[:, kk]    from the SAME registers of G^T: the column of the table the next H update gathers from, its sum as colsum(G)^T W'[:, kk].
+// Nothing a workgroup needs comes from another workgroup of the launch, so what were two launches with a boundary between them - the update
+// per entry of W (m k workgroups, each loading a row of A and a row of G^T for ONE dot product) and the rows of G W' (which need all of W') -
+// is one: configuration 5's W step is two launches behind the fused one instead of three.  What IS global - mean(W') for
+// rel_W (base.py:323) - is formed by one extra wave (the finisher) from the columns' sums, which arrive as 8-byte granules {launch nonce,
+// fp32 sum}: value and "it is there" in one store, no counter to reset, stale content of the scratch never matches (the nonce is the
+// process's launch count).  The entries of W' the finisher compares are stored write-through (sc1) and drained before the granule, and read
+// with sc1 loads behind it (MI355X_MICROARCH.md, valid forms: data-tagged granules; sc1 payload drained before the flag, sc1 loads).
+// Built for m <= GC_MMAX columns and n_pad <= GC_CPT * GC_THREADS channels; anything else keeps the launches above.
+constexpr int GC_THREADS = 1024, GC_CPT = 2, GC_MMAX = 32;
+
+// the extra workgroup of a sharded exchange launch: boundary rows of H' (16-byte write-through stores), this rank's statistics as granules, the rows' flag
+__device__ __forceinline__ void gxchg_extra_role(const WGxchgArgs& x, int nthreads) {
+  auto record = [&](int dst, int src_rank) { return x.mbox[dst] + x.slot_base + (size_t)src_rank * x.rec_bytes; };
+  auto flag = [&](int dst, int src_rank) {
+    return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + (x.nfl - 1)) * sizeof(unsigned int));
+  };
+  const size_t GRAN = (size_t)34 * x.nfl + 2 * ESPM_HS_STRIDE;
+  auto gran = [&](int dst, int src_rank, int g) {
+    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
+  };
+  if (x.with_halo) {
+    for (int d = -1; d <= 1; ++d) {
+      const int r = x.rank + d;
+      if (r < 0 || r >= x.world) continue;
+      float* top = reinterpret_cast<float*>(record(r, x.rank) + x.top_off);
+      float* bot = reinterpret_cast<float*>(record(r, x.rank) + x.bot_off);
+      if ((x.halo_ny & 3) == 0) {
+        typedef float xf4 __attribute__((ext_vector_type(4)));
+        for (int e = 4 * threadIdx.x; e < x.halo_k * x.halo_ny; e += 4 * nthreads) {
+          const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+          const xf4 vt = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + j);
+          const xf4 vb = *reinterpret_cast<const xf4*>(x.halo_h + (size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j);
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(top + e), "v"(vt) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(bot + e), "v"(vb) : "memory");
+        }
+      } else {
+        for (int e = threadIdx.x; e < x.halo_k * x.halo_ny; e += nthreads) {
+          const int kk = e / x.halo_ny, j = e - kk * x.halo_ny;
+          __hip_atomic_store(top + e, x.halo_h[(size_t)kk * x.halo_ppad + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(bot + e, x.halo_h[(size_t)kk * x.halo_ppad + (size_t)(x.halo_nx - 1) * x.halo_ny + j], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < x.world * 2 * ESPM_HS_STRIDE; i += nthreads) {
+    const int r = i / (2 * ESPM_HS_STRIDE), j = i - r * 2 * ESPM_HS_STRIDE;
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, x.hstat_local[j >> 1]);
+    const unsigned int half = (j & 1) ? (unsigned int)(bits >> 32) : (unsigned int)bits;
+    __hip_atomic_store(gran(r, x.rank, 34 * x.nfl + j), ((unsigned long long)x.seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < x.world) xchg_store_flag(flag(threadIdx.x, x.rank), x.seq, x.release);
+}
+
+// one wave: the global statistics of the new H from the ranks' granules (the NEXT launch reads them), then the neighbours' boundary rows' flag
+__device__ __forceinline__ void gxchg_global_stats_role(const WGxchgArgs& x, int lane) {
+  auto flag = [&](int dst, int src_rank) {
+    return reinterpret_cast<unsigned int*>(x.mbox[dst] + x.wgflags_off + ((size_t)src_rank * x.nfl + (x.nfl - 1)) * sizeof(unsigned int));
+  };
+  const size_t GRAN = (size_t)34 * x.nfl + 2 * ESPM_HS_STRIDE;
+  auto gran = [&](int dst, int src_rank, int g) {
+    return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
+  };
+  unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
+  const bool p2 = lane < 2 * ESPM_HS_STRIDE;
+  unsigned int hv[16];
+  const long long t0 = wall_clock64();
+  for (;;) {
+    unsigned long long v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                 : ((unsigned long long)x.seq << 32);
+    bool all = true;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      all = all && (unsigned int)(v[r] >> 32) == x.seq;
+      hv[r] = (unsigned int)v[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+    if (wall_clock64() - t0 > x.max_ticks) {
+      if (!all) atomicAdd(err, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  double g = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (r < x.world) {
+      const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
+      const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
+      const double v2 = __builtin_bit_cast(double, bits);
+      g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+    }
+  if (p2 && !(lane & 1)) x.hstat_out[lane >> 1] = g;
+  if (lane < x.world) xchg_wait_flag(flag(x.rank, lane), x.seq, x.max_ticks, err);
+}
+
+// grid: [XCHG: workgroup 0 = the exchange's extra workgroup] k column workgroups, then the finisher (one wave does the work)
+template <bool XCHG>
+__global__ __launch_bounds__(GC_THREADS) void w_gcol_kernel(const WGxchgArgs x, unsigned int nonce) {
+  const WFinishArgs& a = x.f;
+  __shared__ float s_red[GC_THREADS / 64][GC_MMAX];
+  __shared__ unsigned int s_got[GC_MMAX + 2][16];
+  __shared__ float s_w[GC_MMAX], s_csg[GC_MMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = a.m, k = a.k, mk = m * k;
+  const int first = XCHG ? 1 : 0;
+  unsigned long long* colgran = reinterpret_cast<unsigned long long*>(a.scratch);   // [k] {nonce, fp32 sum of W'[:, kk]}
+  if (XCHG && blockIdx.x == 0) {
+    gxchg_extra_role(x, GC_THREADS);
+    return;
+  }
+  if ((int)blockIdx.x == first + k) {   // ---- the finisher: mean(W'), rel_W (base.py:323); sharded: the global statistics of H'
+    if (tid >= 64) return;
+    if (XCHG) gxchg_global_stats_role(x, lane);
+    if (lane < KP - k) a.colsum_gw[k + lane] = 0.0;
+    if (!a.hist_slot) return;
+    float sw = 0.f;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      const unsigned long long v = lane < k ? __hip_atomic_load(colgran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)nonce << 32);
+      const bool ok = (unsigned int)(v >> 32) == nonce;
+      sw = __uint_as_float((unsigned int)v);
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+      if (wall_clock64() - t0 > 4 * x.max_ticks) break;   // (every column workgroup reaches its granule: its own waits are bounded)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double sum = 0.0;
+    for (int kk = 0; kk < k; ++kk) sum += (double)__uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(sw), kk));
+    const double shift = (double)a.rel_tol * (sum / (double)mk);
+    double rel = 0.0;
+    for (int e = lane; e < mk; e += 64) {
+      const double wn = (double)__hip_atomic_load(a.w_new + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), wov = (double)a.w_old[e];
+      rel = fmax(rel, fabs(wn - wov) / (wn + shift));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rel = fmax(rel, __shfl_xor(rel, off, 64));
+    if (lane == 0) a.hist_slot[ESPM_HI_REL_W] = rel;
+    return;
+  }
+  // ---- column kk ----
+  const int kk = (int)blockIdx.x - first;
+  float av[GC_CPT], gv[GC_MMAX][GC_CPT];
+#pragma unroll
+  for (int u = 0; u < GC_CPT; ++u) {
+    const int c = tid + GC_THREADS * u;
+    av[u] = c < a.n ? a.a[(size_t)kk * a.n_pad + c] : 0.f;
+#pragma unroll
+    for (int mm = 0; mm < GC_MMAX; ++mm) gv[mm][u] = (c < a.n && mm < m) ? a.g_t[(size_t)mm * a.n_pad + c] : 0.f;
+  }
+  float wo = 1.f, fx = -1.f;
+  if (tid < m) {
+    wo = a.w_old[tid * k + kk];
+    if (a.fixed_w) fx = a.fixed_w[tid * k + kk];
+    s_csg[tid] = a.colsum_g[tid];
+  }
+#pragma unroll
+  for (int mm = 0; mm < GC_MMAX; ++mm) {
+    if (mm < m) {   // (uniform)
+      float part = gv[mm][0] * av[0];
+#pragma unroll
+      for (int u = 1; u < GC_CPT; ++u) part = fmaf(gv[mm][u], av[u], part);
+      part = wave_sum(part);
+      if (lane == 0) s_red[wave][mm] = part;
+    }
+  }
+  __syncthreads();
+  float gta = 0.f;
+  if (tid < m) {
+#pragma unroll
+    for (int w = 0; w < GC_THREADS / 64; ++w) gta += s_red[w][tid];   // wave order
+  }
+  double rs;
+  if constexpr (XCHG) {
+    const size_t GRAN = (size_t)34 * x.nfl + 2 * ESPM_HS_STRIDE;
+    auto gran = [&](int dst, int src_rank, int g) {
+      return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
+    };
+    unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
+    if (tid < m) {   // this rank's value of entry (tid, kk), to every rank
+      const unsigned long long g = ((unsigned long long)x.seq << 32) | __float_as_uint(gta);
+      for (int r = 0; r < x.world; ++r) __hip_atomic_store(gran(r, x.rank, tid * k + kk), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // thread (row, r): rank r's value of entry row (< m), or (rows m, m + 1) the low / high half of rank r's row sum kk of its new H block
+    const int row = tid >> 4, r_of = tid & 15;
+    if (row < m + 2) {   // (whole waves: 16 threads per row, 4 rows per wave)
+      const bool polls = r_of < x.world;
+      const int g_idx = row < m ? row * k + kk : 34 * x.nfl + 2 * (ESPM_HS_ROWSUM + kk) + (row - m);
+      unsigned int got = 0;
+      const long long t0 = wall_clock64();
+      for (;;) {
+        const unsigned long long v = polls ? __hip_atomic_load(gran(x.rank, r_of, g_idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : ((unsigned long long)x.seq << 32);
+        const bool ok = (unsigned int)(v >> 32) == x.seq;
+        got = (unsigned int)v;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        if (wall_clock64() - t0 > x.max_ticks) {
+          if (!ok) atomicAdd(err, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_got[row][r_of] = got;
+    }
+    __syncthreads();
+    gta = 0.f;
+    rs = 0.0;
+    for (int r = 0; r < x.world; ++r) {   // rank order: the same sums on every rank
+      if (tid < m) gta += __uint_as_float(s_got[tid][r]);
+      rs += __builtin_bit_cast(double, ((unsigned long long)s_got[m + 1][r] << 32) | s_got[m][r]);
+    }
+  } else {
+    rs = a.hstat[ESPM_HS_ROWSUM + kk];
+  }
+  if (tid < m) {   // updates.py:58-60, :70-76
+    const float num = wo * gta, den = s_csg[tid] * (float)rs;
+    float wn = fmaxf(num / den, a.log_shift);
+    if (fx >= 0.f) wn = fx;
+    __hip_atomic_store(a.w_new + tid * k + kk, wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sc1: the finisher reads it in this launch)
+    s_w[tid] = wn;
+  }
+  __syncthreads();
+  // the column of G W' (updates.py:107 of the next half step), stored / xscale with a positive floor; padding channels: X = 0 there
+  const float inv_scale = 1.f / a.xscale;
+#pragma unroll
+  for (int u = 0; u < GC_CPT; ++u) {
+    const int c = tid + GC_THREADS * u;
+    if (c < a.n_pad) {
+      float v = 1.f;
+      if (c < a.n) {
+        float row = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < GC_MMAX; ++mm)
+          if (mm < m) row = fmaf(gv[mm][u], s_w[mm], row);
+        v = fmaxf(row, a.gw_floor) * inv_scale;
+      }
+      a.gw_s[(size_t)c * KP + kk] = v;
+    }
+  }
+  if (wave == 0) {   // (the threads that stored W'[:, kk] are this wave's: its drain covers them)
+    double cs = 0.0;
+    float swf = 0.f;
+    if (lane == 0) {
+      for (int mm = 0; mm < m; ++mm) {
+        cs += (double)s_csg[mm] * (double)s_w[mm];   // colsum(G W')[kk] = colsum(G)^T W'[:, kk] (round 4: DESIGN.md section 2)
+        swf += s_w[mm];
+      }
+      a.colsum_gw[kk] = cs;
+    }
+    if (a.hist_slot) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(colgran + kk, ((unsigned long long)nonce << 32) | __float_as_uint(swf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static bool w_gcol_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("ESPM_W_GCOL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+bool w_gsplit_applies(const WFinishArgs& args);
+// the column form applies where the two-launch form does, the dictionary has at most GC_MMAX columns and a thread holds its channels
+bool w_gcol_applies(const WFinishArgs& args) {
+  return w_gsplit_applies(args) && args.m <= GC_MMAX && args.n_pad <= GC_CPT * GC_THREADS && args.k <= KP && (size_t)2 * args.m * args.k * sizeof(float) >= (size_t)args.k * 8 &&
+         w_gcol_enabled();
+}
+static unsigned int w_gcol_nonce() {
+  static std::atomic<unsigned int> count{0};
+  unsigned int v = ++count;
+  if (v == 0) v = ++count;   // (0 is what a zeroed scratch holds)
+  return v;
+}
+int launch_w_gcol(const WFinishArgs& f, hipStream_t stream) {
+  WGxchgArgs x = {};
+  x.f = f;
+  x.world = 1;
+  x.max_ticks = 200000000LL;
+  hipLaunchKernelGGL(w_gcol_kernel<false>, dim3(f.k + 1), dim3(GC_THREADS), 0, stream, x, w_gcol_nonce());
+  return check_hip(hipGetLastError(), "w_finish (dictionary G, by columns)");
+}
+
 static bool w_gsplit_enabled();
 bool w_gsplit_applies(const WFinishArgs& args) {
   const long mk = (long)args.m * args.k;
@@ -2013,6 +2307,10 @@ int launch_w_gxchg_update(const WFinishArgs& f, const espm_xchg* xc, unsigned in
   x.halo_nx = nx;
   x.halo_ny = ny;
   x.halo_ppad = p_pad;
+  if (w_gcol_applies(f)) {   // one launch: G^T A by columns, the exchange, W', the columns of G W' (w_gcol_kernel)
+    hipLaunchKernelGGL(w_gcol_kernel<true>, dim3(f.k + 2), dim3(GC_THREADS), 0, stream, x, w_gcol_nonce());
+    return check_hip(hipGetLastError(), "w_gcol (exchange) launch");
+  }
   hipLaunchKernelGGL(w_gxchg_update_kernel, dim3(mk + 1), dim3(256), 0, stream, x);
   if (int rc = check_hip(hipGetLastError(), "w_gxchg_update launch")) return rc;
   return launch_w_gfinish_gw(f, stream);
@@ -2038,6 +2336,7 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   const long mk = (long)M * args.k;
   // dictionary G, W' = max(W (G^T A) / (colsum G rowsum H'), eps): the two-launch finish above
   // (scratch: w_scratch's 2 m k floats must hold the second launch's partial column sums and its ticket - zero between launches)
+  if (w_gcol_applies(args)) return launch_w_gcol(args, stream);
   if (w_gsplit_applies(args)) {
     hipLaunchKernelGGL(w_gfinish_update_kernel, dim3((unsigned)mk), dim3(256), 0, stream, args);
     if (int rc = check_hip(hipGetLastError(), "w_finish (dictionary G: update)")) return rc;

@@ -865,6 +865,23 @@ class MUEngine:
             if final_loss:
                 self.eval_current(False)
 
+    def iterate_timed(self, n_iter):
+        """``n_iter`` iterations of the library's own loop (``espm_mu_iterate``: enqueued from C, the device never waits for the
+        host) with HIP events on the launch stream around the launches of every iteration: returns (first_us, rest_us) - the
+        iteration's first launch (the H update; fused: with the W accumulation) and what follows up to the new W.  One GPU, not
+        for the Frobenius fit.  Synchronises."""
+        st = self.st
+        n_iter = int(n_iter)
+        if st.it + n_iter + 1 > self.hist_len:
+            raise ValueError("history buffer exhausted: raise max_iter")
+        if self.sharded or self.frobenius:
+            raise NotImplementedError("iterate_timed: the unsharded multiplicative loop (timed_iterations serves a sharded engine)")
+        self._flush_finalize()
+        self._accum_done = False
+        first, rest = (C.c_float * n_iter)(), (C.c_float * n_iter)()
+        self._check(self.lib.espm_mu_iterate_timed(C.byref(st), n_iter, first, rest, _stream()))
+        return np.array(first[:], dtype=np.float64) * 1e3, np.array(rest[:], dtype=np.float64) * 1e3
+
     def timed_iterations(self, n_iter):
         """``n_iter`` iterations with HIP events between the launches, for diagnosis (bench.py prints the per-rank figures of a
         multi-GPU run): returns (half_steps_us, w_step_us), two float arrays of length n_iter.  ``half_steps``: the launch(es)

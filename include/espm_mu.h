@@ -442,6 +442,12 @@ int espm_xchg_destroy(espm_xchg* x);
  * waits, and waits only for the workgroup of its own index on the other ranks (csrc/mu_w_step.hip). */
 int espm_mu_shard_exchange_finish(const espm_mu_state* st, espm_xchg* x, uint32_t seq, int src, int slot, espm_stream_t stream);
 
+/* espm_mu_iterate with HIP events on the launch stream around the launches of every iteration (diagnostics: bench.py's roofline line).
+ * first_ms[i]: iteration i's first launch (the H update; with the W accumulation where the fused kernel applies), rest_ms[i]: what
+ * follows it up to the new W.  Host arrays of n_iter floats, 1 <= n_iter <= 4096; synchronises the stream before it returns.  The loop
+ * is the one espm_mu_iterate runs (same launches, same order, enqueued from C: the device never waits for the host). */
+int espm_mu_iterate_timed(espm_mu_state* st, int n_iter, float* first_ms, float* rest_ms, espm_stream_t stream);
+
 /* n_iter iterations of a SHARDED image (pixel rows split over the ranks of x) without host synchronisation and without a
  * host-side collective: per iteration espm_mu_step_hw, espm_mu_w_reduce_pack into the staged record, espm_xchg_post /
  * _wait, espm_mu_shard_combine_finish on the gathered records; the halo rows of the next H-step are the neighbours'
