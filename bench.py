@@ -298,6 +298,36 @@ def main():
             mine_ = dict(rank=rank, rows=rows, half_steps_us=float(np.median(hs)), w_step_with_exchange_us=float(np.median(ws)),
                          w_step_with_exchange_p90_us=float(np.percentile(ws, 90)), lost_peers=int(eng.exchange.lost_peers()),
                          exchange_selftest=eng.exchange.selftest_result)
+            # First-contact insurance for a node nobody has measured on: what this rank's shard costs with NO peer at
+            # all - the unsharded engine on the rank's own block, the library's loop with HIP events around its launches - so that the
+            # line separates "the shard is slow" from "the rank waits": `exchange_wait_us` = the W step with the exchange in it minus
+            # the same shard's W step without one; `local_iteration_us` = the projected single-rank time of the shard.
+            try:
+                e_loc = MUEngine(X, K, layout="pm", shape_2d=(rows, NY), lambda_L=args.lambda_l, simplex_H=True, simplex_W=False, tol=0.0,
+                                 max_iter=400, device=device, x_store=args.x_store, fused=not args.no_fused, autotune=False)
+                e_loc.load_state(W0d, H0d)
+                e_loc.iterate(30, final_loss=False)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                e_loc.iterate(100, final_loss=False)
+                torch.cuda.synchronize()
+                loc_it = (time.perf_counter() - t0_) / 100 * 1e6
+                lf, lr = e_loc.iterate_timed(40)
+                mine_.update(local_iteration_us=float(loc_it), local_half_steps_us=float(np.median(lf)), local_w_step_us=float(np.median(lr)),
+                             exchange_wait_us=float(np.median(ws) - np.median(lr)))
+                del e_loc
+            except Exception as e:   # noqa: BLE001 - diagnostics must not cost the line
+                mine_["local_iteration_error"] = f"{type(e).__name__}: {e}"
+            # the replicated W must be the same bits on every rank (the records are summed in rank order everywhere)
+            import zlib
+            mine_["w_crc32"] = int(zlib.crc32(eng.get_W().tobytes()))
+            sr = eng.exchange.selftest_result or {}
+            mine_["exchange_transport"] = eng.exchange.transport
+            mine_["exchange_fallback_reason"] = (None if eng.exchange.transport == "p2p" else
+                                                 ("forced by ESPM_XCHG" if os.environ.get("ESPM_XCHG") == "collective" else
+                                                  f"self-test at start-up: lost {sr.get('lost')}, corrupt {sr.get('corrupt')}" if sr.get("fell_back_from") and (sr.get("lost") or sr.get("corrupt"))
+                                                  else "a bounded wait gave up during the run (ranks sharing a device, or a peer that did not deliver)" if sr.get("n") else
+                                                  "the one-shot exchange could not be opened (hipIpc peer mapping)"))
         return dt_, steady_, mine_
 
     dt, steady, mine = timed_legs()

@@ -201,6 +201,7 @@ class MUEngine:
                 code = 2
             else:   # (the bf16 round trip is two more passes over X and two temporaries of its size: only when it decides)
                 code = 1 if bool((Xd.to(torch.bfloat16).to(Xd.dtype) - Xd).abs().max() <= 1e-16) else 0
+            self.x_store_note = None
             if code == 2:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
@@ -208,6 +209,15 @@ class MUEngine:
                 sparse = float(known["nnz"] if known else (Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
+                elif sparse and not fits:
+                    # not silently (missing 3): sparse count data that the sparse store would take - about 3 x the dense store's
+                    # rate at 20 % non-zero entries - but whose G W table does not fit a workgroup's LDS next to a tile's numerators
+                    # (rows of 12 / 16 floats from 9 / 13 components on: 16 components stop at 1784 channels, 12 at 2552)
+                    import warnings
+                    self.x_store_note = (f"sparse count data, but the sparse store's table for n={self.n}, k={k} needs "
+                                         f"{_ell.lds_bytes_h(n_pad8, k)} bytes of LDS (limit {_lib.ELL_LDS_MAX}): the dense 8-bit store is used, "
+                                         "about 3 x slower per iteration at this density")
+                    warnings.warn("espm_amd: " + self.x_store_note, RuntimeWarning, stacklevel=3)
             flag = torch.tensor([code], device=dev, dtype=torch.int32)
             _tick("storage type (integer counts, bf16-exact, density)")
             if group is not None:
@@ -224,6 +234,7 @@ class MUEngine:
         if x_store not in ("u8", "bf16", "f32", "ell"):
             raise ValueError("x_store must be 'auto', 'ell', 'u8', 'bf16' or 'f32'")
         self.x_store = x_store
+        self.x_store_note = getattr(self, "x_store_note", None)   # (why 'auto' did not take the sparse store for sparse count data, if so)
 
         st = MUState()
         self.st = st

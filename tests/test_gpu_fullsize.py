@@ -318,3 +318,36 @@ def test_matrix_core_w_accumulation_is_bit_reproducible_over_200_launches(k, sto
         eng._check(eng.lib.espm_mu_w_accum(ctypes.byref(st), s))
         differing += (eng.a_slab != ref).any().to(torch.int64)
     assert int(differing.item()) == 0, f"{int(differing.item())} of 200 launches differ from the first one"
+
+
+@pytest.mark.parametrize("k", [13, 16])
+@pytest.mark.parametrize("store", ["u8", "bf16"])
+def test_matrix_core_h_step_is_bit_reproducible_over_200_launches(k, store):
+    """The same gate on the H side: `h_step_mfma_kernel` of the wide build (13..16 components, the 16-slot matrix
+    instruction - the form that ships: the 32-slot form differed from run to run in THIS kernel and was never pinned down, DESIGN.md
+    section 4).  200 launches of the H update from one state at the headline size: the new H and every workgroup's record (loss
+    pieces, row sums, maxima) compared with the first launch's on the device - one differing bit fails the build."""
+    import ctypes
+    from espm_amd import synth
+    from espm_amd.engine import MUEngine, _stream
+    prob = synth.make_problem(N, NX, NY, k, N=500.0, seed=4)
+    X = synth.sample_torch(prob, "cuda", seed=1004)
+    W0, H0 = synth.random_init(N, k, NX * NY, seed=4, scale=500.0 / N)
+    eng = MUEngine(X, k, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4, x_store=store)
+    del X
+    assert eng.x_store == store and eng.V.KP == 16 and eng.st.no_fused == 0      # matrix-core kernels allowed
+    eng.load_state(W0, H0)
+    eng._flush_finalize()
+    st, s = eng.st, _stream()
+    cur = st.cur
+    prev = eng.h[1 - cur].clone()             # (the H update reads the other buffer - the previous H, for rel_H - before it overwrites it)
+    eng._check(eng.lib.espm_mu_step_h(ctypes.byref(st), cur, 1, s))
+    ref_h, ref_rec = eng.h[1 - cur].clone(), eng.hpart.clone()
+    assert bool(torch.isfinite(ref_h).all()) and float(ref_rec.abs().max()) > 0
+    differing = torch.zeros((), dtype=torch.int64, device=ref_h.device)
+    for _ in range(200):
+        eng.h[1 - cur].copy_(prev)
+        eng.hpart.fill_(-1.0)
+        eng._check(eng.lib.espm_mu_step_h(ctypes.byref(st), cur, 1, s))
+        differing += ((eng.h[1 - cur] != ref_h).any() | (eng.hpart != ref_rec).any()).to(torch.int64)
+    assert int(differing.item()) == 0, f"{int(differing.item())} of 200 launches differ from the first one"
