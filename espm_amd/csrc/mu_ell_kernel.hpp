@@ -297,6 +297,59 @@ struct EllGetUnit {
   }
 };
 
+// The fused kernel's tables (mu_h_kernel.hpp: FixTab): one address register per entry, the second part of a row at a constant offset.
+template <int K>
+struct EllGetUnitFix {
+  static constexpr bool FIXED = FixTab<K>::TWO && FixTab<K>::FIXED;
+  uint32_t lds_q;   // (only without the fixed layout: the float4 part's run-time base)
+  __device__ __forceinline__ EllGetUnitFix(int rows = 0) : lds_q((uint32_t)(EllTab<K>::WB * rows) * 4u) {}
+  static __device__ __forceinline__ void row(uint32_t off, float (&g)[K]) {   // off = 16 * row: LDS address of the row's float4
+    const lds_v4f lo = *(ESPM_LDS(lds_v4f))(uintptr_t)off;
+#pragma unroll
+    for (int i = 0; i < (K < 4 ? K : 4); ++i) g[i] = lo[i];
+    if constexpr (K == 5) g[4] = *(ESPM_LDS(float))(uintptr_t)(off + ESPM_TAB2_BASE);
+    if constexpr (K == 6) {
+      const lds_v2f v = *(ESPM_LDS(lds_v2f))(uintptr_t)(off + ESPM_TAB2_BASE);
+      g[4] = v[0];
+      g[5] = v[1];
+    }
+    if constexpr (K >= 7) {
+      const lds_v4f v = *(ESPM_LDS(lds_v4f))(uintptr_t)(off + ESPM_TAB2_BASE);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 + i < K) g[4 + i] = v[i];
+    }
+  }
+  __device__ __forceinline__ float operator()(uint32_t e, int half, float (&g)[K]) const {
+    if constexpr (FIXED || K <= 4) row(half ? e >> 16 : e & 0xffffu, g);
+    else EllTab<K>::get_unit(lds_q, half ? e >> 16 : e & 0xffffu, g);
+    return 1.f;
+  }
+};
+template <int K>
+struct EllGetFix {
+  const float* tab;
+  int rows, idx_bits;
+  uint32_t mask;
+  __device__ __forceinline__ EllGetFix(const float* t, int r, int bits) : tab(t), rows(r), idx_bits(bits), mask((1u << bits) - 1u) {}
+  __device__ __forceinline__ float operator()(uint32_t e, int half, float (&g)[K]) const {
+    const uint32_t v = half ? e >> 16 : e & 0xffffu;
+    if constexpr (EllGetUnitFix<K>::FIXED || K <= 4) EllGetUnitFix<K>::row((v & mask) << 4, g);
+    else EllTab<K>::get(tab, rows, v & mask, g);
+    return (float)(v >> idx_bits);
+  }
+};
+template <int K, bool FIX>
+struct EllGetters {
+  typedef EllGetUnit<K> Unit;
+  typedef EllGet<K> General;
+};
+template <int K>
+struct EllGetters<K, true> {
+  typedef EllGetUnitFix<K> Unit;
+  typedef EllGetFix<K> General;
+};
+
 // The H walk over rows [x0, x1) of a list group whose first `mid` rows are unit rows: num += GW^T (X / (GW H)) of the lane's
 // pixel (updates.py:127-128 at the non-zero entries) and, with LOSS, kl += sum x log2(x / y).
 // ESPM_ELL_KLPROD: the unit rows' part of the loss, sum log2(1 / y), as ONE logarithm per batch of 2 UNR entries - of the
@@ -310,13 +363,13 @@ struct EllGetUnit {
 #ifndef ESPM_ELL_KLPROD
 #define ESPM_ELL_KLPROD 1
 #endif
-template <int K, bool LOSS, int UNR, int PF, int PRIO = 0, bool STREAM = false>
+template <int K, bool LOSS, int UNR, int PF, int PRIO = 0, bool STREAM = false, bool FIX = false>   // FIX: the fused kernel's table layout
 __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1, int mid, const float* tab, int n_pad, int ell_bits,
                                            const float (&hk)[K], float (&acc)[K], float& kl) {
   if (x0 < mid) {
     if constexpr (LOSS && ESPM_ELL_KLPROD) {
       float prod = 1.f;
-      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad),
+      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad),
         [&](float, const float (&g)[K]) {
           const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
           ell_axpy<K>(acc, g, r);
@@ -332,7 +385,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
           prod = 1.f;
         });
     } else {
-      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, EllGetUnit<K>(n_pad), [&](float, const float (&g)[K]) {
+      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad), [&](float, const float (&g)[K]) {
         const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
         ell_axpy<K>(acc, g, r);
         if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
@@ -341,7 +394,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
   }
   if (x1 > mid) {
     const int g0 = max(x0, mid);
-    ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)g0 * 64, x1 - g0, EllGet<K>(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
+    ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)g0 * 64, x1 - g0, typename EllGetters<K, FIX>::General(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
       const float y = ell_dot<K>(g, hk);
       // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
       const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);

@@ -63,16 +63,26 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
   FusedArgs args = args_in;
   const int pb = args.w.pb;
   const int tab_rows = args.h.n_pad > pb ? args.h.n_pad : pb;
-  size_t part0 = (size_t)(pb == ESPM_ELL_PB ? FusedGeom<K>::S : ESPM_ELL_PB / pb) * FusedGeom<K>::PROWS * pb * sizeof(float);
+  const bool full = pb == ESPM_ELL_PB;
+  ESPM_REQUIRE(K <= 4 || tab_rows <= FixTab<K>::MAX_ROWS, "fused half-steps: a table of %d rows, at most %d from 5 components on", tab_rows, FixTab<K>::MAX_ROWS);
   const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
-  if (red > part0) part0 = red;
-  if (tail_scratch > part0) part0 = tail_scratch;
+  const size_t red_own = (size_t)(ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);   // the one-barrier record reduction's scratch
+  auto part_of = [&](int segs) {
+    size_t part = (size_t)segs * FusedGeom<K>::PROWS * pb * sizeof(float);
+    if (red > part) part = red;
+    if (tail_scratch > part) part = tail_scratch;
+    return part;
+  };
   size_t bytes = 0;
-  auto layout = [&](size_t part) {   // the workgroup's LDS with `part` bytes for the numerators' region
-    bytes = (size_t)tab_rows * EllTab<K>::FLOATS * sizeof(float) + part;
-    args.cnt_lds_off = (int)bytes;   // the two unit counters
-    bytes += 16;
+  // the workgroup's LDS with `part` bytes for the numerators' region.  red_in_table: the scratch of the record reduction in the part of the
+  // table region that is dead by then - the G W table is read by the H walk only, the H' table of the W walk occupies the first pb rows'
+  // worth of it (mu_fused_kernel.hpp) - where the region is long enough; otherwise (and by default) behind the permutations
+  auto layout = [&](size_t part, bool red_in_table) {
+    const size_t tab_bytes = FixTab<K>::bytes(tab_rows);   // (float4 parts from address 0, components 4.. from ESPM_TAB2_BASE: mu_h_kernel.hpp)
+    bytes = tab_bytes + part;
+    args.cnt_lds_off = (int)bytes;   // the two unit counters, then the units' KL sums
+    bytes += 16 + ESPM_FUSED_MAX_UNITS * sizeof(float);
     args.meta_lds_off = (int)bytes;  // the block's list offsets
     bytes += (size_t)(3 * (pb / 64) + 2 * args.w.n_cg + 1 + 3) / 4 * 16;
     args.perm_lds_off = (int)bytes;  // below the full geometry: the block's pix_perm and chan_perm
@@ -81,29 +91,51 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
     args.perm_lds = pb != ESPM_ELL_PB || (ESPM_FUSED_FULL_PERM_LDS && bytes + perm_bytes + KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT);
     if (args.perm_lds) bytes += perm_bytes;
     args.red_lds_off = -1;
-    if (ESPM_FUSED_RED_ONE_BARRIER && bytes + (ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double) + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
+    const size_t hp_tab = FixTab<K>::bytes(pb);   // (the end of the H' table's last part: what lies behind it up to tab_bytes held rows pb.. of G W)
+    if (ESPM_FUSED_RED_ONE_BARRIER && red_in_table && hp_tab + red_own <= tab_bytes) {
+      args.red_lds_off = (int)hp_tab;
+    } else if (ESPM_FUSED_RED_ONE_BARRIER && bytes + red_own + 2 * KP * sizeof(double) <= ESPM_FUSED_LDS_LIMIT) {
       bytes = (bytes + 7) / 8 * 8;
       args.red_lds_off = (int)bytes;
-      bytes += (size_t)(ESPM_ELL_WTHREADS / 64) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
+      bytes += red_own;
     }
     if (args.h.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators (and, for the shared tail, the sums of W')
+      bytes = (bytes + 7) / 8 * 8;
       args.h.cs_lds_off = (int)bytes;
       bytes += 2 * KP * sizeof(double);
     }
   };
+  // segments per list group of the H walk: below the full geometry 1024 / pb (16 units); at the full geometry as many as fit, S_MAX down to S
+  args.h_segs = full ? FusedGeom<K>::S : ESPM_ELL_PB / pb;
+  size_t part0 = part_of(args.h_segs);
+  bool red_in_table = false;
+  if (full) {
+    for (int segs = FusedGeom<K>::S_MAX; segs > FusedGeom<K>::S; --segs) {
+      bool ok = false;
+      for (int rit = 0; rit < 2 && !ok; ++rit) {
+        layout(part_of(segs), rit != 0);
+        ok = bytes <= ESPM_FUSED_LDS_LIMIT && args.red_lds_off >= 0;
+        if (ok) red_in_table = rit != 0;
+      }
+      if (ok) {
+        args.h_segs = segs;
+        part0 = part_of(segs);
+        break;
+      }
+    }
+  }
   // the slab of the block collected in the numerators' region (mu_fused_kernel.hpp, ESPM_FUSED_SLAB_LDS): needs that region to itself from
   // the epilogue's barrier on (the record reduction's scratch elsewhere) and k n_pad floats of it - below the full geometry the
   // region is grown to that where the workgroup's LDS allows
   const size_t slab = (size_t)K * args.w.n_pad * sizeof(float);
   args.slab_lds = 0;
-  layout(part0);
+  layout(part0, red_in_table);
   args.w_split = 0;
-  args.h_segs = ESPM_ELL_PB / pb;
   if (ESPM_FUSED_SLAB_LDS && args.w.n_pad % 4 == 0) {
     if (slab > part0) {
-      layout(slab);
+      layout(slab, false);
       if (bytes > ESPM_FUSED_LDS_LIMIT || args.red_lds_off < 0) {
-        layout(part0);
+        layout(part0, red_in_table);
       } else {
         args.slab_lds = 1;
         // the region grown for the slab holds more partial sets than 1024 / pb: more (group, segment) units than waves, so that the
@@ -160,15 +192,18 @@ static int launch_fused_k(const FusedArgs& args_in, int nblk, hipStream_t stream
 size_t fused_ell_lds_bytes(int n_pad, int k, int pb) {
   if (pb < 128 || pb > ESPM_ELL_PB || (pb & (pb - 1))) return (size_t)-1;
   const int tab_rows = n_pad > pb ? n_pad : pb;
-  const int tabf = 4 + (k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4)));
-  const int seg = pb == ESPM_ELL_PB ? (k <= 5 ? 4 : (k == 6 ? 3 : 2)) : ESPM_ELL_PB / pb;   // FusedGeom<K>::S | 1024 / pb
+  const bool fixed = k > 4 && k >= ESPM_FIXTAB_MIN_K;   // (FixTab, mu_h_kernel.hpp)
+  if (fixed && tab_rows > ESPM_TAB2_BASE / 16) return (size_t)-1;   // (those tables hold at most 2048 rows)
+  const int wb = k <= 4 ? 0 : (k == 5 ? 1 : (k == 6 ? 2 : 4));
+  const size_t tab_bytes = fixed ? (size_t)ESPM_TAB2_BASE + (size_t)16 * tab_rows : (size_t)(4 + wb) * 4 * tab_rows;
+  const int seg = pb == ESPM_ELL_PB ? (k <= 4 ? 4 : (k <= 6 ? 3 : 2)) : ESPM_ELL_PB / pb;   // FusedGeom<K>::S | 1024 / pb
   const int n_cg = (n_pad + 63) / 64;   // (>= the channel groups of any n with this n_pad)
-  size_t part = (size_t)seg * (k + 1) * pb * 4;
+  size_t part = (size_t)seg * k * pb * 4;   // (FusedGeom<K>::PROWS = K: the units' KL sums are ESPM_FUSED_MAX_UNITS floats of their own)
   const size_t red = (size_t)(ESPM_ELL_WTHREADS / 64 + 1) * (ESPM_HP_NSCALAR + 2 * k + 1) * sizeof(double);
   const size_t tail_scratch = (size_t)((ESPM_ELL_WTHREADS / 64 + 1) * (KP + 1) + 1) * sizeof(double);
   if (red > part) part = red;
   if (tail_scratch > part) part = tail_scratch;
-  return (size_t)tab_rows * tabf * 4 + part + 16 + (size_t)(3 * (pb / 64) + 2 * n_cg + 4) / 4 * 16 + 2 * KP * sizeof(double) +
+  return tab_bytes + part + 16 + ESPM_FUSED_MAX_UNITS * sizeof(float) + (size_t)(3 * (pb / 64) + 2 * n_cg + 4) / 4 * 16 + 2 * KP * sizeof(double) + 8 +
          (pb != ESPM_ELL_PB ? (size_t)(pb + 64 * n_cg) * sizeof(int) : 0);
 }
 

@@ -113,14 +113,15 @@ namespace espm {
 struct FusedArgs {
   HStepArgs h;      // write_h = 1, ell_tp = w.pb / 2; h_t unused
   WAccumArgs w;     // h_t unused
-  int cnt_lds_off;  // byte offset of the two unit counters in LDS
+  int cnt_lds_off;  // byte offset of the two unit counters in LDS; behind them (+ 16) the H walk's units leave their KL sums: ESPM_FUSED_MAX_UNITS floats
   int meta_lds_off; // byte offset of the block's list offsets in LDS: pb / 64 x (first row, first general row, end) of the
                     // pixel-list groups, then the 2 n_cg + 1 offsets of the block's channel-list groups
   int perm_lds_off; // below the full geometry: byte offset of the block's copy of pix_perm (pb ints) and chan_perm (64 n_cg ints) in LDS
   int static_units; // A/B only (espm_mu_state.no_fused = 2): wave w takes the units w, w + 16, ... instead of the next free one
   int red_lds_off;  // byte offset of the scratch of the record reduction (16 waves x 21 doubles), < 0: the numerators' region after a barrier of its own
   int perm_lds;     // the block's pix_perm / chan_perm are copied to LDS (always below the full geometry; at the full geometry where they fit)
-  int h_segs;       // below the full geometry: segments per list group of the H walk (at least 1024 / pb, at most ESPM_FUSED_MAX_SEGS)
+  int h_segs;       // segments per list group of the H walk: below the full geometry at least 1024 / pb, at most ESPM_FUSED_MAX_SEGS; at the full
+                    // geometry from 6 components on as many as the LDS holds partials for (FusedGeom<K>::S_MIN .. S_MAX)
   int w_split;      // the W walk's units are half channel groups, summed through two copies of the slab in LDS (needs slab_lds and room for the second copy)
   int stream_lists; // espm_mu_state.ell_stream: the STREAM instance where one is built (the full geometry's lean instances)
   int slab_lds;     // the W walk collects the block's slab in the numerators' region and the workgroup writes it out as rows (the launcher: where k n_pad floats fit there and the record reduction has scratch of its own)
@@ -136,11 +137,19 @@ struct FusedArgs {
 #ifndef ESPM_FUSED_CUT4_C
 #define ESPM_FUSED_CUT4_C 92
 #endif
-// segments per list group of the H walk: as many as the LDS holds partials for (K + 1 rows of pb floats each)
+// Segments per list group of the H walk: as many as the LDS holds partials for (K rows of pb floats each).
+// Round 5: a unit's part of the KL sum no longer occupies a row of the partials - the unit's wave adds its 64 lanes' values and leaves ONE float
+// (FusedArgs::cnt_lds_off + 16 + 4 unit; summed per unit index, not per walker: the loss stays bit-reproducible) - so a third segment fits at
+// k = 7, 8 where the table leaves room (configuration 5: 1984 rows of 32 bytes + 3 x 8 x 4 KB, with the record reduction's scratch in the part
+// of the table that is dead once the H walk is over) and a fourth at k = 6: the launcher picks S_MIN .. S_MAX (FusedArgs::h_segs).
+// Why: at k = 7, 8 two segments were 32 units for 16 waves - every wave one long and one short unit, nothing to hand to a wave that is done
+// early: the slowest wave ended 7.8 us after wave 0 of a 65 us walk (profiles/r04ah_phase_c5_1024.log).
+#define ESPM_FUSED_MAX_UNITS 64
 template <int K>
 struct FusedGeom {
-  static constexpr int S = K <= 5 ? 4 : (K == 6 ? 3 : 2);
-  static constexpr int PROWS = K + 1;   // K numerators + the KL part
+  static constexpr int S = K <= 4 ? 4 : (K <= 6 ? 3 : 2);       // S_MIN: what always fits where the fused kernel applies (fused_ell_lds_bytes; from 5 components on a row of the table is 32 bytes: FixTab)
+  static constexpr int S_MAX = K <= 6 ? 4 : 3;
+  static constexpr int PROWS = K;
   // first row of segment s of a group of `len` rows: the segments shrink (45 / 30 / 17 / 8 % of the rows; 35 / 30 / 20 / 15 until the end
   // of round 3: with the last units half as long the waves of a walk end 1.5 us closer together, profiles/r03bf_*), so that the
   // units handed out last are the short ones and the waves end close together
@@ -150,6 +159,13 @@ struct FusedGeom {
     if (len < MIN_SPLIT) return s == 0 ? 0 : len;
     constexpr int cut4[5] = {0, ESPM_FUSED_CUT4_A, ESPM_FUSED_CUT4_B, ESPM_FUSED_CUT4_C, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, ESPM_FUSED_CUT2, 100};
     const int c = S == 4 ? cut4[s] : (S == 3 ? cut3[s] : cut2[s]);
+    return (int)((long)len * c / 100);
+  }
+  // the full geometry with a run-time number of segments (k >= 6)
+  static __device__ __forceinline__ int seg_begin_rt(int len, int s, int segs) {
+    if (len < MIN_SPLIT) return s == 0 ? 0 : len;
+    constexpr int cut4[5] = {0, ESPM_FUSED_CUT4_A, ESPM_FUSED_CUT4_B, ESPM_FUSED_CUT4_C, 100}, cut3[4] = {0, 45, 80, 100}, cut2[3] = {0, ESPM_FUSED_CUT2, 100};
+    const int c = segs == 4 ? cut4[s] : (segs == 3 ? cut3[s] : cut2[s]);
     return (int)((long)len * c / 100);
   }
   // below the full geometry: `segs` equal segments
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   const int GPT_SHIFT = PBITS - 7;                 // log2(list groups per tile)
   constexpr int PROWS = FusedGeom<K>::PROWS;
   // segments per list group of the H walk: below the full geometry 1024 / PB, i.e. always 16 (group, segment) units
-  const int S = FULL ? FusedGeom<K>::S : fa.h_segs;   // (the launcher: 1024 / PB, or more where the numerators' region - grown for the slab - holds them)
+  constexpr bool S_RT = FULL && FusedGeom<K>::S_MAX > FusedGeom<K>::S;   // (k >= 5 at the full geometry: as many segments as fit, the launcher's choice)
+  const int S = (FULL && !S_RT) ? FusedGeom<K>::S : fa.h_segs;   // (below the full geometry: 1024 / PB, or more where the numerators' region - grown for the slab - holds them)
   constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
   constexpr int PRIO = FULL ? (K >= 5 ? ESPM_FUSED_FULL_PRIO : 0) : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
@@ -185,8 +202,9 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   ESPM_PHASE_STAMP(0);
   ESPM_PHASE_WHERE();
   const int tab_rows = a.n_pad > PB ? a.n_pad : PB;
-  float* part = smem + (size_t)tab_rows * EllTab<K>::FLOATS;   // [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
+  float* part = smem + FixTab<K>::bytes(tab_rows) / sizeof(float);   // (the tables: FixTab, mu_h_kernel.hpp) [S][PROWS][PB] partials (pixel = its place in the block), then reduction scratch
   int* cnt = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + fa.cnt_lds_off);   // [0]: next unit of the H walk, [1]: of the W walk
+  float* ukl = reinterpret_cast<float*>(cnt + 4);   // [NGRP S]: unit u's part of the KL sum
   if (!PLAIN && a.tail_on == 1 && blockIdx.x == gridDim.x - 1) {   // (uniform) the extra workgroup: tail of the previous W update
     w_tail_body<(10 * ESPM_ELL_WTHREADS) / NT>(a.tail, reinterpret_cast<double*>(smem));
     ESPM_PHASE_STAMP(7);   // (instrumented build: when the extra workgroup got a CU - stamp 0 - and when it was done)
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
       for (int i = 0; i < TR; ++i) {
         const int r = threadIdx.x + i * NT;
-        if (r < a.n_pad) lds_table_put<K>(tab, a.n_pad, r, tlo[i], thi[i]);
+        if (r < a.n_pad) FixTab<K>::put(tab, a.n_pad, r, tlo[i], thi[i]);
       }
 #pragma unroll
       for (int i = 0; i < PC; ++i) {
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
         if ((threadIdx.x & 63) == 0) (kk < K ? cs_lds : cs_lds + KP - K)[kk] = v;
       }
     }
-    for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
+    for (int r = threadIdx.x; r < a.n_pad; r += NT) FixTab<K>::put_row(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
     if (threadIdx.x == 0) cnt[0] = cnt[1] = 0;
     // the block's list offsets, once: a unit then starts from LDS instead of from two dependent scalar loads
     if ((int)threadIdx.x < 3 * NGRP) {
@@ -357,22 +375,27 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
     if (blk0 + (gi >> GPT_SHIFT) * TP < a.p_pad) {   // (an odd number of tiles: the last block has one; the other's pixels lie beyond p)
       lp = perm_lds ? lpix[gi * 64 + lane] : a.ell_pix[grp * 64 + lane];   // slot -> pixel of the window (lists ordered by length)
       const int beg = meta[3 * gi], mid = meta[3 * gi + 1] - beg, len = meta[3 * gi + 2] - beg;
-      const int x0 = FULL ? FusedGeom<K>::seg_begin(len, seg) : FusedGeom<K>::seg_begin_even(len, seg, S);
-      const int x1 = FULL ? FusedGeom<K>::seg_begin(len, seg + 1) : FusedGeom<K>::seg_begin_even(len, seg + 1, S);
+      const int x0 = FULL ? (S_RT ? FusedGeom<K>::seg_begin_rt(len, seg, S) : FusedGeom<K>::seg_begin(len, seg)) : FusedGeom<K>::seg_begin_even(len, seg, S);
+      const int x1 = FULL ? (S_RT ? FusedGeom<K>::seg_begin_rt(len, seg + 1, S) : FusedGeom<K>::seg_begin(len, seg + 1)) : FusedGeom<K>::seg_begin_even(len, seg + 1, S);
       if (x0 < x1) {
         const int px = blk0 + (gi >> GPT_SHIFT) * TP + lp;
         float hk[K];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-        ell_h_rows<K, LOSS, UNR_H, PF, PRIO, STREAM>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
+        ell_h_rows<K, LOSS, UNR_H, PF, PRIO, STREAM, true>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
         if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
     float* dst = part + (size_t)seg * PROWS * PB + (gi >> GPT_SHIFT) * TP + lp;
 #pragma unroll
     for (int kk = 0; kk < K; ++kk) dst[(size_t)kk * PB] = acc[kk];
-    dst[(size_t)K * PB] = kl;
+    if constexpr (LOSS) {
+      const float klw = wave_sum(kl);   // (a fixed butterfly: the same bits whoever walks the unit)
+      if (lane == 0) ukl[u] = klw;
+    } else if (lane == 0) {
+      ukl[u] = 0.f;
+    }
   }
   ESPM_PHASE_STAMP(2);   // wave 0 found no unit left
   ESPM_WAVE_STAMP(8);
@@ -399,9 +422,10 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
     }
   };
-  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S : ESPM_FUSED_MAX_SEGS) : 0, PLAIN>(
-      a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, true,
-      (PLAIN || fa.red_lds_off >= 0) ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr, relw, request_w);
+  h_epilogue<K, true, 0, ESPM_FUSED_SUM_BATCHED ? (FULL ? FusedGeom<K>::S_MAX : ESPM_FUSED_MAX_SEGS) : 0, PLAIN>(
+      a, part, S, PB, blk0, 0.f, cs_lds, tab, PB, false,
+      (PLAIN || fa.red_lds_off >= 0) ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + fa.red_lds_off) : nullptr, relw, request_w,
+      ukl, NGRP * S);
 
   ESPM_PHASE_STAMP(5);   // epilogue done (3: every wave has walked, 4: per-pixel work of wave 0 done - stamped inside h_epilogue)
   // ---- W accumulation: the block's channel groups, longest first (w_accum_ell_kernel's walk) ----
@@ -444,10 +468,10 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
     }
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnit<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnitFix<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     }, EllNoFlush(), wkind == 1, fw_rows);
-    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGet<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGetFix<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     }, EllNoFlush(), wkind == 2, fw_rows);

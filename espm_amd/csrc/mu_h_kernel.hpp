@@ -43,6 +43,52 @@ __device__ __forceinline__ void lds_table_put(float* tab, int rows, int r, const
   }   // (more than 8 components: the fused kernel, the only caller with two float4, is not built for them)
 }
 
+// ---- the FUSED kernel's gather tables (round 5): both parts of a row behind ONE address register ------------------------------------------
+// The layout above puts components 4.. first (1, 2 or 4 floats per row) so that a unit entry - the byte offset 16 r of its row's float4 -
+// reaches them with a shift; the float4 part then sits behind them, at a base that depends on the rows of the table (a run-time value in
+// the H walk, and in both walks below the full geometry): one vector add per entry, one shift or bit-field extract for the other address -
+// two of a unit entry's 11 (k = 5) .. 14 (k = 8) vector instructions.  Here the float4 part of row r is at byte 16 r from LDS address 0
+// and components 4.. at byte ESPM_TAB2_BASE + 16 r - a COMPILE-TIME distance, so both reads take the entry's 16 bits as their address
+// register and differ in the instruction's offset field: ONE vector instruction (and / shift) decodes a unit entry.  Rows of the second
+// part are 16 bytes whatever k (2 or 4 floats used): 32 bytes of LDS per row (k = 6: 64 KB instead of 48 for 2048
+// rows - the room is there since the KL part left the partials), at most ESPM_TAB2_BASE / 16 = 2048 rows (the launcher checks; larger
+// tables keep the two-launch kernels and their layout).
+#define ESPM_TAB2_BASE 32768
+// MEASURED (one box, tools/analysis/variant_ab.py, profiles/r05j_ab_*.log; layout above | this one, us per iteration): k = 6 headline image
+// 141.0-141.8 | 138.3; k = 8 161.4 | 159.5-159.9; configuration 5's 128-row shard 94.8 | 92.5-92.9 (its whole image 643 -> 638).  But k = 5:
+// 131.6-131.9 | 140.4 at the headline, 30.8 | 32.0 on a 64-row shard, 41.7 | 45.0 on 128 rows - the fifth component's 4-byte reads at a
+// 16-byte stride meet in a quarter of the banks (two passes each, by construction of the unit rows' placement), the table grows from 40 to
+// 64 KB, and at k = 5 the LDS array, not the saved vector instruction, decides.  Hence from 6 components on.
+#ifndef ESPM_FIXTAB_MIN_K   // component counts from which the fused kernel's tables take this layout (A/B: 9 keeps the layout above for all)
+#define ESPM_FIXTAB_MIN_K 6
+#endif
+template <int K>
+struct FixTab {
+  static constexpr bool TWO = K > 4;
+  static constexpr bool FIXED = K >= ESPM_FIXTAB_MIN_K;   // (K <= 4: one part either way)
+  static constexpr int MAX_ROWS = (TWO && FIXED) ? ESPM_TAB2_BASE / 16 : (1 << 30);
+  __host__ __device__ static constexpr size_t bytes(int rows) {
+    return (TWO && FIXED) ? (size_t)ESPM_TAB2_BASE + 16u * (size_t)rows : (size_t)(4 + LdsTabGeom<K>::WB) * 4u * (size_t)rows;
+  }
+  static __device__ __forceinline__ void put(float* tab, int rows, int r, const float4 lo, const float4 hi) {
+    if constexpr (!(TWO && FIXED)) {
+      lds_table_put<K>(tab, rows, r, lo, hi);
+    } else {
+      reinterpret_cast<float4*>(tab)[r] = lo;
+      float* p2 = tab + ESPM_TAB2_BASE / 4 + 4 * (size_t)r;
+      if constexpr (K == 5) p2[0] = hi.x;
+      else if constexpr (K == 6) *reinterpret_cast<float2*>(p2) = make_float2(hi.x, hi.y);
+      else *reinterpret_cast<float4*>(p2) = hi;
+    }
+  }
+  static __device__ __forceinline__ void put_row(float* tab, int rows, int r, const float* src) {   // src: a KP-strided row of gw_s
+    const float4 lo = *reinterpret_cast<const float4*>(src);
+    float4 hi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (TWO && KP > 4) hi = *reinterpret_cast<const float4*>(src + 4);
+    put(tab, rows, r, lo, hi);
+  }
+};
+
 // What the epilogue needs of one pixel besides its numerators: requested in one go (no branch between the
 // loads, so they are all in flight together) BEFORE the barrier that ends the accumulation phase - a wave that
 // finishes its part early has them by the time the slowest wave arrives.
@@ -124,7 +170,8 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
                                            const double* colsum = nullptr,   // the workgroup's own copy of colsum(GW) (LDS), else a.colsum_gw
                                            float* lds_tab = nullptr, int lds_rows = 0, bool kl_rows = false,
                                            double* red_scratch = nullptr,   // fused half-steps: scratch of its own for the waves' sums -> ONE barrier after the per-pixel work
-                                           float relw_lane = -1.f, Hook after_pixels = Hook()) {
+                                           float relw_lane = -1.f, Hook after_pixels = Hook(),
+                                           const float* unit_kl = nullptr, int n_unit_kl = 0) {   // fused half-steps (round 5): the H walk's units leave their KL sums as n_unit_kl floats in LDS instead of a row of the partials
   constexpr int NRED = ESPM_HP_NSCALAR + 2 * K + 1;  // sums: scalars (but RELH) + K row sums; max: RELH + K row maxima + RELW
   float red[NRED];   // per-thread partials in fp32 (one or two pixels per thread); fp64 from the wave results on (block_reduce_f32)
 #pragma unroll
@@ -149,7 +196,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   }
   // likewise ahead of the barrier: what every pixel needs of the state's global statistics (scalar loads the compiler may
   // not move across a barrier itself) and the pixel's loss constant / fill mark
-  const bool want_klc = kl_rows || f_fill;
+  const bool want_klc = kl_rows || f_fill || unit_kl != nullptr;
   float klc_first = 0.f;
   bool klc_loaded = false;
   if (want_klc && (int)threadIdx.x < TP && tile0 + (int)threadIdx.x < a.p) {
@@ -174,7 +221,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     if (lds_tab) {
       float4 hi = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (KP > 4 && K > 4) hi = make_float4(ht[4], ht[5], ht[6], ht[7]);
-      lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(ht[0], ht[1], ht[2], ht[3]), hi);
+      FixTab<K>::put(lds_tab, lds_rows, jj, make_float4(ht[0], ht[1], ht[2], ht[3]), hi);   // (a table handed to the epilogue is the fused kernel's)
     } else {
       store_row_kp(a.h_t + (size_t)q * KP, ht);
     }
@@ -183,7 +230,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
   for (int jj = threadIdx.x; jj < TP; jj += (int)blockDim.x) {
     const int q = tile0 + jj;
     if (q >= a.p) {
-      if (lds_tab) lds_table_put<K>(lds_tab, lds_rows, jj, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f));
+      if (lds_tab) FixTab<K>::put(lds_tab, lds_rows, jj, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f));
       continue;
     }
     if (!loaded) h_epilogue_load<K, PLAIN>(a, q, stencil, in);  // tiles wider than the workgroup: later pixels of a thread
@@ -216,6 +263,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
       };
       auto sum_rows = [&](auto nslots) {
         if (kl_rows) red[ESPM_HP_KL] += row_sum_n(nslots, K, fmaxf(klc, 0.f));   // (negative: the mark of a pixel without counts, no constant)
+        else if (unit_kl) red[ESPM_HP_KL] += fmaxf(klc, 0.f);
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) nv[kk] = row_sum_n(nslots, kk, 0.f) * a.xscale;
       };
@@ -232,6 +280,8 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
         float s = fmaxf(klc, 0.f);   // (negative: the mark of a pixel without counts, no constant)
         for (int w = 0; w < nparts; ++w) s += smem[((size_t)w * prows + K) * TP + jj];
         red[ESPM_HP_KL] += s;
+      } else if (unit_kl) {
+        red[ESPM_HP_KL] += fmaxf(klc, 0.f);
       }
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) {
@@ -424,6 +474,7 @@ __device__ __forceinline__ void h_epilogue(const HStepArgs& a, float* smem, int 
     emit_ht(q, jj, ht);
   }
 
+  if (unit_kl && (int)threadIdx.x < n_unit_kl) red[ESPM_HP_KL] += unit_kl[threadIdx.x];   // (thread u: unit u's sum - a fixed assignment, whoever walked the unit)
   ESPM_PHASE_STAMP(4);
   after_pixels();
   // field-major records: hpart[field][block], so that the finalize kernel reads them coalesced; thread i of the

@@ -638,6 +638,9 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             self.physics_model_ = None
             G = self.G
         self._identity_G = G is None
+        # (Round 5, measured and withdrawn: the engine's build - it needs the uploaded X and G, not W or H - on a worker thread and a stream of its
+        #  own BESIDE the initialisation: the two take 28.5 + 12.6 ms one after the other and 39.6 + 0.1 side by side - both are chains of
+        #  launches that fill the device, not waits; profiles/r05g_fit_timing*.log)
         self.G_, self.W_, self.H_ = initialize_algorithms(X=self.X_, G=G, W=W, H=H, n_components=self.n_components,
                                                           init=self.init, random_state=self.random_state,
                                                           simplex_H=self.simplex_H, simplex_W=self.simplex_W,

@@ -105,10 +105,12 @@ def _qr_tall(A):
     return Ad.to(A.dtype)
 
 
-def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
+def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10, long_on_device=False):
     """sklearn.utils.extmath._randomized_svd(M, n_components, random_state=...) with its defaults, M on the device.
 
-    Returns numpy (U (n_samples, k), s (k), Vt (k, n_features))."""
+    Returns numpy (U (n_samples, k), s (k), Vt (k, n_features)).  ``long_on_device`` (more features than samples - an image's
+    pixels against its channels): Vt comes back as a DEVICE tensor (k, n_features), signs applied - the NNDSVD's passes over it run
+    there (initialize_nmf_device) and 15 floats per pixel stay off the PCIe link."""
     from scipy import linalg
     from sklearn.utils import check_random_state
 
@@ -126,6 +128,13 @@ def randomized_svd_device(Xd, n_components, random_state, n_oversamples=10):
     Q = _qr_tall(M @ Q) if os.environ.get("ESPM_INIT_QR") != "torch" else torch.linalg.qr(M @ Q, mode="reduced")[0]
     B = (Q.T @ M).cpu().numpy()
     Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
+    if transpose and long_on_device:
+        # svd_flip with u_based_decision=False: the signs come from the rows of the SHORT factor, which is on the host anyway
+        idx = np.argmax(np.abs(Vt), axis=1)
+        signs = np.sign(Vt[np.arange(Vt.shape[0]), idx])
+        Vt *= signs[:, np.newaxis]
+        Ud = Q @ torch.from_numpy(Uhat[:, :n_components] * signs[np.newaxis, :n_components]).to(device=Xd.device, dtype=Xd.dtype)   # (p, k)
+        return Vt[:n_components, :].T, s[:n_components], Ud.T.contiguous()
     U = (Q @ torch.from_numpy(Uhat).to(device=Xd.device, dtype=Xd.dtype)).cpu().numpy()
     # svd_flip: signs from the rows of Vt when transposed (u_based_decision=False), from the columns of U otherwise
     if transpose:
@@ -212,6 +221,52 @@ def randomized_svd_sharded(Xd, n_components, random_state, shard, n_oversamples=
     return Vt[:n_components, :].T, s[:n_components], V_full
 
 
+_TORCH_OF = {"float32": torch.float32, "float64": torch.float64}
+
+
+def _nndsvd_long_on_device(U, S, Vd, n_components, init, random_state, eps, avg):
+    """The NNDSVD post-processing of sklearn.decomposition._nmf._initialize_nmf (the loop over the singular triplets, the zeroing
+    below eps, the fill of the zeros) with the LONG factor - Vd (k, pixels) - on the device: at 5 x 262144 its ~15 numpy passes per
+    component were 17 of the initialisation's 36 ms on the host (profiles/r05f_init_profile.log).  The same operations in the same
+    order and dtype; what differs from the host route is the summation order inside the four norms (1e-7 relative).  The short factor
+    U (channels, k) stays in numpy.  Returns numpy (W, H)."""
+    from sklearn.utils import check_random_state
+    dev, dt = Vd.device, Vd.dtype
+    k = n_components
+    Yp, Yn = Vd.clamp_min(0), (-Vd).clamp_min(0)            # max(y, 0), |min(y, 0)|
+    nrm = torch.stack((torch.linalg.vector_norm(Yp, dim=1), torch.linalg.vector_norm(Yn, dim=1))).cpu().numpy()   # ONE read-back
+    W = np.zeros_like(U)
+    Hd = torch.zeros_like(Vd)
+    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+    Hd[0] = float(np.sqrt(S[0])) * Vd[0].abs()
+    for j in range(1, k):
+        x = U[:, j]
+        x_p, x_n = np.maximum(x, 0), np.abs(np.minimum(x, 0))
+        x_p_nrm, x_n_nrm = np.linalg.norm(x_p), np.linalg.norm(x_n)
+        y_p_nrm, y_n_nrm = nrm[0, j].astype(U.dtype), nrm[1, j].astype(U.dtype)
+        m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+        if m_p > m_n:
+            u, vd, vn, sigma = x_p / x_p_nrm, Yp[j], y_p_nrm, m_p
+        else:
+            u, vd, vn, sigma = x_n / x_n_nrm, Yn[j], y_n_nrm, m_n
+        lbd = np.sqrt(S[j] * sigma)
+        W[:, j] = lbd * u
+        Hd[j] = float(lbd) * (vd / float(vn))
+    del Yp, Yn
+    zw, zh = W < eps, Hd < eps
+    W[zw] = 0
+    Hd[zh] = 0
+    if init == "nndsvda":
+        W[zw] = avg
+        Hd[zh] = avg
+    elif init == "nndsvdar":
+        rng = check_random_state(random_state)
+        W[zw] = abs(avg * rng.standard_normal(size=int(zw.sum())) / 100)
+        vals = abs(avg * rng.standard_normal(size=int(zh.sum())) / 100)       # (the same stream, W's draw first)
+        Hd[zh] = torch.from_numpy(np.asarray(vals)).to(device=dev, dtype=dt)  # (boolean-mask assignment fills in C order on both sides)
+    return W, Hd.cpu().numpy()
+
+
 def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-6, device=None, X_device=None, X_mean=None, shard=None):
     """sklearn.decomposition._nmf._initialize_nmf for the NNDSVD family with the passes over X on the GPU.
 
@@ -240,10 +295,13 @@ def initialize_nmf_device(X, n_components, init=None, random_state=None, eps=1e-
             raise ValueError("sharded initialisation needs the device block and the mean of the image")
         U, S, V = randomized_svd_sharded(Xd, n_components, random_state, shard)
     else:
-        U, S, V = randomized_svd_device(Xd, n_components, random_state)
+        U, S, V = randomized_svd_device(Xd, n_components, random_state, long_on_device=os.environ.get("ESPM_INIT_NNDSVD") != "host")
     # (X_mean: the caller knows the mean of X_device already - one pass over X less)
     avg = (float(X_mean) if X_mean is not None else float(Xd.mean(dtype=torch.float64))) if init != "nndsvd" else 0.0
     del Xd
+    if isinstance(V, torch.Tensor):
+        return _nndsvd_long_on_device(U.astype(X.dtype, copy=False), S.astype(X.dtype, copy=False), V.to(_TORCH_OF[np.dtype(X.dtype).name]), n_components, init,
+                                      random_state, eps, avg)
     U, S, V = U.astype(X.dtype, copy=False), S.astype(X.dtype, copy=False), V.astype(X.dtype, copy=False)
     # (the randomized SVD hands back transposed views: rows of V 15 floats apart in memory - every pass below over a row of 262144
     #  entries would touch a cache line per entry)
