@@ -12,12 +12,14 @@ sharded over the ranks (strong scaling: same total problem).  W warm-up iteratio
 between barrier + synchronize on both sides, maximum over ranks.
 
 Prints ONE JSON line on rank 0.  Beside the contract's fields:
-  roofline      the dominant kernel (the fused H update + W accumulation launch): algorithmic bytes per launch over its
-                mean duration from HIP events on the launch stream.  `frac` follows SURVEY 8(d)'s definition (X ONCE per
-                iteration + H read + written, X = its stored form: 2 bytes per non-zero entry); `frac_lists_twice` counts
-                both list sets the kernel streams (X is held once per half-step's access order).  `traffic`: HBM bytes per
-                launch from the PMC counters (rocprofv3, separate passes), read from profiles/hbm_traffic.json with the
-                binaries' round named in `traffic_source`.
+  roofline      the dominant kernel (the fused H update + W accumulation launch): algorithmic bytes per launch over its duration, measured live with HIP
+                events on the launch stream inside the library's own loop (espm_mu_iterate_timed).  `launch_ms` = the timed region's step minus the launch
+                that follows the fused one (that launch between events: `second_launch_ms`) - what the fused launch occupies of the timed loop, so
+                `fits_in_step` holds by construction; `launch_ms_event_brackets` = the fused launch between its own events (every bracket serialises the
+                next dispatch behind the last completion: the upper end; `frac_event_brackets`).  rocprofv3's median of the kernel lies between the two
+                (profiles/*_ks_kernel_summary.csv).  `frac` follows SURVEY 8(d)'s definition (X ONCE per iteration + H read + written, X = its stored
+                form: 2 bytes per non-zero entry); `frac_lists_twice` counts both list sets the kernel streams.  `traffic`: HBM bytes per launch from the
+                PMC counters (rocprofv3, separate passes), read from profiles/hbm_traffic.json with the binaries' round named in `traffic_source`.
   dense_store   the same iteration on the dense 8-bit and bf16 stores (the sparse rate depends on the 21 % non-zero
                 entries of this dose; the dense rates do not)
   steady_state  300 further iterations timed the same way: the first tens of milliseconds after an idle phase run
@@ -32,8 +34,10 @@ Prints ONE JSON line on rank 0.  Beside the contract's fields:
                 arrays out: seconds each
   c5            BASELINE configuration 5 on ONE GPU (1980 ch x 1024 x 1024 px, k = 8, G 1980 x 17, mu = 0.05): iteration time and
                 its fused kernel against its own algorithmic bytes
-  per_rank      (N > 1) every rank's launch times from HIP events: the local half-steps, and the W step with the record
-                exchange in it (where a rank waits for its peers); `record_exchange`: the start-up self-test of the transport
+  per_rank      (N > 1) every rank's launch times from HIP events: the local half-steps, and the W step with the record exchange in it (where a rank
+                waits for its peers); the same shard with NO peer (`local_iteration_us`, `local_half_steps_us`, `local_w_step_us`: an unsharded engine on the
+                rank's block) and `exchange_wait_us` = the difference of the two W steps; `exchange_transport` with `exchange_fallback_reason`; `w_crc32`
+                (the replicated W: equal on all ranks); `record_exchange`: the start-up self-test of the transport
 """
 import argparse
 import json

@@ -194,9 +194,20 @@ def gradH(X, G, W, H, mu=0, lambda_L=0, L=None, epsilon_reg=1, log_shift=log_shi
 
 def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,
                      dicotomy_tol=dicotomy_tol, lambda_L=0, L=None, l2=False, fixed_H=None):
-    """Projected-gradient step in H (espm/estimators/updates.py:372-395, KL branch)."""
+    """Projected-gradient step in H (espm/estimators/updates.py:372-395).  The KL branch is the engine's h_rule = 2; with l2=True - a
+    branch only a direct call reaches, smooth_nmf.py:233-237 - the step is composed of the module-level pieces, as the reference
+    composes it: gradH(l2=True), the gradient step, dichotomy_simplex_projected_gradient, the clamp, fixed_H."""
     if l2:
-        raise NotImplementedError("the Frobenius gradient (l2=True) is not built for the GPU")
+        if safe:  # updates.py:376-378
+            H = np.maximum(H, log_shift)
+            W = np.maximum(W, log_shift)
+        from espm_amd.estimators.dicotomy import dichotomy_simplex_projected_gradient
+        new_H = np.asarray(H) - 1 / gamma * gradH(X, G, W, H, mu=mu, lambda_L=lambda_L, L=L, epsilon_reg=epsilon_reg, log_shift=log_shift, safe=safe, l2=True)
+        nu = dichotomy_simplex_projected_gradient(new_H, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
+        new_H = np.maximum(new_H + nu, log_shift)
+        if fixed_H is not None:
+            new_H[fixed_H >= 0] = fixed_H[fixed_H >= 0]
+        return new_H
     shape_2d = None
     W = np.asarray(W)
     H = np.asarray(H)
@@ -215,9 +226,16 @@ def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=log_shif
 
 
 def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=log_shift, safe=True, l2=False, fixed_W=None):
-    """Projected-gradient step in W (espm/estimators/updates.py:353-370, KL branch)."""
-    if l2:
-        raise NotImplementedError("the Frobenius gradient (l2=True) is not built for the GPU")
+    """Projected-gradient step in W (espm/estimators/updates.py:353-370; l2=True: composed of gradW(l2=True), the step, the clamp and
+    fixed_W, as the reference composes it)."""
+    if l2 and not simplex_W:
+        if safe:
+            H = np.maximum(H, log_shift)
+            W = np.maximum(W, log_shift)
+        new_W = np.maximum(np.asarray(W) - 1 / gamma * gradW(X, G, W, H, log_shift=log_shift, safe=safe, l2=True), log_shift)
+        if fixed_W is not None:
+            new_W[fixed_W >= 0] = fixed_W[fixed_W >= 0]
+        return new_W
     if simplex_W:  # updates.py:368-369 (the reference raises after the step; here before)
         raise NotImplementedError("Simplex constraint not implemented for W using the projected gradient method")
     W = np.asarray(W)

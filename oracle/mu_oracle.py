@@ -468,12 +468,12 @@ def dichotomy_simplex_projected_gradient(a, log_shift=LOG_SHIFT, tol=DICOTOMY_TO
     return bisect(nu_max, nu_min, lambda x: np.sum(np.maximum(a + x, log_shift), axis=0) - 1, maxit, tol)[0]
 
 
-def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=LOG_SHIFT, safe=True, fixed_W=None):
-    """updates.py:353-370: W - grad / gamma, clamped; no simplex over W with this method."""
+def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=LOG_SHIFT, safe=True, fixed_W=None, l2=False):
+    """updates.py:353-370: W - grad / gamma, clamped; no simplex over W with this method (l2: the Frobenius gradient, :361)."""
     if safe:
         H = np.maximum(H, log_shift)
         W = np.maximum(W, log_shift)
-    new_W = np.maximum(W - 1 / gamma * gradW(X, G, W, H, log_shift=log_shift, safe=safe), log_shift)
+    new_W = np.maximum(W - 1 / gamma * gradW(X, G, W, H, log_shift=log_shift, safe=safe, l2=l2), log_shift)
     if fixed_W is not None:
         keep = fixed_W >= 0
         new_W[keep] = fixed_W[keep]
@@ -483,12 +483,12 @@ def proj_grad_step_w(X, G, W, H, gamma, simplex_W=True, log_shift=LOG_SHIFT, saf
 
 
 def proj_grad_step_h(X, G, W, H, gamma, simplex_H=True, mu=0, log_shift=LOG_SHIFT, epsilon_reg=1, safe=True,
-                     dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, fixed_H=None):
-    """updates.py:372-395: H - grad / gamma, projected on the simplex (or just clamped)."""
+                     dicotomy_tol=DICOTOMY_TOL, lambda_L=0, L=None, fixed_H=None, l2=False):
+    """updates.py:372-395: H - grad / gamma, projected on the simplex (or just clamped); l2: the Frobenius gradient (:380)."""
     if safe:
         H = np.maximum(H, log_shift)
         W = np.maximum(W, log_shift)
-    new_H = H - 1 / gamma * gradH(X, G, W, H, log_shift=log_shift, safe=safe, mu=mu, epsilon_reg=epsilon_reg, lambda_L=lambda_L, L=L)
+    new_H = H - 1 / gamma * gradH(X, G, W, H, log_shift=log_shift, safe=safe, mu=mu, epsilon_reg=epsilon_reg, lambda_L=lambda_L, L=L, l2=l2)
     nu = dichotomy_simplex_projected_gradient(new_H, log_shift=log_shift, tol=dicotomy_tol) if simplex_H else 0
     new_H = np.maximum(new_H + nu, log_shift)
     if fixed_H is not None:

@@ -645,6 +645,39 @@ def f15():
     save("f15_gradients", **out)
 
 
+# ------------------------------------------------------------------ F18: the projected-gradient steps with the Frobenius gradient (l2=True)
+def f18():
+    """espm/estimators/updates.py:353-395 called directly with l2=True (the branch a fit never takes: smooth_nmf.py resets l2 outside
+    algo="l2_surrogate"), with and without the simplex over H, fixed entries, a dictionary G."""
+    from espm.estimators.updates import proj_grad_step_h, proj_grad_step_w
+    rng = np.random.default_rng(1818)
+    out = {}
+    names = []
+    for name, (n, nx, ny, k, m) in {"i": (40, 6, 7, 3, None), "g": (36, 5, 8, 4, 7)}.items():
+        X, G, W, H = synth(rng, n, nx, ny, k, m)
+        Gd = np.eye(n) if G is None else G
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((k, nx * ny)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        L = create_laplacian_matrix(nx, ny)
+        mu = rng.random(k) * 0.3
+        fixed_W = np.where(rng.random(W0.shape) < 0.1, rng.random(W0.shape), -1.0)
+        fixed_H = np.where(rng.random(H0.shape) < 0.1, 0.5 * rng.random(H0.shape), -1.0)
+        gw = 4.0 * float(np.abs(2 * Gd.T @ ((Gd @ W0) @ H0 - X) @ H0.T).max()) / float(W0.mean())   # step sizes that keep most entries off the clamp
+        gh = 4.0 * float(np.abs((Gd @ W0).T @ ((Gd @ W0) @ H0 - X)).max())
+        out[f"{name}_X"], out[f"{name}_G"], out[f"{name}_W0"], out[f"{name}_H0"], out[f"{name}_mu"] = X, Gd, W0, H0, mu
+        out[f"{name}_shape"], out[f"{name}_gamma"] = np.array([nx, ny]), np.array([gh, gw])
+        out[f"{name}_fixed_W"], out[f"{name}_fixed_H"] = fixed_W, fixed_H
+        out[f"{name}_W_l2"] = proj_grad_step_w(X, Gd, W0, H0, gw, simplex_W=False, l2=True)
+        out[f"{name}_W_l2_fixed"] = proj_grad_step_w(X, Gd, W0, H0, gw, simplex_W=False, l2=True, fixed_W=fixed_W)
+        out[f"{name}_H_l2"] = proj_grad_step_h(X, Gd, W0, H0, gh, simplex_H=True, l2=True)
+        out[f"{name}_H_l2_free"] = proj_grad_step_h(X, Gd, W0, H0, gh, simplex_H=False, mu=mu, lambda_L=0.6, L=L, epsilon_reg=0.8, l2=True, fixed_H=fixed_H)
+        out[f"{name}_H_l2_reg"] = proj_grad_step_h(X, Gd, W0, H0, gh, simplex_H=True, mu=0.2, lambda_L=0.5, L=L, l2=True)
+        names.append(name)
+    out["names"] = np.array(names)
+    save("f18_projected_gradient_l2", **out)
+
+
 # ------------------------------------------------------------------ F16: a physics model that refreshes G every third iteration
 PHYS = {
     # the reference's default constraint (simplex over the rows NMF_simplex() names), Laplacian
@@ -750,6 +783,6 @@ def f17():
 
 
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -439,6 +439,30 @@ def test_gradients_and_q_step_golden(golden):
         gradH(X, G, W0, H0, lambda_L=1.0)
 
 
+def test_projected_gradient_steps_with_the_frobenius_gradient_golden(golden):
+    """proj_grad_step_w / _h(l2=True) - NotImplementedError until round 5 (missing 5) - against fixture F18 from the
+    reference (espm/estimators/updates.py:353-395)."""
+    from espm_amd.estimators.updates import proj_grad_step_h, proj_grad_step_w
+    from espm_amd.utils import create_laplacian_matrix
+    g = golden("f18_projected_gradient_l2")
+    for name in g["names"]:
+        X, G, W0, H0, mu = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "mu"))
+        gh, gw = (float(v) for v in g[f"{name}_gamma"])
+        fW, fH = g[f"{name}_fixed_W"], g[f"{name}_fixed_H"]
+        L = create_laplacian_matrix(*(int(v) for v in g[f"{name}_shape"]))
+        np.testing.assert_allclose(proj_grad_step_w(X, G, W0, H0, gw, simplex_W=False, l2=True), g[f"{name}_W_l2"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(proj_grad_step_w(X, G, W0, H0, gw, simplex_W=False, l2=True, fixed_W=fW), g[f"{name}_W_l2_fixed"], rtol=1e-9, atol=1e-12)
+        # (the reference's multiplier stops at dicotomy_tol = 1e-5 under a global rule, the device kernel per column)
+        np.testing.assert_allclose(proj_grad_step_h(X, G, W0, H0, gh, simplex_H=True, l2=True), g[f"{name}_H_l2"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(proj_grad_step_h(X, G, W0, H0, gh, simplex_H=False, mu=mu, lambda_L=0.6, L=L, epsilon_reg=0.8, l2=True, fixed_H=fH),
+                                   g[f"{name}_H_l2_free"], rtol=1e-6, atol=1e-9)
+        H2 = proj_grad_step_h(X, G, W0, H0, gh, simplex_H=True, mu=0.2, lambda_L=0.5, L=L, l2=True)
+        np.testing.assert_allclose(H2, g[f"{name}_H_l2_reg"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(H2.sum(axis=0), 1.0, atol=2e-5)
+    with pytest.raises(NotImplementedError):
+        proj_grad_step_w(X, G, W0, H0, gw, simplex_W=True, l2=True)
+
+
 def test_simplex_multiplier_with_tiny_numerators():
     """All numerators ~1e-13 next to denominators ~30 (a pixel without counts: only the reference's log_shift fill feeds
     its column, base.py:519-528): the bracket's upper end 2 k max(num) - min(den) + d* must not cancel to zero."""

@@ -302,6 +302,24 @@ def test_f15_gradients_and_q_step(golden):
         np.testing.assert_allclose(oc.update_q(G @ W0, H0), g[f"{name}_Q"], rtol=1e-12, atol=1e-15)
 
 
+def test_f18_projected_gradient_steps_with_the_frobenius_gradient(golden):
+    """proj_grad_step_w / _h called with l2=True (updates.py:353-395; the branch only a direct call reaches): dictionary and identity G,
+    with / without the simplex over H, regularisers, fixed entries.  (The multiplier's bisection stops at dicotomy_tol = 1e-5: the
+    simplex cases agree to that.)"""
+    g = golden("f18_projected_gradient_l2")
+    for name in g["names"]:
+        X, G, W0, H0, mu = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "mu"))
+        gh, gw = (float(v) for v in g[f"{name}_gamma"])
+        fW, fH = g[f"{name}_fixed_W"], g[f"{name}_fixed_H"]
+        L = oc.laplacian_matrix(*(int(v) for v in g[f"{name}_shape"]))
+        np.testing.assert_allclose(oc.proj_grad_step_w(X, G, W0, H0, gw, simplex_W=False, l2=True), g[f"{name}_W_l2"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(oc.proj_grad_step_w(X, G, W0, H0, gw, simplex_W=False, l2=True, fixed_W=fW), g[f"{name}_W_l2_fixed"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(oc.proj_grad_step_h(X, G, W0, H0, gh, simplex_H=True, l2=True), g[f"{name}_H_l2"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(oc.proj_grad_step_h(X, G, W0, H0, gh, simplex_H=False, mu=mu, lambda_L=0.6, L=L, epsilon_reg=0.8, l2=True, fixed_H=fH),
+                                   g[f"{name}_H_l2_free"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(oc.proj_grad_step_h(X, G, W0, H0, gh, simplex_H=True, mu=0.2, lambda_L=0.5, L=L, l2=True), g[f"{name}_H_l2_reg"], rtol=0, atol=3e-5)
+
+
 def test_f12_projected_gradient(golden):
     """algo="projected_gradient" with a given gamma = [gamma_H, gamma_W] (updates.py:317-395, dicotomy.py:84-108)."""
     g = golden("f12_projected_gradient")
