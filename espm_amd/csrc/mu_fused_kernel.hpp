@@ -101,6 +101,18 @@
 #ifndef ESPM_FUSED_MAX_SEGS
 #define ESPM_FUSED_MAX_SEGS 8
 #endif
+// Below the full geometry the H walk has as many units as the workgroup has waves (16): one each, all of the same length - and the waves of a
+// SIMD are served oldest first, so waves 12-15 of configuration 5's 128-row shard end their unit 5 us after waves 0-3 (35.2 against 29.8 us,
+// profiles/r05fin_phase_clock_c5_128.log) and the walk ends with the SIMDs one wave deep.  ESPM_FUSED_SMALL_SKEW (per cent): wave w walks unit w
+// (segment w / groups: the older waves of every SIMD hold the earlier segments) and the segments shrink linearly from (100 + skew) % to
+// (100 - skew) % of the even share, so that the younger waves have less to walk.  The partial numerators are summed by segment index as before:
+// results do not depend on it beyond the order of the rows inside a pixel's sum, which follows the cuts.  0: even segments, dynamic hand-out.
+// MEASURED (profiles/r05m_ab_*.log, skew 0 | 4 | 8 | 12 | 16, us per iteration): 64 rows 31.0 | 30.9 | 30.8 | 30.7 | 30.8, 128 rows 41.8 | 42.3 | 42.3 | 42.2 | 42.2,
+// 256 rows 68.2 | 70.5 | 69.3 | 69.1 | 68.9, configuration 5's shard 93.9 | 94.2 | 94.8 | 94.3 | 94.4: nothing - the fixed assignment loses what the shorter units of the
+// young waves gain (with the dynamic hand-out a wave that starts late simply takes a later unit).  Off.
+#ifndef ESPM_FUSED_SMALL_SKEW
+#define ESPM_FUSED_SMALL_SKEW 0
+#endif
 #ifndef ESPM_FUSED_W_SPLIT
 #define ESPM_FUSED_W_SPLIT 0
 #endif
@@ -171,6 +183,10 @@ struct FusedGeom {
   // below the full geometry: `segs` equal segments
   static __device__ __forceinline__ int seg_begin_even(int len, int s, int segs) {
     if (len < MIN_SPLIT) return s == 0 ? 0 : len;
+    if constexpr (ESPM_FUSED_SMALL_SKEW != 0) {
+      // segment j holds (1 + a (1 - (2 j + 1) / segs)) / segs of the rows, a = skew / 100: the first s of them hold s / segs (1 + a (1 - s / segs))
+      if (segs > 1) return (int)(((long)len * s * (100L * segs + (long)ESPM_FUSED_SMALL_SKEW * (segs - s))) / (100L * segs * segs));
+    }
     return (int)((long)len * s / segs);
   }
 };
@@ -233,6 +249,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
   for (int u = 0; u < RW; ++u) rwn[u] = rwo[u] = 1.f;
   // (ESPM_FUSED_FIRST_PREFETCH: the W walk's first unit per wave is requested ahead, below)
+  constexpr bool OWN_H = PLAIN && !FULL && ESPM_FUSED_SMALL_SKEW != 0;   // (the H walk's first unit per wave is its own: ESPM_FUSED_SMALL_SKEW)
   constexpr bool PREF_W = PLAIN && !FULL && K <= 6 && ESPM_FUSED_FIRST_PREFETCH != 0;   // (k = 7, 8: the request's registers are spilled ones, configuration 5's shard 100.5 -> 101.1 us)
   const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   bool staged = false;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
         if ((threadIdx.x & 63) == 0) (cw < K ? cs_lds : cs_lds + KP - K)[cw] = csv;   // (sums of W' behind the KP column sums)
       }
       if (threadIdx.x == 0) {
-        cnt[0] = 0;
+        cnt[0] = OWN_H ? NT / 64 : 0;    // (OWN_H: unit w of the H walk is wave w's)
         cnt[1] = PREF_W ? NT / 64 : 0;   // (PREF_W: channel group w is wave w's)
       }
     }
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   };
 
   // ---- H walk: units u = segment * 16 + group (segment-major: every group is started early) ----
-  for (int u = next_unit(0); u < NGRP * S; u = next_unit(0)) {
+  for (int u = OWN_H ? wave_id : next_unit(0); u < NGRP * S; u = next_unit(0)) {
     const int seg = u / NGRP, gi = u - seg * NGRP;     // group gi of the block: tile gi >> GPT_SHIFT
     const int grp = blk0 / 64 + gi;
     float acc[K];
