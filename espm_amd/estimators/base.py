@@ -444,7 +444,22 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
 
     # ---- fit --------------------------------------------------------------------------------------------
     def fit_transform(self, X, y=None, W=None, H=None):
-        """Learn X ~ G W H and return G W (or H.T with ``hspy_comp``), espm/estimators/base.py:209-420."""
+        """Learn X ~ G W H and return G W (or H.T with ``hspy_comp``), espm/estimators/base.py:209-420.
+
+        Six stages, each a method that reads and fills the fit's context ``f`` (a SimpleNamespace; the stages' docstrings name the reference lines
+        they stand for): validation, ingest (for a large X: ONE upload whose scans replace the reference's host passes), the initial W / H / G, the
+        engine, the iteration loop with the stop rules, the results."""
+        import types
+        f = types.SimpleNamespace()
+        self._fit_validate(f, X)
+        self._fit_ingest(f)
+        self._fit_initial_state(f, W, H)
+        eng = self._fit_engine(f)
+        self._fit_loop(f, eng)
+        return self._fit_results(f, eng)
+
+    def _fit_validate(self, f, X):
+        """base.py:243-259: scikit-learn's validation (the finiteness scan of a large array moves to its device copy), the hyperspy caller check, the l2 guard."""
         # base.py:243-247.  For a large array that will be uploaded anyway the finiteness scan of validate_data (a full
         # host pass: 0.18 s at 2048 x 512^2 fp32) moves to the device copy below; everything else
         # (dtype, shape, n_features_in_, feature names) is still scikit-learn's.
@@ -473,7 +488,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
                 #  EVERY frame of the stack - linecache stat calls that took 76 ms in one fit of five - and its list of frames
                 #  holds this frame, which holds the list: a cycle that kept every local of the fit alive until the collector ran.)
                 import sys
-                caller = sys._getframe(1)
+                caller = sys._getframe(2)   # (this method <- fit_transform <- the caller the reference's check looks at)
                 calframe = [None, (caller, caller.f_code.co_filename, caller.f_lineno, caller.f_code.co_name)]
                 caller = None
                 if calframe[1][3] == "decomposition" and "hyperspy" in calframe[1][1]:
@@ -488,6 +503,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         if self.l2 and getattr(self, "algo", None) != "l2_surrogate":
             raise NotImplementedError("the Frobenius loss (l2=True) is built for SmoothNMF(algo='l2_surrogate'), the one "
                                       "combination in which the reference keeps it (smooth_nmf.py:223-237)")
+        f.marks, f.mark, f.big, f.Xv = marks, mark, big, Xv
+
+    def _fit_ingest(self, f):
+        """base.py:261-268, :519-528, :200-201: sign check, zero lines, mean / normalisation, X_, const_KL_ - for a large X on ONE device copy (a sharded fit: on this rank's block, scans combined over the ranks)."""
+        Xv, big, mark = f.Xv, f.big, f.mark
 
         # Large X: ONE upload; the passes the reference makes over X on the host before the loop (sign check, zero
         # lines base.py:519-528, mean for normalize, const_KL_ base.py:200-201, the NNDSVD's products) run on that
@@ -631,6 +651,14 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             del xs, rows_of
 
         mark("const_KL read back")
+        f.Xd, f.Xd_raw, f.x_facts, f.dev_layout, f.lazy, f.shard, f.x_local = Xd, Xd_raw, x_facts, dev_layout, lazy, shard, x_local
+        f.xscale, f.X_fixed, f.mean_x, f.empty_ch, f.empty_px, f.X_init_dev = xscale, X_fixed, mean_x, empty_ch, empty_px, X_init_dev
+        f.fill = bool(fill) if Xd is not None else False
+
+    def _fit_initial_state(self, f, W, H):
+        """base.py:269-295 with updates.py:160-223: the physics model's G, W0 / H0 (NNDSVD on the device for a large X), rank 0's arrays on every rank of a sharded fit."""
+        mark, shard, x_local, Xd, xscale, mean_x, X_init_dev = f.mark, f.shard, f.x_local, f.Xd, f.xscale, f.mean_x, f.X_init_dev
+        f.X_init_dev = None
         if _is_physical_model(self.G):
             self.physics_model_ = self.G
             G = self.physics_model_.NMF_update()
@@ -663,6 +691,13 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._L_pixels = int(self.X_.shape[1])
 
         out_dtype = self.X_.dtype
+        f.say, f.out_dtype = say, out_dtype
+
+    def _fit_engine(self, f):
+        """The device engine of the fit with its state loaded (a sharded fit: the record exchange rehearsed), const_KL_."""
+        mark, shard, x_local, Xd, Xd_raw, X_fixed, xscale, fill, Xv = f.mark, f.shard, f.x_local, f.Xd, f.Xd_raw, f.X_fixed, f.xscale, f.fill, f.Xv
+        empty_ch, empty_px, dev_layout, x_facts = f.empty_ch, f.empty_px, f.dev_layout, f.x_facts
+        f.Xd = f.Xd_raw = f.X_fixed = None   # (the context must not keep the device copies of X alive past the engine's build)
         no_fill = Xd is not None and not fill      # (known from the upload's scans: no read-back to ask again)
         self._engine = eng = self._make_engine(X_fixed if Xd is None else Xd_raw, xscale, None if self._identity_G else self.G_,
                                                 filled_channels=None if no_fill or not bool(empty_ch.any()) else empty_ch,
@@ -689,6 +724,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         self._const_KL_dev = None
 
         mark("state loaded, const_KL")
+        return eng
+
+    def _fit_loop(self, f, eng):
+        """base.py:313-394: the iterations, the bookkeeping of every one of them and the stop rules; a sharded fit that loses a peer restarts once on the collective transport."""
+        mark, shard, lazy, say, out_dtype = f.mark, f.shard, f.lazy, f.say, f.out_dtype
         algo_start = time.time()
         self.n_iter_ = 0
         self._begin_fit()
@@ -806,6 +846,11 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
             if lazy is not None:   # the host copy that was made meanwhile - also when the loop raised: X_ must not stay a stand-in
                 self.X_ = lazy.result()   # (holding a thread and an event: not picklable)
         mark("host copy X_ joined")
+        f.algo_start = algo_start
+
+    def _fit_results(self, f, eng):
+        """base.py:396-420: W_, H_ read back, rescaled_DH without a simplex, reconstruction_err_, the un-normalised W_, the return value by hspy_comp."""
+        mark, marks, say, out_dtype, algo_start = f.mark, f.marks, f.say, f.out_dtype, f.algo_start
         self.W_ = eng.get_W().astype(out_dtype)
         self.H_ = self._full_H(eng).astype(out_dtype)
         mark("W, H read back")
