@@ -304,3 +304,33 @@ def test_bench_line_keeps_the_drivers_contract():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
     assert "workload" in line["config"] and "model" not in line["config"]
     assert line["n_gpus"] == 1 and line["higher_is_better"] is True and abs(line["ms_per_step"] * line["value"] / 1e3 - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("init", ["nndsvd", "nndsvda", "nndsvdar"])
+def test_nndsvd_with_the_long_factor_on_the_device_matches_sklearn_on_cpu_tensors(init):
+    """espm_amd/init_device.py (round 5): the NNDSVD's post-processing of the long factor runs as tensor operations where the factor
+    lives (`_nndsvd_long_on_device`); here on CPU tensors, against scikit-learn's `_initialize_nmf` (the reference's call,
+    espm/estimators/updates.py:179) and against the host route it replaced (ESPM_INIT_NNDSVD=host)."""
+    import torch
+    from sklearn.decomposition._nmf import _initialize_nmf
+    from espm_amd import init_device
+    rng = np.random.default_rng(21)
+    n, p, k = 40, 900, 4
+    X = rng.poisson(3.0 * (rng.random((n, k)) ** 3) @ (rng.random((k, p)) ** 2)).astype(np.float64)
+    Wr, Hr = _initialize_nmf(X, n_components=k, init=init, random_state=3)
+    Wd, Hd = init_device.initialize_nmf_device(X, k, init=init, random_state=3, X_device=torch.from_numpy(X))
+    assert Wd.dtype == Wr.dtype and Hd.dtype == Hr.dtype and Hd.shape == Hr.shape
+    if init == "nndsvdar":   # (the random fill follows the zero pattern: compare where both routes decided the entry by the SVD)
+        kept = (Hr > 1e-3 * Hr.max()) & (Hd > 1e-3 * Hd.max())
+        np.testing.assert_allclose(Hd[kept], Hr[kept], rtol=1e-6, atol=1e-9)
+    else:
+        np.testing.assert_allclose(Wd, Wr, rtol=1e-6, atol=1e-9 * np.abs(Wr).max())
+        np.testing.assert_allclose(Hd, Hr, rtol=1e-6, atol=1e-9 * np.abs(Hr).max())
+    os.environ["ESPM_INIT_NNDSVD"] = "host"
+    try:
+        Wh, Hh = init_device.initialize_nmf_device(X, k, init=init, random_state=3, X_device=torch.from_numpy(X))
+    finally:
+        del os.environ["ESPM_INIT_NNDSVD"]
+    np.testing.assert_allclose(Wd, Wh, rtol=1e-9, atol=1e-12)
+    if init != "nndsvdar":
+        np.testing.assert_allclose(Hd, Hh, rtol=1e-9, atol=1e-12)
