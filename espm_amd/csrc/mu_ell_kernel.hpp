@@ -125,9 +125,16 @@ struct EllTab {
 #ifndef ESPM_ELL_DOT_PLAIN
 #define ESPM_ELL_DOT_PLAIN 0
 #endif
+// Round 5, measured again on the final kernels (profiles/r05q_ab_*.log, seven interleaved repetitions on one box): at k = 5 the chain of five
+// FMAs wins in EVERY repetition - headline 132.8-134.7 -> 131.4-132.4 us per iteration, a 64-row shard 31.4 -> 31.1 - as the issue costs say
+// (v_pk_fma_f32 4.0 cycles, v_fma_f32 2.5: 12.6 against 13.4 for an odd k = 5, where the packed form pays a horizontal add AND a scalar FMA);
+// k = 3: 108.5 -> 108.9 (no gain), even k: the packed form is cheaper by the same arithmetic.  Hence for k = 5 only.
+#ifndef ESPM_ELL_DOT_PLAIN_K
+#define ESPM_ELL_DOT_PLAIN_K 5
+#endif
 template <int K>
 __device__ __forceinline__ float ell_dot(const float (&g)[K], const float (&h)[K]) {
-  if constexpr (ESPM_ELL_DOT_PLAIN) {
+  if constexpr (ESPM_ELL_DOT_PLAIN || K == ESPM_ELL_DOT_PLAIN_K) {
     float y = g[0] * h[0];
 #pragma unroll
     for (int i = 1; i < K; ++i) y = fmaf(g[i], h[i], y);
