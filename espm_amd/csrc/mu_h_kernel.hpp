@@ -58,7 +58,8 @@ __device__ __forceinline__ void lds_table_put(float* tab, int rows, int r, const
 // 141.0-141.8 | 138.3; k = 8 161.4 | 159.5-159.9; configuration 5's 128-row shard 94.8 | 92.5-92.9 (its whole image 643 -> 638).  But k = 5:
 // 131.6-131.9 | 140.4 at the headline, 30.8 | 32.0 on a 64-row shard, 41.7 | 45.0 on 128 rows - the fifth component's 4-byte reads at a
 // 16-byte stride meet in a quarter of the banks (two passes each, by construction of the unit rows' placement), the table grows from 40 to
-// 64 KB, and at k = 5 the LDS array, not the saved vector instruction, decides.  Hence from 6 components on.
+// 64 KB, and at k = 5 the LDS array, not the saved vector instruction, decides.  (The fifth component through an 8- or 16-byte read instead - 2-way and
+// conflict-free by the same placement - was tried too: 131.8 | 134.1 | 138.7 us, profiles/r05s_ab_*.log.)  Hence from 6 components on.
 #ifndef ESPM_FIXTAB_MIN_K   // component counts from which the fused kernel's tables take this layout (A/B: 9 keeps the layout above for all)
 #define ESPM_FIXTAB_MIN_K 6
 #endif
