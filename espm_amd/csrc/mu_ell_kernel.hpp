@@ -207,7 +207,15 @@ __device__ __forceinline__ bool ell_walk_request(const uint32_t* row, int len, u
   }
   return true;
 }
-template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, typename Get, typename Body, typename Flush = EllNoFlush>
+// PP: the list dwords of the batch in hand and of the batch requested ahead in two register sets used in turn (below).  The caller's choice: it
+// pays where the registers are there - the fused kernel at its full geometry up to ESPM_ELL_WALK_PP_MAX_K components.  MEASURED at the headline
+// image (profiles/r05u_ab_k*_512.log, ring | two sets, us per iteration): k = 1 106.6 | 100.2, k = 2 103.9 | 92.5, k = 3 107.1 | 99.5, k = 4 113.0 | 107.6,
+// k = 5 128.4 | 127.2 (and 128.2 | 127.1 in r05t); k = 6 137.6 | 191.6, k = 7 153.5 | 551.7, k = 8 162.3 | 544.6: from 6 components on the second set spills.
+// Below the full geometry (a 64-row shard, k = 5) 30.9 | 31.4: not there.  Same rows in the same order: the same bits.
+#ifndef ESPM_ELL_WALK_PP_MAX_K
+#define ESPM_ELL_WALK_PP_MAX_K 5
+#endif
+template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, bool PP = false, typename Get, typename Body, typename Flush = EllNoFlush>
 __device__ __forceinline__ void ell_walk_pre(const uint32_t* row, int len, Get get, Body body, Flush flush, bool use_pre, const uint32_t (&pre)[PF][UNR]) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
@@ -231,7 +239,38 @@ __device__ __forceinline__ void ell_walk_pre(const uint32_t* row, int len, Get g
     });
   };
   int j = 0;
-  if (len >= UNR) {
+  if constexpr (PF == 1 && PP) {
+    // One batch requested ahead, in TWO register sets used in turn: the ring below copies the arrived dwords out of the registers the next
+    // request is about to overwrite - UNR vector moves per batch, 4 of a k = 5 batch's 102 vector instructions - where two sets need none.
+    // The same rows in the same order: results bit for bit.
+    if (len >= UNR) {
+      uint32_t qa[UNR], qb[UNR];
+      if (use_pre) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) qa[u] = pre[0][u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) qa[u] = ell_list_load<STREAM>(row + (size_t)u * 64);
+      }
+      for (; j + 2 * UNR <= len; j += 2 * UNR) {
+        ell_walk_prio<PRIO>(len - j);
+        const int jb = min(j + UNR, len - UNR);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) qb[u] = ell_list_load<STREAM>(row + (size_t)(jb + u) * 64);
+        batch(qa);
+        ell_walk_prio<PRIO>(len - j - UNR);
+        const int ja = min(j + 2 * UNR, len - UNR);   // (the last batches re-request the last rows: no branch, no overrun)
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) qa[u] = ell_list_load<STREAM>(row + (size_t)(ja + u) * 64);
+        batch(qb);
+      }
+      if (j + UNR <= len) {   // (one whole batch left: its rows are the ones qa holds)
+        ell_walk_prio<PRIO>(len - j);
+        batch(qa);
+        j += UNR;
+      }
+    }
+  } else if (len >= UNR) {
     uint32_t q[PF][UNR];
     if (use_pre) {
 #pragma unroll
@@ -275,10 +314,10 @@ __device__ __forceinline__ void ell_walk_pre(const uint32_t* row, int len, Get g
     });
   }
 }
-template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, typename Get, typename Body, typename Flush = EllNoFlush>
+template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, bool PP = false, typename Get, typename Body, typename Flush = EllNoFlush>
 __device__ __forceinline__ void ell_walk(const uint32_t* row, int len, Get get, Body body, Flush flush = Flush()) {
   uint32_t none[PF][UNR];   // (never read)
-  ell_walk_pre<K, UNR, PF, PRIO, STREAM>(row, len, get, body, flush, false, none);
+  ell_walk_pre<K, UNR, PF, PRIO, STREAM, PP>(row, len, get, body, flush, false, none);
 }
 // general entries: count << idx_bits | index
 template <int K>
@@ -370,13 +409,13 @@ struct EllGetters<K, true> {
 #ifndef ESPM_ELL_KLPROD
 #define ESPM_ELL_KLPROD 1
 #endif
-template <int K, bool LOSS, int UNR, int PF, int PRIO = 0, bool STREAM = false, bool FIX = false>   // FIX: the fused kernel's table layout
+template <int K, bool LOSS, int UNR, int PF, int PRIO = 0, bool STREAM = false, bool FIX = false, bool PP = false>   // FIX: the fused kernel's table layout; PP: ell_walk_pre
 __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1, int mid, const float* tab, int n_pad, int ell_bits,
                                            const float (&hk)[K], float (&acc)[K], float& kl) {
   if (x0 < mid) {
     if constexpr (LOSS && ESPM_ELL_KLPROD) {
       float prod = 1.f;
-      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad),
+      ell_walk<K, UNR, PF, PRIO, STREAM, PP>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad),
         [&](float, const float (&g)[K]) {
           const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
           ell_axpy<K>(acc, g, r);
@@ -392,7 +431,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
           prod = 1.f;
         });
     } else {
-      ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad), [&](float, const float (&g)[K]) {
+      ell_walk<K, UNR, PF, PRIO, STREAM, PP>(lrow + (size_t)x0 * 64, min(x1, mid) - x0, typename EllGetters<K, FIX>::Unit(n_pad), [&](float, const float (&g)[K]) {
         const float r = __builtin_amdgcn_rcpf(ell_dot<K>(g, hk));
         ell_axpy<K>(acc, g, r);
         if constexpr (LOSS) kl += __builtin_amdgcn_logf(r);
@@ -401,7 +440,7 @@ __device__ __forceinline__ void ell_h_rows(const uint32_t* lrow, int x0, int x1,
   }
   if (x1 > mid) {
     const int g0 = max(x0, mid);
-    ell_walk<K, UNR, PF, PRIO, STREAM>(lrow + (size_t)g0 * 64, x1 - g0, typename EllGetters<K, FIX>::General(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
+    ell_walk<K, UNR, PF, PRIO, STREAM, PP>(lrow + (size_t)g0 * 64, x1 - g0, typename EllGetters<K, FIX>::General(tab, n_pad, ell_bits), [&](float x, const float (&g)[K]) {
       const float y = ell_dot<K>(g, hk);
       // (+1e-37: a padding entry has x = 0 and must give 0 * log2(tiny), not 0 * -inf; same guard as the dense kernels)
       const float r = LOSS ? fmaf(x, __builtin_amdgcn_rcpf(y), 1e-37f) : x * __builtin_amdgcn_rcpf(y);

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
   constexpr bool S_RT = FULL && FusedGeom<K>::S_MAX > FusedGeom<K>::S;   // (k >= 5 at the full geometry: as many segments as fit, the launcher's choice)
   const int S = (FULL && !S_RT) ? FusedGeom<K>::S : fa.h_segs;   // (below the full geometry: 1024 / PB, or more where the numerators' region - grown for the slab - holds them)
   constexpr int PF = FULL ? ESPM_FUSED_FULL_PREFETCH : ESPM_FUSED_SMALL_PREFETCH;   // list batches requested ahead (ell_walk)
+  constexpr bool WALK_PP = FULL && K <= ESPM_ELL_WALK_PP_MAX_K;   // (mu_ell_kernel.hpp: the list dwords in two register sets used in turn)
   constexpr int PRIO = FULL ? (K >= 5 ? ESPM_FUSED_FULL_PRIO : 0) : ESPM_FUSED_SMALL_PRIO;                            // (ell_walk_prio)
   const int NGRP = PB / 64;                        // pixel-list groups of the block
   const HStepArgs& a = fa.h;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) hk[kk] = a.h_in[(size_t)kk * a.p_pad + px];
         const uint32_t* lrow = a.ell + (size_t)beg * 64 + lane;
-        ell_h_rows<K, LOSS, UNR_H, PF, PRIO, STREAM, true>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
+        ell_h_rows<K, LOSS, UNR_H, PF, PRIO, STREAM, true, WALK_PP>(lrow, x0, x1, mid, tab, a.n_pad, a.ell_bits, hk, acc, kl);
         if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -485,10 +486,10 @@ __global__ __launch_bounds__(NT) void mu_fused_ell_kernel(const FusedArgs fa) {
       }
     }
     const uint32_t* lrow = w.ell + (size_t)beg * 64 + lane;
-    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnitFix<K>(PB), [&](float, const float (&h)[K]) {
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM, WALK_PP>(lrow + (size_t)(u0 - beg) * 64, u1 - u0, EllGetUnitFix<K>(PB), [&](float, const float (&h)[K]) {
       ell_axpy<K>(acc, h, __builtin_amdgcn_rcpf(ell_dot<K>(h, gw)));
     }, EllNoFlush(), wkind == 1, fw_rows);
-    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGetFix<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
+    ell_walk_pre<K, UNR_W, PF, PRIO, STREAM, WALK_PP>(lrow + (size_t)(g0 - beg) * 64, g1 - g0, EllGetFix<K>(tab, PB, PBITS), [&](float x, const float (&h)[K]) {
       const float r = x * __builtin_amdgcn_rcpf(ell_dot<K>(h, gw));
       ell_axpy<K>(acc, h, r);
     }, EllNoFlush(), wkind == 2, fw_rows);
