@@ -215,19 +215,32 @@ __device__ __forceinline__ bool ell_walk_request(const uint32_t* row, int len, u
 #ifndef ESPM_ELL_WALK_PP_MAX_K
 #define ESPM_ELL_WALK_PP_MAX_K 5
 #endif
+// MEASURED (profiles/r05w_ab_*.log, whole batch | halves, us per iteration at the headline image): k = 6 138.9 | 138.8, k = 7 153.6 | 151.3, k = 8 161.7 | 159.7;
+// configuration 5 634.4 | 628.7, its 128-row shard 91.6 | 91.1.  (The two register sets of PP on top still spill at k >= 6: 242 ... 619 us.)  From 7 components on.
+#ifndef ESPM_ELL_BATCH_HALVES_K
+#define ESPM_ELL_BATCH_HALVES_K 7
+#endif
 template <int K, int UNR, int PF = 1, int PRIO = 0, bool STREAM = false, bool PP = false, typename Get, typename Body, typename Flush = EllNoFlush>
 __device__ __forceinline__ void ell_walk_pre(const uint32_t* row, int len, Get get, Body body, Flush flush, bool use_pre, const uint32_t (&pre)[PF][UNR]) {
   // PF: batches requested ahead of their use (1: the next one - enough with four waves per SIMD taking turns; a workgroup
   // that has a SIMD almost to itself needs the memory latency covered by its own requests)
   auto batch = [&](const uint32_t (&e)[UNR]) {
-    float g[2 * UNR][K], x[2 * UNR];
+    // ESPM_ELL_BATCH_HALVES_K: from that many components on the batch's 2 UNR gathers are issued and consumed in two halves - half the
+    // gathered rows live at a time (2 UNR K registers are 64 of a wave's 128 at k = 8) - with a scheduling fence between the halves
+    constexpr int HALVES = (K >= ESPM_ELL_BATCH_HALVES_K && K <= 8 && UNR % 2 == 0) ? 2 : 1;   // (measured for 7, 8; the wide build's counts keep their batches of 2 dwords whole)
+    constexpr int UH = UNR / HALVES;
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      x[2 * u] = get(e[u], 0, g[2 * u]);
-      x[2 * u + 1] = get(e[u], 1, g[2 * u + 1]);
+    for (int hh = 0; hh < HALVES; ++hh) {
+      float g[2 * UH][K], x[2 * UH];
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        x[2 * u] = get(e[hh * UH + u], 0, g[2 * u]);
+        x[2 * u + 1] = get(e[hh * UH + u], 1, g[2 * u + 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * UH; ++u) body(x[u], g[u]);
+      if constexpr (HALVES > 1) __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int u = 0; u < 2 * UNR; ++u) body(x[u], g[u]);
     flush([&](auto alt) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
