@@ -34,7 +34,8 @@ KP, PPAD, NPAD = _D["ESPM_KP"], _D["ESPM_PPAD"], _D["ESPM_NPAD"]         # (the 
 MAX_K = KP
 HP_STRIDE, HS_STRIDE, HI_STRIDE = 8 + 2 * KP, 2 * KP, _D["ESPM_HI_STRIDE"]
 HS_ROWSUM, HS_MAX = 0, KP
-WIDE_MAX_K = 16
+WIDE_MAX_K = 16      # libespm_mu_wide.so: 9..16 components (and the sparse count store's limit)
+WIDEST_MAX_K = 32    # libespm_mu_wide32.so: 17..32 components, dense stores only
 TAIL_DEFER, TAIL_RIDE = _D["ESPM_TAIL_DEFER"], _D["ESPM_TAIL_RIDE"]
 HI_KLX, HI_REG, HI_LAP, HI_SUMY, HI_BAD, HI_REL_W, HI_REL_H = (_D["ESPM_HI_" + n] for n in ("KLX", "REG", "LAP", "SUMY", "BAD", "REL_W", "REL_H"))
 
@@ -176,16 +177,23 @@ class Variant:
 
 _narrow = Variant(lib, KP, 1, MAX_K)
 _wide = None
+_widest = None
 WIDE_LIB_PATH = os.environ.get("ESPM_MU_WIDE_LIB", os.path.join(_HERE, "lib", "libespm_mu_wide.so"))
+WIDEST_LIB_PATH = os.environ.get("ESPM_MU_WIDEST_LIB", os.path.join(_HERE, "lib", "libespm_mu_wide32.so"))
 
 
 def variant(k) -> Variant:
-    """The build that holds the kernels for k components: 1..8 libespm_mu.so, 9..16 libespm_mu_wide.so (dense stores)."""
-    global _wide
+    """The build that holds the kernels for k components: 1..8 libespm_mu.so, 9..16 libespm_mu_wide.so, 17..32 libespm_mu_wide32.so
+    (the dense stores, both contractions on the matrix cores)."""
+    global _wide, _widest
     if k <= MAX_K:
         return _narrow
-    if k > WIDE_MAX_K:
-        raise NotImplementedError(f"n_components = {k}: the kernels are built for 1..{WIDE_MAX_K} components")
-    if _wide is None:
-        _wide = Variant(_load(WIDE_LIB_PATH), 16, MAX_K + 1, WIDE_MAX_K)
-    return _wide
+    if k > WIDEST_MAX_K:
+        raise NotImplementedError(f"n_components = {k}: the kernels are built for 1..{WIDEST_MAX_K} components")
+    if k <= WIDE_MAX_K:
+        if _wide is None:
+            _wide = Variant(_load(WIDE_LIB_PATH), 16, MAX_K + 1, WIDE_MAX_K)
+        return _wide
+    if _widest is None:
+        _widest = Variant(_load(WIDEST_LIB_PATH), 32, WIDE_MAX_K + 1, WIDEST_MAX_K)
+    return _widest

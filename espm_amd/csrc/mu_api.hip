@@ -147,8 +147,9 @@ int espm_mu_query(espm_mu_state* st) {
     cus = prop.multiProcessorCount;
   // H-step: 256-pixel tiles (4 waves) when that gives >= 2 workgroups per CU, else 128-pixel tiles
   // with 8 waves splitting the channel range (tuned on MI355X, tools/tune).
+  // (the widest build, 17..32 components: 128-pixel tiles only - the partial numerators of a 256-pixel tile would take 68..128 KB of LDS)
   const int big = 256;
-  st->tile_px = ((st->p + big - 1) / big >= 2 * cus) ? big : 128;
+  st->tile_px = (ESPM_KP <= 16 && (st->p + big - 1) / big >= 2 * cus) ? big : 128;
   st->x_tile = st->tile_px;
   st->n_cm = roundup(st->n, ESPM_NCM);
   st->h_variant = 0;

@@ -8,14 +8,17 @@
 namespace espm {
 
 constexpr int KP = ESPM_KP;
-static_assert(KP == 8 || KP == 16, "ESPM_KP: 8 or 16");
+static_assert(KP == 8 || KP == 16 || KP == 32, "ESPM_KP: 8, 16 or 32");
 static_assert(ESPM_MIN_K >= 1 && ESPM_MAX_K <= KP && ESPM_MIN_K <= ESPM_MAX_K, "ESPM_MIN_K .. ESPM_MAX_K must fit the stride");
 
-// the component counts this build instantiates its kernels for: X(1) .. X(8), or X(9) .. X(16) in the wide build
+// the component counts this build instantiates its kernels for: X(1) .. X(8), X(9) .. X(16) in the wide build, X(17) .. X(32) in the
+// widest (KP = 32)
 #if ESPM_MIN_K <= 8
 #define ESPM_K_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
-#else
+#elif ESPM_MIN_K <= 16
 #define ESPM_K_CASES(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#else
+#define ESPM_K_CASES(X) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 #endif
 
 // one KP-strided row (gw_s, h_t) as 16-byte stores

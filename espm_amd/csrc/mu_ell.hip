@@ -59,9 +59,11 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.ell_tp == 64 || args.ell_tp == 128 || args.ell_tp == 256 || args.ell_tp == 512, "h_step: sparse store tile_px=%d must be 64, 128, 256 or 512", args.ell_tp);
   ESPM_REQUIRE(args.ell_bits >= 1 && args.ell_bits <= 14 && (1 << args.ell_bits) >= args.n, "h_step: ell_cbits=%d does not cover n=%d", args.ell_bits, args.n);
   switch (args.k) {
+#if ESPM_KP <= 16   // (the widest build - 17..32 components - has the dense stores only: a table row of 32 floats leaves the LDS no room)
 #define ESPM_X(KK) case KK: return launch_h_ell_k<KK>(args, nblk, stream);
     ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
+#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "h_step: k=%d not built", args.k);
 }
@@ -104,9 +106,11 @@ int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream) {
   ESPM_REQUIRE(args.pb >= 128 && args.pb <= ESPM_ELL_PB && (args.pb & (args.pb - 1)) == 0 && nblk == (args.p + args.pb - 1) / args.pb,
                "w_accum: nblk_w=%d must be ceil(p / %d) for the sparse store", nblk, args.pb);
   switch (k) {
+#if ESPM_KP <= 16
 #define ESPM_X(KK) case KK: return launch_w_ell_k<KK>(args, nblk, stream);
     ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
+#endif
   }
   return set_error(ESPM_EUNSUPPORTED, "w_accum: k=%d not built", k);
 }

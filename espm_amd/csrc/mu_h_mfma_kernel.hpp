@@ -1,4 +1,4 @@
-// Dense H-step on the matrix cores: 9..16 components (the wide build, KP = 16).
+// Dense H-step on the matrix cores: 9..16 components (the wide build, KP = 16), 17..32 in two halves of 16 (the widest, KP = 32).
 //
 // updates.py:127-132 on a dense store: Y = GW H, R = X / Y, num = GW^T R - the (GW)^T X contraction BASELINE.json's north
 // star names - plus the KL term of the input state.  Same reasoning as mu_w_mfma_kernel.hpp: from 9 components on the two
@@ -59,8 +59,10 @@ __device__ __forceinline__ void mf_load_px_row(MfRow<XT>& row, const XT* x_pm, i
 
 template <int K, typename XT, int STEPS, int PASSES, bool LOSS>
 __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(const HStepArgs a) {   // (two workgroups per CU by their LDS: <= 256 registers)
-  static_assert(KP == 16 || KP == 8, "component stride 8 or 16: the 16-wide tile is zero-filled beyond it");
+  static_assert(KP == 32 || KP == 16 || KP == 8, "component stride 8, 16 or 32: a 16-wide tile is zero-filled beyond it");
   constexpr int TP = 16 * STEPS * PASSES, NW = 4;
+  constexpr int KH = (K + 15) / 16;   // halves of 16 components (mu_w_mfma_kernel.hpp: two from 17 components on)
+  static_assert(KH <= MF_KH, "k beyond the stride");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [NW][K][TP]
   const int lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,45 +72,56 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
   float kl = 0.f;
   // GW operands of one channel tile, both layouts, four sub-tiles: requested one tile ahead of their use
   struct GRaw {
-    float4 a[4];     // sub-tile j: GW[channel of row l16, components 4 q .. 4 q + 3]
-    float b[4][4];   // sub-tile j: GW[channel of row 4 q + i, component l16]
+    float4 a[4][KH];     // sub-tile j: GW[channel of row l16, components 16 hf + 4 q .. + 3]
+    float b[4][KH][4];   // sub-tile j: GW[channel of row 4 q + i, component 16 hf + l16]
   };
   auto load_g = [&](GRaw& g, int T) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ca = min(64 * T + 16 * (l16 >> 2) + 4 * j + (l16 & 3), a.n_pad - 1);   // (rows beyond n_pad: X = 0 there)
-      g.a[j] = (4 * q < KP) ? *reinterpret_cast<const float4*>(a.gw_s + (size_t)ca * KP + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g.b[j][i] = l16 < KP ? a.gw_s[(size_t)min(64 * T + 16 * q + 4 * j + i, a.n_pad - 1) * KP + l16] : 0.f;
+      for (int hf = 0; hf < KH; ++hf) {
+        g.a[j][hf] = (4 * q < MF_KW) ? *reinterpret_cast<const float4*>(a.gw_s + (size_t)ca * KP + 16 * hf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.b[j][hf][i] = l16 < MF_KW ? a.gw_s[(size_t)min(64 * T + 16 * q + 4 * j + i, a.n_pad - 1) * KP + 16 * hf + l16] : 0.f;
+      }
     }
   };
 
 #pragma unroll 1
   for (int ps = 0; ps < PASSES; ++ps) {
     const int px0 = tile0 + ps * 16 * STEPS;
-    // B operand of step 1: H[components 4 q + i, pixel 16 s + l16], split once (pad pixels hold positive values)
-    mf_s4 hh[STEPS], hl[STEPS];
+    // B operand of step 1: H[components 16 hf + 4 q + i, pixel 16 s + l16], split once (pad pixels hold positive values)
+    mf_s4 hh[STEPS][KH], hl[STEPS][KH];
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      float hv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hv[i] = (4 * q + i < K) ? a.h_in[(size_t)(4 * q + i) * a.p_pad + px0 + 16 * s + l16] : 0.f;
-      mf_split(hv, hh[s], hl[s]);
+      for (int hf = 0; hf < KH; ++hf) {
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hv[i] = (16 * hf + 4 * q + i < K) ? a.h_in[(size_t)(16 * hf + 4 * q + i) * a.p_pad + px0 + 16 * s + l16] : 0.f;
+        mf_split(hv, hh[s][hf], hl[s][hf]);
+      }
     }
-    mf_f4 acc[STEPS];
+    mf_f4 acc[STEPS][KH];
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) acc[s] = mf_f4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+      for (int hf = 0; hf < KH; ++hf) acc[s][hf] = mf_f4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int T = wave; T < tiles; T += NW) {
       GRaw gn;
       load_g(gn, T);
-      mf_s4 a1h[4], a1l[4], b3h[4], b3l[4];
+      mf_s4 a1h[4][KH], a1l[4][KH], b3h[4][KH], b3l[4][KH];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gav[4] = {gn.a[j].x, gn.a[j].y, gn.a[j].z, gn.a[j].w};
-        mf_split(gav, a1h[j], a1l[j]);
-        mf_split(gn.b[j], b3h[j], b3l[j]);
+#pragma unroll
+        for (int hf = 0; hf < KH; ++hf) {
+          const float gav[4] = {gn.a[j][hf].x, gn.a[j][hf].y, gn.a[j][hf].z, gn.a[j][hf].w};
+          mf_split(gav, a1h[j][hf], a1l[j][hf]);
+          mf_split(gn.b[j][hf], b3h[j][hf], b3l[j][hf]);
+        }
       }
       const int c0 = 64 * T + 16 * q;
       MfRow<XT> xr[2];
@@ -120,7 +133,9 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
         for (int j = 0; j < 4; ++j) {
           float x[4], r[4];
           xr[s & 1].quad(j, x);
-          mf_f4 y = mf_mma3<1>(a1h[j], a1l[j], hh[s], hl[s], mf_f4{0.f, 0.f, 0.f, 0.f});
+          mf_f4 y = mf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int hf = KH - 1; hf >= 0; --hf) y = mf_mma3<1>(a1h[j][hf], a1l[j][hf], hh[s][hf], hl[s][hf], y);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // The first reader of a matrix-core result must be an instruction the compiler knows (it owes the wait states
@@ -137,7 +152,8 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
           }
           mf_s4 rh, rl;
           mf_split(r, rh, rl);
-          acc[s] = mf_mma3<2>(rh, rl, b3h[j], b3l[j], acc[s]);
+#pragma unroll
+          for (int hf = 0; hf < KH; ++hf) acc[s][hf] = mf_mma3<2>(rh, rl, b3h[j][hf], b3l[j][hf], acc[s][hf]);
         }
         // the four sub-tile chains of a step are enough to keep the matrix and the vector pipes busy; without the fence the
         // scheduler interleaves all eight steps and spills 250 registers (with the loss term)
@@ -146,12 +162,15 @@ __global__ __launch_bounds__(256, ESPM_H_MFMA_MINBLK) void h_step_mfma_kernel(co
 #endif
       }
     }
-    // partial numerators of this wave: num[component l16, pixels 16 s + 4 q + r of the pass]
-    if (l16 < K) {
+    // partial numerators of this wave: num[component 16 hf + l16, pixels 16 s + 4 q + r of the pass]
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s)
-        *reinterpret_cast<float4*>(smem + ((size_t)wave * K + l16) * TP + ps * 16 * STEPS + 16 * s + 4 * q) =
-            make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    for (int hf = 0; hf < KH; ++hf) {
+      if (16 * hf + l16 < K) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+          *reinterpret_cast<float4*>(smem + ((size_t)wave * K + 16 * hf + l16) * TP + ps * 16 * STEPS + 16 * s + 4 * q) =
+              make_float4(acc[s][hf][0], acc[s][hf][1], acc[s][hf][2], acc[s][hf][3]);
+      }
     }
   }
   h_epilogue<K, true, 0>(a, smem, NW, TP, tile0, LOSS ? kl : 0.f);

@@ -40,15 +40,27 @@ __global__ __launch_bounds__(256) void h_finalize_kernel(const HFinalizeArgs a) 
 #endif
 
 // ---- dispatch ---------------------------------------------------------------------------------
+// Partial numerators of more than 16 components (the widest build) pass the 64 KB of LDS a kernel gets without asking: granted per
+// kernel, up to the CU's 160 KB (K * 4096 bytes with the vector kernels' tiles: 128 KB at 32 components).
+template <typename KernelT>
+static int allow_lds(KernelT kern, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return ESPM_OK;
+  if (bytes > 160 * 1024) return set_error(ESPM_EUNSUPPORTED, "%s: %zu bytes of LDS exceed a CU's 160 KB", what, bytes);
+  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), what);
+}
+
 template <int K, typename XT, int PX, int NW, int U, int NBUF>
 static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
-  if (args.compute_loss)
+  if (args.compute_loss) {
+    if (int rc = allow_lds(h_step_kernel<K, XT, PX, NW, true, U, NBUF>, bytes, "h_step")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
-  else
+  } else {
+    if (int rc = allow_lds(h_step_kernel<K, XT, PX, NW, false, U, NBUF>, bytes, "h_step")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+  }
   return check_hip(hipGetLastError(), "h_step launch");
 }
 
@@ -65,10 +77,13 @@ static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h_step_mfma_kernel<K, XT, STEPS, PASSES, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   }
 #endif
-  if (args.compute_loss)
+  if (args.compute_loss) {
+    if (int rc = allow_lds(h_step_mfma_kernel<K, XT, STEPS, PASSES, true>, bytes, "h_step (mfma)")) return rc;
     hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), dim3(nblk), dim3(256), bytes, stream, args);
-  else
+  } else {
+    if (int rc = allow_lds(h_step_mfma_kernel<K, XT, STEPS, PASSES, false>, bytes, "h_step (mfma)")) return rc;
     hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, false>), dim3(nblk), dim3(256), bytes, stream, args);
+  }
   return check_hip(hipGetLastError(), "h_step (mfma) launch");
 }
 
@@ -76,6 +91,7 @@ template <int K, int PX, int NW, int U, int NBUF>
 static int launch_h_l2(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
+  if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, false, U, NBUF, true>, lds > lds_min ? lds : lds_min, "h_step (l2)")) return rc;
   hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, true>), dim3(nblk), dim3(NW * 64), lds > lds_min ? lds : lds_min,
                      stream, args);
   return check_hip(hipGetLastError(), "h_step (l2) launch");
@@ -86,10 +102,13 @@ static int launch_h_rule(const HStepArgs& args, int nblk, hipStream_t stream) {
   const size_t lds = (size_t)NW * K * 64 * PX * sizeof(float);
   const size_t lds_min = (size_t)(NW + 1) * (ESPM_HP_NSCALAR + 2 * K + 1) * sizeof(double);
   const size_t bytes = lds > lds_min ? lds : lds_min;
-  if (args.compute_loss)
+  if (args.compute_loss) {
+    if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>, bytes, "h_step (alternate rule)")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
-  else
+  } else {
+    if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, false, U, NBUF, false, RULE>, bytes, "h_step (alternate rule)")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+  }
   return check_hip(hipGetLastError(), "h_step (alternate rule) launch");
 }
 
@@ -97,33 +116,48 @@ template <int K>
 static int dispatch_h_k(const HStepArgs& args, int x_dtype, int tile_px, int nblk, hipStream_t stream) {
   if (args.h_rule != 0) {  // quadratic surrogate / projected gradient: dense stores through the fp32 one
     if (x_dtype != ESPM_X_F32) return set_error(ESPM_EUNSUPPORTED, "h_rule %d is built for the sparse and the f32 store", args.h_rule);
-    if (args.h_rule == 1 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 1>(args, nblk, stream);
+    if constexpr (K <= 16) if (args.h_rule == 1 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 1>(args, nblk, stream);
     if (args.h_rule == 1 && tile_px == 128) return launch_h_rule<K, 2, 8, 8, 2, 1>(args, nblk, stream);
-    if (args.h_rule == 2 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 2>(args, nblk, stream);
+    if constexpr (K <= 16) if (args.h_rule == 2 && tile_px == 256) return launch_h_rule<K, 4, 4, 8, 0, 2>(args, nblk, stream);
     if (args.h_rule == 2 && tile_px == 128) return launch_h_rule<K, 2, 8, 8, 2, 2>(args, nblk, stream);
     return set_error(ESPM_EINVAL, "h_step (rule %d): tile_px %d not available", args.h_rule, tile_px);
   }
   if (args.l2_m) {  // Frobenius branch: fp32 store only
     if (x_dtype != ESPM_X_F32 || args.compute_loss) return set_error(ESPM_EUNSUPPORTED, "the l2 H-step needs the f32 store and no loss");
-    if (tile_px == 256) return launch_h_l2<K, 4, 4, 8, 0>(args, nblk, stream);
+    if constexpr (K <= 16) if (tile_px == 256) return launch_h_l2<K, 4, 4, 8, 0>(args, nblk, stream);
     if (tile_px == 128) return launch_h_l2<K, 2, 8, 8, 2>(args, nblk, stream);
     return set_error(ESPM_EINVAL, "h_step (l2): tile_px %d not available", tile_px);
   }
   if constexpr (K >= ESPM_H_MFMA_MIN_K) {   // matrix cores (mu_h_mfma_kernel.hpp): the pixel-major copy of X, tiles of 16 pixel steps
-    if (args.mfma && args.x_pm && (tile_px == 256 || tile_px == 128)) {
-      if (x_dtype == ESPM_X_U8) return tile_px == 256 ? launch_h_mfma<K, uint8_t, 256>(args, nblk, stream) : launch_h_mfma<K, uint8_t, 128>(args, nblk, stream);
-      if (x_dtype == ESPM_X_BF16) return tile_px == 256 ? launch_h_mfma<K, bf16_t, 256>(args, nblk, stream) : launch_h_mfma<K, bf16_t, 128>(args, nblk, stream);
-      return tile_px == 256 ? launch_h_mfma<K, float, 256>(args, nblk, stream) : launch_h_mfma<K, float, 128>(args, nblk, stream);
+    if constexpr (K <= 16) {
+      if (args.mfma && args.x_pm && tile_px == 256) {
+        if (x_dtype == ESPM_X_U8) return launch_h_mfma<K, uint8_t, 256>(args, nblk, stream);
+        if (x_dtype == ESPM_X_BF16) return launch_h_mfma<K, bf16_t, 256>(args, nblk, stream);
+        return launch_h_mfma<K, float, 256>(args, nblk, stream);
+      }
+    }
+    if (args.mfma && args.x_pm && tile_px == 128) {   // (the widest build: 128-pixel tiles only - espm_mu_query; 4 waves' partial numerators of 32 components and 128 pixels are the 64 KB of LDS a kernel gets without asking)
+      if (x_dtype == ESPM_X_U8) return launch_h_mfma<K, uint8_t, 128>(args, nblk, stream);
+      if (x_dtype == ESPM_X_BF16) return launch_h_mfma<K, bf16_t, 128>(args, nblk, stream);
+      return launch_h_mfma<K, float, 128>(args, nblk, stream);
     }
   }
+  if constexpr (K > 16) {   // the widest build keeps the vector kernels for the fp32 store only (the alternate rules, the Frobenius branch, A/B)
+    if (x_dtype != ESPM_X_F32)
+      return set_error(ESPM_EUNSUPPORTED, "h_step: %d components on the 8-bit / bf16 store run on the matrix cores only (pixel-major copy of X, no_fused = 0, tile_px 128)", K);
+  }
   if (x_dtype == ESPM_X_U8) {
-    if (tile_px == 256) return launch_h<K, uint8_t, 4, 4, 8, 0>(args, nblk, stream);
-    if (tile_px == 128) return launch_h<K, uint8_t, 2, 8, 8, 2>(args, nblk, stream);
+    if constexpr (K <= 16) {
+      if (tile_px == 256) return launch_h<K, uint8_t, 4, 4, 8, 0>(args, nblk, stream);
+      if (tile_px == 128) return launch_h<K, uint8_t, 2, 8, 8, 2>(args, nblk, stream);
+    }
   } else if (x_dtype == ESPM_X_BF16) {
-    if (tile_px == 256) return launch_h<K, bf16_t, 4, 4, 8, 0>(args, nblk, stream);
-    if (tile_px == 128) return launch_h<K, bf16_t, 2, 8, 8, 2>(args, nblk, stream);
+    if constexpr (K <= 16) {
+      if (tile_px == 256) return launch_h<K, bf16_t, 4, 4, 8, 0>(args, nblk, stream);
+      if (tile_px == 128) return launch_h<K, bf16_t, 2, 8, 8, 2>(args, nblk, stream);
+    }
   } else {
-    if (tile_px == 256) return launch_h<K, float, 4, 4, 8, 0>(args, nblk, stream);
+    if constexpr (K <= 16) if (tile_px == 256) return launch_h<K, float, 4, 4, 8, 0>(args, nblk, stream);
     if (tile_px == 128) return launch_h<K, float, 2, 8, 8, 2>(args, nblk, stream);
   }
   return set_error(ESPM_EINVAL, "h_step: tile_px %d not available for x_dtype %d", tile_px, x_dtype);

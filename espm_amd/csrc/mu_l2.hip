@@ -16,8 +16,9 @@ namespace espm {
 
 // out[a][b] = sum_r M[r][a] M[r][b] for M (rows, KP) fp32, a, b < k.  Workgroup = GRAM_GROUPS row groups x KP * KP
 // (a, b) pairs; partials [KP * KP][nblk] doubles, then one workgroup sums them in fixed order.
-constexpr int GRAM_PAIRS = KP * KP, GRAM_GROUPS = 256 / GRAM_PAIRS;   // 64 x 4, or 256 x 1 in the wide build
-__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ m, int rows, int k, double* __restrict__ part) {
+constexpr int GRAM_PAIRS = KP * KP, GRAM_GROUPS = GRAM_PAIRS >= 256 ? 1 : 256 / GRAM_PAIRS;   // 64 x 4, 256 x 1 in the wide build, 1024 x 1 with KP = 32
+constexpr int GRAM_THREADS = GRAM_PAIRS * GRAM_GROUPS;
+__global__ __launch_bounds__(GRAM_THREADS) void gram_partial_kernel(const float* __restrict__ m, int rows, int k, double* __restrict__ part) {
   __shared__ double s[GRAM_GROUPS][GRAM_PAIRS];
   const int e = threadIdx.x % GRAM_PAIRS, grp = threadIdx.x / GRAM_PAIRS;
   const int ia = e / KP, ib = e % KP;
@@ -48,7 +49,7 @@ int launch_gram(const float* m, int rows, int k, double* part, int part_cap, flo
   if (nblk > cap) nblk = cap;
   if (nblk > 256) nblk = 256;
   if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblk), dim3(256), 0, stream, m, rows, k, part);
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblk), dim3(GRAM_THREADS), 0, stream, m, rows, k, part);
   hipLaunchKernelGGL(gram_sum_kernel, dim3(1), dim3(GRAM_PAIRS), 0, stream, part, nblk, out);
   return check_hip(hipGetLastError(), "gram launch");
 }

@@ -1,4 +1,5 @@
-// Dense W accumulation on the matrix cores: 9..16 components (the wide build, KP = 16) and, with half-empty tiles, 7..8.
+// Dense W accumulation on the matrix cores: 9..16 components (the wide build, KP = 16), 17..32 in two halves of 16 (the widest build,
+// KP = 32) and, with half-empty tiles, 7..8.
 //
 // updates.py:38-39, :53, :59 on a dense store: Y = GW H', R = X / Y, A = R H'^T.  With k <= 8 the two contractions are
 // 2 k of the ~2 k + 6 vector instructions an element costs, and padding k to a matrix-core tile wastes most of the tile:
@@ -149,28 +150,42 @@ struct MfRow<float> {
 };
 
 // (The Frobenius variant - L2: no Y product - keeps the 16-slot form: it was not part of the reproducibility runs above.)
+// 17..32 components (the widest build, KP = 32): the component range in MF_KH = 2 halves of 16 - step 1 contracts over both (two chains into
+// the same Y), step 3 keeps one accumulator tile per half; MF_CT = 4 channel tiles per wave instead of 8 (the operands of two halves
+// next to 8 tiles' accumulators do not fit the registers).
+constexpr int MF_KH = KP > 16 ? KP / 16 : 1;
+constexpr int MF_CT = KP > 16 ? 4 : 8;
+constexpr int MF_KW = KP < 16 ? KP : 16;   // components of one half that exist in the KP-strided rows
+
 template <int K, typename XT, bool L2>
 __device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
-  static_assert(KP == 16 || KP == 8, "component stride 8 or 16: the 16-wide tile is zero-filled beyond it");
-  constexpr int CT = 8;                          // channel tiles of 16 per wave
+  static_assert(KP == 32 || KP == 16 || KP == 8, "component stride 8, 16 or 32: a 16-wide tile is zero-filled beyond it");
+  constexpr int CT = MF_CT;                      // channel tiles of 16 per wave
+  constexpr int KH = (K + 15) / 16;              // halves that hold components
+  static_assert(KH <= MF_KH, "k beyond the stride");
   const int lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cbase = (blockIdx.y * 4 + wave) * 16 * CT;
   if (cbase >= a.n_pad) return;                  // (whole waves)
 
-  // B operand of step 1: GW[channel, 4 q .. 4 q + 3] per channel tile, split once
-  mf_s4 gh[CT], gl[CT];
+  // B operand of step 1: GW[channel, 16 hf + 4 q .. + 3] per channel tile, split once
+  mf_s4 gh[CT][KH], gl[CT][KH];
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     const int c = min(cbase + 16 * t + l16, a.n_pad - 1);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * q < KP) g = *reinterpret_cast<const float4*>(a.gw_s + (size_t)c * KP + 4 * q);
-    const float gv[4] = {g.x, g.y, g.z, g.w};
-    mf_split(gv, gh[t], gl[t]);
-  }
-  mf_f4 acc[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) acc[t] = mf_f4{0.f, 0.f, 0.f, 0.f};
+    for (int hf = 0; hf < KH; ++hf) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * q < MF_KW) g = *reinterpret_cast<const float4*>(a.gw_s + (size_t)c * KP + 16 * hf + 4 * q);
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+      mf_split(gv, gh[t][hf], gl[t][hf]);
+    }
+  }
+  mf_f4 acc[CT][KH];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int hf = 0; hf < KH; ++hf) acc[t][hf] = mf_f4{0.f, 0.f, 0.f, 0.f};
 
   const int groups = a.p_pad / 64;
   const int gpb = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -178,17 +193,20 @@ __device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
   const XT* x_cm = static_cast<const XT*>(a.x_cm);
   // raw H' operands of a pixel group (both layouts, four steps): requested one group ahead of their use
   struct HRaw {
-    float4 a[4];      // step s: H'[4 q .. 4 q + 3, pixel of slot l16]
-    float b[4][4];    // step s: H'[component l16, pixels of slots 4 q + r]
+    float4 a[4][KH];      // step s: H'[16 hf + 4 q .. + 3, pixel of slot l16]
+    float b[4][KH][4];    // step s: H'[component 16 hf + l16, pixels of slots 4 q + r]
   };
   auto load_h = [&](HRaw& h, int g) {
     const int px0 = g * 64;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int pa = min(px0 + 16 * (l16 >> 2) + 4 * s + (l16 & 3), a.p - 1);      // pixel of slot l16 (rows beyond p: X = 0)
-      h.a[s] = (4 * q < KP) ? *reinterpret_cast<const float4*>(a.h_t + (size_t)pa * KP + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h.b[s][r] = l16 < KP ? a.h_t[(size_t)min(px0 + 16 * q + 4 * s + r, a.p - 1) * KP + l16] : 0.f;
+      for (int hf = 0; hf < KH; ++hf) {
+        h.a[s][hf] = (4 * q < MF_KW) ? *reinterpret_cast<const float4*>(a.h_t + (size_t)pa * KP + 16 * hf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h.b[s][hf][r] = l16 < MF_KW ? a.h_t[(size_t)min(px0 + 16 * q + 4 * s + r, a.p - 1) * KP + 16 * hf + l16] : 0.f;
+      }
     }
   };
   HRaw hn;
@@ -196,12 +214,15 @@ __device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
   for (int g = g_begin; g < g_end; ++g) {
     const int px0 = g * 64;
     if (px0 >= a.p) break;                       // (only padding beyond: X = 0 there)
-    mf_s4 a1h[4], a1l[4], b3h[4], b3l[4];
+    mf_s4 a1h[4][KH], a1l[4][KH], b3h[4][KH], b3l[4][KH];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const float hav[4] = {hn.a[s].x, hn.a[s].y, hn.a[s].z, hn.a[s].w};
-      mf_split(hav, a1h[s], a1l[s]);
-      mf_split(hn.b[s], b3h[s], b3l[s]);
+#pragma unroll
+      for (int hf = 0; hf < KH; ++hf) {
+        const float hav[4] = {hn.a[s][hf].x, hn.a[s][hf].y, hn.a[s][hf].z, hn.a[s][hf].w};
+        mf_split(hav, a1h[s][hf], a1l[s][hf]);
+        mf_split(hn.b[s][hf], b3h[s][hf], b3l[s][hf]);
+      }
     }
     if (g + 1 < g_end) load_h(hn, g + 1);        // in flight while this group's tiles are worked
     const size_t xoff = (size_t)(px0 / a.x_tile) * a.n_cm * a.x_tile + (px0 % a.x_tile) + 16 * q;
@@ -218,7 +239,9 @@ __device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) r[i] = x[i];
         } else {
-          mf_f4 y = mf_mma3<L2 ? 0 : 4>(a1h[s], a1l[s], gh[t], gl[t], mf_f4{0.f, 0.f, 0.f, 0.f});
+          mf_f4 y = mf_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int hf = KH - 1; hf >= 0; --hf) y = mf_mma3<L2 ? 0 : 4>(a1h[s][hf], a1l[s][hf], gh[t][hf], gl[t][hf], y);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             // The first reader of a matrix-core result must be an instruction the compiler knows: it owes the wait states
@@ -231,17 +254,21 @@ __device__ __forceinline__ void w_accum_mfma_body(const WAccumArgs& a) {
         }
         mf_s4 rh, rl;
         mf_split(r, rh, rl);
-        acc[t] = mf_mma3<L2 ? 0 : 8>(rh, rl, b3h[s], b3l[s], acc[t]);
+#pragma unroll
+        for (int hf = 0; hf < KH; ++hf) acc[t][hf] = mf_mma3<L2 ? 0 : 8>(rh, rl, b3h[s][hf], b3l[s][hf], acc[t][hf]);
       }
     }
   }
-  // A[channels cbase + 16 t + 4 q + r, component l16] -> slab (k, n_pad): 4 consecutive channels per lane
-  if (l16 < K) {
+  // A[channels cbase + 16 t + 4 q + r, component 16 hf + l16] -> slab (k, n_pad): 4 consecutive channels per lane
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
-      const int c0 = cbase + 16 * t + 4 * q;
-      if (c0 < a.n_pad)   // (n_pad is a multiple of 8: a quad is inside or outside as a whole)
-        *reinterpret_cast<float4*>(a.a_slab + ((size_t)blockIdx.x * K + l16) * a.n_pad + c0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  for (int hf = 0; hf < KH; ++hf) {
+    if (16 * hf + l16 < K) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c0 = cbase + 16 * t + 4 * q;
+        if (c0 < a.n_pad)   // (n_pad is a multiple of 8: a quad is inside or outside as a whole)
+          *reinterpret_cast<float4*>(a.a_slab + ((size_t)blockIdx.x * K + 16 * hf + l16) * a.n_pad + c0) = make_float4(acc[t][hf][0], acc[t][hf][1], acc[t][hf][2], acc[t][hf][3]);
+      }
     }
   }
 }

@@ -647,8 +647,9 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
 #else
     if (wg == 0) {  // global statistics of the new H (as shard_combine): every rank's extra workgroup sends them as granules
 #endif
-      static_assert(2 * ESPM_HS_STRIDE <= 64, "one lane per half of a statistic");
-      const bool polls = lane < 2 * ESPM_HS_STRIDE;
+      // one lane per half of a statistic: 2 ESPM_HS_STRIDE halves, 64 per pass (one pass up to 16 components, two in the widest build)
+      for (int hl = lane; hl < ((2 * ESPM_HS_STRIDE + 63) & ~63); hl += 64) {
+      const bool polls = hl < 2 * ESPM_HS_STRIDE;
       unsigned int hv[MAXW];
       {
         const long long t0 = wall_clock64();
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
           unsigned long long v[MAXW];
 #pragma unroll
           for (int r = 0; r < MAXW; ++r)
-            v[r] = (polls && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+            v[r] = (polls && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + hl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                           : ((unsigned long long)x.seq << 32);
           all = true;
 #pragma unroll
@@ -680,9 +681,10 @@ __global__ __launch_bounds__(256) void w_exchange_update_kernel(const WExchangeA
           const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
           const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
           const double v2 = __builtin_bit_cast(double, bits);
-          g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+          g = (hl >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
         }
-      if (polls && !(lane & 1)) a.hstat_out[lane >> 1] = g;
+      if (polls && !(lane & 1)) a.hstat_out[hl >> 1] = g;
+      }
       // the boundary rows of the neighbours (the next launch reads them): their flag
       if (lane < x.world) xchg_wait_flag(flag(x.rank, lane, nwg), x.seq, x.max_ticks, err);
     }
@@ -1286,8 +1288,20 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
       } else {
         gta = load_a(a, kk, mm);
       }
-      numv[e] = a.w_old[e] * gta;
-      denv[e] = (a.g ? a.colsum_g[mm] : 1.f) * (float)a.hstat[ESPM_HS_ROWSUM + kk];
+      const float wo = a.w_old[e];
+      float nvv = wo * gta;
+      float dvv = (a.g ? a.colsum_g[mm] : 1.f) * (float)a.hstat[ESPM_HS_ROWSUM + kk];
+      if (a.pg_gamma_w > 0.f) {           // projected gradient: W - (colsum(G) rowsum(H) - G^T A) / gamma, updates.py:353-362 (as w_finish_fast_kernel)
+        const float pgr = dvv - gta;
+        nvv = wo - pgr / a.pg_gamma_w;
+        dvv = pgr;                        // (the denominator is 1: its slot carries the gradient for the linesearch term below)
+      } else if (a.breg_sr) {             // Bregman variant (G = identity), updates.py:41-48
+        const float sr = a.xscale * a.breg_sr[mm];
+        dvv = (dvv - gta) * wo + sr;
+        nvv = sr * wo;
+      }
+      numv[e] = nvv;
+      denv[e] = dvv;
     }
     __syncthreads();
 
@@ -1348,15 +1362,24 @@ __global__ __launch_bounds__(WF_THREADS) void w_finish_kernel(const WFinishArgs 
     }
 
     // W' = max(num / (den + nu), eps), fixed entries, updates.py:70-76
-    double sum_l = 0.0;
+    double sum_l = 0.0, q_l = 0.0;
+    const bool pg = a.pg_gamma_w > 0.f;   // (never with the simplex over W: espm_mu's state check)
     for (int e = tid; e < M * k; e += WF_THREADS) {
       const int mm = e / k, kk = e - mm * k;
-      float den = denv[e];
+      float den = pg ? 1.f : denv[e];
       if (a.simplex_w && (!a.simplex_rows || a.simplex_rows[mm])) den += (float)s_mid[kk];
       float wn = fmaxf(numv[e] / den, a.log_shift);
       if (a.fixed_w && a.fixed_w[e] >= 0.f) wn = a.fixed_w[e];
       a.w_new[e] = wn;
       sum_l += (double)wn;
+      if (pg) {   // the linesearch term sum <W' - W, grad> + gamma ||W' - W||^2
+        const double dw = (double)wn - (double)a.w_old[e];
+        q_l += dw * (double)denv[e] + (double)a.pg_gamma_w * dw * dw;
+      }
+    }
+    if (a.pg_q) {   // (uniform)
+      const double q_w = block_sum1(q_l, scratch);
+      if (tid == 0) *a.pg_q = q_w;
     }
     const double mean_w = block_sum1(sum_l, scratch) / ((double)M * k);
     double rel_l = 0.0;
@@ -1411,7 +1434,7 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
   // both contractions on the matrix cores (mu_w_mfma_kernel.hpp) from MFMA_MIN_K components on: below, the vector kernel's 2 k + 6
   // instructions per element are fewer than what the split operands and the tile traffic cost
   if (K >= ESPM_MFMA_MIN_K && args.mfma && args.x_cm && args.n_pad % 8 == 0) {
-    const dim3 grid(nblk, (args.n_pad + 4 * 16 * 8 - 1) / (4 * 16 * 8));
+    const dim3 grid(nblk, (args.n_pad + 4 * 16 * MF_CT - 1) / (4 * 16 * MF_CT));
     if (x_dtype == ESPM_X_U8) {
       hipLaunchKernelGGL((w_accum_mfma_kernel<K, uint8_t>), grid, dim3(256), 0, stream, args);
     } else if (x_dtype == ESPM_X_BF16) {
@@ -1423,12 +1446,20 @@ static int dispatch_w_k(const WAccumArgs& args, int x_dtype, int nblk, hipStream
     }
     return check_hip(hipGetLastError(), "w_accum (mfma) launch");
   }
+  if constexpr (K > 16) {   // the widest build keeps the vector kernel for the fp32 store only (mu_h_step.hip)
+    if (x_dtype != ESPM_X_F32)
+      return set_error(ESPM_EUNSUPPORTED, "w_accum: %d components on the 8-bit / bf16 store run on the matrix cores only (no_fused = 0, n_pad a multiple of 8)", K);
+  }
   if (x_dtype == ESPM_X_U8) {
-    dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
-    hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, CH8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
+    if constexpr (K <= 16) {
+      dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
+      hipLaunchKernelGGL((w_accum_kernel<K, uint8_t, CH8, 4, 3>), grid, dim3(256), 0, stream, args);  // ring of 3: tools/tune
+    }
   } else if (x_dtype == ESPM_X_BF16) {
-    dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
-    hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, CH8, 4, 0>), grid, dim3(256), 0, stream, args);
+    if constexpr (K <= 16) {
+      dim3 grid(nblk, (args.n_pad + 4 * 64 * CH8 - 1) / (4 * 64 * CH8));
+      hipLaunchKernelGGL((w_accum_kernel<K, bf16_t, CH8, 4, 0>), grid, dim3(256), 0, stream, args);
+    }
   } else {
     dim3 grid(nblk, (args.n_pad + 4 * 64 * 4 - 1) / (4 * 64 * 4));
     if (args.l2)
@@ -1939,14 +1970,15 @@ __global__ __launch_bounds__(256) void w_gxchg_update_kernel(const WGxchgArgs x)
     a.w_new[e] = wn;
   }
   if (e == 0) {   // the global statistics of the new H (the NEXT launch reads them) and the neighbours' boundary rows' flag
-    const bool p2 = lane < 2 * ESPM_HS_STRIDE;
+    for (int hl = lane; hl < ((2 * ESPM_HS_STRIDE + 63) & ~63); hl += 64) {   // (64 halves of statistics per pass: two passes in the widest build)
+    const bool p2 = hl < 2 * ESPM_HS_STRIDE;
     unsigned int hv[16];
     const long long t0 = wall_clock64();
     for (;;) {
       unsigned long long v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+        v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + hl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                    : ((unsigned long long)x.seq << 32);
       bool all = true;
 #pragma unroll
@@ -1968,9 +2000,10 @@ __global__ __launch_bounds__(256) void w_gxchg_update_kernel(const WGxchgArgs x)
         const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
         const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
         const double v2 = __builtin_bit_cast(double, bits);
-        g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+        g = (hl >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
       }
-    if (p2 && !(lane & 1)) x.hstat_out[lane >> 1] = g;
+    if (p2 && !(lane & 1)) x.hstat_out[hl >> 1] = g;
+    }
     if (lane < x.world) xchg_wait_flag(flag(x.rank, lane), x.seq, x.max_ticks, err);
   }
 }
@@ -2047,14 +2080,15 @@ __device__ __forceinline__ void gxchg_global_stats_role(const WGxchgArgs& x, int
     return reinterpret_cast<unsigned long long*>(x.mbox[dst] + x.gran_off) + (size_t)src_rank * GRAN + g;
   };
   unsigned int* err = reinterpret_cast<unsigned int*>(x.mbox[x.rank] + x.err_off);
-  const bool p2 = lane < 2 * ESPM_HS_STRIDE;
+  for (int hl = lane; hl < ((2 * ESPM_HS_STRIDE + 63) & ~63); hl += 64) {   // (64 halves of statistics per pass: two passes in the widest build)
+  const bool p2 = hl < 2 * ESPM_HS_STRIDE;
   unsigned int hv[16];
   const long long t0 = wall_clock64();
   for (;;) {
     unsigned long long v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+      v[r] = (p2 && r < x.world) ? __hip_atomic_load(gran(x.rank, r, 34 * x.nfl + hl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                  : ((unsigned long long)x.seq << 32);
     bool all = true;
 #pragma unroll
@@ -2076,9 +2110,10 @@ __device__ __forceinline__ void gxchg_global_stats_role(const WGxchgArgs& x, int
       const unsigned int other = (unsigned int)__shfl_xor((int)hv[r], 1, 64);
       const unsigned long long bits = (lane & 1) ? (((unsigned long long)hv[r] << 32) | other) : (((unsigned long long)other << 32) | hv[r]);
       const double v2 = __builtin_bit_cast(double, bits);
-      g = (lane >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
+      g = (hl >> 1) < ESPM_HS_MAX ? g + v2 : fmax(g, v2);
     }
-  if (p2 && !(lane & 1)) x.hstat_out[lane >> 1] = g;
+  if (p2 && !(lane & 1)) x.hstat_out[hl >> 1] = g;
+  }
   if (lane < x.world) xchg_wait_flag(flag(x.rank, lane), x.seq, x.max_ticks, err);
 }
 
@@ -2352,8 +2387,12 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
   // G given: [M][k rounded up to 4] new W, [M k] G^T A, and the per-wave partials of the all-threads G^T A (within the 64 KB a
   // kernel gets without asking)
   const size_t lds = args.g ? ((size_t)M * ((args.k + 3) / 4 * 4) + (size_t)mk * (1 + (args.g_t && mk <= WF_GTA_PAR ? WF_THREADS / 64 : 0))) * sizeof(float) : 0;
-  if (crows <= (nt == 256 ? 8 : 4) && rows <= (nt == 256 ? 8 : 4) && (!args.g || (mk <= WF_GTA_MAX && lds <= 64 * 1024))) {
+  // (the widest build - 17..32 components - has the general one-workgroup finish only: the register-resident ones are not built there;
+  //  ESPM_W_FINISH_GENERAL=1 sends the other builds there too - tests: images small enough for the register-resident kernels never reach it)
+  static const bool general_only = [] { const char* e = getenv("ESPM_W_FINISH_GENERAL"); return e && e[0] == '1'; }();
+  if (KP <= 16 && !general_only && crows <= (nt == 256 ? 8 : 4) && rows <= (nt == 256 ? 8 : 4) && (!args.g || (mk <= WF_GTA_MAX && lds <= 64 * 1024))) {
     switch (args.k) {
+#if ESPM_KP <= 16
 #define ESPM_X(KK)                                                              \
   case KK:                                                                      \
     if (nt == WF_FEW_THREADS) launch_fast<KK, (KK <= WF_HALF_MAX_K ? WF_FEW_THREADS : WF_THREADS)>(args, rows, crows, lds, stream); \
@@ -2361,6 +2400,7 @@ int launch_w_finish(const WFinishArgs& args, hipStream_t stream) {
     break;
       ESPM_K_CASES(ESPM_X)
 #undef ESPM_X
+#endif
       default: return set_error(ESPM_EUNSUPPORTED, "w_finish: k=%d not built", args.k);
     }
   } else {

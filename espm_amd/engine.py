@@ -80,7 +80,7 @@ class MUEngine:
         dev = self.device
         k = int(n_components)
         self.k = k
-        self.V = _lib.variant(k)          # the build with the kernels for k components (1..8, or 9..16 on the dense stores)
+        self.V = _lib.variant(k)          # the build with the kernels for k components (1..8, 9..16, or 17..32 on the dense stores)
         self.lib, self._check = self.V.lib, self.V.check
 
         _t_dbg = [time.perf_counter()] if os.environ.get("ESPM_ENGINE_TIMING") else None
@@ -209,6 +209,9 @@ class MUEngine:
                 sparse = float(known["nnz"] if known else (Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
+                elif sparse and k > _lib.WIDE_MAX_K:
+                    self.x_store_note = (f"sparse count data, but the sparse store is built for up to {_lib.WIDE_MAX_K} components (k={k}: a table row of "
+                                         "32 floats leaves a workgroup's LDS no room): the dense 8-bit store is used, both contractions on the matrix cores")
                 elif sparse and not fits:
                     # not silently (missing 3): sparse count data that the sparse store would take - about 3 x the dense store's
                     # rate at 20 % non-zero entries - but whose G W table does not fit a workgroup's LDS next to a tile's numerators

@@ -897,11 +897,12 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
     def fit(self, X, y=None, **params):
         """Learn a NMF model for the data X (espm/estimators/base.py:422-441).
 
-        Deviation from the reference: ``n_components`` is limited to 16 (``NotImplementedError`` above that, raised before anything is
+        Deviation from the reference: ``n_components`` is limited to 32 (``NotImplementedError`` above that, raised before anything is
         uploaded).  The reference has no limit (base.py:126-132 stores the argument, updates.py:160-223 initialise any rank); here the
-        kernels are compiled per component count - 1..8 in libespm_mu.so, 9..16 in libespm_mu_wide.so - with the components of a pixel
-        or channel in registers.  Sparse count data with 13-16 components and more than 1784-1880 channels (9-12: 2552-2680) take the dense 8-bit
-        store, with a RuntimeWarning: the sparse store's G W table would not fit a workgroup's LDS."""
+        kernels are compiled per component count - 1..8 in libespm_mu.so, 9..16 in libespm_mu_wide.so, 17..32 in libespm_mu_wide32.so -
+        with the components of a pixel or channel in registers.  The sparse count store serves up to 16 components: sparse count data with
+        more, or with 13-16 components and more than 1784-1880 channels (9-12: 2552-2680), take the dense 8-bit store (below 17 components
+        with a RuntimeWarning: the sparse store's G W table would not fit a workgroup's LDS)."""
         self.fit_transform(X, **params)
         return self
 

@@ -25,8 +25,8 @@ from dataclasses import dataclass
 import torch
 
 def hs_stride(k: int) -> int:
-    """ESPM_HS_STRIDE of the build that serves k components (2 KP: KP = 8 up to 8 components, else 16)."""
-    return 16 if k <= 8 else 32
+    """ESPM_HS_STRIDE of the build that serves k components (2 KP: KP = 8 up to 8 components, 16 up to 16, else 32)."""
+    return 16 if k <= 8 else (32 if k <= 16 else 64)
 
 
 def split_rows(nx: int, world: int, rank: int):

@@ -81,12 +81,14 @@ enum { ESPM_X_F32 = 0, ESPM_X_BF16 = 1, ESPM_X_U8 = 2 /* integer counts <= 255 *
 enum { ESPM_SRC_F32 = 0, ESPM_SRC_F64 = 1 };
 enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, n) pixel-major */ };
 
-/* The library is built twice from the same sources: libespm_mu.so (1..8 components, the strides below = 8) and
+/* The library is built three times from the same sources: libespm_mu.so (1..8 components, the strides below = 8),
+ * libespm_mu_wide32.so (-DESPM_KP=32 -DESPM_MIN_K=17 -DESPM_MAX_K=32: 17..32 components; the dense stores only, H tiles of 128 pixels, on the
+ * 8-bit and bf16 stores the matrix-core kernels only - espm/estimators/base.py:126-132 has no limit on n_components) and
  * libespm_mu_wide.so (-DESPM_KP=16 -DESPM_MIN_K=9 -DESPM_MAX_K=16: 9..16 components; the sparse store's LDS table then has
  * rows of 12 or 16 floats and must fit ESPM_ELL_LDS_MAX together with the numerators of a tile).  Same entry points, same state struct; every
  * size below that names KP follows the build. */
 #ifndef ESPM_KP
-#define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP): 8 or 16 */
+#define ESPM_KP 8          /* padded component stride of GW (n_pad, KP) and H^T (p, KP): 8, 16 or 32 */
 #endif
 #ifndef ESPM_MAX_K
 #define ESPM_MAX_K ESPM_KP /* components supported by the built kernels */

@@ -287,7 +287,7 @@ def test_matrix_core_kernels_of_the_wide_build_at_full_size(store, tile):
     assert dh < 2e-5 and dw < 2e-4, (dh, dw)
 
 
-@pytest.mark.parametrize("k", [9, 12, 16])
+@pytest.mark.parametrize("k", [9, 12, 16, 17, 24, 32])
 @pytest.mark.parametrize("store", ["u8", "bf16"])
 def test_matrix_core_w_accumulation_is_bit_reproducible_over_200_launches(k, store):
     """The gate on the 32-slot matrix instruction: `w_accum_mfma_kernel` of the wide build runs both its
@@ -304,7 +304,7 @@ def test_matrix_core_w_accumulation_is_bit_reproducible_over_200_launches(k, sto
     W0, H0 = synth.random_init(N, k, NX * NY, seed=3, scale=500.0 / N)
     eng = MUEngine(X, k, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4, x_store=store)
     del X
-    assert eng.x_store == store and eng.V.KP == 16 and eng.st.no_fused == 0      # matrix-core kernels allowed
+    assert eng.x_store == store and eng.V.KP == (16 if k <= 16 else 32) and eng.st.no_fused == 0      # matrix-core kernels allowed (17..32 components: the third build, two halves of 16)
     eng.load_state(W0, H0)
     eng.eval_current(advance_h=True)          # H' and its transposed copy, the inputs of the accumulation
     eng._flush_finalize()
@@ -320,7 +320,7 @@ def test_matrix_core_w_accumulation_is_bit_reproducible_over_200_launches(k, sto
     assert int(differing.item()) == 0, f"{int(differing.item())} of 200 launches differ from the first one"
 
 
-@pytest.mark.parametrize("k", [13, 16])
+@pytest.mark.parametrize("k", [13, 16, 17, 24, 32])
 @pytest.mark.parametrize("store", ["u8", "bf16"])
 def test_matrix_core_h_step_is_bit_reproducible_over_200_launches(k, store):
     """The same gate on the H side: `h_step_mfma_kernel` of the wide build (13..16 components, the 16-slot matrix
@@ -335,7 +335,7 @@ def test_matrix_core_h_step_is_bit_reproducible_over_200_launches(k, store):
     W0, H0 = synth.random_init(N, k, NX * NY, seed=4, scale=500.0 / N)
     eng = MUEngine(X, k, layout="pm", shape_2d=(NX, NY), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=4, x_store=store)
     del X
-    assert eng.x_store == store and eng.V.KP == 16 and eng.st.no_fused == 0      # matrix-core kernels allowed
+    assert eng.x_store == store and eng.V.KP == (16 if k <= 16 else 32) and eng.st.no_fused == 0      # matrix-core kernels allowed (17..32 components: the third build, two halves of 16)
     eng.load_state(W0, H0)
     eng._flush_finalize()
     st, s = eng.st, _stream()

@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(seed, wide=False):
-    rng = np.random.default_rng((5000 if wide else 1000) + seed)
+    rng = np.random.default_rng((1000, 5000, 9000)[int(wide)] + seed)
     n = int(rng.integers(20, 260))
     nx, ny = int(rng.integers(3, 18)), int(rng.integers(3, 18))
-    k = int(rng.integers(9, 17)) if wide else int(rng.integers(1, 9))   # 9..16: the second build of the library
+    # 9..16: the second build of the library; 17..32 (wide = 2): the third
+    k = int(rng.integers(17, 33)) if int(wide) == 2 else (int(rng.integers(9, 17)) if wide else int(rng.integers(1, 9)))
     p = nx * ny
     algo = ["log_surrogate", "log_surrogate", "bmd", "l2_surrogate", "projected_gradient"][seed % 5]
     use_G = algo != "bmd" and rng.random() < 0.45
@@ -64,7 +65,7 @@ def _case(seed, wide=False):
         extra["fixed_H"] = fH
     # empty lines (base.py:519-528: filled with log_shift by the reference; the sparse store keeps its lists empty): one draw
     # in four has channels, one in four pixels without a single count (a generator of its own: the draws above stay as they were)
-    rz = np.random.default_rng(77000 + seed + (500 if wide else 0))
+    rz = np.random.default_rng(77000 + seed + 500 * int(wide))
     if rz.random() < 0.25:
         X[rz.choice(n, size=int(rz.integers(1, 6)), replace=False), :] = 0
     if rz.random() < 0.25 and algo != "bmd" and not (algo == "l2_surrogate" and kw["lambda_L"] == 0 and kw["simplex_H"]):
@@ -99,6 +100,47 @@ def test_random_configuration_on_the_fused_kernel(seed, blocks, monkeypatch):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_WIDE_CASES", "20"))))
 def test_random_configuration_with_9_to_16_components_matches_oracle(seed):
     _run(_case(seed, wide=True), seed)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ESPM_FUZZ_WIDEST_CASES", "20"))))
+def test_random_configuration_with_17_to_32_components_matches_oracle(seed):
+    _run(_case(seed, wide=2), seed)
+
+
+def _general_finish_cases(count):
+    """(child process, ESPM_W_FINISH_GENERAL=1) the draws that reach a one-workgroup W finish, one line per draw."""
+    import json, traceback
+    for wide in (0, 1):
+        for seed in range(count):
+            c = _case(seed, wide=wide)
+            if c["G"] is None and not c["kw"]["simplex_W"] and c["X"].shape[0] >= 64:
+                continue   # G = identity without the simplex over W: the reduction workgroups finish W themselves
+            try:
+                _run(c, seed)
+                status, msg = "passed", ""
+            except pytest.skip.Exception as e:
+                status, msg = "skipped", str(e)
+            except Exception:
+                status, msg = "failed", traceback.format_exc()[-1500:]
+            print("CASE " + json.dumps(dict(seed=seed, wide=wide, algo=c["algo"], k=c["k"], status=status, msg=msg)), flush=True)
+
+
+def test_random_configurations_on_the_general_w_finish():
+    """The one-workgroup W finish that keeps nothing in registers (`w_finish_kernel`: a dictionary G or a simplex over W with more
+    rows than the register-resident kernels hold; the only one of the 17..32-component build) - images of the fuzz's size never
+    reach it by themselves.  It had no projected-gradient and no Bregman branch until round 5 (found by the 17..32 fuzz above).
+    The knob is read once per process: ONE child process runs the draws of both narrower builds under ESPM_W_FINISH_GENERAL=1."""
+    import json, os, subprocess, sys
+    count = int(os.environ.get("ESPM_FUZZ_GENERAL_CASES", "30"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_fuzz as t; t._general_finish_cases(%d)" % (here, os.path.dirname(here), count)
+    pr = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ESPM_W_FINISH_GENERAL="1"), capture_output=True, text=True, timeout=1500)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    cases = [json.loads(ln[5:]) for ln in pr.stdout.splitlines() if ln.startswith("CASE ")]
+    failed = [c for c in cases if c["status"] == "failed"]
+    passed = [c for c in cases if c["status"] == "passed"]
+    assert not failed, "\n".join(f"seed {c['seed']} wide {c['wide']} {c['algo']} k={c['k']}: {c['msg']}" for c in failed[:5])
+    assert len(passed) >= count // 3 and {"projected_gradient", "bmd"} <= {c["algo"] for c in passed} or count < 20, [(c["algo"], c["status"]) for c in cases]
 
 
 def _run(c, seed, expect_fused=False):

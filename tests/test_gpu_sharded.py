@@ -20,19 +20,24 @@ pytestmark = pytest.mark.gpu
 NX, NY, K, ITERS = 24, 40, 5, 12
 # "h": the headline's constraints; "w": the reference's default ones - the simplex over W, whose multipliers come from sums over
 # the channels that the sum over the ranks' records leaves (224 channels: a multiple of 32, the many-workgroup update applies)
+# "h20", "w24": 17..32 components - the third build of the library (component stride 32: the records' statistics are 64 doubles, two
+# passes of the granule polls), the dense 8-bit store
 CASES = {"h": (200, dict(lambda_L=1.0, mu=0.1, simplex_H=True, simplex_W=False, tol=0.0)),
-         "w": (224, dict(lambda_L=0.5, mu=0.05, simplex_H=False, simplex_W=True, tol=0.0))}
+         "w": (224, dict(lambda_L=0.5, mu=0.05, simplex_H=False, simplex_W=True, tol=0.0)),
+         "h20": (200, dict(lambda_L=1.0, mu=0.1, simplex_H=True, simplex_W=False, tol=0.0)),
+         "w24": (224, dict(lambda_L=0.5, mu=0.05, simplex_H=False, simplex_W=True, tol=0.0))}
+KS = {"h": K, "w": K, "h20": 20, "w24": 24}
 
 
 def _data(case):
     from espm_amd import synth
-    n = CASES[case][0]
+    n, K = CASES[case][0], KS[case]
     prob = synth.make_problem(n, NX, NY, K, N=40.0, seed=2)
     X = synth.sample_numpy(prob, seed=2)
     X[7] = 0                       # a channel without counts in the whole image, pixels without counts in two shards
     X[:, [3, NY + 1, (NX - 1) * NY + 5]] = 0
     W0, H0 = synth.random_init(n, K, NX * NY, seed=2, scale=0.5)
-    if case == "w":
+    if case[0] == "w":
         W0 /= W0.sum(axis=0, keepdims=True)
     return X, W0, H0
 
@@ -45,7 +50,7 @@ def _worker(rank, world, port, out, transport, granular, case):
         from espm_amd.engine import MUEngine
         torch.cuda.set_device(0)
         X, W0, H0 = _data(case)
-        KW = CASES[case][1]
+        KW, K = CASES[case][1], KS[case]
         row0, rows = sharding.split_rows(NX, world, rank)
         sl = slice(row0 * NY, (row0 + rows) * NY)
         eng = MUEngine(X[:, sl], K, shape_2d=(rows, NY), max_iter=ITERS, group=dist.group.WORLD, device="cuda:0", **KW)
@@ -73,15 +78,20 @@ def _free_port():
 
 @pytest.mark.parametrize("world,transport,granular,case", [(2, "p2p", False, "h"), (3, "p2p", False, "h"), (3, "p2p", True, "h"),
                                                            (2, "collective", False, "h"), (3, "collective", True, "h"),
-                                                           (2, "p2p", False, "w"), (3, "collective", True, "w")])
+                                                           (2, "p2p", False, "w"), (3, "collective", True, "w"),
+                                                           (2, "p2p", False, "h20"), (3, "collective", True, "h20"), (3, "p2p", True, "h20"),
+                                                           (2, "p2p", False, "w24")])
 def test_sharded_engine_matches_single_gpu(world, transport, granular, case):
     from espm_amd.engine import MUEngine
     from oracle import mu_oracle as oc
     X, W0, H0 = _data(case)
-    KW = CASES[case][1]
+    KW, K = CASES[case][1], KS[case]
     eng = MUEngine(X, K, shape_2d=(NX, NY), max_iter=ITERS, device="cuda:0", **KW)
-    assert eng.x_store == "ell" and eng.st.ell_fill_n == 3    # the sparse store, with its pass for the pixels without counts
-    assert case == "h" or eng.st.n_pad % 32 == 0
+    if K <= 16:
+        assert eng.x_store == "ell" and eng.st.ell_fill_n == 3    # the sparse store, with its pass for the pixels without counts
+    else:
+        assert eng.x_store == "f32" and eng.V.KP == 32   # (dense stores only; the lines without counts carry the reference's 1e-14 fill: fp32)
+    assert case[0] == "h" or eng.st.n_pad % 32 == 0
     eng.load_state(W0, H0)
     eng.iterate(ITERS, final_loss=True)
     torch.cuda.synchronize()

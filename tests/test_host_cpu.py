@@ -32,7 +32,7 @@ def _declared_functions():
 def test_every_declared_symbol_is_exported_and_bound(lib):
     declared = _declared_functions()
     assert len(declared) >= 18
-    for path in (lib.LIB_PATH, lib.WIDE_LIB_PATH):   # both builds of the sources: 1..8 and 9..16 components
+    for path in (lib.LIB_PATH, lib.WIDE_LIB_PATH, lib.WIDEST_LIB_PATH):   # the three builds of the sources: 1..8, 9..16 and 17..32 components
         cdll = C.CDLL(path)
         for name in declared:
             assert hasattr(cdll, name), f"{name} declared in espm_mu.h but not exported by {path}"
@@ -42,8 +42,11 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     wide = lib.variant(12)
     assert wide.lib is not lib.lib and (wide.KP, wide.HP_STRIDE, wide.HS_STRIDE, wide.HS_MAX) == (16, 40, 32, 16)
     assert lib.variant(8).lib is lib.lib
+    widest = lib.variant(17)
+    assert widest is lib.variant(32) and widest.lib is not wide.lib and (widest.KP, widest.HP_STRIDE, widest.HS_STRIDE, widest.HS_MAX) == (32, 72, 64, 32)
+    assert widest.lib.espm_mu_state_size() == lib.lib.espm_mu_state_size()
     with pytest.raises(NotImplementedError):
-        lib.variant(17)
+        lib.variant(33)
 
 
 def test_header_constants_and_struct_match_ctypes(lib):

@@ -149,7 +149,8 @@ def test_record_layout_matches_the_library():
     ge.build()
     from espm_amd import _lib
     for n, k, ny, p in ((2048, 5, 512, 512 * 64), (1980, 8, 1024, 1024 * 128), (100, 3, 20, 400), (7, 1, 0, 1),
-                        (2048, 12, 512, 512 * 64), (300, 16, 30, 900)):   # (9..16 components: the wide build's statistics block)
+                        (2048, 12, 512, 512 * 64), (300, 16, 30, 900),    # (9..16 components: the wide build's statistics block)
+                        (2048, 17, 512, 512 * 64), (300, 32, 30, 900)):   # (17..32: the third build's)
         st = _lib.MUState()
         st.n, st.p, st.k, st.ny, st.x_dtype = n, p, k, ny, 1
         lib = _lib.variant(k).lib
