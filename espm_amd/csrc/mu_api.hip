@@ -227,9 +227,11 @@ int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t
                      espm_stream_t stream) {
   if (int rc = check_ell_geometry(st)) return rc;
   ESPM_REQUIRE(x_pm_u8 && chan_perm && pix_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
+  // st->x_cm, if set: the 8-bit counts once more, channel-major in tiles of ESPM_PPAD pixels (include/espm_mu.h) - the channel lists are filled from it
+  ESPM_REQUIRE(!st->x_cm || st->n_cm == roundup(st->n, ESPM_NCM), "ell_fill: x_cm is set but n_cm=%d is not n rounded up to %d", st->n_cm, ESPM_NCM);
   return launch_ell_fill(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
                          st->nblk_w, st->tile_px, st->ell_pb, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w,
-                         static_cast<hipStream_t>(stream));
+                         static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(st->x_cm), st->n_cm);
 }
 
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {

@@ -955,7 +955,7 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
                     int32_t* chan_perm, int32_t* pix_perm, int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
 int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
-                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream);
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm = nullptr, int n_cm = 0);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int launch_ell_fill_num(const float* gw_s, const float* h_in, const int32_t* fill_px, int fill_n, int n, int k, int p_pad, float fill,
                         float* fill_num, hipStream_t stream);

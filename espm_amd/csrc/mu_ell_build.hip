@@ -334,7 +334,12 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
 #ifndef ESPM_ELL_FILLW_WAVES
 #define ESPM_ELL_FILLW_WAVES 4
 #endif
-__global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, int n_pad, int p, int n_cg, int pb, int pbits,
+// x_cm (optional): the same counts channel-major inside tiles of ESPM_PPAD pixels, [tile][channel row, n_cm of them][ESPM_PPAD]
+// (espm_mu_pack_x's other output), zero beyond p: a lane then fetches 16 pixels of ITS channel with one 16-byte load instead of
+// 16 byte loads that each drag a cache line of the pixel's row through the memory pipe (3.7 -> 1.x ms at the headline size: this
+// kernel was the longest of the build).
+__global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, const uint8_t* __restrict__ x_cm, int n_cm,
+                                                        int n_pad, int p, int n_cg, int pb, int pbits,
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
                                                         uint32_t* __restrict__ ell_w) {
   constexpr int NT = 64 * ESPM_ELL_FILLW_WAVES;
@@ -353,6 +358,30 @@ __global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(c
   // the channel's counts over the block's pixels, 16 loads in flight at a time (one by one, each waited for, this kernel
   // was the longest of the build: the lanes' bytes of a pixel lie all over its row)
   auto for_each_count = [&](auto f) {
+    if (x_cm) {   // (uniform) 64 pixels = four 16-byte loads in flight; blocks start on multiples of 128 pixels, tiles hold ESPM_PPAD
+      for (int qb = q0; qb < q1; qb += 64) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = qb + 16 * u;
+          v[u] = q < q1 ? *reinterpret_cast<const uint4*>(x_cm + ((size_t)(q / ESPM_PPAD) * n_cm + c) * ESPM_PPAD + (q % ESPM_PPAD)) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (w[d] == 0u) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int x = (int)((w[d] >> (8 * e)) & 255u);
+              if (x != 0) f(qb + 16 * u + 4 * d + e - q0, x);
+            }
+          }
+        }
+      }
+      return;
+    }
     for (int qb = q0; qb < q1; qb += 16) {
       int x[16];
 #pragma unroll
@@ -386,15 +415,51 @@ __global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(c
   });
 }
 
+// The pixel lists' and the channel lists' kernels of a step do not depend on each other and neither fills the device's memory
+// pipes (one owner lane per list, byte-granular reads): the channel lists' kernel runs on a side stream of the device, forked
+// from and joined to the caller's stream by events.  ESPM_ELL_BUILD_SIDE=0: one after the other on the caller's stream (A/B).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream* side_stream() {
+  static const bool enabled = [] { const char* e = getenv("ESPM_ELL_BUILD_SIDE"); return !(e && e[0] == '0'); }();
+  if (!enabled) return nullptr;
+  static SideStream per_device[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = per_device[dev];
+  if (!s.stream) {   // (first use on this device; the build of a fit is single-threaded host code)
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    s.ok = hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return s.ok ? &s : nullptr;
+}
+// the stream the second kernel of a pair goes to (the side stream after the fork, or the caller's own)
+static hipStream_t side_fork(SideStream* s, hipStream_t stream) {
+  if (!s) return stream;
+  if (hipEventRecord(s->fork, stream) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess) return stream;
+  return s->stream;
+}
+static int side_join(SideStream* s, hipStream_t used, hipStream_t stream) {
+  if (!s || used == stream) return ESPM_OK;
+  if (int rc = check_hip(hipEventRecord(s->join, s->stream), "ell build: side stream")) return rc;
+  return check_hip(hipStreamWaitEvent(stream, s->join, 0), "ell build: side stream");
+}
+
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
   const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ell_pbits(pb))) - 1;
   // a unit entry holds index << 4 in 16 bits
+  SideStream* side = side_stream();
+  const hipStream_t s2 = side_fork(side, stream);   // (before the first kernel: the side stream waits for what precedes the pair only)
   hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
                      n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc);
-  hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p,
+  hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, s2, x_pm, n, n_pad, p,
                      n_cg * 64, xmax_w, pb, cnt_bc);
-  return check_hip(hipGetLastError(), "ell_count launch");
+  if (int rc = check_hip(hipGetLastError(), "ell_count launch")) return rc;
+  return side_join(side, s2, stream);
 }
 
 int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
@@ -416,11 +481,14 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
 
 int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
-                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream) {
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm, int n_cm) {
+  SideStream* side = side_stream();
+  const hipStream_t s2 = side_fork(side, stream);
   hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
                      pix_perm, h_off, ell_h);
-  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, stream, x_pm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
-  return check_hip(hipGetLastError(), "ell_fill launch");
+  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, s2, x_pm, x_cm, n_cm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
+  if (int rc = check_hip(hipGetLastError(), "ell_fill launch")) return rc;
+  return side_join(side, s2, stream);
 }
 
 }  // namespace espm

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -89,7 +90,7 @@ class MUEngine:
             if _t_dbg is not None:
                 torch.cuda.synchronize()
                 now = time.perf_counter()
-                print(f"[engine set-up] {name}: {1e3 * (now - _t_dbg[0]):.1f} ms", flush=True)
+                print(f"[engine set-up] {name}: {1e3 * (now - _t_dbg[0]):.1f} ms", file=sys.stderr, flush=True)
                 _t_dbg[0] = now
 
         # ---- X to the device, zero lines, storage type ------------------------------------------
@@ -206,7 +207,9 @@ class MUEngine:
                 from . import ell as _ell
                 n_pad8 = (self.n + 7) // 8 * 8
                 fits = k <= _lib.WIDE_MAX_K and self.n <= 16384 and _ell.lds_bytes_h(n_pad8, k) <= _lib.ELL_LDS_MAX
-                sparse = float(known["nnz"] if known else (Xd != 0).sum()) <= ELL_MAX_DENSITY * Xd.numel()
+                nnz_x = int(known["nnz"]) if known else int(torch.count_nonzero(Xd))
+                self._nnz_known = nnz_x          # (the sparse store's build does not count again: a pass over the 8-bit copy was 2.6 of its 12 ms)
+                sparse = float(nnz_x) <= ELL_MAX_DENSITY * Xd.numel()
                 if fits and (x_store == "ell" or sparse):
                     code = 3
                 elif sparse and k > _lib.WIDE_MAX_K:
@@ -433,9 +436,11 @@ class MUEngine:
         st, dev = self.st, self.device
         i32 = dict(dtype=torch.int32, device=dev)
         x8 = torch.empty((self.p, st.n_pad), dtype=torch.uint8, device=dev)
+        # (the channel-major copy beside it: the channel lists' fill reads it with 16-byte loads, include/espm_mu.h; ESPM_ELL_BUILD_CM=0: without, A/B)
+        x8c = torch.empty((st.p_pad // _lib.PPAD, st.n_cm, _lib.PPAD), dtype=torch.uint8, device=dev) if os.environ.get("ESPM_ELL_BUILD_CM") != "0" else None
         self._check(self.lib.espm_mu_pack_x(_ptr(Xd), _lib.SRC_F64 if Xd.dtype == torch.float64 else _lib.SRC_F32,
                                  _lib.LAYOUT_PM if layout == "pm" else _lib.LAYOUT_CM, Xd.shape[1], self.n, self.p,
-                                 None, _ptr(x8), _lib.X_U8, st.n_pad, st.p_pad, _lib.PPAD, st.n_cm, _stream()))
+                                 _ptr(x8c) if x8c is not None else None, _ptr(x8), _lib.X_U8, st.n_pad, st.p_pad, _lib.PPAD, st.n_cm, _stream()))
         cnt_px = torch.empty((2, st.p_pad), **i32)                    # entries, elements equal to 1
         cnt_bc = torch.empty((2, st.nblk_w, st.n_cg * 64), **i32)
         klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
@@ -452,9 +457,15 @@ class MUEngine:
             raise ValueError("sparse count store: the lists exceed 2^31 dwords")
         ell_h = torch.zeros(max(rows_h, 1) * 64, **i32)
         ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
-        self._check(self.lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
-                                   _ptr(ell_h), _ptr(ell_w), _stream()))
-        nnz = int((x8[:, :self.n] != 0).sum())
+        st.x_cm = x8c.data_ptr() if x8c is not None else None
+        try:
+            self._check(self.lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
+                                       _ptr(ell_h), _ptr(ell_w), _stream()))
+        finally:
+            st.x_cm = None
+        nnz = getattr(self, "_nnz_known", None)
+        if nnz is None:
+            nnz = int(torch.count_nonzero(x8))   # (padding channels hold zeros)
         torch.cuda.current_stream().synchronize()
         return dict(ell_h=ell_h, ell_h_off=h_off, klc=klc, pix_perm=pix_perm, ell_w=ell_w, ell_w_off=w_off, chan_perm=chan_perm, n_cg=st.n_cg,
                     nblk_w=st.nblk_w, nnz=nnz, entries_h=int(cnt_px[0].sum()), entries_w=int(cnt_bc[0].sum()), rows_h=rows_h,

@@ -76,6 +76,22 @@ def _lu_pl_device(A):
     return out
 
 
+def _gram64(Ad):
+    """Ad^T Ad of a tall fp64 matrix (m >> r) as a batched product over blocks of 1024 rows, summed: rocBLAS gives the plain
+    `Ad.T @ Ad` of a 262144 x 15 matrix ONE workgroup's worth of parallelism - 7.0 ms, against 0.04 ms for the blocks
+    (profiles/r05z_qr_bench.log); two of them were half of the initialisation's device time."""
+    m, r = Ad.shape
+    blk = 1024
+    main = (m // blk) * blk
+    if main < 4 * blk:
+        return Ad.T @ Ad
+    A3 = Ad[:main].reshape(main // blk, blk, r)
+    G = torch.bmm(A3.transpose(1, 2), A3).sum(dim=0)
+    if main < m:
+        G = G + Ad[main:].T @ Ad[main:]
+    return G
+
+
 def _qr_tall(A):
     """Q of the reduced QR factorisation of a tall matrix (m >> r columns), up to the signs of its columns - which the randomized
     SVD does not see: U = Q Uhat with Uhat from the SVD of Q^T M is the same for Q and Q D, D = diag(+-1).
@@ -84,14 +100,14 @@ def _qr_tall(A):
     more); here: Cholesky QR, twice (A = Q1 R1 with R1 = chol(A^T A), then the same on Q1, whose Gram matrix is the identity to
     cond(A)^2 eps: the second pass restores orthonormality to rounding - Yamamoto et al., "Roundoff error analysis of the
     CholeskyQR2 algorithm", ETNA 44, 2015), Gram matrices, factors and products in fp64 whatever the dtype of A: two r x r
-    Gram products over A, two r x r factorisations on the host and two products with R^-1, under 1 ms.  The triangular factors keep the nesting of the column spaces, so this is
+    Gram products over A (_gram64), two r x r factorisations on the host and two products with R^-1, under 1 ms.  The triangular factors keep the nesting of the column spaces, so this is
     THE QR factor up to signs, not just some orthonormal basis.  A Gram matrix that is not numerically positive definite
     (rank-deficient A: fewer independent directions in X than n_components + 10) goes to torch.linalg.qr."""
     Ad = A.to(torch.float64)
     for _ in range(2):
         # the r x r factor on the host (numpy / scipy, fp64): the device only forms the Gram matrix and multiplies by R^-1 - a
         # triangular solve with 262144 right-hand rows takes rocBLAS 60 ms, the product with the explicit inverse 0.1
-        G = (Ad.T @ Ad).cpu().numpy()
+        G = _gram64(Ad).cpu().numpy()
         try:
             R = np.linalg.cholesky(G).T                      # upper factor: G = R^T R
         except np.linalg.LinAlgError:
@@ -159,7 +175,7 @@ def _cholqr_rows_sharded(A, group, passes):
     from scipy.linalg import solve_triangular
     Ad = A.to(torch.float64)
     for _ in range(passes):
-        G = Ad.T @ Ad
+        G = _gram64(Ad)
         torch.distributed.all_reduce(G, group=group)
         Gh = G.cpu().numpy()
         Gh = 0.5 * (Gh + Gh.T)

@@ -321,7 +321,9 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
  *          ell_w_off (2 nblk_w n_cg + 1) and rows[2] (device):
  *          rows of 64 dwords of the H-step and of the W-step lists.  The caller reads rows[] back, checks
  *          64 rows < 2^31 and allocates ell_h (rows[0], 64) and ell_w (rows[1], 64), ZERO-initialised.
- *   fill : writes the entries.  The dense x_pm_u8 can be released afterwards. */
+ *   fill : writes the entries.  The dense x_pm_u8 can be released afterwards.  Optional, for speed: st->x_cm != NULL hands the fill the
+ *          same 8-bit counts channel-major, [p_pad / ESPM_PPAD][n_cm][ESPM_PPAD] - espm_mu_pack_x's x_cm output with x_tile = ESPM_PPAD -
+ *          from which the channel lists are read with 16-byte loads (the lists come out the same); reset st->x_cm to NULL afterwards. */
 int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
                       espm_stream_t stream);
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
