@@ -10,6 +10,8 @@
 //                       unit elements / (2 ESPM_ELL_UNIT_ROWS)); 2 * (unit rows) of a list's elements with count 1
 //                       go there as index << 4, placed so that the gathers of a wave spread over the LDS banks
 //                       (EllBuckets), everything else to the general rows.
+#include <mutex>
+
 #include "mu_common.hpp"
 
 namespace espm {
@@ -419,47 +421,55 @@ __global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(c
 // pipes (one owner lane per list, byte-granular reads): the channel lists' kernel runs on a side stream of the device, forked
 // from and joined to the caller's stream by events.  ESPM_ELL_BUILD_SIDE=0: one after the other on the caller's stream (A/B).
 struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
+  hipStream_t stream = nullptr;   // the device's side stream (shared by the host threads that build on this device: work on it is ordered)
+  hipEvent_t fork = nullptr, join = nullptr;   // this call's own events (two threads building at once must not share them)
 };
-static SideStream* side_stream() {
+static hipStream_t side_stream_of_device() {
   static const bool enabled = [] { const char* e = getenv("ESPM_ELL_BUILD_SIDE"); return !(e && e[0] == '0'); }();
   if (!enabled) return nullptr;
-  static SideStream per_device[64];
+  static std::mutex mu;
+  static hipStream_t per_device[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& s = per_device[dev];
-  if (!s.stream) {   // (first use on this device; the build of a fit is single-threaded host code)
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    s.ok = hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!per_device[dev] && hipStreamCreateWithFlags(&per_device[dev], hipStreamNonBlocking) != hipSuccess) per_device[dev] = nullptr;
+  return per_device[dev];
+}
+// the stream the second kernel of a pair goes to: the side stream, made to wait for what the caller's stream holds so far - or the caller's own
+static hipStream_t side_fork(SideStream& s, hipStream_t stream) {
+  s.stream = side_stream_of_device();
+  if (!s.stream) return stream;
+  if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventRecord(s.fork, stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.fork, 0) != hipSuccess) {
+    s.stream = nullptr;
+    return stream;
   }
-  return s.ok ? &s : nullptr;
+  return s.stream;
 }
-// the stream the second kernel of a pair goes to (the side stream after the fork, or the caller's own)
-static hipStream_t side_fork(SideStream* s, hipStream_t stream) {
-  if (!s) return stream;
-  if (hipEventRecord(s->fork, stream) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess) return stream;
-  return s->stream;
-}
-static int side_join(SideStream* s, hipStream_t used, hipStream_t stream) {
-  if (!s || used == stream) return ESPM_OK;
-  if (int rc = check_hip(hipEventRecord(s->join, s->stream), "ell build: side stream")) return rc;
-  return check_hip(hipStreamWaitEvent(stream, s->join, 0), "ell build: side stream");
+static int side_join(SideStream& s, hipStream_t stream) {
+  int rc = ESPM_OK;
+  if (s.stream) {
+    rc = check_hip(hipEventRecord(s.join, s.stream), "ell build: side stream");
+    if (!rc) rc = check_hip(hipStreamWaitEvent(stream, s.join, 0), "ell build: side stream");
+  }
+  if (s.fork) (void)hipEventDestroy(s.fork);   // (released once the work that refers to them has completed)
+  if (s.join) (void)hipEventDestroy(s.join);
+  return rc;
 }
 
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
                      int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
   const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ell_pbits(pb))) - 1;
   // a unit entry holds index << 4 in 16 bits
-  SideStream* side = side_stream();
+  SideStream side;
   const hipStream_t s2 = side_fork(side, stream);   // (before the first kernel: the side stream waits for what precedes the pair only)
   hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
                      n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc);
   hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, s2, x_pm, n, n_pad, p,
                      n_cg * 64, xmax_w, pb, cnt_bc);
-  if (int rc = check_hip(hipGetLastError(), "ell_count launch")) return rc;
-  return side_join(side, s2, stream);
+  const int rc = check_hip(hipGetLastError(), "ell_count launch");
+  const int rc2 = side_join(side, stream);
+  return rc ? rc : rc2;
 }
 
 int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
@@ -482,13 +492,14 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
 int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
                     uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm, int n_cm) {
-  SideStream* side = side_stream();
+  SideStream side;
   const hipStream_t s2 = side_fork(side, stream);
   hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
                      pix_perm, h_off, ell_h);
   hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, s2, x_pm, x_cm, n_cm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
-  if (int rc = check_hip(hipGetLastError(), "ell_fill launch")) return rc;
-  return side_join(side, s2, stream);
+  const int rc = check_hip(hipGetLastError(), "ell_fill launch");
+  const int rc2 = side_join(side, stream);
+  return rc ? rc : rc2;
 }
 
 }  // namespace espm
