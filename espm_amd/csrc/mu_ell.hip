@@ -30,8 +30,14 @@ static int launch_h_ell_k(const HStepArgs& args_in, int nblk, hipStream_t stream
   HStepArgs args = args_in;
   size_t bytes = (size_t)args.n_pad * EllTab<K>::FLOATS * sizeof(float) + part;
   if (args.cs_parts) {   // the workgroup's own copy of colsum(GW'): k doubles behind the numerators
-    args.cs_lds_off = (int)bytes;
-    bytes += KP * sizeof(double);
+    if (bytes + KP * sizeof(double) <= ESPM_ELL_LDS_MAX) {
+      args.cs_lds_off = (int)bytes;
+      bytes += KP * sizeof(double);
+    } else {
+      // ... or, where table and numerators take the workgroup's LDS to the last byte (16 components at 2048 channels: 128 + 32 KB), in the
+      // table's first bytes once the walk is over and the table dead (the kernel: cs_late)
+      args.cs_lds_off = 0;
+    }
   }
   const dim3 grid(nblk + (args.tail_on ? 1 : 0));   // (+ the tail of the previous W update, espm_mu_iterate)
   if (args.h_rule == 1 || args.h_rule == 2) {  // quadratic surrogate of the Laplacian term / projected gradient

@@ -490,14 +490,16 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_ker
     return;
   }
   double* cs_lds = a.cs_parts ? reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(smem) + a.cs_lds_off) : nullptr;
-  if (cs_lds) {      // wave w: column sums w, w + 8, ... of G W' from the W update's partials
+  const bool cs_late = cs_lds && a.cs_lds_off == 0;   // (no room behind the numerators: the sums go where the table was, after the walk - mu_ell.hip)
+  auto form_cs = [&]() {   // wave w: column sums w, w + 8, ... of G W' from the W update's partials
     for (int kk = threadIdx.x >> 6; kk < K; kk += NT / 64) {
       double v = 0.0;
       for (int j = threadIdx.x & 63; j < a.cs_nbk; j += 64) v += a.cs_parts[(size_t)kk * a.cs_nbk + j];
       v = wave_sum(v);
       if ((threadIdx.x & 63) == 0) cs_lds[kk] = v;
     }
-  }
+  };
+  if (cs_lds && !cs_late) form_cs();
   for (int r = threadIdx.x; r < a.n_pad; r += NT) EllTab<K>::put(tab, a.n_pad, r, a.gw_s + (size_t)r * KP);
   if (pairs) {  // second partial numerator: only the pixels of the longer group of a pair receive one
 #pragma unroll
@@ -549,6 +551,10 @@ __global__ __launch_bounds__(ESPM_ELL_TILE, (K > 8 ? 2 : 4)) void h_step_ell_ker
     const int len = group_rows(gi);
     walk_rows(gi, (int)((long)len * si / nsplit), (int)((long)len * (si + 1) / nsplit), si);
     nparts = nsplit;
+  }
+  if (cs_late) {   // (uniform) every wave has left the table; the epilogue's barrier orders these stores before its reads
+    __syncthreads();
+    form_cs();
   }
   h_epilogue<K, true, RULE>(a, part, nparts, TP, tile0, LOSS ? kl : 0.f, cs_lds);
 }

@@ -151,10 +151,13 @@ struct MfRow<float> {
 
 // (The Frobenius variant - L2: no Y product - keeps the 16-slot form: it was not part of the reproducibility runs above.)
 // 17..32 components (the widest build, KP = 32): the component range in MF_KH = 2 halves of 16 - step 1 contracts over both (two chains into
-// the same Y), step 3 keeps one accumulator tile per half; MF_CT = 4 channel tiles per wave instead of 8 (the operands of two halves
-// next to 8 tiles' accumulators do not fit the registers).
+// the same Y), step 3 keeps one accumulator tile per half; MF_CT channel tiles per wave (8, like the 16-component build: with 4 the
+// H' operands of a pixel group were loaded and split for half as many channels).
 constexpr int MF_KH = KP > 16 ? KP / 16 : 1;
-constexpr int MF_CT = KP > 16 ? 4 : 8;
+#ifndef ESPM_MF_CT32
+#define ESPM_MF_CT32 8   // channel tiles per wave with two halves of components (A/B with tools/analysis/build_variant_wide32.sh, profiles/r05z_wide32_ab.log: 8-bit store 1038 -> 928 us per iteration at k = 17, 1321 -> 1208 at 32 against 4 tiles; bf16 store unchanged)
+#endif
+constexpr int MF_CT = KP > 16 ? ESPM_MF_CT32 : 8;
 constexpr int MF_KW = KP < 16 ? KP : 16;   // components of one half that exist in the KP-strided rows
 
 template <int K, typename XT, bool L2>

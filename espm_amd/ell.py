@@ -221,6 +221,6 @@ def lds_bytes_h(n_pad, k):
     wb = 0 if k <= 4 else (1 if k == 5 else (2 if k == 6 else (4 if k <= 8 else (8 if k <= 12 else 12))))
     sets = 2 if k <= _lib.ELL_PAIR_MAX_K else 1
     kp = 8 if k <= 8 else 16
-    # (+ the tail workgroup's scratch as a lower bound of the second term, + k doubles for the workgroup's copy of colsum(GW):
-    #  what launch_h_ell_k adds when the W update's tail rides in the launch)
-    return n_pad * (4 + wb) * 4 + max(sets * k * _lib.ELL_TILE * 4, 9 * (5 + 2 * k) * 8, (9 * (kp + 1) + 1) * 8) + kp * 8
+    # (the tail workgroup's scratch is a lower bound of the second term; the k doubles of the workgroup's copy of colsum(GW), when the W update's tail rides in the launch, go behind these - or, without room
+    #  there, into the table once it is dead: launch_h_ell_k)
+    return n_pad * (4 + wb) * 4 + max(sets * k * _lib.ELL_TILE * 4, 9 * (5 + 2 * k) * 8, (9 * (kp + 1) + 1) * 8)

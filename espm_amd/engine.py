@@ -218,7 +218,7 @@ class MUEngine:
                 elif sparse and not fits:
                     # not silently (missing 3): sparse count data that the sparse store would take - about 3 x the dense store's
                     # rate at 20 % non-zero entries - but whose G W table does not fit a workgroup's LDS next to a tile's numerators
-                    # (rows of 12 / 16 floats from 9 / 13 components on: 16 components stop at 1784 channels, 12 at 2552)
+                    # (rows of 12 / 16 floats from 9 / 13 components on: 16 components stop at 2048 channels, 12 at 2896)
                     import warnings
                     self.x_store_note = (f"sparse count data, but the sparse store's table for n={self.n}, k={k} needs "
                                          f"{_ell.lds_bytes_h(n_pad8, k)} bytes of LDS (limit {_lib.ELL_LDS_MAX}): the dense 8-bit store is used, "

@@ -910,7 +910,7 @@ class NMFEstimator(ABC, TransformerMixin, BaseEstimator):
         uploaded).  The reference has no limit (base.py:126-132 stores the argument, updates.py:160-223 initialise any rank); here the
         kernels are compiled per component count - 1..8 in libespm_mu.so, 9..16 in libespm_mu_wide.so, 17..32 in libespm_mu_wide32.so -
         with the components of a pixel or channel in registers.  The sparse count store serves up to 16 components: sparse count data with
-        more, or with 13-16 components and more than 1784-1880 channels (9-12: 2552-2680), take the dense 8-bit store (below 17 components
+        more, or with 13-16 components and more than 2048-2144 channels (9-12: 2896-3024), take the dense 8-bit store (below 17 components
         with a RuntimeWarning: the sparse store's G W table would not fit a workgroup's LDS)."""
         self.fit_transform(X, **params)
         return self

@@ -110,7 +110,7 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
                                    * headline image has 256 of 128 pixels; config 2's 128 blocks leave half the chip to the two launches,
                                    * which then win: 27.6 against 35.2 us per iteration, profiles/r03e_c2_iter.log)                              */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
-#define ESPM_ELL_LDS_MAX (144 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators)         */
+#define ESPM_ELL_LDS_MAX (160 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators): a workgroup's LDS on gfx950 (144 KB until round 5) */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
 #define ESPM_W_DICOTOMY_TOL 1e-5f /* tolerance of the simplex multiplier of the W update: espm/conf.py dicotomy_tol, which the
                                      reference's multiplicative_step_w always uses (updates.py:61-68); the state's

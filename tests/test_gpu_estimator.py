@@ -861,13 +861,14 @@ def test_projected_gradient_linesearch_golden(SmoothNMF, golden):
 
 def test_sparse_store_at_its_lds_limit():
     """The widest spectrum whose GW table, numerators, riding tail scratch and column-sum copy still fit the sparse H-step's LDS
-    budget (k = 5: 6344 channels), and one channel more (dense store): iterations in the C loop against the oracle."""
+    budget (k = 5: 7168 channels with the workgroup's whole 160 KB - table and numerators to the last byte, the column-sum copy then
+    sits in the dead table, `cs_late`), and one channel row more (dense store): iterations in the C loop against the oracle."""
     import torch
     from espm_amd import _lib, ell, synth
     from espm_amd.engine import MUEngine
     k, nx, ny = 5, 16, 20
-    n = 6344
-    assert ell.lds_bytes_h(n, k) <= _lib.ELL_LDS_MAX < ell.lds_bytes_h(n + 8, k)
+    n = max(v for v in range(8, 16384, 8) if ell.lds_bytes_h(v, k) <= _lib.ELL_LDS_MAX)
+    assert n == 7168 and ell.lds_bytes_h(n, k) == _lib.ELL_LDS_MAX < ell.lds_bytes_h(n + 8, k)
     rng = np.random.default_rng(4)
     for nn, store in ((n, "ell"), (n + 8, "u8")):
         prob = synth.make_problem(nn, nx, ny, k, N=400.0, seed=4)
@@ -1074,7 +1075,7 @@ def test_sparse_counts_whose_table_does_not_fit_take_the_dense_store_and_say_so(
     from espm_amd.engine import MUEngine
     from oracle import mu_oracle as oc
     rng = np.random.default_rng(3)
-    n, nx, ny, k = 2048, 12, 12, 14
+    n, nx, ny, k = 2120, 12, 12, 14      # (14 components: up to 2112 channels)
     X = rng.poisson(0.2, size=(n, nx * ny)).astype(np.float64)
     X[:, 0] += 1.0
     X[0, :] += 1.0
@@ -1094,3 +1095,36 @@ def test_sparse_counts_whose_table_does_not_fit_take_the_dense_store_and_say_so(
         warnings.simplefilter("error")
         eng5 = MUEngine(torch.from_numpy(X.astype(np.float32)).cuda(), 5, layout="cm", shape_2d=(nx, ny), lambda_L=0.5, simplex_H=True, simplex_W=False, tol=0.0, max_iter=6)
     assert eng5.x_store == "ell" and eng5.x_store_note is None
+
+
+@pytest.mark.parametrize("k", [13, 15, 16])
+def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
+    """sparse count data with 13-16 components at the headline's 2048 channels used to drop to the dense 8-bit store
+    (the sparse H-step was given 144 KB of LDS; table rows of 16 floats: 128 KB + the numerators).  With the workgroup's whole 160 KB
+    13-15 components fit, and 16 to the last byte - its column-sum copy then lives in the table once the walk has left it.  Whole
+    iterations (the C loop, the W update's tail riding in the H-step launch) against the oracle."""
+    import warnings
+    import torch
+    from espm_amd import _lib, ell, synth
+    from espm_amd.engine import MUEngine
+    n, nx, ny = 2048, 20, 30
+    assert ell.lds_bytes_h(n, k) <= _lib.ELL_LDS_MAX and (k < 16 or ell.lds_bytes_h(n, k) == _lib.ELL_LDS_MAX)
+    prob = synth.make_problem(n, nx, ny, k, N=300.0, seed=k)
+    X = np.minimum(synth.sample_numpy(prob, seed=k), 255.0)
+    X[X.sum(axis=1) == 0, 0] = 1.0
+    X[0, X.sum(axis=0) == 0] = 1.0
+    W0, H0 = synth.random_init(n, k, nx * ny, seed=k, scale=0.1)
+    kw = dict(shape_2d=(nx, ny), lambda_L=0.6, mu=0.02, simplex_H=True, simplex_W=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng = MUEngine(X, k, max_iter=6, tol=0, **kw)
+    assert eng.x_store == "ell" and eng.V.KP == 16 and eng.x_store_note is None
+    eng.load_state(W0, H0)
+    eng.iterate(6, final_loss=True)
+    torch.cuda.synchronize()
+    h = eng.history()
+    ref = oc.fit(X, k, W=W0.copy(), H=H0.copy(), exact_root=True, no_stop_criterion=True, max_iter=6, tol=0, **kw)
+    np.testing.assert_allclose(h["loss"][1:], ref["losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
+    assert h["bad"].sum() == 0

@@ -18,7 +18,7 @@ for k in [int(v) for v in os.environ.get("K", "8 12 16").split()]:
     # (wide builds: fused=False = the vector-ALU kernels, True = matrix cores; from 17 components on the 8-bit and bf16 stores have the matrix-core kernels only)
     for store, fused in ([("ell", True), ("u8", False), ("u8", True)] if k <= 16 else [("u8", True), ("bf16", True)]):
         eng = MUEngine(X, k, layout="pm", shape_2d=(nx, ny), lambda_L=1.0, simplex_H=True, simplex_W=False, tol=0.0, max_iter=200,
-                       device=dev, x_store=store, fused=fused) if not (store == "ell" and k > 12) else None
+                       device=dev, x_store=store, fused=fused) if not (store == "ell" and k > 16) else None
         if eng is None:
             continue
         eng.load_state(W0, H0)
