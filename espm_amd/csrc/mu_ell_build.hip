@@ -441,6 +441,7 @@ static hipStream_t side_fork(SideStream& s, hipStream_t stream) {
   if (!s.stream) return stream;
   if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
       hipEventRecord(s.fork, stream) != hipSuccess || hipStreamWaitEvent(s.stream, s.fork, 0) != hipSuccess) {
+    (void)hipGetLastError();   // (the pair then runs on the caller's stream: the failed call's error is not the launch's)
     s.stream = nullptr;
     return stream;
   }
