@@ -29,6 +29,10 @@
 #define ESPM_CAT2(a, b) a##b
 #define ESPM_CAT(a, b) ESPM_CAT2(a, b)
 
+// From this many components on only the instances WITH the loss terms are built (the widest build: 16 component counts of kernels that
+// unroll over K - compile time); a launch that did not ask for the loss gets it computed all the same (the `false` instance below IS the `true` one there), the state and the records are the same.
+#define ESPM_H_LOSS_ALWAYS_ABOVE 16
+
 namespace espm {
 
 #if ESPM_H_PART == 0
@@ -58,8 +62,8 @@ static int launch_h(const HStepArgs& args, int nblk, hipStream_t stream) {
     if (int rc = allow_lds(h_step_kernel<K, XT, PX, NW, true, U, NBUF>, bytes, "h_step")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, true, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   } else {
-    if (int rc = allow_lds(h_step_kernel<K, XT, PX, NW, false, U, NBUF>, bytes, "h_step")) return rc;
-    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, false, U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+    if (int rc = allow_lds(h_step_kernel<K, XT, PX, NW, (K > ESPM_H_LOSS_ALWAYS_ABOVE), U, NBUF>, bytes, "h_step")) return rc;
+    hipLaunchKernelGGL((h_step_kernel<K, XT, PX, NW, (K > ESPM_H_LOSS_ALWAYS_ABOVE), U, NBUF>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   }
   return check_hip(hipGetLastError(), "h_step launch");
 }
@@ -81,8 +85,8 @@ static int launch_h_mfma(const HStepArgs& args, int nblk, hipStream_t stream) {
     if (int rc = allow_lds(h_step_mfma_kernel<K, XT, STEPS, PASSES, true>, bytes, "h_step (mfma)")) return rc;
     hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, true>), dim3(nblk), dim3(256), bytes, stream, args);
   } else {
-    if (int rc = allow_lds(h_step_mfma_kernel<K, XT, STEPS, PASSES, false>, bytes, "h_step (mfma)")) return rc;
-    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, false>), dim3(nblk), dim3(256), bytes, stream, args);
+    if (int rc = allow_lds(h_step_mfma_kernel<K, XT, STEPS, PASSES, (K > ESPM_H_LOSS_ALWAYS_ABOVE)>, bytes, "h_step (mfma)")) return rc;
+    hipLaunchKernelGGL((h_step_mfma_kernel<K, XT, STEPS, PASSES, (K > ESPM_H_LOSS_ALWAYS_ABOVE)>), dim3(nblk), dim3(256), bytes, stream, args);
   }
   return check_hip(hipGetLastError(), "h_step (mfma) launch");
 }
@@ -106,8 +110,8 @@ static int launch_h_rule(const HStepArgs& args, int nblk, hipStream_t stream) {
     if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>, bytes, "h_step (alternate rule)")) return rc;
     hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, true, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   } else {
-    if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, false, U, NBUF, false, RULE>, bytes, "h_step (alternate rule)")) return rc;
-    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, false, U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
+    if (int rc = allow_lds(h_step_kernel<K, float, PX, NW, (K > ESPM_H_LOSS_ALWAYS_ABOVE), U, NBUF, false, RULE>, bytes, "h_step (alternate rule)")) return rc;
+    hipLaunchKernelGGL((h_step_kernel<K, float, PX, NW, (K > ESPM_H_LOSS_ALWAYS_ABOVE), U, NBUF, false, RULE>), dim3(nblk), dim3(NW * 64), bytes, stream, args);
   }
   return check_hip(hipGetLastError(), "h_step (alternate rule) launch");
 }
