@@ -29,6 +29,7 @@ ABI_VERSION = _D["ESPM_MU_ABI_VERSION"]
 XCHG_HANDLE_BYTES = _D["ESPM_XCHG_HANDLE_BYTES"]
 ELL_TILE, ELL_PB, ELL_PBITS, ELL_LDS_MAX = _D["ESPM_ELL_TILE"], _D["ESPM_ELL_PB"], _D["ESPM_ELL_PBITS"], _D["ESPM_ELL_LDS_MAX"]
 ELL_STREAM_BYTES = _D["ESPM_ELL_STREAM_BYTES"]
+ELL_BUCKETS = _D["ESPM_ELL_BUCKETS"]
 ELL_UNIT_ROWS, ELL_UNIT_MAX_N, ELL_PAIR_MAX_K = _D["ESPM_ELL_UNIT_ROWS"], _D["ESPM_ELL_UNIT_MAX_N"], _D["ESPM_ELL_PAIR_MAX_K"]
 KP, PPAD, NPAD = _D["ESPM_KP"], _D["ESPM_PPAD"], _D["ESPM_NPAD"]         # (the default build; `variant(k)` below for the wide one)
 MAX_K = KP
@@ -66,6 +67,8 @@ SYMBOLS = {
     "espm_mu_w_update_tail": (C.c_int, [_SP, C.c_int, C.c_int, _vp]),
     "espm_mu_pack_x": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "espm_mu_ell_count": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_count_hist": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "espm_mu_ell_fill_hist": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_ell_plan": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_ell_fill": (C.c_int, [_SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "espm_mu_hstat": (C.c_int, [_SP, C.c_int, _vp]),

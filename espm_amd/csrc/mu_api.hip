@@ -206,12 +206,18 @@ static int check_ell_geometry(const espm_mu_state* st) {
   return ESPM_OK;
 }
 
-int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
-                      espm_stream_t stream) {
+int espm_mu_ell_count_hist(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc, uint8_t* bkt_px,
+                           uint8_t* bkt_bc, espm_stream_t stream) {
   if (int rc = check_ell_geometry(st)) return rc;
   ESPM_REQUIRE(x_pm_u8 && cnt_px && cnt_bc && ell_klc, "ell_count: NULL pointer");
+  ESPM_REQUIRE((bkt_px == nullptr) == (bkt_bc == nullptr), "ell_count: the two histograms come together");
   return launch_ell_count(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
-                          st->nblk_w, st->ell_pb, cnt_px, cnt_bc, ell_klc, static_cast<hipStream_t>(stream));
+                          st->nblk_w, st->ell_pb, cnt_px, cnt_bc, ell_klc, static_cast<hipStream_t>(stream), bkt_px, bkt_bc);
+}
+
+int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
+                      espm_stream_t stream) {
+  return espm_mu_ell_count_hist(st, x_pm_u8, cnt_px, cnt_bc, ell_klc, nullptr, nullptr, stream);
 }
 
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
@@ -225,13 +231,20 @@ int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32
 int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,
                      const int32_t* ell_h_off, const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w,
                      espm_stream_t stream) {
+  return espm_mu_ell_fill_hist(st, x_pm_u8, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w, nullptr, nullptr, stream);
+}
+
+int espm_mu_ell_fill_hist(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,
+                          const int32_t* ell_h_off, const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, const uint8_t* bkt_px,
+                          const uint8_t* bkt_bc, espm_stream_t stream) {
   if (int rc = check_ell_geometry(st)) return rc;
+  ESPM_REQUIRE((bkt_px == nullptr) == (bkt_bc == nullptr), "ell_fill: the two histograms come together");
   ESPM_REQUIRE(x_pm_u8 && chan_perm && pix_perm && ell_h_off && ell_w_off && ell_h && ell_w, "ell_fill: NULL pointer");
   // st->x_cm, if set: the 8-bit counts once more, channel-major in tiles of ESPM_PPAD pixels (include/espm_mu.h) - the channel lists are filled from it
   ESPM_REQUIRE(!st->x_cm || st->n_cm == roundup(st->n, ESPM_NCM), "ell_fill: x_cm is set but n_cm=%d is not n rounded up to %d", st->n_cm, ESPM_NCM);
   return launch_ell_fill(static_cast<const uint8_t*>(x_pm_u8), st->n, st->n_pad, st->p, st->p_pad, st->ell_cbits, st->n_cg,
                          st->nblk_w, st->tile_px, st->ell_pb, chan_perm, pix_perm, ell_h_off, ell_w_off, ell_h, ell_w,
-                         static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(st->x_cm), st->n_cm);
+                         static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(st->x_cm), st->n_cm, bkt_px, bkt_bc);
 }
 
 int espm_mu_hstat(const espm_mu_state* st, int which, espm_stream_t stream) {

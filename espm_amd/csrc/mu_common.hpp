@@ -950,12 +950,13 @@ int launch_h_ell(const HStepArgs& args, int nblk, hipStream_t stream);
 int launch_fused_ell(const HStepArgs& h, const WAccumArgs& w, int nblk, hipStream_t stream, int static_units = 0, int stream_lists = 0);
 size_t fused_ell_lds_bytes(int n_pad, int k, int pb);
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
-                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream);
+                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream, uint8_t* bkt_px = nullptr, uint8_t* bkt_bc = nullptr);
 int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_cg, int nblk, int p_pad, int win,
                     int32_t* chan_perm, int32_t* pix_perm, int32_t* h_off, int32_t* w_off, long long* rows, hipStream_t stream);
 int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
-                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm = nullptr, int n_cm = 0);
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm = nullptr, int n_cm = 0, const uint8_t* bkt_px = nullptr,
+                    const uint8_t* bkt_bc = nullptr);
 int launch_w_ell(const WAccumArgs& args, int k, int nblk, hipStream_t stream);
 int launch_ell_fill_num(const float* gw_s, const float* h_in, const int32_t* fill_px, int fill_n, int n, int k, int p_pad, float fill,
                         float* fill_num, hipStream_t stream);

@@ -60,19 +60,25 @@ __device__ __forceinline__ void ell_block_for_each_count(const uint8_t* __restri
 }
 
 // lane = pixel: walks the pixel's row of the (p, n_pad) 8-bit matrix
+// bkt (optional): the list's ones per residue class of the channel index, ESPM_ELL_BUCKETS bytes per pixel - what the fill's placement
+// of the unit rows (EllBuckets) otherwise finds out in a pass of its own over X.
 __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
                                                           int xmax, int unit_ok, int32_t* __restrict__ cnt_px,
-                                                          float* __restrict__ klc) {
+                                                          float* __restrict__ klc, uint8_t* __restrict__ bkt) {
   __shared__ uint32_t s_tile[256 * 33];
   __shared__ int s_q[256];
+  __shared__ uint8_t s_bk[ESPM_ELL_BUCKETS * 256];
   const int q = blockIdx.x * 256 + threadIdx.x;   // (p_pad is a multiple of 256: every thread has a slot)
   int cnt = 0, ones = 0;
   double corr = 0.0;
   const double lxm = (double)xmax * log2((double)xmax);
-  ell_block_for_each_count(x_pm, n, n_pad, q < p ? q : -1, s_tile, s_q, [&](int, int x) {
+  if (bkt)
+    for (int i = 0; i < ESPM_ELL_BUCKETS; ++i) s_bk[i * 256 + threadIdx.x] = 0;
+  ell_block_for_each_count(x_pm, n, n_pad, q < p ? q : -1, s_tile, s_q, [&](int c, int x) {
     const int r = ell_reps(x, xmax);
     cnt += r;
     ones += x == 1;
+    if (bkt && x == 1) s_bk[(c & (ESPM_ELL_BUCKETS - 1)) * 256 + threadIdx.x] += 1;   // (8 bits: as EllBuckets' counters)
     if (r > 1) {  // x log2 x - sum over its entries of x_i log2 x_i
       const int rest = x - (r - 1) * xmax;
       corr += (double)x * log2((double)x) - (double)(r - 1) * lxm - (double)rest * log2((double)(rest > 1 ? rest : 1));
@@ -82,24 +88,33 @@ __global__ __launch_bounds__(256) void ell_count_h_kernel(const uint8_t* __restr
   cnt_px[q] = cnt;
   cnt_px[p_pad + q] = unit_ok ? ones : 0;
   klc[q] = (float)corr;
+  if (bkt)
+    for (int i = 0; i < ESPM_ELL_BUCKETS; ++i) bkt[(size_t)q * ESPM_ELL_BUCKETS + i] = s_bk[i * 256 + threadIdx.x];
 }
 
 // lane = channel: walks the pixels of one block
+// (bkt: as ell_count_h_kernel's, per (block, channel) list and residue class of the pixel's index inside the block)
 __global__ __launch_bounds__(256) void ell_count_w_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int ncol,
-                                                          int xmax, int pb, int32_t* __restrict__ cnt_bc) {
+                                                          int xmax, int pb, int32_t* __restrict__ cnt_bc, uint8_t* __restrict__ bkt) {
+  __shared__ uint8_t s_bk[ESPM_ELL_BUCKETS * 256];
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= ncol) return;
+  if (c >= ncol) return;   // (no barrier below)
   int cnt = 0, ones = 0;
+  if (bkt)
+    for (int i = 0; i < ESPM_ELL_BUCKETS; ++i) s_bk[i * 256 + threadIdx.x] = 0;
   if (c < n) {
     const int q0 = b * pb, q1 = min(p, q0 + pb);
     for (int q = q0; q < q1; ++q) {
       const int x = x_pm[(size_t)q * n_pad + c];
       if (x) cnt += ell_reps(x, xmax);
       ones += x == 1;
+      if (bkt && x == 1) s_bk[((q - q0) & (ESPM_ELL_BUCKETS - 1)) * 256 + threadIdx.x] += 1;
     }
   }
   cnt_bc[(size_t)b * ncol + c] = cnt;
   cnt_bc[((size_t)gridDim.x + b) * ncol + c] = ones;
+  if (bkt)
+    for (int i = 0; i < ESPM_ELL_BUCKETS; ++i) bkt[((size_t)b * ncol + c) * ESPM_ELL_BUCKETS + i] = s_bk[i * 256 + threadIdx.x];
 }
 
 // Row offsets of `count` list groups, one workgroup of 1024 threads: f(i, unit) returns the rows of group i and sets
@@ -234,9 +249,7 @@ __global__ __launch_bounds__(1024) void ell_offsets_kernel(int n_cg, int nblk, i
 // MEASURED (round 4, profiles/r04u_buckets_ab_*.log): B = 32 buys nothing - headline 137.1 (16) against 137.5 us (32), k = 3 113.2 / 113.8, a
 // 64-row shard 31.7 / 31.8, configuration 5's 128-row shard 110.3 / 111.5: the second pass of the 4-byte reads was not on the critical
 // path, and half-size buckets leave more holes for the 16-byte reads.  16 stays the default.
-#ifndef ESPM_ELL_BUCKETS
-#define ESPM_ELL_BUCKETS 16
-#endif
+// (ESPM_ELL_BUCKETS: include/espm_mu.h - the count step can hand the histograms to the fill, espm_mu_ell_count_hist)
 struct EllBuckets {
   static constexpr int B = ESPM_ELL_BUCKETS;
   static_assert(B == 16 || B == 32, "16 or 32 buckets");
@@ -287,7 +300,8 @@ __device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, in
 // lane = list slot (a wave = one group of 64 slots); slot -> pixel through pix_perm
 __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restrict__ x_pm, int n, int n_pad, int p, int p_pad,
                                                          int cbits, int win, const int32_t* __restrict__ pix_perm,
-                                                         const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h) {
+                                                         const int32_t* __restrict__ h_off, uint32_t* __restrict__ ell_h,
+                                                         const uint8_t* __restrict__ bkt) {
   __shared__ uint8_t s_b[EllBuckets::bytes(256)];
   __shared__ uint32_t s_tile[256 * 33];
   __shared__ int s_q[256];
@@ -309,9 +323,14 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
   EllBuckets b{s_b, s_b + EllBuckets::B * 256, 256, (int)threadIdx.x};
   int holes = 0;
   b.clear();
-  ell_block_for_each_count(x_pm, n, n_pad, q, s_tile, s_q, [&](int c, int x) {
-    if (x == 1 && units) b.count(c);
-  });
+  if (bkt) {   // (uniform) the count step left the ones per residue class: no first pass over X
+    if (q >= 0 && units)
+      for (int i = 0; i < EllBuckets::B; ++i) b.c(i) = bkt[(size_t)q * EllBuckets::B + i];
+  } else {
+    ell_block_for_each_count(x_pm, n, n_pad, q, s_tile, s_q, [&](int c, int x) {
+      if (x == 1 && units) b.count(c);
+    });
+  }
   if (units) holes = b.plan(lane, units);
   int j = 0, overflow = 0;
   ell_block_for_each_count(x_pm, n, n_pad, q, s_tile, s_q, [&](int c, int x) {
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256) void ell_fill_h_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(const uint8_t* __restrict__ x_pm, const uint8_t* __restrict__ x_cm, int n_cm,
                                                         int n_pad, int p, int n_cg, int pb, int pbits,
                                                         const int32_t* __restrict__ chan_perm, const int32_t* __restrict__ w_off,
-                                                        uint32_t* __restrict__ ell_w) {
+                                                        uint32_t* __restrict__ ell_w, const uint8_t* __restrict__ bkt) {
   constexpr int NT = 64 * ESPM_ELL_FILLW_WAVES;
   __shared__ uint8_t s_b[EllBuckets::bytes(NT)];
   const int b = blockIdx.x, cg = blockIdx.y * ESPM_ELL_FILLW_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -395,9 +414,13 @@ __global__ __launch_bounds__(64 * ESPM_ELL_FILLW_WAVES) void ell_fill_w_kernel(c
   };
   if (units) {
     bk.clear();
-    for_each_count([&](int i, int x) {
-      if (x == 1) bk.count(i);
-    });
+    if (bkt) {   // (uniform) from the count step
+      for (int i = 0; i < EllBuckets::B; ++i) bk.c(i) = bkt[((size_t)b * n_cg * 64 + c) * EllBuckets::B + i];
+    } else {
+      for_each_count([&](int i, int x) {
+        if (x == 1) bk.count(i);
+      });
+    }
     holes = bk.plan(lane, units);
   }
   int j = 0, overflow = 0;
@@ -459,15 +482,15 @@ static int side_join(SideStream& s, hipStream_t stream) {
 }
 
 int launch_ell_count(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int pb,
-                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream) {
+                     int32_t* cnt_px, int32_t* cnt_bc, float* klc, hipStream_t stream, uint8_t* bkt_px, uint8_t* bkt_bc) {
   const int xmax_h = (1 << (16 - cbits)) - 1, xmax_w = (1 << (16 - ell_pbits(pb))) - 1;
   // a unit entry holds index << 4 in 16 bits
   SideStream side;
   const hipStream_t s2 = side_fork(side, stream);   // (before the first kernel: the side stream waits for what precedes the pair only)
   hipLaunchKernelGGL(ell_count_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, xmax_h,
-                     n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc);
+                     n <= ESPM_ELL_UNIT_MAX_N ? 1 : 0, cnt_px, klc, bkt_px);
   hipLaunchKernelGGL(ell_count_w_kernel, dim3(nblk, (n_cg * 64 + 255) / 256), dim3(256), 0, s2, x_pm, n, n_pad, p,
-                     n_cg * 64, xmax_w, pb, cnt_bc);
+                     n_cg * 64, xmax_w, pb, cnt_bc, bkt_bc);
   const int rc = check_hip(hipGetLastError(), "ell_count launch");
   const int rc2 = side_join(side, stream);
   return rc ? rc : rc2;
@@ -492,12 +515,13 @@ int launch_ell_plan(const int32_t* cnt_px, const int32_t* cnt_bc, int n, int n_c
 
 int launch_ell_fill(const uint8_t* x_pm, int n, int n_pad, int p, int p_pad, int cbits, int n_cg, int nblk, int win, int pb,
                     const int32_t* chan_perm, const int32_t* pix_perm, const int32_t* h_off, const int32_t* w_off,
-                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm, int n_cm) {
+                    uint32_t* ell_h, uint32_t* ell_w, hipStream_t stream, const uint8_t* x_cm, int n_cm, const uint8_t* bkt_px,
+                    const uint8_t* bkt_bc) {
   SideStream side;
   const hipStream_t s2 = side_fork(side, stream);
   hipLaunchKernelGGL(ell_fill_h_kernel, dim3((p_pad + 255) / 256), dim3(256), 0, stream, x_pm, n, n_pad, p, p_pad, cbits, win,
-                     pix_perm, h_off, ell_h);
-  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, s2, x_pm, x_cm, n_cm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w);
+                     pix_perm, h_off, ell_h, bkt_px);
+  hipLaunchKernelGGL(ell_fill_w_kernel, dim3(nblk, (n_cg + ESPM_ELL_FILLW_WAVES - 1) / ESPM_ELL_FILLW_WAVES), dim3(64 * ESPM_ELL_FILLW_WAVES), 0, s2, x_pm, x_cm, n_cm, n_pad, p, n_cg, pb, ell_pbits(pb), chan_perm, w_off, ell_w, bkt_bc);
   const int rc = check_hip(hipGetLastError(), "ell_fill launch");
   const int rc2 = side_join(side, stream);
   return rc ? rc : rc2;

@@ -444,7 +444,13 @@ class MUEngine:
         cnt_px = torch.empty((2, st.p_pad), **i32)                    # entries, elements equal to 1
         cnt_bc = torch.empty((2, st.nblk_w, st.n_cg * 64), **i32)
         klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
-        self._check(self.lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
+        # (the lists' histograms of unit elements go from the count to the fill, which then walks X once instead of twice: include/espm_mu.h;
+        #  ESPM_ELL_BUILD_HIST=0: without, A/B)
+        hist = os.environ.get("ESPM_ELL_BUILD_HIST") != "0"
+        bkt_px = torch.empty((st.p_pad, _lib.ELL_BUCKETS), dtype=torch.uint8, device=dev) if hist else None
+        bkt_bc = torch.empty((st.nblk_w, st.n_cg * 64, _lib.ELL_BUCKETS), dtype=torch.uint8, device=dev) if hist else None
+        self._check(self.lib.espm_mu_ell_count_hist(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc),
+                                                    _ptr(bkt_px) if hist else None, _ptr(bkt_bc) if hist else None, _stream()))
         chan_perm = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
         pix_perm = torch.empty(st.p_pad, **i32)
         h_off = torch.empty(2 * (st.p_pad // 64) + 1, **i32)          # per group: first unit row, first general row
@@ -459,8 +465,8 @@ class MUEngine:
         ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
         st.x_cm = x8c.data_ptr() if x8c is not None else None
         try:
-            self._check(self.lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
-                                       _ptr(ell_h), _ptr(ell_w), _stream()))
+            self._check(self.lib.espm_mu_ell_fill_hist(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off),
+                                                       _ptr(ell_h), _ptr(ell_w), _ptr(bkt_px) if hist else None, _ptr(bkt_bc) if hist else None, _stream()))
         finally:
             st.x_cm = None
         nnz = getattr(self, "_nnz_known", None)

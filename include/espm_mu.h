@@ -110,6 +110,9 @@ enum { ESPM_LAYOUT_CM = 0 /* (n, p) channel-major */, ESPM_LAYOUT_PM = 1 /* (p, 
                                    * headline image has 256 of 128 pixels; config 2's 128 blocks leave half the chip to the two launches,
                                    * which then win: 27.6 against 35.2 us per iteration, profiles/r03e_c2_iter.log)                              */
 #define ESPM_ELL_WTHREADS 1024 /* threads of a W-accumulation workgroup of the sparse store (16 waves)      */
+#ifndef ESPM_ELL_BUCKETS
+#define ESPM_ELL_BUCKETS 16    /* residue classes of the index by which a list's unit elements are placed in its unit rows (mu_ell_build.hip) */
+#endif
 #define ESPM_ELL_LDS_MAX (160 * 1024) /* LDS bytes the sparse H-step may use (GW table + numerators): a workgroup's LDS on gfx950 (144 KB until round 5) */
 #define ESPM_NCM 16        /* channel rows of x_cm are padded to a multiple of this */
 #define ESPM_W_DICOTOMY_TOL 1e-5f /* tolerance of the simplex multiplier of the W update: espm/conf.py dicotomy_tol, which the
@@ -326,6 +329,15 @@ int espm_mu_pack_x(const void* src, int src_dtype, int src_layout, int64_t ld, i
  *          from which the channel lists are read with 16-byte loads (the lists come out the same); reset st->x_cm to NULL afterwards. */
 int espm_mu_ell_count(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc,
                       espm_stream_t stream);
+/* The same two steps with the lists' histograms of unit elements handed from count to fill, which saves the fill its first of two passes
+ * over X: ESPM_ELL_BUCKETS bytes per list - its elements equal to 1 per residue class of their index (channel; pixel inside the block) mod
+ * ESPM_ELL_BUCKETS, what the placement of the unit rows goes by.  bkt_px (p_pad, ESPM_ELL_BUCKETS) and bkt_bc (nblk_w, 64 n_cg,
+ * ESPM_ELL_BUCKETS) bytes, caller-allocated, both or neither (NULL, NULL = the functions without _hist).  The lists come out the same. */
+int espm_mu_ell_count_hist(const espm_mu_state* st, const void* x_pm_u8, int32_t* cnt_px, int32_t* cnt_bc, float* ell_klc, uint8_t* bkt_px,
+                           uint8_t* bkt_bc, espm_stream_t stream);
+int espm_mu_ell_fill_hist(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,
+                          const int32_t* ell_h_off, const int32_t* ell_w_off, uint32_t* ell_h, uint32_t* ell_w, const uint8_t* bkt_px,
+                          const uint8_t* bkt_bc, espm_stream_t stream);
 int espm_mu_ell_plan(const espm_mu_state* st, const int32_t* cnt_px, const int32_t* cnt_bc, int32_t* chan_perm,
                      int32_t* pix_perm, int32_t* ell_h_off, int32_t* ell_w_off, int64_t* rows, espm_stream_t stream);
 int espm_mu_ell_fill(const espm_mu_state* st, const void* x_pm_u8, const int32_t* chan_perm, const int32_t* pix_perm,

@@ -37,7 +37,10 @@ for rep in range(3):
     cnt_px = torch.empty((2, st.p_pad), **i32)
     cnt_bc = torch.empty((2, st.nblk_w, st.n_cg * 64), **i32)
     klc = torch.empty(st.p_pad, dtype=torch.float32, device=dev)
-    eng._check(lib.espm_mu_ell_count(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _stream()))
+    hist = os.environ.get("ESPM_ELL_BUILD_HIST") != "0"
+    bkt_px = torch.empty((st.p_pad, _lib.ELL_BUCKETS), dtype=torch.uint8, device=dev) if hist else None
+    bkt_bc = torch.empty((st.nblk_w, st.n_cg * 64, _lib.ELL_BUCKETS), dtype=torch.uint8, device=dev) if hist else None
+    eng._check(lib.espm_mu_ell_count_hist(C.byref(st), _ptr(x8), _ptr(cnt_px), _ptr(cnt_bc), _ptr(klc), _ptr(bkt_px) if hist else None, _ptr(bkt_bc) if hist else None, _stream()))
     t0 = stamp("ell_count", t0)
     chan_perm = torch.empty((st.nblk_w, st.n_cg * 64), **i32)
     pix_perm = torch.empty(st.p_pad, **i32)
@@ -52,7 +55,8 @@ for rep in range(3):
     ell_w = torch.zeros(max(rows_w, 1) * 64, **i32)
     t0 = stamp(f"lists allocated and zeroed ({(rows_h + rows_w) * 256 / 1e6:.0f} MB)", t0)
     st.x_cm = x8c.data_ptr() if cm else None
-    eng._check(lib.espm_mu_ell_fill(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off), _ptr(ell_h), _ptr(ell_w), _stream()))
+    eng._check(lib.espm_mu_ell_fill_hist(C.byref(st), _ptr(x8), _ptr(chan_perm), _ptr(pix_perm), _ptr(h_off), _ptr(w_off), _ptr(ell_h), _ptr(ell_w),
+                                         _ptr(bkt_px) if hist else None, _ptr(bkt_bc) if hist else None, _stream()))
     st.x_cm = None
     t0 = stamp("ell_fill", t0)
     if rep == 0:
