@@ -294,6 +294,10 @@ struct EllBuckets {
 };
 
 __device__ __forceinline__ void ell_put(uint16_t* base16, size_t row0, int j, int lane, uint32_t entry) {
+#ifdef ESPM_EXPERIMENT_FILL_NO_STORE   // TIMING ONLY (tools/analysis): what the fill's 2-byte stores cost - one entry per lane into a line of its own
+  if (entry == 0xffffffffu) base16[0] = 0;
+  return;
+#endif
   base16[((row0 + (size_t)(j >> 1)) * 64 + lane) * 2 + (j & 1)] = (uint16_t)entry;
 }
 
