@@ -508,7 +508,7 @@ def main():
             torch.cuda.synchronize()
             if rep:                                       # (the first fit of a process loads kernels and libraries)
                 secs.append(time.perf_counter() - t0)
-        whole_fit = dict(seconds=secs, iterations=int(est.n_iter_), loss_last=float(est.losses_[-1]),
+        whole_fit = dict(seconds=secs, median_s=float(sorted(secs)[len(secs) // 2]), min_s=float(min(secs)), iterations=int(est.n_iter_), loss_last=float(est.losses_[-1]),
                          note="SmoothNMF(...).fit_transform(host fp32 array (2048, 262144)): five consecutive fits after one warm-up fit")
         del est, Xh
 
