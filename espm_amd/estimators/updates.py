@@ -53,13 +53,32 @@ def multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe
 
 
 def multiplicative_step_wq(X, G, W, H, simplex_W=True, log_shift=log_shift, safe=True, physics_model=None):
-    """Multiplicative step in W "using the WQ technique" (espm/estimators/updates.py:232-261): by its own docstring exactly
-    multiplicative_step_w (it adds log_shift to GW and GWH instead of clamping them, a difference of that order)."""
+    """Multiplicative step in W "using the WQ technique" (espm/estimators/updates.py:232-261), as the reference runs it.
+
+    By its docstring exactly multiplicative_step_w, and without the simplex it is (term1 = G^T (XQ / (GW + log_shift)) is G^T ((X / GWH) H^T)
+    with log_shift added instead of clamped).  WITH simplex_W - its default - the reference finds the multiplier from
+    dichotomy_simplex(term1, term2), the numerators without their factor W (updates.py:253-258), so W' = W / (term2 + nu) * term1 is not on the
+    simplex (column sums 0.5-0.9 on the fixture F19); that is what comes back here too.  The streaming part - term1 - is the HIP W step without a
+    simplex (W'_free = W term1 / term2), the multiplier the module's dichotomy_simplex; nothing in a fit calls this function."""
+    W = np.asarray(W)
+    H = np.asarray(H)
     if safe:  # asserts only, no clamping (updates.py:239-243)
-        assert np.sum(np.asarray(H) < -log_shift / 2) == 0
-        assert np.sum(np.asarray(W) < -log_shift / 2) == 0
+        assert np.sum(H < -log_shift / 2) == 0
+        assert np.sum(W < -log_shift / 2) == 0
         assert np.sum(np.asarray(G) < -log_shift / 2) == 0
-    return multiplicative_step_w(X, G, W, H, simplex_W=simplex_W, log_shift=log_shift, safe=False, physics_model=physics_model)
+    free = multiplicative_step_w(X, G, W, H, simplex_W=False, log_shift=log_shift, safe=False)
+    if not simplex_W:
+        return free
+    from espm_amd.estimators.dicotomy import dichotomy_simplex
+    Gd = np.asarray(G() if callable(G) else G, dtype=np.float64)
+    term2 = np.sum(Gd, axis=0, keepdims=True).T @ np.sum(H.astype(np.float64), axis=1, keepdims=True).T   # updates.py:251
+    term1 = free.astype(np.float64) * term2 / np.maximum(W.astype(np.float64), log_shift)
+    if physics_model is not None:
+        rows = physics_model.NMF_simplex()
+        term2[rows, :] = term2[rows, :] + dichotomy_simplex(term1[rows, :], term2[rows, :], log_shift=log_shift, tol=dicotomy_tol)
+    else:
+        term2 = term2 + dichotomy_simplex(term1, term2, log_shift=log_shift, tol=dicotomy_tol)
+    return (W / term2 * term1).astype(free.dtype)
 
 
 def multiplicative_step_h(X, G, W, H, simplex_H=False, mu=0, log_shift=log_shift, epsilon_reg=1, safe=True,

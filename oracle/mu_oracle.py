@@ -430,6 +430,27 @@ def update_q(D, H, log_shift=LOG_SHIFT):
     return H.T[None, :, :] * (D[:, None, :] / ((D @ H)[:, :, None] + log_shift))
 
 
+def multiplicative_step_wq(X, G, W, H, simplex_W=True, log_shift=LOG_SHIFT, safe=True, rows=None):
+    """updates.py:232-261, the W step "using the WQ technique", as the reference runs it: term1 = G^T (XQ / (GW + log_shift)) with
+    XQ = sum_j X[:, j] Q[:, j, :], term2 = colsum(G)^T rowsum(H)^T, W' = W / (term2 + nu) * term1 - where nu comes from
+    dichotomy_simplex(term1, term2), the numerators WITHOUT their factor W (updates.py:253-258): with simplex_W the result is not on the
+    simplex, whatever the docstring says.  rows: the physics model's NMF_simplex() subset."""
+    if safe:
+        assert np.sum(H < -log_shift / 2) == 0 and np.sum(W < -log_shift / 2) == 0 and np.sum(G < -log_shift / 2) == 0
+    GW = G @ W
+    Q = update_q(GW, H, log_shift=log_shift)
+    XQ = np.sum(X[:, :, None] * Q, axis=1)
+    term1 = G.T @ (XQ / (GW + log_shift))
+    term2 = np.sum(G, axis=0, keepdims=True).T @ np.sum(H, axis=1, keepdims=True).T
+    if simplex_W:
+        if rows is not None:
+            nu = dichotomy_simplex(term1[rows, :], term2[rows, :], log_shift=log_shift, tol=DICOTOMY_TOL)
+            term2[rows, :] = term2[rows, :] + nu
+        else:
+            term2 = term2 + dichotomy_simplex(term1, term2, log_shift=log_shift, tol=DICOTOMY_TOL)
+    return W / term2 * term1
+
+
 def gradW(X, G, W, H, log_shift=LOG_SHIFT, safe=False, l2=False):
     """updates.py:303-313: G^T (-(X / GWH) H^T + rowsum(H)^T); l2: 2 G^T (GWH - X) H^T."""
     if safe:

@@ -678,6 +678,41 @@ def f18():
     save("f18_projected_gradient_l2", **out)
 
 
+def f19():
+    """espm/estimators/updates.py:232-261, `multiplicative_step_wq`: the W step "using the WQ technique".  Its docstring says it does exactly
+    what `multiplicative_step_w` does; with simplex_W=True (its default) it does not: the multiplier is found for the numerators WITHOUT their
+    factor W (dichotomy_simplex(term1, term2), updates.py:253-258), so W' is not on the simplex.  Captured as the reference runs it, beside
+    `multiplicative_step_w` on the same inputs; identity G and a dictionary; with the physics model's row subset."""
+    from espm.estimators.updates import multiplicative_step_w, multiplicative_step_wq
+
+    class Rows:
+        def __init__(self, rows):
+            self.rows = rows
+
+        def NMF_simplex(self):
+            return self.rows
+
+    rng = np.random.default_rng(1919)
+    out = {}
+    names = []
+    for name, (n, nx, ny, k, m) in {"i": (40, 6, 7, 3, None), "g": (36, 5, 8, 4, 7)}.items():
+        X, G, W, H = synth(rng, n, nx, ny, k, m)
+        Gd = np.eye(n) if G is None else G
+        W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+        H0 = rng.random((k, nx * ny)) + 0.05
+        H0 /= H0.sum(axis=0, keepdims=True)
+        rows = np.sort(rng.choice(W0.shape[0], size=max(2, W0.shape[0] // 2), replace=False))
+        out[f"{name}_X"], out[f"{name}_G"], out[f"{name}_W0"], out[f"{name}_H0"], out[f"{name}_rows"] = X, Gd, W0, H0, rows
+        out[f"{name}_wq_simplex"] = multiplicative_step_wq(X, Gd, W0, H0, simplex_W=True)
+        out[f"{name}_wq_free"] = multiplicative_step_wq(X, Gd, W0, H0, simplex_W=False)
+        out[f"{name}_wq_rows"] = multiplicative_step_wq(X, Gd, W0, H0, simplex_W=True, physics_model=Rows(rows))
+        out[f"{name}_w_simplex"] = multiplicative_step_w(X, Gd, W0, H0, simplex_W=True)
+        out[f"{name}_w_free"] = multiplicative_step_w(X, Gd, W0, H0, simplex_W=False)
+        names.append(name)
+    out["names"] = np.array(names)
+    save("f19_multiplicative_step_wq", **out)
+
+
 # ------------------------------------------------------------------ F16: a physics model that refreshes G every third iteration
 PHYS = {
     # the reference's default constraint (simplex over the rows NMF_simplex() names), Laplacian
@@ -783,6 +818,6 @@ def f17():
 
 
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18, f19)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -439,6 +439,31 @@ def test_gradients_and_q_step_golden(golden):
         gradH(X, G, W0, H0, lambda_L=1.0)
 
 
+def test_multiplicative_step_wq_golden(golden):
+    """`multiplicative_step_wq` (espm/estimators/updates.py:232-261) against fixture F19 from the reference: the W step of the HIP path without
+    the simplex; with simplex_W=True what the reference RETURNS - not on the simplex, its multiplier is found for the numerators without their
+    factor W - also over the physics model's row subset.  (Until round 5 this returned multiplicative_step_w's result, as the docstring reads.)"""
+    from espm_amd.estimators.updates import multiplicative_step_wq
+
+    class Rows:
+        def __init__(self, rows):
+            self.rows = rows
+
+        def NMF_simplex(self):
+            return self.rows
+
+    g = golden("f19_multiplicative_step_wq")
+    for name in g["names"]:
+        X, G, W0, H0, rows = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "rows"))
+        scale = np.abs(g[f"{name}_wq_free"]).max()
+        np.testing.assert_allclose(multiplicative_step_wq(X, G, W0, H0, simplex_W=False), g[f"{name}_wq_free"], rtol=2e-5, atol=2e-6 * scale)
+        got = multiplicative_step_wq(X, G, W0, H0, simplex_W=True)
+        np.testing.assert_allclose(got, g[f"{name}_wq_simplex"], rtol=5e-5, atol=5e-6 * scale)
+        assert np.abs(got.sum(axis=0) - 1).min() > 0.05     # (the reference's result is not on the simplex)
+        np.testing.assert_allclose(multiplicative_step_wq(X, G, W0, H0, simplex_W=True, physics_model=Rows(rows)), g[f"{name}_wq_rows"],
+                                   rtol=5e-5, atol=5e-6 * scale)
+
+
 def test_projected_gradient_steps_with_the_frobenius_gradient_golden(golden):
     """proj_grad_step_w / _h(l2=True) - NotImplementedError until round 5 (missing 5) - against fixture F18 from the
     reference (espm/estimators/updates.py:353-395)."""

@@ -10,6 +10,21 @@ from oracle import mu_oracle as oc
 RT = dict(rtol=1e-12, atol=1e-14)
 
 
+def test_multiplicative_step_wq_golden(golden):
+    """F19: `multiplicative_step_wq` as the reference runs it (updates.py:232-261) - without the simplex the same as
+    `multiplicative_step_w`, with it NOT on the simplex (the multiplier is found for the numerators without their factor W)."""
+    g = golden("f19_multiplicative_step_wq")
+
+    for name in g["names"]:
+        X, G, W0, H0, rows = (g[f"{name}_{v}"] for v in ("X", "G", "W0", "H0", "rows"))
+        np.testing.assert_allclose(oc.multiplicative_step_wq(X, G, W0, H0, simplex_W=True), g[f"{name}_wq_simplex"], rtol=1e-9)
+        np.testing.assert_allclose(oc.multiplicative_step_wq(X, G, W0, H0, simplex_W=False), g[f"{name}_wq_free"], rtol=1e-10)
+        np.testing.assert_allclose(oc.multiplicative_step_wq(X, G, W0, H0, simplex_W=True, rows=rows), g[f"{name}_wq_rows"], rtol=1e-9)
+        np.testing.assert_allclose(g[f"{name}_wq_free"], g[f"{name}_w_free"], rtol=1e-10)           # what its docstring promises ...
+        assert np.abs(g[f"{name}_wq_simplex"].sum(axis=0) - 1).min() > 0.05                            # ... and what it does not
+        np.testing.assert_allclose(g[f"{name}_w_simplex"].sum(axis=0), 1.0, atol=2e-5)
+
+
 def test_f1_dichotomy_known_answers(golden):
     g = golden("f1_dichotomy")
     for i in range(int(g["n_kat"])):
