@@ -87,3 +87,32 @@ def dichotomy_simplex_projected_gradient(a, log_shift=log_shift, tol=dicotomy_to
     d_nu = torch.empty(p, dtype=torch.float64, device=dev)
     _lib.check(_lib.lib.espm_dichotomy_simplex_pg(_ptr(d_a), k, p, float(log_shift), float(tol), int(maxit), _ptr(d_nu), _stream()))
     return d_nu.cpu().numpy()
+
+
+def dicotomy(a, b, func, maxit, tol):
+    """Bisection for func(x) = 0 on arrays of brackets, func(a) > 0 > func(b) (espm/estimators/dicotomy.py:111-173).
+
+    `func` is a Python callable, so this one runs where the arrays are - numpy on the host; the three simplex multipliers above, which
+    the reference builds on it, have kernels of their own (the per-pixel root of the H update: csrc/mu_common.hpp::simplex_root).
+    The reference's contract, kept: the sign checks of the bracket as assertions; ONE stop rule for all entries (every entry is halved until
+    the largest |func| is within tol, or maxit sweeps); the half that keeps the sign change is chosen from func(a) * func(mid) <= 0; `a` and `b`
+    are updated in place."""
+    f_lo, f_hi = func(a), func(b)
+    assert np.sum(f_hi >= 0) == 0
+    assert np.sum(f_lo <= 0) == 0
+    assert np.sum(np.isnan(f_lo)) == 0
+    assert np.sum(np.isnan(f_hi)) == 0
+    mid = (a + b) / 2
+    f_mid = func(mid)
+    sweeps = 0
+    while np.max(np.abs(f_mid)) > tol:
+        sweeps += 1
+        root_left = func(a) * f_mid <= 0          # the sign change lies between a and mid: mid becomes the right end
+        np.copyto(b, mid, where=root_left)
+        np.copyto(a, mid, where=np.logical_not(root_left))
+        mid = (a + b) / 2
+        f_mid = func(mid)
+        if sweeps >= maxit:
+            print("Dicotomy stopped for maximum number of iterations with an error of : {}".format(np.max(np.abs(f_mid))))
+            break
+    return mid

@@ -1,5 +1,6 @@
-"""Objective pieces of the path (espm/measures.py:456-504, :524-548, :560-577) on the GPU, and the ground-truth
-comparison of a fit (espm/measures.py:13-47, :125-285, :579-626; k x k problems, host numpy)."""
+"""Objective pieces of the path (espm/measures.py:456-504, :524-548, :560-577; KLdiv :387-425) on the GPU, the majorisers the path's
+tests check the updates against (KL_loss_surrogate, log_surrogate: host numpy) and the ground-truth comparison of a fit
+(espm/measures.py:13-47, :99-119, :125-339, :579-626; k x k problems, host numpy)."""
 import ctypes as C
 
 import numpy as np
@@ -28,6 +29,59 @@ def KLdiv_loss(X, W, H, log_shift=log_shift, average=False):
     xlogx = float(torch.xlogy(Xd, Xd.clamp_min(log_shift)).sum())
     val = kl_div + eng.sum_x - xlogx                # (eps * log Y on empty bins is below the sum's resolution)
     return val / X.size if average else val
+
+
+def KLdiv(X, D, H, log_shift=log_shift, average=False):
+    """Generalised KL divergence D_KL(X || D H) = sum X log(X / DH) + sum(DH - X), all three clamped at log_shift (espm/measures.py:387-425).
+
+    The factorised form of the path's data term: the H-step kernel in loss-only mode forms exactly this sum per pixel tile (the state's
+    record: KL part + sum of D H - sum of X), in fp32 element-wise with fp64 sums."""
+    from espm_amd.engine import MUEngine
+
+    X = np.asarray(X)
+    D = np.maximum(np.asarray(D), log_shift)
+    H = np.maximum(np.asarray(H), log_shift)
+    eng = MUEngine(X, H.shape[0], fix_zero_lines=False, max_iter=1, log_shift=log_shift, simplex_W=False)
+    eng.load_state(D, H)
+    eng.eval_current(advance_h=False)
+    val = float(eng.history(average=False)["kl"][0])   # (X = 0 contributes log_shift * log(log_shift / Y) in the reference: below the sum's resolution)
+    return val / X.size if average else val
+
+
+def KL(X, Y, log_shift=log_shift, average=False):
+    """Generalised KL divergence of two matrices, sum X log(X / Y) + sum(Y - X) with both clamped at log_shift (espm/measures.py:427-454):
+    a reporting measure of arbitrary arrays - element-wise in fp64 with torch where the arrays are, the host for numpy input."""
+    import torch
+
+    Xt = torch.as_tensor(np.asarray(X) if not isinstance(X, torch.Tensor) else X).to(torch.float64).clamp_min(log_shift)
+    Yt = torch.as_tensor(np.asarray(Y) if not isinstance(Y, torch.Tensor) else Y).to(torch.float64).clamp_min(log_shift)
+    red = torch.mean if average else torch.sum
+    return float((red(Yt) - red(Xt)) + (red(Xt * torch.log(Xt)) - red(Xt * torch.log(Yt))))
+
+
+def KL_loss_surrogate(X, W, H, Ht, log_shift=log_shift, average=False):
+    """The majoriser of the KL data term at Ht that the multiplicative H update minimises (espm/measures.py:506-522):
+    sum_ij X_ij sum_k U_ikj log(U_ikj / (W_ik H_kj)) + sum(W Ht), U_ikj = W_ik Ht_kj / (W Ht)_ij.
+
+    The inner sum over k collapses - log(U / (W H)) = log(Ht / H)_kj - log(W Ht)_ij and sum_k U = 1 - to
+    (W (Ht log(Ht / H)))_ij / (W Ht)_ij - log (W Ht)_ij: two small products instead of the reference's n x k x p arrays, the same value to rounding."""
+    W = np.maximum(np.asarray(W, dtype=np.float64), log_shift)
+    H = np.maximum(np.asarray(H, dtype=np.float64), log_shift)
+    Ht = np.maximum(np.asarray(Ht, dtype=np.float64), log_shift)
+    X = np.maximum(np.asarray(X, dtype=np.float64), log_shift)
+    WHt = W @ Ht
+    inner = (W @ (Ht * np.log(Ht / H))) / WHt - np.log(WHt)
+    if average:   # (the reference averages X * inner + sum_k W Ht over the n x p entries)
+        return float(np.mean(X * inner + WHt))
+    return float(np.sum(X * inner) + np.sum(WHt))
+
+
+def log_surrogate(H, Ht, mu, epsilon, average=False):
+    """The tangent majoriser of the log sparsity term at Ht (espm/measures.py:550-558): sum_kj mu_k (log(Ht + eps) + (H - Ht) / (Ht + eps))."""
+    H, Ht = np.asarray(H), np.asarray(Ht)
+    weight = mu if np.isscalar(mu) else np.asarray(mu)[:, None]
+    terms = weight * (np.log(Ht + epsilon) + (H - Ht) / (Ht + epsilon))
+    return np.mean(terms) if average else np.sum(terms)
 
 
 def log_reg(H, mu, epsilon=1, average=False):
@@ -136,6 +190,19 @@ def mse(map1, map2):
 def mae(map1, map2):
     """Mean absolute error between two maps (espm/measures.py:75-96)."""
     return np.mean(np.abs(np.asarray(map1) - np.asarray(map2)))
+
+
+def r2(map_true, map_pred):
+    """Coefficient of determination between two maps, every leading index an output (espm/measures.py:99-119: scikit-learn's r2_score
+    on the maps reshaped to (first axis, rest))."""
+    from sklearn.metrics import r2_score
+    a, b = np.asarray(map_true), np.asarray(map_pred)
+    return r2_score(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1))
+
+
+def ordered_r2(true_maps, algo_maps, input_inds):
+    """R^2 of every phase for a given correspondence (espm/measures.py:315-327)."""
+    return [float(r2(true_maps[j], algo_maps[i])) for i, j in enumerate(input_inds)]
 
 
 def ordered_mse(true_maps, algo_maps, input_inds):

@@ -713,6 +713,39 @@ def f19():
     save("f19_multiplicative_step_wq", **out)
 
 
+def f20():
+    """The measures of espm/measures.py that the path's own tests lean on and that had no counterpart until round 5 - KL, KLdiv (:387-454),
+    KL_loss_surrogate (:506-522), log_surrogate (:550-558), r2 / ordered_r2 (:99-119, :315-327) - and the generic bisection `dicotomy`
+    (estimators/dicotomy.py:111-173) on a vector of brackets with a transcendental function."""
+    from espm.estimators.dicotomy import dicotomy
+    from espm.measures import KL, KL_loss_surrogate, KLdiv, log_surrogate, ordered_r2, r2
+    rng = np.random.default_rng(2020)
+    n, k, p = 23, 4, 31
+    W = rng.random((n, k)) + 0.01
+    H = rng.random((k, p)) + 0.01
+    Ht = H * (0.5 + rng.random((k, p)))
+    X = rng.poisson(40 * W @ H).astype(np.float64) / 40
+    X[3, :] = 0
+    Y = (W @ H) * (0.7 + 0.6 * rng.random((n, p)))
+    mu = rng.random(k) * 0.4
+    out = dict(X=X, W=W, H=H, Ht=Ht, Y=Y, mu=mu)
+    out["KL"], out["KL_avg"] = KL(X, Y), KL(X, Y, average=True)
+    out["KLdiv"], out["KLdiv_avg"] = KLdiv(X, W, H), KLdiv(X, W, H, average=True)
+    out["KLs"], out["KLs_avg"], out["KLs_at"] = KL_loss_surrogate(X, W, H, Ht), KL_loss_surrogate(X, W, H, Ht, average=True), KL_loss_surrogate(X, W, Ht, Ht)
+    out["logs"], out["logs_avg"], out["logs_scalar"] = log_surrogate(H, Ht, mu, 0.8), log_surrogate(H, Ht, mu, 0.8, average=True), log_surrogate(H, Ht, 0.3, 1.0)
+    maps_t = rng.random((k, 6, 7))
+    maps_a = maps_t[[2, 0, 3, 1]] + 0.1 * rng.standard_normal((k, 6, 7))
+    out["maps_t"], out["maps_a"] = maps_t, maps_a
+    out["r2"] = r2(maps_t[0], maps_a[1])
+    out["ordered_r2"] = np.array(ordered_r2(maps_t, maps_a, [2, 0, 3, 1]))
+    t = rng.random(9) * 3 + 0.2
+    lo, hi = np.zeros(9), np.full(9, 8.0)
+    out["dic_t"] = t
+    out["dic_root"] = dicotomy(lo, hi, lambda x: np.exp(-x) * (t - x) + 0.1 * (t - x), 100, 1e-7)   # (decreasing in x, root x = t)
+    out["dic_a"], out["dic_b"] = lo, hi      # (the brackets as the routine leaves them: updated in place)
+    save("f20_measures_and_dicotomy", **out)
+
+
 # ------------------------------------------------------------------ F16: a physics model that refreshes G every third iteration
 PHYS = {
     # the reference's default constraint (simplex over the rows NMF_simplex() names), Laplacian
@@ -818,6 +851,6 @@ def f17():
 
 
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18, f19)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18, f19, f20)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

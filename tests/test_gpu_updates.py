@@ -439,6 +439,15 @@ def test_gradients_and_q_step_golden(golden):
         gradH(X, G, W0, H0, lambda_L=1.0)
 
 
+def test_kldiv_measure_golden(golden):
+    """`espm.measures.KLdiv` (measures.py:387-425) - the factorised KL divergence, evaluated by the H-step kernel in loss-only mode - against
+    fixture F20 from the reference (its X holds an empty channel: clamped at log_shift there)."""
+    from espm_amd.measures import KLdiv
+    g = golden("f20_measures_and_dicotomy")
+    np.testing.assert_allclose(KLdiv(g["X"], g["W"], g["H"]), g["KLdiv"], rtol=1e-5)
+    np.testing.assert_allclose(KLdiv(g["X"], g["W"], g["H"], average=True), g["KLdiv_avg"], rtol=1e-5)
+
+
 def test_multiplicative_step_wq_golden(golden):
     """`multiplicative_step_wq` (espm/estimators/updates.py:232-261) against fixture F19 from the reference: the W step of the HIP path without
     the simplex; with simplex_W=True what the reference RETURNS - not on the simplex, its multiplier is found for the numerators without their

@@ -337,3 +337,33 @@ def test_nndsvd_with_the_long_factor_on_the_device_matches_sklearn_on_cpu_tensor
     np.testing.assert_allclose(Wd, Wh, rtol=1e-9, atol=1e-12)
     if init != "nndsvdar":
         np.testing.assert_allclose(Hd, Hh, rtol=1e-9, atol=1e-12)
+
+
+def test_host_measures_and_generic_bisection_golden(golden):
+    """Fixture F20, from the reference: the measures the path's own tests lean on (espm/measures.py: KL :427-454, KL_loss_surrogate :506-522 -
+    here without the reference's n x k x p arrays -, log_surrogate :550-558, r2 / ordered_r2 :99-119, :315-327) and the generic bisection
+    `dicotomy` (estimators/dicotomy.py:111-173: one stop rule for all entries, brackets updated in place).  Host functions: no GPU needed."""
+    from espm_amd import measures as M
+    from espm_amd.estimators.dicotomy import dicotomy
+    g = golden("f20_measures_and_dicotomy")
+    X, W, H, Ht, Y, mu = (g[k] for k in ("X", "W", "H", "Ht", "Y", "mu"))
+    np.testing.assert_allclose(M.KL(X, Y), g["KL"], rtol=1e-12)
+    np.testing.assert_allclose(M.KL(X, Y, average=True), g["KL_avg"], rtol=1e-12)
+    np.testing.assert_allclose(M.KL_loss_surrogate(X, W, H, Ht), g["KLs"], rtol=1e-12)
+    np.testing.assert_allclose(M.KL_loss_surrogate(X, W, H, Ht, average=True), g["KLs_avg"], rtol=1e-12)
+    np.testing.assert_allclose(M.KL_loss_surrogate(X, W, Ht, Ht), g["KLs_at"], rtol=1e-12)
+    # the majoriser touches the divergence where H = Ht (measures.py's test_surrogates; the factorised KL restated in numpy here)
+    Xc, Yc = np.maximum(X, 1e-14), W @ Ht
+    np.testing.assert_allclose(g["KLs_at"] - np.sum(Xc), np.sum(Yc) - np.sum(Xc) - np.sum(Xc * np.log(Yc)), rtol=1e-10)
+    np.testing.assert_allclose(M.log_surrogate(H, Ht, mu, 0.8), g["logs"], rtol=1e-13)
+    np.testing.assert_allclose(M.log_surrogate(H, Ht, mu, 0.8, average=True), g["logs_avg"], rtol=1e-13)
+    np.testing.assert_allclose(M.log_surrogate(H, Ht, 0.3, 1.0), g["logs_scalar"], rtol=1e-13)
+    np.testing.assert_allclose(M.r2(g["maps_t"][0], g["maps_a"][1]), g["r2"], rtol=1e-13)
+    np.testing.assert_allclose(M.ordered_r2(g["maps_t"], g["maps_a"], [2, 0, 3, 1]), g["ordered_r2"], rtol=1e-13)
+    t = g["dic_t"]
+    lo, hi = np.zeros(9), np.full(9, 8.0)
+    root = dicotomy(lo, hi, lambda x: np.exp(-x) * (t - x) + 0.1 * (t - x), 100, 1e-7)
+    assert np.array_equal(root, g["dic_root"]) and np.array_equal(lo, g["dic_a"]) and np.array_equal(hi, g["dic_b"])
+    with pytest.raises(AssertionError):
+        dicotomy(np.zeros(3), np.ones(3), lambda x: x + 1.0, 10, 1e-6)     # no sign change: the reference's assertion
+
