@@ -1128,3 +1128,37 @@ def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
     np.testing.assert_allclose(h["rel_W"][1:], ref["rel"][:, 0], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(eng.get_H(), ref["H"], rtol=2e-4, atol=2e-5)
     assert h["bad"].sum() == 0
+
+
+def test_general_w_finish_at_its_natural_size(SmoothNMF):
+    """The one-workgroup W finish that keeps nothing in registers is what a dictionary G over MORE than 4096 channels gets (the register-resident
+    finishes hold up to four channels per thread): the projected-gradient W step through it - the branch it lacked until round 5 - at 5000
+    channels, against the oracle."""
+    rng = np.random.default_rng(11)
+    n, nx, ny, k, m = 5000, 10, 12, 3, 9
+    p = nx * ny
+    G = rng.random((n, m)) * (rng.random((n, m)) < 0.5) + 0.01
+    W = rng.random((m, k)) * 30.0 / n
+    H = rng.random((k, p)) ** 2 + 0.03
+    H /= H.sum(axis=0, keepdims=True)
+    X = rng.poisson(G @ W @ H * 40).astype(np.float64) / 40
+    X[X.sum(axis=1) == 0, 0] = 0.025
+    X[0, X.sum(axis=0) == 0] = 0.025
+    W0 = rng.random(W.shape) * W.mean() * 2 + 1e-3
+    H0 = rng.random((k, p)) + 0.05
+    H0 /= H0.sum(axis=0, keepdims=True)
+    kw = dict(simplex_H=True, simplex_W=False, lambda_L=0.3, mu=0)
+    L = oc.laplacian_matrix(nx, ny)
+    gh = np.abs(oc.gradH(X, G, W0, H0, mu=0, lambda_L=0.3, L=L)).max()
+    gw = np.abs(oc.gradW(X, G, W0, H0)).max()
+    gamma = [float(gh / 0.05), float(gw / (0.2 * W0.mean()))]
+    ref = oc.fit(X, k, G=G, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), algo="projected_gradient", tol=0, no_stop_criterion=True, max_iter=5,
+                 gamma=gamma, **kw)
+    assert np.isfinite(ref["losses"]).all() and (np.diff(ref["losses"]) <= 0).all()
+    est = SmoothNMF(n_components=k, G=G, shape_2d=(nx, ny), algo="projected_gradient", tol=0, no_stop_criterion=True, max_iter=5, verbose=0,
+                    gamma=gamma, **kw)
+    quiet(est.fit, X, W=W0.copy(), H=H0.copy())
+    np.testing.assert_allclose(est.losses_, ref["losses"], rtol=1e-4)
+    np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(est.W_, ref["W"], rtol=2e-3, atol=2e-3 * np.abs(ref["W"]).mean())
+
