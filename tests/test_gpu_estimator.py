@@ -1130,10 +1130,12 @@ def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
     assert h["bad"].sum() == 0
 
 
-def test_general_w_finish_at_its_natural_size(SmoothNMF):
-    """The one-workgroup W finish that keeps nothing in registers is what a dictionary G over MORE than 4096 channels gets (the register-resident
-    finishes hold up to four channels per thread): the projected-gradient W step through it - the branch it lacked until round 5 - at 5000
-    channels, against the oracle."""
+@pytest.mark.parametrize("algo", ["projected_gradient", "log_surrogate"])
+def test_w_finishes_of_a_dictionary_over_5000_channels(SmoothNMF, algo):
+    """A dictionary G over MORE than 4096 channels.  projected_gradient: the one-workgroup W finish that keeps nothing in registers (the
+    register-resident finishes hold up to four channels per thread) - the branch it lacked until round 5.  log_surrogate: the two-launch finish
+    (`w_gfinish_update_kernel` + `w_gfinish_gw_kernel`), which configuration 5 ran until its one-launch column form took over at up to 2048
+    channels.  Against the oracle."""
     rng = np.random.default_rng(11)
     n, nx, ny, k, m = 5000, 10, 12, 3, 9
     p = nx * ny
@@ -1152,11 +1154,11 @@ def test_general_w_finish_at_its_natural_size(SmoothNMF):
     gh = np.abs(oc.gradH(X, G, W0, H0, mu=0, lambda_L=0.3, L=L)).max()
     gw = np.abs(oc.gradW(X, G, W0, H0)).max()
     gamma = [float(gh / 0.05), float(gw / (0.2 * W0.mean()))]
-    ref = oc.fit(X, k, G=G, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), algo="projected_gradient", tol=0, no_stop_criterion=True, max_iter=5,
-                 gamma=gamma, **kw)
+    extra = dict(gamma=gamma) if algo == "projected_gradient" else {}
+    ref = oc.fit(X, k, G=G, W=W0.copy(), H=H0.copy(), shape_2d=(nx, ny), algo=algo, tol=0, no_stop_criterion=True, max_iter=5,
+                 exact_root=(algo == "log_surrogate"), **extra, **kw)
     assert np.isfinite(ref["losses"]).all() and (np.diff(ref["losses"]) <= 0).all()
-    est = SmoothNMF(n_components=k, G=G, shape_2d=(nx, ny), algo="projected_gradient", tol=0, no_stop_criterion=True, max_iter=5, verbose=0,
-                    gamma=gamma, **kw)
+    est = SmoothNMF(n_components=k, G=G, shape_2d=(nx, ny), algo=algo, tol=0, no_stop_criterion=True, max_iter=5, verbose=0, **extra, **kw)
     quiet(est.fit, X, W=W0.copy(), H=H0.copy())
     np.testing.assert_allclose(est.losses_, ref["losses"], rtol=1e-4)
     np.testing.assert_allclose(est.H_, ref["H"], rtol=2e-3, atol=2e-4)
