@@ -746,6 +746,42 @@ def f20():
     save("f20_measures_and_dicotomy", **out)
 
 
+def f21():
+    """The REFERENCE's estimator on the draws of the randomised parity sweep (tests/test_gpu_fuzz.py::_case: every solver and option
+    combination, 1..32 components, dictionaries, fixed entries, lines without counts): what the sweep otherwise checks against the oracle
+    only.  The inputs are regenerated from the seeds by the tests (the same numpy generator); stored here: whether the reference accepts the
+    draw, its losses and the factors it returns (fp32: the comparison is at 1e-4 ... 2e-3)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_gpu_fuzz as fz
+    out = {}
+    index = []
+    for wide, count in ((0, 24), (1, 12), (2, 12)):
+        for seed in range(count):
+            c = fz._case(seed, wide=wide)
+            tag = f"w{wide}_s{seed}"
+            status = "ok"
+            try:
+                est = SmoothNMF(n_components=c["k"], G=c["G"], shape_2d=c["shape"], algo=c["algo"], tol=0, no_stop_criterion=True, max_iter=6,
+                                verbose=0, **c["kw"], **c["extra"])
+                GW = quiet(est.fit_transform, c["X"].copy(), W=c["W0"].copy(), H=c["H0"].copy())
+                losses = np.array(est.losses_, dtype=float)
+                if not np.isfinite(losses).all():
+                    status = "nonfinite"
+                elif c["algo"] == "projected_gradient" and (np.diff(losses) > 0).any():
+                    status = "unstable"
+            except AssertionError:
+                status = "refused"
+            index.append((tag, status))
+            if status == "ok":
+                out[f"{tag}_losses"] = losses
+                out[f"{tag}_W"], out[f"{tag}_H"] = np.asarray(est.W_, dtype=np.float32), np.asarray(est.H_, dtype=np.float32)
+                out[f"{tag}_x_sum"] = np.array(float(c["X"].sum()))     # (the test's regenerated input must be this one)
+            print(tag, c["algo"], c["k"], status, flush=True)
+    out["index"] = np.array(json.dumps(index))
+    save("f21_reference_on_the_fuzz_draws", **out)
+
+
 # ------------------------------------------------------------------ F16: a physics model that refreshes G every third iteration
 PHYS = {
     # the reference's default constraint (simplex over the rows NMF_simplex() names), Laplacian
@@ -851,6 +887,6 @@ def f17():
 
 
 if __name__ == "__main__":
-    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18, f19, f20)}
+    todo = {f.__name__: f for f in (f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15, f16, f17, f18, f19, f20, f21)}
     for name in (sys.argv[1:] or list(todo)):   # e.g. `make_golden.py f9` adds a family without rewriting the others
         todo[name]()

@@ -143,6 +143,34 @@ def test_random_configurations_on_the_general_w_finish():
     assert len(passed) >= count // 3 and {"projected_gradient", "bmd"} <= {c["algo"] for c in passed} or count < 20, [(c["algo"], c["status"]) for c in cases]
 
 
+def test_estimator_matches_the_reference_itself_on_the_fuzz_draws(golden):
+    """Fixture F21 holds what the REFERENCE's SmoothNMF returns on 48 of the draws above (generated by tests/golden/make_golden.py f21): the
+    HIP path against it directly, without the oracle in between.  (Under simplex_H the reference's multiplier is its bisection's, accurate to
+    1e-5, where this path converges the root: the looser of the two tolerances.)"""
+    import json
+    from espm_amd.estimators import SmoothNMF
+    g = golden("f21_reference_on_the_fuzz_draws")
+    n_ok = 0
+    for tag, status in json.loads(str(g["index"])):
+        if status != "ok":
+            continue
+        wide, seed = int(tag[1]), int(tag.split("_s")[1])
+        c = _case(seed, wide=wide)
+        assert float(c["X"].sum()) == float(g[f"{tag}_x_sum"]), tag
+        est = SmoothNMF(n_components=c["k"], G=c["G"], shape_2d=c["shape"], algo=c["algo"], tol=0, no_stop_criterion=True, max_iter=6,
+                        verbose=0, **c["kw"], **c["extra"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            est.fit_transform(c["X"], W=c["W0"].copy(), H=c["H0"].copy())
+        loose = c["kw"]["simplex_H"]
+        msg = f"{tag}: {c['algo']} k={c['k']} {c['kw']} {sorted(c['extra'])} store={est._engine.x_store}"
+        np.testing.assert_allclose(est.losses_, g[f"{tag}_losses"], rtol=1e-4 if loose else 2e-5, err_msg=msg)
+        np.testing.assert_allclose(est.H_, g[f"{tag}_H"], rtol=2e-3 if loose else 5e-4, atol=2e-4 if loose else 5e-5, err_msg=msg)
+        Wr = g[f"{tag}_W"]
+        np.testing.assert_allclose(est.W_, Wr, rtol=2e-3 if loose else 5e-4, atol=(2e-3 if loose else 5e-4) * np.abs(Wr).mean(), err_msg=msg)
+        n_ok += 1
+    assert n_ok >= 40
+
+
 def _run(c, seed, expect_fused=False):
     from espm_amd.estimators import SmoothNMF
     iters = 6

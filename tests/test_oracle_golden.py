@@ -455,3 +455,40 @@ def test_f17_hyperspy_calling_convention(golden):
     ls = np.concatenate([[r["eval_init"]], g["stop_losses"]])
     dec = np.abs(np.diff(ls)) / abs(r["eval_init"])
     assert dec[-1] < 6e-4 * 0.98 and (dec[:-1] > 6e-4 * 1.02).all(), dec
+
+
+def _fuzz_draws(golden):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_fuzz as fz
+    g = golden("f21_reference_on_the_fuzz_draws")
+    for tag, status in json.loads(str(g["index"])):
+        wide, seed = int(tag[1]), int(tag.split("_s")[1])
+        yield tag, status, (lambda w=wide, sd=seed: fz._case(sd, wide=w)), g
+
+
+def test_oracle_fit_equals_the_reference_on_the_fuzz_draws(golden):
+    """Fixture F21: the REFERENCE's SmoothNMF on 48 draws of the randomised sweep (all four solvers, linesearch, dictionaries, fixed entries,
+    mu vectors, lines without counts, 1..32 components).  The oracle's fit loop in its reference-faithful mode (the reference's own bisection,
+    not the converged root) reproduces the losses to 1e-9 and the factors to fp32 storage - and refuses / diverges on the draws the reference
+    refuses / diverges on."""
+    n_ok = 0
+    for tag, status, make, g in _fuzz_draws(golden):
+        c = make()
+        if status == "refused":
+            with pytest.raises(AssertionError):
+                oc.fit(c["X"], c["k"], G=c["G"], W=c["W0"].copy(), H=c["H0"].copy(), shape_2d=c["shape"], algo=c["algo"], tol=0,
+                       no_stop_criterion=True, max_iter=6, **c["kw"], **c["extra"])
+            continue
+        if status != "ok":
+            continue
+        assert float(c["X"].sum()) == float(g[f"{tag}_x_sum"]), tag       # the draw regenerated here is the one the reference saw
+        ref = oc.fit(c["X"], c["k"], G=c["G"], W=c["W0"].copy(), H=c["H0"].copy(), shape_2d=c["shape"], algo=c["algo"], tol=0,
+                     no_stop_criterion=True, max_iter=6, **c["kw"], **c["extra"])
+        np.testing.assert_allclose(ref["losses"], g[f"{tag}_losses"], rtol=1e-9, err_msg=tag)
+        np.testing.assert_allclose(ref["H"], g[f"{tag}_H"], rtol=2e-6, atol=1e-7, err_msg=tag)
+        np.testing.assert_allclose(ref["W"], g[f"{tag}_W"], rtol=2e-6, atol=1e-7 * np.abs(g[f"{tag}_W"]).max(), err_msg=tag)
+        n_ok += 1
+    assert n_ok >= 40
+
