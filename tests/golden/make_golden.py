@@ -751,8 +751,13 @@ def f21():
     combination, 1..32 components, dictionaries, fixed entries, lines without counts): what the sweep otherwise checks against the oracle
     only.  The inputs are regenerated from the seeds by the tests (the same numpy generator); stored here: whether the reference accepts the
     draw, its losses and the factors it returns (fp32: the comparison is at 1e-4 ... 2e-3)."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    sys.path.insert(0, os.path.dirname(HERE))
+    # (the draws' generator lives with the tests: beside this script's directory, or - when the script was copied elsewhere to check that it
+    #  reproduces the committed fixtures - under ESPM_REPO / /root/repo)
+    for root in (os.path.dirname(os.path.dirname(HERE)), os.environ.get("ESPM_REPO", ""), "/root/repo"):
+        if root and os.path.exists(os.path.join(root, "tests", "test_gpu_fuzz.py")):
+            sys.path.insert(0, root)
+            sys.path.insert(0, os.path.join(root, "tests"))
+            break
     import test_gpu_fuzz as fz
     out = {}
     index = []
