@@ -33,6 +33,8 @@ CASES = {
              ("test_empty_channels_keep_the_sparse_store", (dict(simplex_H=False, simplex_W=True), None, "auto")),
              ("test_bregman_variant_golden", (G, "auto")), ("test_frobenius_fit_golden", (G,))],
     "pg": [("test_projected_gradient_golden", (G,)), ("test_projected_gradient_linesearch_golden", (G,))],
+    # 17..32 components: whole fits (NNDSVD, default stop rule) on the third build of the library, sharded
+    "wide32": [("test_whole_fit_with_more_than_sixteen_components", (20, True)), ("test_whole_fit_with_more_than_sixteen_components", (32, False))],
 }
 
 
@@ -91,7 +93,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,transport,group", [(2, "p2p", "trajectories"), (3, "collective", "trajectories"), (2, "p2p", "linesearch_truth"),
-                                                   (3, "collective", "linesearch_truth"), (2, "p2p", "physics"), (2, "collective", "misc"), (2, "p2p", "pg")])
+                                                   (3, "collective", "linesearch_truth"), (2, "p2p", "physics"), (2, "collective", "misc"), (2, "p2p", "pg"),
+                                                   (2, "collective", "wide32"), (2, "p2p", "wide32")])
 def test_sharded_estimator_reproduces_the_golden_fits(world, transport, group):
     with mp.Manager() as mgr:
         out = mgr.dict()
