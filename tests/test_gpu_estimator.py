@@ -1097,8 +1097,8 @@ def test_sparse_counts_whose_table_does_not_fit_take_the_dense_store_and_say_so(
     assert eng5.x_store == "ell" and eng5.x_store_note is None
 
 
-@pytest.mark.parametrize("k", [13, 15, 16])
-def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
+@pytest.mark.parametrize("k,n", [(13, 2048), (15, 2048), (16, 2048), (12, 2896), (9, 3024), (8, 4608), (4, 9216)])
+def test_sparse_store_at_the_160_kb_limits(k, n):
     """sparse count data with 13-16 components at the headline's 2048 channels used to drop to the dense 8-bit store
     (the sparse H-step was given 144 KB of LDS; table rows of 16 floats: 128 KB + the numerators).  With the workgroup's whole 160 KB
     13-15 components fit, and 16 to the last byte - its column-sum copy then lives in the table once the walk has left it.  Whole
@@ -1107,8 +1107,10 @@ def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
     import torch
     from espm_amd import _lib, ell, synth
     from espm_amd.engine import MUEngine
-    n, nx, ny = 2048, 20, 30
-    assert ell.lds_bytes_h(n, k) <= _lib.ELL_LDS_MAX and (k < 16 or ell.lds_bytes_h(n, k) == _lib.ELL_LDS_MAX)
+    nx, ny = 20, 30
+    # (the other pairs: the widest spectrum the 160 KB hold at 12, 9, 8 and 4 components - 144 KB held 2552, 2680, 4088, 8184)
+    assert ell.lds_bytes_h(n, k) <= _lib.ELL_LDS_MAX and (n == 2048 and k < 16 or ell.lds_bytes_h(n + 8, k) > _lib.ELL_LDS_MAX)
+    assert k != 16 or ell.lds_bytes_h(n, k) == _lib.ELL_LDS_MAX
     prob = synth.make_problem(n, nx, ny, k, N=300.0, seed=k)
     X = np.minimum(synth.sample_numpy(prob, seed=k), 255.0)
     X[X.sum(axis=1) == 0, 0] = 1.0
@@ -1118,7 +1120,7 @@ def test_sparse_store_with_13_to_16_components_at_2048_channels(k):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         eng = MUEngine(X, k, max_iter=6, tol=0, **kw)
-    assert eng.x_store == "ell" and eng.V.KP == 16 and eng.x_store_note is None
+    assert eng.x_store == "ell" and eng.V.KP == (16 if k > 8 else 8) and eng.x_store_note is None
     eng.load_state(W0, H0)
     eng.iterate(6, final_loss=True)
     torch.cuda.synchronize()
